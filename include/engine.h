@@ -1,0 +1,89 @@
+// engine.h -- SimpleInfer::Engine, the drop-in entry point (reference include/engine.h:12-38):
+// LoadModel / Release / InputNames / OutputNames / Input / Forward / Extract with the same
+// signatures, operand-name keys (std::map order) and ownership rules:
+//   * Input() borrows the caller's buffer; it is read at Forward() time
+//     (reference src/engine_impl.cpp:522-531), so call Input once, Forward many times.
+//   * Forward() is synchronous: outputs are valid when it returns.
+//   * Extract() hands out a non-owning view of engine memory, valid until the next Forward /
+//     Release (reference src/engine_impl.cpp:546-555).
+// Behind it: the pnnx graph is loaded, one Layer is created per operator through the
+// LayerRegistry, weights are uploaded to HBM once, and Forward() launches hand-written gfx950
+// HIP kernels in topological order on one stream (optionally replayed as a hipGraph).
+//
+// Extensions (no reference counterpart): SetOption(), device-resident Input / Extract, profiling.
+#ifndef SIMPLE_INFER_INCLUDE_ENGINE_H_
+#define SIMPLE_INFER_INCLUDE_ENGINE_H_
+
+#include <string>
+#include <vector>
+
+#include "tensor.h"
+#include "types.h"
+
+namespace SimpleInfer {
+
+class EngineImpl;
+
+struct LayerProfile {
+    std::string name;   // operator name
+    std::string type;   // pnnx type string
+    std::string kernel; // kernel family that ran ("conv_igemm", "maxpool", ...)
+    float ms = 0.f;     // HIP-event time of the layer's launches
+    double flops = 0.0; // algorithmic (direct-convolution) flops, 0 for non-conv layers
+    double bytes = 0.0; // algorithmic HBM bytes (inputs + outputs + weights, each once)
+};
+
+class Engine {
+public:
+    Engine();
+
+    ~Engine();
+
+public:
+    Status LoadModel(const std::string& parampath, const std::string& binpath);
+
+    Status Release();
+
+public:
+    const std::vector<std::string> InputNames();
+    const std::vector<std::string> OutputNames();
+
+public:
+    Status Input(const std::string& name, const Tensor& input);
+
+    Status Forward();
+
+    Status Extract(const std::string& name, Tensor& output);
+
+public:
+    // ---- extensions -------------------------------------------------------------------
+    // Must be called before LoadModel.  Keys:
+    //   "device"          HIP device ordinal (default: current device)
+    //   "fuse"            1/0  fold activation / residual add into the conv epilogue (default 1)
+    //   "alias_cat"       1/0  producers write straight into torch.cat outputs (default 1)
+    //   "graph"           1/0  replay Forward() as a captured hipGraph (default 0)
+    //   "outputs_to_host" 1/0  copy outputs to pinned host memory in Forward() (default 1);
+    //                          with 0, Extract() returns device tensors
+    Status SetOption(const std::string& key, int value);
+
+    // shape (NHWC / as stored) of any input or output operand
+    Status OperandShape(const std::string& name, std::vector<int>& shape);
+
+    // run one instrumented forward: per-layer HIP-event timings on the engine's stream
+    Status Profile(std::vector<LayerProfile>& layers);
+
+    // HIP stream the engine launches on (hipStream_t as void*)
+    void* Stream();
+
+    // timing of the most recent Forward() measured with HIP events on the engine stream
+    float LastForwardMs();
+
+private:
+    EngineImpl* impl_ = nullptr;
+};
+
+void InitializeContext();
+
+}  // namespace SimpleInfer
+
+#endif  // SIMPLE_INFER_INCLUDE_ENGINE_H_

@@ -1,0 +1,175 @@
+/*
+ * si_hip.h -- thin C-ABI over the hand-written gfx950 (MI355X / CDNA4) HIP
+ * kernels that replace SimpleInfer's src/layer operator set.
+ *
+ * Plain pointers and sizes only: no C++ or torch types cross this boundary.
+ * All activation tensors are NHWC fp32 in HBM.  Every tensor argument carries
+ * a *pixel stride* `ld` (elements between consecutive pixels, >= C) so a
+ * tensor can live inside a wider buffer -- this is how the engine makes
+ * torch.cat zero-copy (producers write straight into their channel slice).
+ *
+ * Return value: 0 on success; a positive hipError_t; or a negative SI_E_*.
+ * Every launch is asynchronous on `stream` (a hipStream_t; NULL = default
+ * stream).  Nothing here allocates or synchronises unless its name says so,
+ * so the whole forward can be captured into a hipGraph.
+ *
+ * Each entry point cites the reference routine (file:line under
+ * /root/reference) it replaces.
+ */
+#ifndef SI_HIP_H_
+#define SI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* si_stream_t; /* hipStream_t */
+typedef void* si_event_t;  /* hipEvent_t  */
+typedef void* si_graph_t;  /* hipGraphExec_t */
+
+#define SI_E_BADARG (-1)
+#define SI_E_UNSUPPORTED (-2)
+#define SI_E_NODEVICE (-3)
+
+/* activation codes used by fused epilogues and si_hip_activation_f32 */
+enum {
+    SI_ACT_NONE = 0,
+    SI_ACT_RELU = 1,        /* src/layer/relu.cpp:55-67 */
+    SI_ACT_SILU = 2,        /* src/layer/silu.cpp:49-62 */
+    SI_ACT_SIGMOID = 3,     /* src/layer/sigmoid.cpp:55-67 */
+    SI_ACT_HARDSIGMOID = 4, /* src/layer/hard_sigmoid.cpp:62-78 */
+    SI_ACT_HARDSWISH = 5,   /* src/layer/hard_swish.cpp:62-80 */
+    SI_ACT_LEAKYRELU = 6    /* north_star extension (no reference layer); slope in desc */
+};
+
+/* ---- runtime ----------------------------------------------------------- */
+const char* si_hip_version(void);
+const char* si_hip_error_string(int code);
+int si_hip_device_count(int* count);
+int si_hip_set_device(int device);
+int si_hip_get_device(int* device);
+/* name (<=255 chars), CU count, HBM bytes, core clock kHz */
+int si_hip_device_info(int device, char* name, int* cus, size_t* hbm_bytes, int* clock_khz);
+int si_hip_malloc(void** ptr, size_t bytes);
+int si_hip_free(void* ptr);
+int si_hip_host_alloc(void** ptr, size_t bytes); /* pinned */
+int si_hip_host_free(void* ptr);
+int si_hip_memset_async(void* ptr, int value, size_t bytes, si_stream_t stream);
+int si_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, si_stream_t stream);
+int si_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, si_stream_t stream);
+int si_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, si_stream_t stream);
+int si_hip_stream_create(si_stream_t* stream);
+int si_hip_stream_destroy(si_stream_t stream);
+int si_hip_stream_sync(si_stream_t stream);
+int si_hip_device_sync(void);
+int si_hip_event_create(si_event_t* ev);
+int si_hip_event_destroy(si_event_t ev);
+int si_hip_event_record(si_event_t ev, si_stream_t stream);
+int si_hip_event_sync(si_event_t ev);
+int si_hip_event_elapsed_ms(si_event_t start, si_event_t stop, float* ms);
+/* stream capture -> executable graph (replaces the CGraph pipeline of
+ * src/engine_impl.cpp:336-437 for launch-bound small batches) */
+int si_hip_graph_begin_capture(si_stream_t stream);
+int si_hip_graph_end_capture(si_stream_t stream, si_graph_t* exec);
+int si_hip_graph_launch(si_graph_t exec, si_stream_t stream);
+int si_hip_graph_destroy(si_graph_t exec);
+
+/* ---- Conv2d ------------------------------------------------------------ */
+/* Replaces Conv2d::ForwardIm2Col / ForwardIm2ColWithGroup / ForwardWinograd23
+ * (src/layer/conv_2d.cpp:207-283, :285-380, :382-487) and the separate
+ * AddBiasNHWC / activation / residual passes (src/layer/simd/binary.cpp:38-53,
+ * src/layer/silu.cpp:49-62, src/layer/binary_op.cpp:52-94) with one
+ * implicit-GEMM kernel on v_mfma_f32_32x32x2_f32:
+ *   y = act2( act1(conv(x, w) + bias) + residual )
+ */
+typedef struct SiConv2dDesc {
+    int n, ih, iw, ic;  /* input  NHWC, ic = total input channels */
+    int in_ld;          /* input pixel stride (elements) */
+    int oh, ow, oc;     /* output NHWC, oc = total output channels */
+    int out_ld;         /* output pixel stride */
+    int kh, kw, sh, sw, dh, dw;
+    int pt, pl;         /* zero padding on top / left (bottom/right implied by oh/ow) */
+    int groups;
+    int has_bias;
+    int act1;           /* applied to conv+bias */
+    int has_residual;   /* residual tensor [n,oh,ow,oc] with pixel stride res_ld */
+    int res_ld;
+    int act2;           /* applied after the residual add */
+    float act_param;    /* leaky-relu slope */
+} SiConv2dDesc;
+
+/* Weight layout expected by the kernels: [oc][kh][kw][icg_pad] ("OHWI",
+ * K = kh*kw*icg_pad contiguous per output channel), icg_pad = ic/groups
+ * rounded up to a multiple of 4 when ic/groups is not one (zero filled), so
+ * that every 16-byte K-vector stays inside one (kh,kw) tap.
+ * si_hip_conv2d_weight_elems returns the element count of that layout and
+ * si_hip_conv2d_pack_weight_host re-lays an OIHW host tensor (the pnnx
+ * attribute layout; replaces the OIHW->HWIO shuffle of conv_2d.cpp:126-150). */
+size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d);
+int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* w_packed);
+int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                      const float* residual, float* out, si_stream_t stream);
+
+/* ---- Linear ------------------------------------------------------------ */
+/* y[n,out] = x[n,in] W[out,in]^T + b   (src/layer/linear.cpp:74-117) */
+int si_hip_linear_f32(const float* x, int n, int in_features, const float* w, const float* bias, int out_features,
+                      float* y, si_stream_t stream);
+
+/* ---- pooling / resampling ---------------------------------------------- */
+typedef struct SiPool2dDesc {
+    int n, ih, iw, c, in_ld;
+    int oh, ow, out_ld;
+    int kh, kw, sh, sw, dh, dw, pt, pl;
+} SiPool2dDesc;
+/* window max, padding = lowest()   (src/layer/max_pool_2d.cpp:77-121) */
+int si_hip_maxpool2d_f32(const SiPool2dDesc* d, const float* in, float* out, si_stream_t stream);
+/* uniform-window mean, kernel = in/out   (src/layer/adaptive_avg_pool_2d.cpp:54-116) */
+int si_hip_adaptive_avgpool2d_f32(const float* in, int n, int ih, int iw, int c, int in_ld, float* out, int oh,
+                                  int ow, int out_ld, si_stream_t stream);
+/* nearest: src = clamp((int)((float)dst * (1.0f/scale)))   (src/layer/upsample.cpp:76-99,164-165) */
+int si_hip_upsample_nearest_f32(const float* in, int n, int ih, int iw, int c, int in_ld, float scale_h,
+                                float scale_w, float* out, int oh, int ow, int out_ld, si_stream_t stream);
+
+/* ---- data movement ----------------------------------------------------- */
+/* strided channel-slice copy: out[p*out_ld + i] = in[p*in_ld + i], i < c  -- one slice-assign of
+ * Cat::Forward on the channel axis (src/layer/cat.cpp:86-105) */
+int si_hip_copy_channels_f32(const float* in, size_t pixels, int c, int in_ld, float* out, int out_ld,
+                             si_stream_t stream);
+/* generic rank-4 slice copy for cat along any NHWC axis (src/layer/cat.cpp:86-105); dense tensors */
+int si_hip_cat_axis_f32(const float* in, const int in_shape[4], float* out, const int out_shape[4], int axis,
+                        int offset, si_stream_t stream);
+/* NHWC -> NCHW + flatten (src/layer/flatten.cpp:55-88) */
+int si_hip_nhwc_to_nchw_f32(const float* in, int n, int h, int w, int c, int in_ld, float* out,
+                            si_stream_t stream);
+
+/* ---- elementwise ------------------------------------------------------- */
+/* y = act(x) over [pixels, c] with pixel strides */
+int si_hip_activation_f32(int act, float act_param, const float* in, size_t pixels, int c, int in_ld, float* out,
+                          int out_ld, si_stream_t stream);
+/* op 0 = add, 2 = mul (src/layer/binary_op.cpp:17-31) with Eigen-style tiling broadcast by integer
+ * factors out/in per dim (:60-75).  Shapes are rank-4 NHWC; *_ld pixel strides. */
+int si_hip_binary_f32(int op, const float* a, const int a_shape[4], int a_ld, const float* b,
+                      const int b_shape[4], int b_ld, float* out, const int out_shape[4], int out_ld,
+                      si_stream_t stream);
+/* (x-mean)*rsqrt(var+eps)*gamma+beta   (src/layer/batch_norm_2d.cpp:84-137) */
+int si_hip_batchnorm2d_f32(const float* in, size_t pixels, int c, int in_ld, const float* mean, const float* var,
+                           const float* gamma, const float* beta, float eps, float* out, int out_ld,
+                           si_stream_t stream);
+
+/* ---- YOLOv5 Detect decode ---------------------------------------------- */
+/* One level of YoloDetect::Forward after its 1x1 conv (src/layer/yolo_detect.cpp:223-266):
+ * conv [n][h][w][na*ne] (dense) -> sigmoid -> rows [h][w][a] of out [n][rows_total][ne] at row_off;
+ * xy = (2s + grid) * stride; wh = (2s)^2 * anchor.  grid / anchor are already re-laid [h][w][na][2]
+ * (the shuffle of :75-79 is done on the host at Init). */
+int si_hip_yolo_decode_f32(const float* conv, int n, int h, int w, int na, int ne, const float* grid_hwa2,
+                           const float* anchor_hwa2, float stride, float* out, int rows_total, int row_off,
+                           si_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SI_HIP_H_ */

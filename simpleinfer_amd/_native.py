@@ -1,0 +1,141 @@
+"""ctypes loader for the two in-tree native libraries.
+
+There is no Python or CPU fallback: if the libraries are missing (not built) this raises, and on a
+machine without a HIP device every compute entry point returns an error code that the wrappers turn
+into an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_HIP_PATH = os.path.join(PKG, "libsi_hip.so")
+LIB_HOST_PATH = os.path.join(PKG, "libsimpleinfer_amd.so")
+
+_hip = None
+_host = None
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise NativeLibraryMissing(
+            "%s is not built: run `python -m simpleinfer_amd.build` (or __graft_entry__.build()); "
+            "simpleinfer_amd has no non-HIP fallback" % path)
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+class SiConv2dDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in
+                ("n", "ih", "iw", "ic", "in_ld", "oh", "ow", "oc", "out_ld", "kh", "kw", "sh", "sw", "dh", "dw",
+                 "pt", "pl", "groups", "has_bias", "act1", "has_residual", "res_ld", "act2")] + [("act_param", C.c_float)]
+
+
+class SiPool2dDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in
+                ("n", "ih", "iw", "c", "in_ld", "oh", "ow", "out_ld", "kh", "kw", "sh", "sw", "dh", "dw", "pt", "pl")]
+
+
+def hip():
+    """libsi_hip.so with argtypes/restypes set (include/si_hip.h)."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    L = _load(LIB_HIP_PATH)
+    vp, sz, i, f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    ip = C.POINTER(C.c_int)
+    sig = {
+        "si_hip_version": (C.c_char_p, []),
+        "si_hip_error_string": (C.c_char_p, [i]),
+        "si_hip_device_count": (i, [ip]),
+        "si_hip_set_device": (i, [i]),
+        "si_hip_get_device": (i, [ip]),
+        "si_hip_device_info": (i, [i, C.c_char_p, ip, C.POINTER(sz), ip]),
+        "si_hip_malloc": (i, [C.POINTER(vp), sz]),
+        "si_hip_free": (i, [vp]),
+        "si_hip_host_alloc": (i, [C.POINTER(vp), sz]),
+        "si_hip_host_free": (i, [vp]),
+        "si_hip_memset_async": (i, [vp, i, sz, vp]),
+        "si_hip_memcpy_h2d": (i, [vp, vp, sz, vp]),
+        "si_hip_memcpy_d2h": (i, [vp, vp, sz, vp]),
+        "si_hip_memcpy_d2d": (i, [vp, vp, sz, vp]),
+        "si_hip_stream_create": (i, [C.POINTER(vp)]),
+        "si_hip_stream_destroy": (i, [vp]),
+        "si_hip_stream_sync": (i, [vp]),
+        "si_hip_device_sync": (i, []),
+        "si_hip_event_create": (i, [C.POINTER(vp)]),
+        "si_hip_event_destroy": (i, [vp]),
+        "si_hip_event_record": (i, [vp, vp]),
+        "si_hip_event_sync": (i, [vp]),
+        "si_hip_event_elapsed_ms": (i, [vp, vp, C.POINTER(f)]),
+        "si_hip_graph_begin_capture": (i, [vp]),
+        "si_hip_graph_end_capture": (i, [vp, C.POINTER(vp)]),
+        "si_hip_graph_launch": (i, [vp, vp]),
+        "si_hip_graph_destroy": (i, [vp]),
+        "si_hip_conv2d_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
+        "si_hip_conv2d_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
+        "si_hip_linear_f32": (i, [vp, i, i, vp, vp, i, vp, vp]),
+        "si_hip_maxpool2d_f32": (i, [C.POINTER(SiPool2dDesc), vp, vp, vp]),
+        "si_hip_adaptive_avgpool2d_f32": (i, [vp, i, i, i, i, i, vp, i, i, i, vp]),
+        "si_hip_upsample_nearest_f32": (i, [vp, i, i, i, i, i, f, f, vp, i, i, i, vp]),
+        "si_hip_copy_channels_f32": (i, [vp, sz, i, i, vp, i, vp]),
+        "si_hip_cat_axis_f32": (i, [vp, ip, vp, ip, i, i, vp]),
+        "si_hip_nhwc_to_nchw_f32": (i, [vp, i, i, i, i, i, vp, vp]),
+        "si_hip_activation_f32": (i, [i, f, vp, sz, i, i, vp, i, vp]),
+        "si_hip_binary_f32": (i, [i, vp, ip, i, vp, ip, i, vp, ip, i, vp]),
+        "si_hip_batchnorm2d_f32": (i, [vp, sz, i, i, vp, vp, vp, vp, f, vp, i, vp]),
+        "si_hip_yolo_decode_f32": (i, [vp, i, i, i, i, i, vp, vp, f, vp, i, i, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = header/library mismatch, which tests check
+        fn.restype = res
+        fn.argtypes = args
+    L._si_signatures = sig
+    _hip = L
+    return L
+
+
+def host():
+    """libsimpleinfer_amd.so with argtypes/restypes set (include/si_engine.h)."""
+    global _host
+    if _host is not None:
+        return _host
+    hip()  # dependency, loaded RTLD_GLOBAL first
+    L = _load(LIB_HOST_PATH)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    cp = C.c_char_p
+    sig = {
+        "si_engine_create": (i, [C.POINTER(vp)]),
+        "si_engine_destroy": (i, [vp]),
+        "si_engine_set_option": (i, [vp, cp, i]),
+        "si_engine_load_model": (i, [vp, cp, cp]),
+        "si_engine_release": (i, [vp]),
+        "si_engine_num_inputs": (i, [vp]),
+        "si_engine_num_outputs": (i, [vp]),
+        "si_engine_input_name": (cp, [vp, i]),
+        "si_engine_output_name": (cp, [vp, i]),
+        "si_engine_operand_shape": (i, [vp, cp, C.POINTER(i), C.POINTER(i)]),
+        "si_engine_input": (i, [vp, cp, vp, i]),
+        "si_engine_forward": (i, [vp]),
+        "si_engine_extract": (i, [vp, cp, C.POINTER(vp), C.POINTER(i)]),
+        "si_engine_stream": (vp, [vp]),
+        "si_engine_last_forward_ms": (C.c_float, [vp]),
+        "si_engine_profile": (i, [vp]),
+        "si_engine_profile_entry": (i, [vp, i, C.POINTER(cp), C.POINTER(cp), C.POINTER(cp), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "si_engine_schedule": (i, [vp, cp, sz]),
+        "si_pnnx_dump": (i, [cp, cp, i, cp]),
+        "si_registry_types": (i, [cp, sz]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    L._si_signatures = sig
+    _host = L
+    return L

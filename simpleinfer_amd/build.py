@@ -1,0 +1,104 @@
+"""In-tree build of the two native libraries (no cmake needed; hipcc + g++ directly).
+
+  libsi_hip.so           hand-written gfx950 HIP kernels behind the C-ABI of include/si_hip.h
+  libsimpleinfer_amd.so  C++17 host: Engine / Tensor / Layer / LayerRegistry / pnnx loader and the
+                         C-ABI of include/si_engine.h; links libsi_hip.so, includes no HIP header
+
+Both land next to this file so they travel with the source snapshot.  ``python -m
+simpleinfer_amd.build`` rebuilds what is stale; ``--force`` rebuilds everything.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+INC = os.path.join(ROOT, "include")
+HIP_DIR = os.path.join(PKG, "csrc", "hip")
+HOST_DIR = os.path.join(PKG, "csrc", "host")
+LIB_HIP = os.path.join(PKG, "libsi_hip.so")
+LIB_HOST = os.path.join(PKG, "libsimpleinfer_amd.so")
+ARCH = "gfx950"
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def _stale(target, deps):
+    return (not os.path.exists(target)) or os.path.getmtime(target) < _newest(deps)
+
+
+def hip_sources():
+    return sorted(glob.glob(os.path.join(HIP_DIR, "*.hip")))
+
+
+def host_sources():
+    return sorted(glob.glob(os.path.join(HOST_DIR, "*.cpp")) + glob.glob(os.path.join(HOST_DIR, "pnnx", "*.cpp")) +
+                  glob.glob(os.path.join(HOST_DIR, "layer", "*.cpp")))
+
+
+def _headers():
+    return (glob.glob(os.path.join(INC, "*.h")) + glob.glob(os.path.join(HIP_DIR, "*.h")) +
+            glob.glob(os.path.join(HOST_DIR, "*.h")) + glob.glob(os.path.join(HOST_DIR, "*", "*.h")))
+
+
+def _run(cmd):
+    print("+ " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_hip(force=False, verbose_resources=False):
+    srcs = hip_sources()
+    if not force and not _stale(LIB_HIP, srcs + _headers()):
+        return LIB_HIP
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INC, "-I" + HIP_DIR]
+    if verbose_resources:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    _run(cmd + srcs + ["-o", LIB_HIP])
+    return LIB_HIP
+
+
+def build_host(force=False):
+    srcs = host_sources()
+    if not force and not _stale(LIB_HOST, srcs + _headers() + [LIB_HIP]):
+        return LIB_HOST
+    cxx = os.environ.get("CXX", "g++")
+    objdir = os.path.join(PKG, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_time = _newest(_headers())
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.relpath(s, HOST_DIR).replace(os.sep, "_") + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            cmd = [cxx, "-std=c++17", "-O2", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-ignored-qualifiers", "-I" + INC,
+                   "-I" + HOST_DIR, "-c", s, "-o", o]
+            print("+ " + " ".join(cmd), flush=True)
+            procs.append(subprocess.Popen(cmd))
+            if len(procs) >= 8:
+                for p in procs:
+                    if p.wait() != 0:
+                        raise subprocess.CalledProcessError(p.returncode, p.args)
+                procs = []
+    for p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, p.args)
+    _run([cxx, "-shared", "-o", LIB_HOST] + objs + ["-L" + PKG, "-lsi_hip", "-Wl,-rpath,$ORIGIN"])
+    return LIB_HOST
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_host(force)
+    return LIB_HIP, LIB_HOST
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("built:", LIB_HIP, LIB_HOST)

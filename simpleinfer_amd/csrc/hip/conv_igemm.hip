@@ -1,0 +1,324 @@
+// conv_igemm.hip -- NHWC fp32 convolution as an implicit GEMM on the gfx950
+// matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+//
+// Replaces Conv2d::ForwardIm2Col / ForwardIm2ColWithGroup / ForwardWinograd23
+// of the reference (src/layer/conv_2d.cpp:207-283, :285-380, :382-487) plus
+// the passes it runs afterwards (AddBiasNHWC src/layer/simd/binary.cpp:38-53,
+// SiLU/ReLU src/layer/silu.cpp:49-62, residual BinaryOp
+// src/layer/binary_op.cpp:52-94) with ONE kernel:
+//
+//     out[m, o] = act2( act1( sum_k A[m,k] * W[o,k] + bias[o] ) + res[m, o] )
+//
+//   m = (n, oh, ow) flattened       M = N*OH*OW
+//   k = (kh, kw, c) flattened       K = KH*KW*ICGp   (ICGp = ic/groups padded to x4)
+//   A[m,k] = in[n, oh*sh-pt+kh*dh, ow*sw-pl+kw*dw, g*icg + c]   (0 outside the image)
+//
+// The im2col matrix is never materialised: each workgroup gathers a BM x 32
+// slice of A and a BN x 32 slice of W with 16-byte loads (channels are the
+// fastest NHWC axis, so a K-vector of 4 is 4 consecutive channels of one tap),
+// stages both through LDS as [row][32+4] (the +4 pad makes ds_write_b128 and
+// the ds_read_b128 fragment reads conflict free: row stride 36 dwords puts 16
+// consecutive rows on 16 distinct 4-bank groups of the 64-bank array), and
+// runs 32x32x2 MFMAs on them.  Global loads for K-tile t+1 are issued before
+// the MFMAs of tile t (register prefetch + two LDS buffers, one barrier per
+// K-tile); 2 workgroups per CU cover each other's barrier.
+//
+// Fragment trick: one ds_read_b128 per lane fetches A[row][8q + 4h .. +3]
+// (h = lane>>5).  MFMA j (j=0..3) of that group consumes register j, i.e. the
+// k pair {8q+j, 8q+4+j}: lanes 0-31 supply the first k, lanes 32-63 the second,
+// for A and W alike, so the products line up (a K permutation inside the
+// tile, not a different sum).
+#include <hip/hip_runtime.h>
+
+#include "si_hip.h"
+#include "si_hip_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct ConvArgs {
+    const float* in;
+    const float* w;
+    const float* bias;
+    const float* res;
+    float* out;
+    int ih, iw, in_ld;
+    int oh, ow, out_ld, res_ld;
+    int kh, kw, sh, sw, dh, dw, pt, pl;
+    int icg, icg_pad, ocg, oc;  // per-group channels
+    int Kp;                     // kh*kw*icg_pad
+    int M;                      // n*oh*ow
+    int ohow;
+    int m_tiles, n_tiles;
+    int act1, act2;
+    float act_param;
+};
+
+__device__ __forceinline__ float apply_act(int act, float v, float p) {
+    switch (act) {
+        case SI_ACT_RELU: return fmaxf(v, 0.0f);
+        case SI_ACT_SILU: return v / (1.0f + __expf(-v));
+        case SI_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;
+        default: return v;
+    }
+}
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+template <int BM, int BN, int WM, int WN, bool VEC_A>
+__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32;  // 32x32 accumulator tiles per wave along M
+    constexpr int TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+    constexpr int A_IT = BM / 32;  // 16-byte vectors per thread per K-tile
+    constexpr int B_IT = BN / 32;
+
+    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_LD];
+
+    // ---- tile mapping: the n_tiles blocks that share one A panel get the same
+    // blockIdx % 8, i.e. the same XCD / L2 (placement is a speed hint only).
+    const int g = blockIdx.y;
+    const int per_chunk = 8 * a.n_tiles;
+    const int chunk = blockIdx.x / per_chunk;
+    const int r = blockIdx.x - chunk * per_chunk;
+    const int m_tile = chunk * 8 + (r & 7);
+    const int n_tile = r >> 3;
+    if (m_tile >= a.m_tiles) return;
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * BN;
+
+    const int tid = threadIdx.x;
+    const int kv = tid & 7;   // which 4-wide K vector of the 32-wide tile
+    const int r0 = tid >> 3;  // base row 0..31
+
+    // ---- per-thread A rows (fixed for the whole K loop)
+    int a_pix[A_IT], a_ih0[A_IT], a_iw0[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < a.M) {
+            const int img = m / a.ohow;
+            const int rem = m - img * a.ohow;
+            const int oy = rem / a.ow;
+            const int ox = rem - oy * a.ow;
+            a_pix[i] = img * a.ih * a.iw;
+            a_ih0[i] = oy * a.sh - a.pt;
+            a_iw0[i] = ox * a.sw - a.pl;
+        } else {
+            a_pix[i] = 0;
+            a_ih0[i] = -(1 << 28);
+            a_iw0[i] = 0;
+        }
+    }
+    const float* in_g = a.in + (size_t)g * a.icg;
+    const float* w_g = a.w + (size_t)g * a.ocg * a.Kp;
+
+    f32x4 pa[A_IT], pb[B_IT];
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kv * 4;
+        const int tap = k / a.icg_pad;
+        const int c = k - tap * a.icg_pad;
+        const int ky = tap / a.kw;
+        const int kx = tap - ky * a.kw;
+        const bool kvalid = k < a.Kp;
+        const int dy = ky * a.dh, dx = kx * a.dw;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int y = a_ih0[i] + dy, x = a_iw0[i] + dx;
+            const bool ok = kvalid && (unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float* p = in_g + (size_t)(a_pix[i] + y * a.iw + x) * a.in_ld + c;
+                if (VEC_A) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                } else {
+                    if (c + 0 < a.icg) v.x = p[0];
+                    if (c + 1 < a.icg) v.y = p[1];
+                    if (c + 2 < a.icg) v.z = p[2];
+                    if (c + 3 < a.icg) v.w = p[3];
+                }
+            }
+            pa[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int o = n0 + r0 + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kvalid && o < a.ocg) v = *reinterpret_cast<const f32x4*>(w_g + (size_t)o * a.Kp + k);
+            pb[i] = v;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* As = lds[buf];
+        float* Bs = lds[buf] + BM * LDS_LD;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(As + (r0 + 32 * i) * LDS_LD + kv * 4) = pa[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(Bs + (r0 + 32 * i) * LDS_LD + kv * 4) = pb[i];
+    };
+
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.0f;
+
+    const int nk = (a.Kp + BK - 1) / BK;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+
+        const float* As = lds[cur] + (wm * TM * 32 + l31) * LDS_LD + lh * 4;
+        const float* Bs = lds[cur] + BM * LDS_LD + (wn * TN * 32 + l31) * LDS_LD + lh * 4;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f32x4*>(As + t * 32 * LDS_LD + q * 8);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f32x4*>(Bs + u * 32 * LDS_LD + q * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int u = 0; u < TN; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[u][j], acc[t][u], 0, 0, 0);
+        }
+
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  32x32 C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    const bool has_bias = a.bias != nullptr;
+    const bool has_res = a.res != nullptr;
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = n0 + (wn * TN + u) * 32 + l31;  // channel inside the group
+        if (o >= a.ocg) continue;
+        const int oc_abs = g * a.ocg + o;
+        const float bv = has_bias ? a.bias[oc_abs] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int mb = m0 + (wm * TM + t) * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < a.M) {
+                    float v = acc[t][u][e] + bv;
+                    v = apply_act(a.act1, v, a.act_param);
+                    if (has_res) v += a.res[(size_t)m * a.res_ld + oc_abs];
+                    v = apply_act(a.act2, v, a.act_param);
+                    a.out[(size_t)m * a.out_ld + oc_abs] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const ConvArgs& a, int groups, bool vec_a, hipStream_t s) {
+    ConvArgs b = a;
+    b.m_tiles = (a.M + BM - 1) / BM;
+    b.n_tiles = (a.ocg + BN - 1) / BN;
+    const int chunks = (b.m_tiles + 7) / 8;
+    dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
+    if (vec_a)
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, b);
+    else
+        hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, b);
+    return (int)hipGetLastError();
+}
+
+inline int round_up4(int v) { return (v + 3) & ~3; }
+
+}  // namespace
+
+extern "C" size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d) {
+    if (!d || d->groups <= 0) return 0;
+    const int icg = d->ic / d->groups;
+    return (size_t)d->oc * d->kh * d->kw * round_up4(icg);
+}
+
+extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* w_packed) {
+    if (!d || !w_oihw || !w_packed || d->groups <= 0) return SI_E_BADARG;
+    const int icg = d->ic / d->groups, icp = round_up4(icg);
+    for (int o = 0; o < d->oc; ++o)
+        for (int y = 0; y < d->kh; ++y)
+            for (int x = 0; x < d->kw; ++x) {
+                float* dst = w_packed + (((size_t)o * d->kh + y) * d->kw + x) * icp;
+                for (int c = 0; c < icp; ++c)
+                    dst[c] = c < icg ? w_oihw[(((size_t)o * icg + c) * d->kh + y) * d->kw + x] : 0.0f;
+            }
+    return 0;
+}
+
+extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                                 const float* residual, float* out, si_stream_t stream) {
+    if (!d || !in || !w_packed || !out) return SI_E_BADARG;
+    if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return SI_E_BADARG;
+    if (d->n <= 0 || d->oh <= 0 || d->ow <= 0) return SI_E_BADARG;
+    if (d->has_bias && !bias) return SI_E_BADARG;
+    if (d->has_residual && !residual) return SI_E_BADARG;
+    if ((long long)d->n * d->oh * d->ow > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    if ((long long)d->n * d->ih * d->iw > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+
+    ConvArgs a;
+    a.in = in;
+    a.w = w_packed;
+    a.bias = d->has_bias ? bias : nullptr;
+    a.res = d->has_residual ? residual : nullptr;
+    a.out = out;
+    a.ih = d->ih; a.iw = d->iw; a.in_ld = d->in_ld;
+    a.oh = d->oh; a.ow = d->ow; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
+    a.kh = d->kh; a.kw = d->kw; a.sh = d->sh; a.sw = d->sw; a.dh = d->dh; a.dw = d->dw;
+    a.pt = d->pt; a.pl = d->pl;
+    a.icg = d->ic / d->groups;
+    a.icg_pad = round_up4(a.icg);
+    a.ocg = d->oc / d->groups;
+    a.oc = d->oc;
+    a.Kp = d->kh * d->kw * a.icg_pad;
+    a.M = d->n * d->oh * d->ow;
+    a.ohow = d->oh * d->ow;
+    a.m_tiles = a.n_tiles = 0;
+    a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
+
+    const bool vec_a = (a.icg % 4 == 0) && (d->in_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int G = d->groups;
+
+    // tile choice: widest N tile the layer fills; drop to 64-row tiles when a
+    // 128-row grid would leave most of the 256 CUs idle.
+    const long long wg128 = (long long)((a.M + 127) / 128) * ((a.ocg + 127) / 128) * G;
+    if (a.ocg > 64) {
+        if (wg128 < 192 && a.M > 64) return launch<64, 64, 2, 2>(a, G, vec_a, s);
+        return launch<128, 128, 2, 2>(a, G, vec_a, s);
+    }
+    if (a.ocg > 32) {
+        if (wg128 < 192 && a.M > 64) return launch<64, 64, 2, 2>(a, G, vec_a, s);
+        return launch<128, 64, 2, 2>(a, G, vec_a, s);
+    }
+    return launch<128, 32, 4, 1>(a, G, vec_a, s);
+}

@@ -1,0 +1,442 @@
+// ops.hip -- the HBM-bound half of the operator set: activations, add/mul with broadcast,
+// batch-norm, max / adaptive-average pooling, nearest upsample, concat slice copies,
+// NHWC->NCHW flatten, linear and the YOLOv5 Detect decode.
+//
+// All of these move bytes, not flops: channels are the fastest NHWC axis, so each lane owns a
+// 16-byte channel vector (consecutive lanes -> consecutive addresses), grids are capped at ~8
+// workgroups per CU and grid-stride over the rest.  Tensors carry a pixel stride (`ld`) so they
+// can sit inside a wider concat buffer.  Reference routines replaced: see include/si_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "si_hip.h"
+#include "si_hip_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float act_apply(int act, float v, float p) {
+    switch (act) {
+        case SI_ACT_RELU: return fmaxf(v, 0.0f);
+        case SI_ACT_SILU: return v / (1.0f + __expf(-v));
+        case SI_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;
+        default: return v;
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- activation ------------------------------------------------------------------------
+template <bool VEC>
+__global__ void activation_kernel(int act, float ap, const float* __restrict__ in, size_t pixels, int c, int in_ld,
+                                  float* __restrict__ out, int out_ld) {
+    const int cv = VEC ? c / 4 : c;
+    const size_t total = pixels * (size_t)cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cv;
+        const int ch = (int)(i - p * cv);
+        if (VEC) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(in + p * in_ld + ch * 4);
+            v.x = act_apply(act, v.x, ap);
+            v.y = act_apply(act, v.y, ap);
+            v.z = act_apply(act, v.z, ap);
+            v.w = act_apply(act, v.w, ap);
+            *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = v;
+        } else {
+            out[p * out_ld + ch] = act_apply(act, in[p * in_ld + ch], ap);
+        }
+    }
+}
+
+// ---- binary add / mul with tiling broadcast ------------------------------------------------
+struct Shape4 {
+    int d[4];
+};
+
+template <bool VEC>
+__global__ void binary_same_kernel(int op, const float* __restrict__ a, int a_ld, const float* __restrict__ b,
+                                   int b_ld, float* __restrict__ out, int out_ld, size_t pixels, int c) {
+    const int cv = VEC ? c / 4 : c;
+    const size_t total = pixels * (size_t)cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cv;
+        const int ch = (int)(i - p * cv);
+        if (VEC) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(a + p * a_ld + ch * 4);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(b + p * b_ld + ch * 4);
+            *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = (op == 0) ? x + y : x * y;
+        } else {
+            const float x = a[p * a_ld + ch], y = b[p * b_ld + ch];
+            out[p * out_ld + ch] = (op == 0) ? x + y : x * y;
+        }
+    }
+}
+
+__global__ void binary_bcast_kernel(int op, const float* __restrict__ a, Shape4 as, int a_ld,
+                                    const float* __restrict__ b, Shape4 bs, int b_ld, float* __restrict__ out,
+                                    Shape4 os, int out_ld) {
+    const size_t total = (size_t)os.d[0] * os.d[1] * os.d[2] * os.d[3];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t t = i;
+        const int i3 = (int)(t % os.d[3]); t /= os.d[3];
+        const int i2 = (int)(t % os.d[2]); t /= os.d[2];
+        const int i1 = (int)(t % os.d[1]); t /= os.d[1];
+        const int i0 = (int)t;
+        const size_t ap = ((size_t)(i0 % as.d[0]) * as.d[1] + (i1 % as.d[1])) * as.d[2] + (i2 % as.d[2]);
+        const size_t bp = ((size_t)(i0 % bs.d[0]) * bs.d[1] + (i1 % bs.d[1])) * bs.d[2] + (i2 % bs.d[2]);
+        const size_t op_ = ((size_t)i0 * os.d[1] + i1) * os.d[2] + i2;
+        const float x = a[ap * a_ld + (i3 % as.d[3])];
+        const float y = b[bp * b_ld + (i3 % bs.d[3])];
+        out[op_ * out_ld + i3] = (op == 0) ? x + y : x * y;
+    }
+}
+
+// ---- batch norm -------------------------------------------------------------------------
+__global__ void batchnorm_kernel(const float* __restrict__ in, size_t pixels, int c, int in_ld,
+                                 const float* __restrict__ mean, const float* __restrict__ var,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                 float* __restrict__ out, int out_ld) {
+    const size_t total = pixels * (size_t)c;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / c;
+        const int ch = (int)(i - p * c);
+        const float inv = 1.0f / sqrtf(var[ch] + eps);
+        out[p * out_ld + ch] = (in[p * in_ld + ch] - mean[ch]) * inv * gamma[ch] + beta[ch];
+    }
+}
+
+// ---- max pool ---------------------------------------------------------------------------
+template <bool VEC>
+__global__ void maxpool_kernel(const SiPool2dDesc d, const float* __restrict__ in, float* __restrict__ out) {
+    const int cv = VEC ? d.c / 4 : d.c;
+    const size_t total = (size_t)d.n * d.oh * d.ow * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t t = i;
+        const int ch = (int)(t % cv); t /= cv;
+        const int x = (int)(t % d.ow); t /= d.ow;
+        const int y = (int)(t % d.oh); t /= d.oh;
+        const int b = (int)t;
+        f32x4 m = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int ky = 0; ky < d.kh; ++ky) {
+            const int yy = y * d.sh - d.pt + ky * d.dh;
+            if ((unsigned)yy >= (unsigned)d.ih) continue;
+            for (int kx = 0; kx < d.kw; ++kx) {
+                const int xx = x * d.sw - d.pl + kx * d.dw;
+                if ((unsigned)xx >= (unsigned)d.iw) continue;
+                const float* p = in + ((size_t)(b * d.ih + yy) * d.iw + xx) * d.in_ld;
+                if (VEC) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(p + ch * 4);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                } else {
+                    m.x = fmaxf(m.x, p[ch]);
+                }
+            }
+        }
+        float* o = out + ((size_t)(b * d.oh + y) * d.ow + x) * d.out_ld;
+        if (VEC)
+            *reinterpret_cast<f32x4*>(o + ch * 4) = m;
+        else
+            o[ch] = m.x;
+    }
+}
+
+// ---- adaptive average pool (uniform windows) -----------------------------------------------
+__global__ void avgpool_kernel(const float* __restrict__ in, int n, int ih, int iw, int c, int in_ld,
+                               float* __restrict__ out, int oh, int ow, int out_ld, int kh, int kw) {
+    const size_t total = (size_t)n * oh * ow * c;
+    const float denom = (float)(kh * kw);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t t = i;
+        const int ch = (int)(t % c); t /= c;
+        const int x = (int)(t % ow); t /= ow;
+        const int y = (int)(t % oh); t /= oh;
+        const int b = (int)t;
+        float s = 0.0f;
+        for (int ky = 0; ky < kh; ++ky)
+            for (int kx = 0; kx < kw; ++kx)
+                s += in[((size_t)(b * ih + y * kh + ky) * iw + x * kw + kx) * in_ld + ch];
+        out[((size_t)(b * oh + y) * ow + x) * out_ld + ch] = s / denom;
+    }
+}
+
+// ---- nearest upsample ----------------------------------------------------------------------
+template <bool VEC>
+__global__ void upsample_kernel(const float* __restrict__ in, int n, int ih, int iw, int c, int in_ld,
+                                float inv_h, float inv_w, float* __restrict__ out, int oh, int ow, int out_ld) {
+    const int cv = VEC ? c / 4 : c;
+    const size_t total = (size_t)n * oh * ow * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t t = i;
+        const int ch = (int)(t % cv); t /= cv;
+        const int x = (int)(t % ow); t /= ow;
+        const int y = (int)(t % oh); t /= oh;
+        const int b = (int)t;
+        // reference src/layer/upsample.cpp:85-92: int(float(dst) * inv), clamped to [0, in-1]
+        int ys = (int)((float)y * inv_h);
+        ys = max(0, min(ih - 1, ys));
+        int xs = (int)((float)x * inv_w);
+        xs = max(0, min(iw - 1, xs));
+        const float* p = in + ((size_t)(b * ih + ys) * iw + xs) * in_ld;
+        float* o = out + ((size_t)(b * oh + y) * ow + x) * out_ld;
+        if (VEC)
+            *reinterpret_cast<f32x4*>(o + ch * 4) = *reinterpret_cast<const f32x4*>(p + ch * 4);
+        else
+            o[ch] = p[ch];
+    }
+}
+
+// ---- strided slice copies --------------------------------------------------------------------
+template <bool VEC>
+__global__ void copy_channels_kernel(const float* __restrict__ in, size_t pixels, int c, int in_ld,
+                                     float* __restrict__ out, int out_ld) {
+    const int cv = VEC ? c / 4 : c;
+    const size_t total = pixels * (size_t)cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cv;
+        const int ch = (int)(i - p * cv);
+        if (VEC)
+            *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = *reinterpret_cast<const f32x4*>(in + p * in_ld + ch * 4);
+        else
+            out[p * out_ld + ch] = in[p * in_ld + ch];
+    }
+}
+
+__global__ void cat_axis_kernel(const float* __restrict__ in, Shape4 s, float* __restrict__ out, Shape4 o, int axis,
+                                int offset) {
+    const size_t total = (size_t)s.d[0] * s.d[1] * s.d[2] * s.d[3];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t t = i;
+        int idx[4];
+        idx[3] = (int)(t % s.d[3]); t /= s.d[3];
+        idx[2] = (int)(t % s.d[2]); t /= s.d[2];
+        idx[1] = (int)(t % s.d[1]); t /= s.d[1];
+        idx[0] = (int)t;
+        idx[axis] += offset;
+        out[(((size_t)idx[0] * o.d[1] + idx[1]) * o.d[2] + idx[2]) * o.d[3] + idx[3]] = in[i];
+    }
+}
+
+// out is NCHW dense: consecutive threads walk w (coalesced writes); reads are strided by ld but
+// the flatten inputs in these nets are tiny (ResNet18: 64x1x1x512).
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int n, int h, int w, int c, int in_ld,
+                                    float* __restrict__ out) {
+    const size_t total = (size_t)n * c * h * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t t = i;
+        const int x = (int)(t % w); t /= w;
+        const int y = (int)(t % h); t /= h;
+        const int ch = (int)(t % c); t /= c;
+        const int b = (int)t;
+        out[i] = in[((size_t)(b * h + y) * w + x) * in_ld + ch];
+    }
+}
+
+// ---- linear: one wave per output element, lanes stride K (coalesced), shuffle reduce --------
+__global__ void linear_kernel(const float* __restrict__ x, int n, int in_f, const float* __restrict__ w,
+                              const float* __restrict__ bias, int out_f, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t total = (size_t)n * out_f;
+    for (size_t e = wave; e < total; e += n_waves) {
+        const int row = (int)(e / out_f), o = (int)(e - (size_t)row * out_f);
+        const float* xr = x + (size_t)row * in_f;
+        const float* wr = w + (size_t)o * in_f;
+        float acc = 0.0f;
+        for (int k = lane; k < in_f; k += 64) acc = fmaf(xr[k], wr[k], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) y[e] = bias ? acc + bias[o] : acc;
+    }
+}
+
+// ---- YOLOv5 Detect decode --------------------------------------------------------------------
+__global__ void yolo_decode_kernel(const float* __restrict__ conv, int n, size_t rows, int ne,
+                                   const float* __restrict__ grid, const float* __restrict__ anchor, float stride,
+                                   float* __restrict__ out, int rows_total, int row_off) {
+    const size_t total = (size_t)n * rows * ne;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % ne);
+        const size_t t = i / ne;
+        const size_t r = t % rows;
+        const size_t b = t / rows;
+        const float s = 1.0f / (1.0f + __expf(-conv[i]));
+        float v = s;
+        if (e < 2) {
+            v = (s * 2.0f + grid[r * 2 + e]) * stride;
+        } else if (e < 4) {
+            const float t2 = s * 2.0f;
+            v = t2 * t2 * anchor[r * 2 + (e - 2)];
+        }
+        out[(b * rows_total + row_off + r) * ne + e] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int si_hip_activation_f32(int act, float act_param, const float* in, size_t pixels, int c, int in_ld, float* out,
+                          int out_ld, si_stream_t stream) {
+    if (!in || !out || c <= 0 || in_ld < c || out_ld < c) return SI_E_BADARG;
+    if (act < SI_ACT_NONE || act > SI_ACT_LEAKYRELU) return SI_E_UNSUPPORTED;
+    if (pixels == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    // a dense tensor is one long row: lets odd channel counts (e.g. 3) still take the 16-byte path
+    if (in_ld == c && out_ld == c) {
+        const size_t total = pixels * (size_t)c;
+        if (total % 4 == 0 && total < 0x7fffffff && aligned16(in) && aligned16(out)) {
+            hipLaunchKernelGGL(activation_kernel<true>, dim3(si_grid_for(total / 4)), dim3(256), 0, s, act, act_param,
+                               in, (size_t)1, (int)total, (int)total, out, (int)total);
+            return (int)hipGetLastError();
+        }
+    }
+    const bool vec = (c % 4 == 0) && (in_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(in) && aligned16(out);
+    if (vec)
+        hipLaunchKernelGGL(activation_kernel<true>, dim3(si_grid_for(pixels * (c / 4))), dim3(256), 0, s, act,
+                           act_param, in, pixels, c, in_ld, out, out_ld);
+    else
+        hipLaunchKernelGGL(activation_kernel<false>, dim3(si_grid_for(pixels * c)), dim3(256), 0, s, act, act_param,
+                           in, pixels, c, in_ld, out, out_ld);
+    return (int)hipGetLastError();
+}
+
+int si_hip_binary_f32(int op, const float* a, const int a_shape[4], int a_ld, const float* b, const int b_shape[4],
+                      int b_ld, float* out, const int out_shape[4], int out_ld, si_stream_t stream) {
+    if (!a || !b || !out || !a_shape || !b_shape || !out_shape) return SI_E_BADARG;
+    if (op != 0 && op != 2) return SI_E_UNSUPPORTED;  // reference binary_op.cpp:27-30
+    bool same = true;
+    Shape4 as, bs, os;
+    for (int i = 0; i < 4; ++i) {
+        as.d[i] = a_shape[i]; bs.d[i] = b_shape[i]; os.d[i] = out_shape[i];
+        if (as.d[i] <= 0 || bs.d[i] <= 0 || os.d[i] <= 0) return SI_E_BADARG;
+        if (os.d[i] % as.d[i] != 0 || os.d[i] % bs.d[i] != 0) return SI_E_BADARG;
+        same = same && as.d[i] == os.d[i] && bs.d[i] == os.d[i];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t pixels = (size_t)os.d[0] * os.d[1] * os.d[2];
+    const int c = os.d[3];
+    if (same) {
+        const bool vec = (c % 4 == 0) && (a_ld % 4 == 0) && (b_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(a) &&
+                         aligned16(b) && aligned16(out);
+        if (vec)
+            hipLaunchKernelGGL(binary_same_kernel<true>, dim3(si_grid_for(pixels * (c / 4))), dim3(256), 0, s, op, a,
+                               a_ld, b, b_ld, out, out_ld, pixels, c);
+        else
+            hipLaunchKernelGGL(binary_same_kernel<false>, dim3(si_grid_for(pixels * c)), dim3(256), 0, s, op, a, a_ld,
+                               b, b_ld, out, out_ld, pixels, c);
+    } else {
+        hipLaunchKernelGGL(binary_bcast_kernel, dim3(si_grid_for(pixels * c)), dim3(256), 0, s, op, a, as, a_ld, b, bs,
+                           b_ld, out, os, out_ld);
+    }
+    return (int)hipGetLastError();
+}
+
+int si_hip_batchnorm2d_f32(const float* in, size_t pixels, int c, int in_ld, const float* mean, const float* var,
+                           const float* gamma, const float* beta, float eps, float* out, int out_ld,
+                           si_stream_t stream) {
+    if (!in || !out || !mean || !var || !gamma || !beta || c <= 0) return SI_E_BADARG;
+    if (pixels == 0) return 0;
+    hipLaunchKernelGGL(batchnorm_kernel, dim3(si_grid_for(pixels * c)), dim3(256), 0, (hipStream_t)stream, in, pixels,
+                       c, in_ld, mean, var, gamma, beta, eps, out, out_ld);
+    return (int)hipGetLastError();
+}
+
+int si_hip_maxpool2d_f32(const SiPool2dDesc* d, const float* in, float* out, si_stream_t stream) {
+    if (!d || !in || !out || d->c <= 0 || d->oh <= 0 || d->ow <= 0) return SI_E_BADARG;
+    const bool vec = (d->c % 4 == 0) && (d->in_ld % 4 == 0) && (d->out_ld % 4 == 0) && aligned16(in) && aligned16(out);
+    const size_t px = (size_t)d->n * d->oh * d->ow;
+    if (vec)
+        hipLaunchKernelGGL(maxpool_kernel<true>, dim3(si_grid_for(px * (d->c / 4))), dim3(256), 0, (hipStream_t)stream,
+                           *d, in, out);
+    else
+        hipLaunchKernelGGL(maxpool_kernel<false>, dim3(si_grid_for(px * d->c)), dim3(256), 0, (hipStream_t)stream, *d,
+                           in, out);
+    return (int)hipGetLastError();
+}
+
+int si_hip_adaptive_avgpool2d_f32(const float* in, int n, int ih, int iw, int c, int in_ld, float* out, int oh, int ow,
+                                  int out_ld, si_stream_t stream) {
+    if (!in || !out || oh <= 0 || ow <= 0) return SI_E_BADARG;
+    if (ih % oh != 0 || iw % ow != 0) return SI_E_UNSUPPORTED;  // reference adaptive_avg_pool_2d.cpp:78-84
+    hipLaunchKernelGGL(avgpool_kernel, dim3(si_grid_for((size_t)n * oh * ow * c)), dim3(256), 0, (hipStream_t)stream,
+                       in, n, ih, iw, c, in_ld, out, oh, ow, out_ld, ih / oh, iw / ow);
+    return (int)hipGetLastError();
+}
+
+int si_hip_upsample_nearest_f32(const float* in, int n, int ih, int iw, int c, int in_ld, float scale_h, float scale_w,
+                                float* out, int oh, int ow, int out_ld, si_stream_t stream) {
+    if (!in || !out || scale_h <= 0.f || scale_w <= 0.f) return SI_E_BADARG;
+    const float inv_h = 1.0f / scale_h, inv_w = 1.0f / scale_w;
+    const bool vec = (c % 4 == 0) && (in_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(in) && aligned16(out);
+    const size_t px = (size_t)n * oh * ow;
+    if (vec)
+        hipLaunchKernelGGL(upsample_kernel<true>, dim3(si_grid_for(px * (c / 4))), dim3(256), 0, (hipStream_t)stream, in,
+                           n, ih, iw, c, in_ld, inv_h, inv_w, out, oh, ow, out_ld);
+    else
+        hipLaunchKernelGGL(upsample_kernel<false>, dim3(si_grid_for(px * c)), dim3(256), 0, (hipStream_t)stream, in, n,
+                           ih, iw, c, in_ld, inv_h, inv_w, out, oh, ow, out_ld);
+    return (int)hipGetLastError();
+}
+
+int si_hip_copy_channels_f32(const float* in, size_t pixels, int c, int in_ld, float* out, int out_ld,
+                             si_stream_t stream) {
+    if (!in || !out || c <= 0) return SI_E_BADARG;
+    if (pixels == 0) return 0;
+    const bool vec = (c % 4 == 0) && (in_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(in) && aligned16(out);
+    if (vec)
+        hipLaunchKernelGGL(copy_channels_kernel<true>, dim3(si_grid_for(pixels * (c / 4))), dim3(256), 0,
+                           (hipStream_t)stream, in, pixels, c, in_ld, out, out_ld);
+    else
+        hipLaunchKernelGGL(copy_channels_kernel<false>, dim3(si_grid_for(pixels * c)), dim3(256), 0,
+                           (hipStream_t)stream, in, pixels, c, in_ld, out, out_ld);
+    return (int)hipGetLastError();
+}
+
+int si_hip_cat_axis_f32(const float* in, const int in_shape[4], float* out, const int out_shape[4], int axis,
+                        int offset, si_stream_t stream) {
+    if (!in || !out || axis < 0 || axis > 3) return SI_E_BADARG;
+    Shape4 s, o;
+    size_t total = 1;
+    for (int i = 0; i < 4; ++i) {
+        s.d[i] = in_shape[i]; o.d[i] = out_shape[i];
+        total *= (size_t)s.d[i];
+    }
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(cat_axis_kernel, dim3(si_grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, s, out, o, axis,
+                       offset);
+    return (int)hipGetLastError();
+}
+
+int si_hip_nhwc_to_nchw_f32(const float* in, int n, int h, int w, int c, int in_ld, float* out, si_stream_t stream) {
+    if (!in || !out) return SI_E_BADARG;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(si_grid_for((size_t)n * h * w * c)), dim3(256), 0, (hipStream_t)stream,
+                       in, n, h, w, c, in_ld, out);
+    return (int)hipGetLastError();
+}
+
+int si_hip_linear_f32(const float* x, int n, int in_features, const float* w, const float* bias, int out_features,
+                      float* y, si_stream_t stream) {
+    if (!x || !w || !y || n <= 0 || in_features <= 0 || out_features <= 0) return SI_E_BADARG;
+    const size_t waves = (size_t)n * out_features;
+    hipLaunchKernelGGL(linear_kernel, dim3(si_grid_for(waves * 64)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       in_features, w, bias, out_features, y);
+    return (int)hipGetLastError();
+}
+
+int si_hip_yolo_decode_f32(const float* conv, int n, int h, int w, int na, int ne, const float* grid_hwa2,
+                           const float* anchor_hwa2, float stride, float* out, int rows_total, int row_off,
+                           si_stream_t stream) {
+    if (!conv || !grid_hwa2 || !anchor_hwa2 || !out || ne < 4) return SI_E_BADARG;
+    const size_t rows = (size_t)h * w * na;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(si_grid_for((size_t)n * rows * ne)), dim3(256), 0, (hipStream_t)stream,
+                       conv, n, rows, ne, grid_hwa2, anchor_hwa2, stride, out, rows_total, row_off);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

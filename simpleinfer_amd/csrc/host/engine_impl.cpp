@@ -1,0 +1,651 @@
+#include "engine_impl.h"
+
+#include <algorithm>
+
+#include "layer/activation.h"
+#include "layer/binary_op.h"
+#include "layer/cat.h"
+#include "layer/conv_2d.h"
+#include "layer_registry.h"
+#include "logger.h"
+#include "pnnx/expand_expression.h"
+
+namespace SimpleInfer {
+
+namespace {
+
+// built-in operator types whose kernels honour a pixel stride on inputs and outputs
+bool HonoursPixelStride(const std::string& type) {
+    static const std::set<std::string> ok = {
+        "nn.Conv2d", "nn.SiLU", "nn.ReLU", "nn.Sigmoid", "nn.Hardsigmoid", "nn.Hardswish", "nn.LeakyReLU",
+        "nn.MaxPool2d", "nn.AdaptiveAvgPool2d", "nn.Upsample", "torch.cat", "BinaryOp", "nn.BatchNorm2d",
+        "torch.flatten", "models.yolo.Detect", "pnnx.Output"};
+    return ok.count(type) > 0;
+}
+
+#define SI_TRY_HIP(expr, what)                                             \
+    {                                                                      \
+        const int _rc = (expr);                                            \
+        if (_rc != 0) {                                                    \
+            LOG(ERROR) << what << ": " << si_hip_error_string(_rc);        \
+            return Status::kFail;                                          \
+        }                                                                  \
+    }
+
+}  // namespace
+
+EngineImpl::EngineImpl() {}
+
+EngineImpl::~EngineImpl() { Release(); }
+
+Status EngineImpl::SetOption(const std::string& key, int value) {
+    if (key == "device") opt_device_ = value;
+    else if (key == "fuse") opt_fuse_ = value != 0;
+    else if (key == "alias_cat") opt_alias_cat_ = value != 0;
+    else if (key == "graph") opt_graph_ = value != 0;
+    else if (key == "outputs_to_host") opt_outputs_to_host_ = value != 0;
+    else {
+        LOG(ERROR) << "unknown engine option [" << key << "]";
+        return Status::kUnsupport;
+    }
+    return Status::kSuccess;
+}
+
+Status EngineImpl::LoadModel(const std::string& parampath, const std::string& binpath) {
+    struct Stage {
+        const char* name;
+        Status (EngineImpl::*fn)();
+    };
+    {
+        Status ret = Release();
+        if (Status::kSuccess != ret) {
+            LOG(ERROR) << "Release fail";
+            return ret;
+        }
+    }
+    {
+        Status ret = CreateContext();
+        if (Status::kSuccess != ret) {
+            LOG(ERROR) << "CreateContext fail";
+            Release();
+            return ret;
+        }
+    }
+    {
+        Status ret = CreateGraph(parampath, binpath);
+        if (Status::kSuccess != ret) {
+            LOG(ERROR) << "CreateGraph fail";
+            Release();
+            return ret;
+        }
+    }
+    const Stage stages[] = {{"CreateTensorNodes", &EngineImpl::CreateTensorNodes},
+                            {"CreateLayers", &EngineImpl::CreateLayers},
+                            {"CreatePipeline", &EngineImpl::CreatePipeline},
+                            {"AllocateTensorMemory", &EngineImpl::AllocateTensorMemory}};
+    for (const Stage& s : stages) {
+        Status ret = (this->*s.fn)();
+        if (Status::kSuccess != ret) {
+            LOG(ERROR) << s.name << " fail";
+            Release();
+            return ret;
+        }
+    }
+    return Status::kSuccess;
+}
+
+Status EngineImpl::Release() {
+    if (context_ && context_->stream()) si_hip_stream_sync(context_->stream());
+    CHECK_STATUS(DeallocateTensorMemory());
+    CHECK_STATUS(DestroyPipeline());
+    CHECK_STATUS(DestroyLayers());
+    CHECK_STATUS(DestroyTensorNodes());
+    CHECK_STATUS(DestroyGraph());
+    CHECK_STATUS(DestroyContext());
+    return Status::kSuccess;
+}
+
+Status EngineImpl::CreateContext() {
+    context_ = new Context;
+    CHECK_STATUS(context_->Init(opt_device_));
+    SI_TRY_HIP(si_hip_event_create(&ev_start_), "event create");
+    SI_TRY_HIP(si_hip_event_create(&ev_stop_), "event create");
+    return Status::kSuccess;
+}
+
+Status EngineImpl::DestroyContext() {
+    if (ev_start_) si_hip_event_destroy(ev_start_);
+    if (ev_stop_) si_hip_event_destroy(ev_stop_);
+    ev_start_ = ev_stop_ = nullptr;
+    delete context_;
+    context_ = nullptr;
+    return Status::kSuccess;
+}
+
+Status EngineImpl::CreateGraph(const std::string& parampath, const std::string& binpath) {
+    graph_ = new pnnx::Graph;
+    if (0 != graph_->load(parampath, binpath)) {
+        LOG(ERROR) << "load graph fail";
+        return Status::kFail;
+    }
+    pnnx::expand_expression(*graph_);
+    return Status::kSuccess;
+}
+
+Status EngineImpl::DestroyGraph() {
+    delete graph_;
+    graph_ = nullptr;
+    return Status::kSuccess;
+}
+
+Status EngineImpl::CreateTensorNodes() {
+    for (pnnx::Operand* opd : graph_->operands) {
+        if (tensor_nodes_.count(opd->name) > 0) {
+            LOG(ERROR) << "tensor node [" << opd->name << "] already exists";
+            return Status::kFail;
+        }
+        TensorNode* node = new TensorNode;
+        node->operand = opd;
+
+        // file shapes are NCHW; tensors are NHWC: the last three dims C,H,W -> H,W,C for rank >= 4
+        std::vector<int> shape = opd->shape;
+        const int rank = (int)shape.size();
+        if (rank > 3) {
+            shape[rank - 3] = opd->shape[rank - 2];
+            shape[rank - 2] = opd->shape[rank - 1];
+            shape[rank - 1] = opd->shape[rank - 3];
+        }
+        node->tensor = Tensor(PnnxToDataType(opd->type), shape, MemoryType::kDevice, false);
+        tensor_nodes_[opd->name] = node;
+
+        // graph inputs: produced by an operator with no inputs (pnnx.Input)
+        if (opd->producer && opd->producer->inputs.empty()) input_tensor_nodes_[opd->name] = node;
+        // graph outputs: consumed by an operator with no outputs (pnnx.Output)
+        for (pnnx::Operator* c : opd->consumers)
+            if (c && c->outputs.empty()) {
+                output_tensor_nodes_[opd->name] = node;
+                break;
+            }
+    }
+    return Status::kSuccess;
+}
+
+Status EngineImpl::DestroyTensorNodes() {
+    input_tensor_nodes_.clear();
+    output_tensor_nodes_.clear();
+    user_inputs_.clear();
+    for (auto& kv : tensor_nodes_) delete kv.second;
+    tensor_nodes_.clear();
+    return Status::kSuccess;
+}
+
+Status EngineImpl::CreateLayers() {
+    for (pnnx::Operator* op : graph_->ops) {
+        if ("pnnx.Input" == op->type || "pnnx.Output" == op->type) continue;
+        if (layers_.count(op->name) > 0) {
+            LOG(ERROR) << "layer [" << op->name << "] already exists";
+            return Status::kFail;
+        }
+        const LayerRegistryEntry* entry = GetLayerRegistry(op->type);
+        if (nullptr == entry) {
+            LOG(ERROR) << "layer type [" << op->type << "] not registered";
+            return Status::kEmpty;
+        }
+        Layer* layer = entry->creator();
+        if (nullptr == layer) {
+            LOG(ERROR) << "create layer [" << op->type << "] fail";
+            return Status::kFail;
+        }
+        layers_[op->name] = layer;  // registered first so a failing Init is still destroyed
+
+        Status ret = layer->Init(op);
+        if (Status::kSuccess != ret) {
+            LOG(ERROR) << "layer [" << op->name << "] init fail";
+            return ret;
+        }
+        layer->SetContext(context_);
+
+        std::vector<TensorNode*> ins, outs;
+        for (pnnx::Operand* r : op->inputs) {
+            auto it = tensor_nodes_.find(r->name);
+            if (it == tensor_nodes_.end()) {
+                LOG(ERROR) << "tensor node [" << r->name << "] not exist";
+                return Status::kEmpty;
+            }
+            ins.push_back(it->second);
+        }
+        for (pnnx::Operand* r : op->outputs) {
+            auto it = tensor_nodes_.find(r->name);
+            if (it == tensor_nodes_.end()) {
+                LOG(ERROR) << "tensor node [" << r->name << "] not exist";
+                return Status::kEmpty;
+            }
+            outs.push_back(it->second);
+        }
+        layer->SetInputNodes(ins);
+        layer->SetOutputNodes(outs);
+
+        ret = layer->Validate();
+        if (Status::kSuccess != ret) {
+            LOG(ERROR) << "layer [" << op->name << "] validate fail";
+            return ret;
+        }
+    }
+    return Status::kSuccess;
+}
+
+Status EngineImpl::DestroyLayers() {
+    for (auto& kv : layers_) {
+        Layer* layer = kv.second;
+        const pnnx::Operator* op = layer->GetOp();
+        Status ret = layer->Deinit();
+        if (Status::kSuccess != ret) LOG(ERROR) << "layer [" << kv.first << "] deinit fail";
+        const LayerRegistryEntry* entry = op ? GetLayerRegistry(op->type) : nullptr;
+        if (entry) {
+            entry->destroyer(layer);
+        } else {
+            delete layer;
+        }
+    }
+    layers_.clear();
+    return Status::kSuccess;
+}
+
+// ---- schedule ------------------------------------------------------------------------------------
+Status EngineImpl::CreatePipeline() {
+    // Kahn topological order over layer operators, stable w.r.t. file order (pnnx writes operators
+    // in execution order, and expression lowering inserts before the expression op)
+    std::vector<Step> order;
+    std::set<const pnnx::Operand*> ready;
+    for (auto& kv : input_tensor_nodes_) ready.insert(kv.second->operand);
+    std::vector<const pnnx::Operator*> pending;
+    for (pnnx::Operator* op : graph_->ops)
+        if (layers_.count(op->name)) pending.push_back(op);
+    while (!pending.empty()) {
+        bool progressed = false;
+        for (auto it = pending.begin(); it != pending.end();) {
+            const pnnx::Operator* op = *it;
+            bool ok = true;
+            for (pnnx::Operand* r : op->inputs) ok = ok && ready.count(r) > 0;
+            if (!ok) {
+                ++it;
+                continue;
+            }
+            Step s;
+            s.layer = layers_[op->name];
+            s.op = op;
+            order.push_back(s);
+            for (pnnx::Operand* r : op->outputs) ready.insert(r);
+            it = pending.erase(it);
+            progressed = true;
+        }
+        if (!progressed) {
+            LOG(ERROR) << "graph has a cycle or an operand without producer near [" << pending.front()->name << "]";
+            return Status::kFail;
+        }
+    }
+
+    if (opt_fuse_) CHECK_STATUS(FuseEpilogues(order));
+    plan_ = order;
+    if (opt_alias_cat_) CHECK_STATUS(AliasConcats());
+    return Status::kSuccess;
+}
+
+Status EngineImpl::DestroyPipeline() {
+    if (graph_exec_) si_hip_graph_destroy(graph_exec_);
+    graph_exec_ = nullptr;
+    forward_count_ = 0;
+    captured_input_ptrs_.clear();
+    plan_.clear();
+    fused_ops_.clear();
+    dead_operands_.clear();
+    aliases_.clear();
+    return Status::kSuccess;
+}
+
+// conv -> [act] -> [add residual -> [act]]  ==>  one conv launch.  The fused conv runs at the slot of
+// the LAST operator of the chain, so a residual produced between the conv and the add is ready.
+Status EngineImpl::FuseEpilogues(std::vector<Step>& order) {
+    std::map<const pnnx::Operator*, size_t> index;
+    for (size_t i = 0; i < order.size(); ++i) index[order[i].op] = i;
+    std::vector<bool> removed(order.size(), false);
+
+    auto sole_consumer = [&](const pnnx::Operand* r) -> const pnnx::Operator* {
+        if (output_tensor_nodes_.count(r->name)) return nullptr;
+        if (r->consumers.size() != 1) return nullptr;
+        const pnnx::Operator* c = r->consumers[0];
+        if (!index.count(c) || removed[index[c]]) return nullptr;  // not a layer, or already absorbed
+        return c;
+    };
+
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (removed[i]) continue;
+        Conv2d* conv = dynamic_cast<Conv2d*>(order[i].layer);
+        if (!conv || order[i].op->type != "nn.Conv2d" || order[i].op->outputs.size() != 1) continue;
+
+        const pnnx::Operand* cur = order[i].op->outputs[0];
+        size_t last = i;
+        int act1 = SI_ACT_NONE, act2 = SI_ACT_NONE;
+        float act_param = 0.f;
+        TensorNode* residual = nullptr;
+        std::vector<const pnnx::Operator*> absorbed;
+        std::vector<const pnnx::Operand*> dead;
+
+        auto try_act = [&](int& slot) {
+            const pnnx::Operator* c = sole_consumer(cur);
+            if (!c) return;
+            ActivationLayer* a = dynamic_cast<ActivationLayer*>(order[index[c]].layer);
+            if (!a || c->inputs.size() != 1 || c->outputs.size() != 1) return;
+            if (slot != SI_ACT_NONE) return;
+            if (a->ActCode() == SI_ACT_LEAKYRELU && (act1 == SI_ACT_LEAKYRELU) && act_param != a->ActParam()) return;
+            slot = a->ActCode();
+            if (a->ActCode() == SI_ACT_LEAKYRELU) act_param = a->ActParam();
+            absorbed.push_back(c);
+            dead.push_back(cur);
+            cur = c->outputs[0];
+            last = index[c];
+        };
+
+        try_act(act1);
+        {
+            const pnnx::Operator* c = sole_consumer(cur);
+            BinaryOp* b = c ? dynamic_cast<BinaryOp*>(order[index[c]].layer) : nullptr;
+            if (b && b->binary_op_type_ == BinaryOp::BinaryOpType::kAdd && c->inputs.size() == 2 && c->outputs.size() == 1 &&
+                c->inputs[0] != c->inputs[1]) {
+                const pnnx::Operand* other = c->inputs[0] == cur ? c->inputs[1] : c->inputs[0];
+                const std::vector<int>& so = tensor_nodes_[c->outputs[0]->name]->tensor.Shape();
+                const bool same = IsSameShape(tensor_nodes_[other->name]->tensor.Shape(), so) &&
+                                  IsSameShape(tensor_nodes_[cur->name]->tensor.Shape(), so);
+                if (same) {
+                    residual = tensor_nodes_[other->name];
+                    absorbed.push_back(c);
+                    dead.push_back(cur);
+                    cur = c->outputs[0];
+                    last = index[c];
+                    try_act(act2);
+                }
+            }
+        }
+        if (absorbed.empty()) continue;
+
+        conv->SetFusion(act1, residual, act2, act_param);
+        conv->SetOutputNodes({tensor_nodes_[cur->name]});
+        for (const pnnx::Operator* c : absorbed) {
+            removed[index[c]] = true;
+            fused_ops_.insert(c->name);
+        }
+        for (const pnnx::Operand* r : dead) dead_operands_.insert(r->name);
+        if (last != i) {
+            order[last] = order[i];
+            removed[last] = false;
+            removed[i] = true;
+        }
+    }
+
+    std::vector<Step> out;
+    for (size_t i = 0; i < order.size(); ++i)
+        if (!removed[i]) out.push_back(order[i]);
+    order.swap(out);
+    return Status::kSuccess;
+}
+
+// torch.cat on the channel axis: every eligible input operand becomes a view into the concat output
+// (same pixel grid, pixel stride = total channels), so its producer writes in place and Cat::Forward
+// finds nothing left to copy.
+Status EngineImpl::AliasConcats() {
+    for (const Step& s : plan_) {
+        Cat* cat = dynamic_cast<Cat*>(s.layer);
+        if (!cat || s.op->type != "torch.cat" || cat->NhwcAxis() != 3 || s.op->outputs.size() != 1) continue;
+        TensorNode* out = tensor_nodes_[s.op->outputs[0]->name];
+        if (out->tensor.Shape().size() != 4) continue;
+        int offset = 0;
+        std::set<const pnnx::Operand*> seen;
+        for (const pnnx::Operand* r : s.op->inputs) {
+            const std::vector<int>& rs = tensor_nodes_[r->name]->tensor.Shape();
+            const int c = rs.empty() ? 0 : rs.back();
+            bool ok = rs.size() == 4 && !seen.count(r) && !aliases_.count(r->name) &&
+                      !input_tensor_nodes_.count(r->name) && !output_tensor_nodes_.count(r->name) && r->producer &&
+                      r->producer->type != "torch.cat" && HonoursPixelStride(r->producer->type) &&
+                      (offset % 4 == 0);
+            for (const pnnx::Operator* c2 : r->consumers) ok = ok && c2 && HonoursPixelStride(c2->type);
+            // flatten writes dense NCHW and Detect writes rank-3 rows: they never feed a rank-4 cat
+            if (ok && (r->producer->type == "torch.flatten" || r->producer->type == "models.yolo.Detect")) ok = false;
+            seen.insert(r);
+            if (ok) {
+                Alias a;
+                a.parent = out;
+                a.channel_offset = offset;
+                aliases_[r->name] = a;
+            }
+            offset += c;
+        }
+    }
+    return Status::kSuccess;
+}
+
+// ---- memory --------------------------------------------------------------------------------------
+Status EngineImpl::AllocateTensorMemory() {
+    // 1. every live operand that is not an alias and not a graph input gets its own HBM buffer
+    for (auto& kv : tensor_nodes_) {
+        const std::string& name = kv.first;
+        Tensor& t = kv.second->tensor;
+        if (dead_operands_.count(name) || aliases_.count(name)) continue;
+        const size_t bytes = t.ByteSize();
+        if (bytes == 0) {
+            LOG(ERROR) << "operand [" << name << "] has no static shape";
+            return Status::kErrorShape;
+        }
+        void* p = nullptr;
+        SI_TRY_HIP(si_hip_malloc(&p, bytes), "hipMalloc operand");
+        device_allocs_.push_back(p);
+        if (input_tensor_nodes_.count(name)) {
+            input_buffers_[name] = p;  // staging for host inputs
+        }
+        t.SetView(p, MemoryType::kDevice, 0);
+    }
+    // 2. aliases point into their concat buffer
+    for (auto& kv : aliases_) {
+        Tensor& t = tensor_nodes_[kv.first]->tensor;
+        Tensor& parent = kv.second.parent->tensor;
+        t.SetView(parent.Data<float>() + kv.second.channel_offset, MemoryType::kDevice, parent.Shape().back());
+    }
+    // 3. pinned host mirrors for outputs
+    if (opt_outputs_to_host_) {
+        for (auto& kv : output_tensor_nodes_) {
+            void* h = nullptr;
+            SI_TRY_HIP(si_hip_host_alloc(&h, kv.second->tensor.ByteSize()), "hipHostMalloc output");
+            host_outputs_[kv.first] = h;
+        }
+    }
+    return Status::kSuccess;
+}
+
+Status EngineImpl::DeallocateTensorMemory() {
+    for (void* p : device_allocs_) si_hip_free(p);
+    device_allocs_.clear();
+    input_buffers_.clear();
+    for (auto& kv : host_outputs_) si_hip_host_free(kv.second);
+    host_outputs_.clear();
+    for (auto& kv : tensor_nodes_) kv.second->tensor.SetView(nullptr, MemoryType::kDevice, 0);
+    return Status::kSuccess;
+}
+
+// ---- I/O -----------------------------------------------------------------------------------------
+const std::vector<std::string> EngineImpl::InputNames() {
+    std::vector<std::string> ret;
+    for (auto& kv : input_tensor_nodes_) ret.push_back(kv.first);
+    return ret;
+}
+
+const std::vector<std::string> EngineImpl::OutputNames() {
+    std::vector<std::string> ret;
+    for (auto& kv : output_tensor_nodes_) ret.push_back(kv.first);
+    return ret;
+}
+
+Status EngineImpl::OperandShape(const std::string& name, std::vector<int>& shape) {
+    auto it = tensor_nodes_.find(name);
+    if (it == tensor_nodes_.end()) return Status::kFail;
+    shape = it->second->tensor.Shape();
+    return Status::kSuccess;
+}
+
+Status EngineImpl::Input(const std::string& name, const Tensor& input) {
+    auto it = input_tensor_nodes_.find(name);
+    if (it == input_tensor_nodes_.end()) {
+        LOG(ERROR) << "tensor [" << name << "] is not an input tensor";
+        return Status::kFail;
+    }
+    if (input.NumElements() != it->second->tensor.NumElements() || input.GetDataType() != it->second->tensor.GetDataType()) {
+        LOG(ERROR) << "tensor [" << name << "] does not match the model's input shape / type";
+        return Status::kErrorShape;
+    }
+    user_inputs_[name] = input;  // alias: the caller keeps ownership (reference engine_impl.cpp:528)
+    return Status::kSuccess;
+}
+
+Status EngineImpl::UploadInputs() {
+    for (auto& kv : input_tensor_nodes_) {
+        auto u = user_inputs_.find(kv.first);
+        if (u == user_inputs_.end() || nullptr == u->second.RawData()) {
+            LOG(ERROR) << "input [" << kv.first << "] was not provided";
+            return Status::kEmpty;
+        }
+        Tensor& node_tensor = kv.second->tensor;
+        if (u->second.GetMemoryType() == MemoryType::kDevice) {
+            // device-resident input: read it in place
+            node_tensor.SetView(u->second.RawData(), MemoryType::kDevice, u->second.PixelStride());
+        } else {
+            void* buf = input_buffers_[kv.first];
+            node_tensor.SetView(buf, MemoryType::kDevice, 0);
+            SI_TRY_HIP(si_hip_memcpy_h2d(buf, u->second.RawData(), node_tensor.ByteSize(), context_->stream()), "input h2d");
+        }
+    }
+    return Status::kSuccess;
+}
+
+Status EngineImpl::LaunchAll() {
+    for (const Step& s : plan_) {
+        Status ret = s.layer->Forward();
+        if (Status::kSuccess != ret) {
+            LOG(ERROR) << "layer [" << s.op->name << "] forward fail";
+            return ret;
+        }
+    }
+    return Status::kSuccess;
+}
+
+Status EngineImpl::Forward() {
+    if (nullptr == context_ || plan_.empty()) {
+        LOG(ERROR) << "Forward before a successful LoadModel";
+        return Status::kFail;
+    }
+    si_hip_set_device(context_->device());
+    si_stream_t stream = context_->stream();
+    CHECK_STATUS(UploadInputs());
+
+    // a captured graph bakes pointers in: re-capture when a device-resident input moved
+    if (graph_exec_) {
+        for (auto& kv : input_tensor_nodes_)
+            if (captured_input_ptrs_[kv.first] != kv.second->tensor.RawData()) {
+                si_hip_graph_destroy(graph_exec_);
+                graph_exec_ = nullptr;
+                break;
+            }
+    }
+
+    SI_TRY_HIP(si_hip_event_record(ev_start_, stream), "event record");
+    if (opt_graph_ && forward_count_ > 0) {
+        if (!graph_exec_) {
+            SI_TRY_HIP(si_hip_graph_begin_capture(stream), "begin capture");
+            Status ret = LaunchAll();
+            si_graph_t exec = nullptr;
+            const int rc = si_hip_graph_end_capture(stream, &exec);
+            CHECK_STATUS(ret);
+            SI_TRY_HIP(rc, "end capture");
+            graph_exec_ = exec;
+            for (auto& kv : input_tensor_nodes_) captured_input_ptrs_[kv.first] = kv.second->tensor.RawData();
+        }
+        SI_TRY_HIP(si_hip_graph_launch(graph_exec_, stream), "graph launch");
+    } else {
+        // first call is always eager: it uploads weights and sizes scratch buffers
+        CHECK_STATUS(LaunchAll());
+    }
+    SI_TRY_HIP(si_hip_event_record(ev_stop_, stream), "event record");
+
+    if (opt_outputs_to_host_) {
+        for (auto& kv : output_tensor_nodes_) {
+            const Tensor& t = kv.second->tensor;
+            SI_TRY_HIP(si_hip_memcpy_d2h(host_outputs_[kv.first], t.RawData(), t.ByteSize(), stream), "output d2h");
+        }
+    }
+    // Forward() is synchronous by contract (reference engine_impl.cpp:533-544)
+    SI_TRY_HIP(si_hip_stream_sync(stream), "stream sync");
+    si_hip_event_elapsed_ms(ev_start_, ev_stop_, &last_forward_ms_);
+    ++forward_count_;
+    return Status::kSuccess;
+}
+
+Status EngineImpl::Extract(const std::string& name, Tensor& output) {
+    auto it = output_tensor_nodes_.find(name);
+    if (it == output_tensor_nodes_.end()) {
+        LOG(ERROR) << "tensor [" << name << "] is not an output tensor";
+        return Status::kFail;
+    }
+    const Tensor& t = it->second->tensor;
+    if (opt_outputs_to_host_) {
+        output = Tensor(t.GetDataType(), t.Shape(), MemoryType::kHost, false);
+        output.SetData(host_outputs_[name], MemoryType::kHost);
+    } else {
+        output = t;  // non-owning device view
+    }
+    return Status::kSuccess;
+}
+
+Status EngineImpl::Profile(std::vector<LayerProfile>& layers) {
+    layers.clear();
+    if (nullptr == context_ || plan_.empty()) return Status::kFail;
+    si_stream_t stream = context_->stream();
+    CHECK_STATUS(UploadInputs());
+    std::vector<si_event_t> ev(plan_.size() + 1, nullptr);
+    for (auto& e : ev) SI_TRY_HIP(si_hip_event_create(&e), "event create");
+    Status ret = Status::kSuccess;
+    si_hip_event_record(ev[0], stream);
+    for (size_t i = 0; i < plan_.size() && ret == Status::kSuccess; ++i) {
+        ret = plan_[i].layer->Forward();
+        si_hip_event_record(ev[i + 1], stream);
+    }
+    si_hip_stream_sync(stream);
+    if (ret == Status::kSuccess) {
+        for (size_t i = 0; i < plan_.size(); ++i) {
+            LayerProfile p;
+            p.name = plan_[i].op->name;
+            p.type = plan_[i].op->type;
+            p.kernel = plan_[i].layer->KernelName();
+            si_hip_event_elapsed_ms(ev[i], ev[i + 1], &p.ms);
+            p.flops = plan_[i].layer->Flops();
+            p.bytes = plan_[i].layer->Bytes();
+            layers.push_back(p);
+        }
+    }
+    for (auto& e : ev) si_hip_event_destroy(e);
+    return ret;
+}
+
+void* EngineImpl::Stream() { return context_ ? context_->stream() : nullptr; }
+
+std::vector<std::string> EngineImpl::ScheduledOps() const {
+    std::vector<std::string> out;
+    for (const Step& s : plan_) out.push_back(s.op->name);
+    return out;
+}
+
+std::vector<std::string> EngineImpl::FusedOps() const { return std::vector<std::string>(fused_ops_.begin(), fused_ops_.end()); }
+
+std::vector<std::string> EngineImpl::AliasedOperands() const {
+    std::vector<std::string> out;
+    for (auto& kv : aliases_) out.push_back(kv.first);
+    return out;
+}
+
+}  // namespace SimpleInfer

@@ -1,0 +1,127 @@
+// engine_impl.h -- the runtime behind SimpleInfer::Engine.
+//
+// LoadModel keeps the reference's stages (src/engine_impl.cpp:16-75): context -> graph (+ expression
+// lowering) -> tensor nodes (NCHW file shapes become NHWC, :182-189) -> layers through the registry
+// (:232-310) -> schedule -> memory.  What changes is everything below the Layer interface:
+//   * the CGraph thread-pool pipeline (:336-437) becomes a topologically ordered launch list on one
+//     HIP stream, optionally captured once and replayed as a hipGraph;
+//   * per-operand malloc (:465-482) becomes HBM buffers, with torch.cat inputs aliased into the
+//     concat buffer (producers write their channel slice in place);
+//   * conv -> activation -> residual-add -> activation chains are folded into the conv kernel's
+//     epilogue, so those layers launch nothing.
+#ifndef SIMPLE_INFER_SRC_ENGINE_IMPL_H_
+#define SIMPLE_INFER_SRC_ENGINE_IMPL_H_
+
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "context.h"
+#include "engine.h"
+#include "layer.h"
+#include "pnnx/pnnx_helper.h"
+#include "tensor.h"
+#include "tensor_node.h"
+#include "types.h"
+
+namespace SimpleInfer {
+
+class EngineImpl {
+public:
+    EngineImpl();
+    ~EngineImpl();
+
+public:
+    Status LoadModel(const std::string& parampath, const std::string& binpath);
+    Status Release();
+
+    Status CreateContext();
+    Status DestroyContext();
+
+    Status CreateGraph(const std::string& parampath, const std::string& binpath);
+    Status DestroyGraph();
+
+    Status CreateTensorNodes();
+    Status DestroyTensorNodes();
+
+    Status CreateLayers();
+    Status DestroyLayers();
+
+    Status CreatePipeline();   // schedule + fusion + concat aliasing
+    Status DestroyPipeline();
+
+    Status AllocateTensorMemory();
+    Status DeallocateTensorMemory();
+
+public:
+    const std::vector<std::string> InputNames();
+    const std::vector<std::string> OutputNames();
+
+    Status Input(const std::string& name, const Tensor& input);
+    Status Forward();
+    Status Extract(const std::string& name, Tensor& output);
+
+    Status SetOption(const std::string& key, int value);
+    Status OperandShape(const std::string& name, std::vector<int>& shape);
+    Status Profile(std::vector<LayerProfile>& layers);
+    void* Stream();
+    float LastForwardMs() const { return last_forward_ms_; }
+
+    // schedule introspection (tests): operator names in launch order, and the fused-away ones
+    std::vector<std::string> ScheduledOps() const;
+    std::vector<std::string> FusedOps() const;
+    std::vector<std::string> AliasedOperands() const;
+
+private:
+    struct Step {
+        Layer* layer = nullptr;
+        const pnnx::Operator* op = nullptr;
+    };
+
+    Status FuseEpilogues(std::vector<Step>& order);
+    Status AliasConcats();
+    Status UploadInputs();
+    Status LaunchAll();
+
+private:
+    // options
+    int opt_device_ = -1;
+    bool opt_fuse_ = true;
+    bool opt_alias_cat_ = true;
+    bool opt_graph_ = false;
+    bool opt_outputs_to_host_ = true;
+
+    Context* context_ = nullptr;
+    pnnx::Graph* graph_ = nullptr;
+
+    std::map<std::string, Layer*> layers_;
+    std::map<std::string, TensorNode*> tensor_nodes_;
+    std::map<std::string, TensorNode*> input_tensor_nodes_;
+    std::map<std::string, TensorNode*> output_tensor_nodes_;
+
+    std::vector<Step> plan_;
+    std::set<std::string> fused_ops_;        // operator names folded into a conv epilogue
+    std::set<std::string> dead_operands_;    // operands that no longer exist after fusion
+    struct Alias {
+        TensorNode* parent = nullptr;
+        int channel_offset = 0;
+    };
+    std::map<std::string, Alias> aliases_;   // operand name -> slice of a concat buffer
+
+    std::vector<void*> device_allocs_;
+    std::map<std::string, Tensor> user_inputs_;     // what Input() bound (host or device alias)
+    std::map<std::string, void*> input_buffers_;    // engine-owned device staging per input
+    std::map<std::string, void*> host_outputs_;     // pinned mirrors per output
+
+    si_graph_t graph_exec_ = nullptr;
+    int forward_count_ = 0;
+    std::map<std::string, void*> captured_input_ptrs_;
+
+    si_event_t ev_start_ = nullptr, ev_stop_ = nullptr;
+    float last_forward_ms_ = 0.f;
+};
+
+}  // namespace SimpleInfer
+
+#endif

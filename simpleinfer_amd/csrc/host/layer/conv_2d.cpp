@@ -1,0 +1,198 @@
+#include "conv_2d.h"
+
+#include <cstring>
+
+#include "layer_util.h"
+
+namespace SimpleInfer {
+
+DEFINE_LAYER_REGISTRY(Conv2d);
+
+Conv2d::Conv2d() {}
+
+Conv2d::~Conv2d() {}
+
+Status Conv2d::Init(const pnnx::Operator* op) {
+    CHECK_STATUS(Layer::Init(op));
+    return Init(op->params, op->attrs);
+}
+
+// keys and their pnnx types: reference src/layer/conv_2d.cpp:27-70 (a missing key is kFail)
+Status Conv2d::Init(const std::map<std::string, pnnx::Parameter>& params,
+                    const std::map<std::string, pnnx::Attribute>& attrs) {
+    CHECK_BOOL(CheckParam(params, "padding_mode", 4));
+    const std::string& mode = params.at("padding_mode").s;
+    if (mode == "zeros") {
+        padding_mode_ = PaddingMode::kZeros;
+    } else if (mode == "replicate") {
+        padding_mode_ = PaddingMode::kReplicate;
+    } else if (mode == "reflect") {
+        padding_mode_ = PaddingMode::kReflect;
+    } else {
+        LOG(ERROR) << "Conv2d::Init fail [unsupport padding mode " << mode << "]";
+        return Status::kUnsupport;
+    }
+
+    struct IntPair { const char* key; int* a; int* b; };
+    const IntPair pairs[] = {{"padding", &padding_t_, &padding_l_},
+                             {"kernel_size", &kernel_h_, &kernel_w_},
+                             {"stride", &stride_h_, &stride_w_},
+                             {"dilation", &dilation_h_, &dilation_w_}};
+    for (const IntPair& p : pairs) {
+        CHECK_BOOL(CheckParam(params, p.key, 5));
+        const std::vector<int>& v = params.at(p.key).ai;
+        CHECK_BOOL(2 == v.size());
+        *p.a = v[0];
+        *p.b = v[1];
+    }
+    padding_b_ = padding_t_;
+    padding_r_ = padding_l_;
+
+    CHECK_BOOL(CheckParam(params, "groups", 2));
+    groups_ = params.at("groups").i;
+    CHECK_BOOL(CheckParam(params, "in_channels", 2));
+    in_channels_ = params.at("in_channels").i;
+    CHECK_BOOL(CheckParam(params, "out_channels", 2));
+    out_channels_ = params.at("out_channels").i;
+    CHECK_BOOL(groups_ > 0);
+
+    // weights (reference InitWeightAndBias, conv_2d.cpp:120-180)
+    CHECK_BOOL(CheckAttr(attrs, "weight", 1));
+    const pnnx::Attribute& w = attrs.at("weight");
+    CHECK_BOOL(4 == w.shape.size());
+    CHECK_BOOL(w.shape[0] == out_channels_ && w.shape[2] == kernel_h_ && w.shape[3] == kernel_w_);
+    const size_t w_count = (size_t)w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3];
+    CHECK_BOOL(w.data.size() == w_count * sizeof(float));
+    weight_.resize(w_count);
+    memcpy(weight_.data(), w.data.data(), w.data.size());
+
+    CHECK_BOOL(CheckParam(params, "bias", 1));
+    use_bias_ = params.at("bias").b;
+    bias_.clear();
+    if (use_bias_) {
+        CHECK_BOOL(CheckAttr(attrs, "bias", 1));
+        const pnnx::Attribute& b = attrs.at("bias");
+        CHECK_BOOL(1 == b.shape.size() && b.shape[0] == out_channels_);
+        CHECK_BOOL(b.data.size() == (size_t)out_channels_ * sizeof(float));
+        bias_.resize(out_channels_);
+        memcpy(bias_.data(), b.data.data(), b.data.size());
+    }
+    device_ready_ = false;
+
+    if (padding_mode_ != PaddingMode::kZeros) {
+        // the reference parses replicate/reflect but every path pads with zeros (conv_2d.cpp:260)
+        LOG(WARNING) << "Conv2d: padding_mode " << mode << " computes with zero padding (as the reference does)";
+    }
+    return Status::kSuccess;
+}
+
+Status Conv2d::SetWeights(const std::vector<float>& weight_oihw, const std::vector<float>& bias) {
+    weight_ = weight_oihw;
+    bias_ = bias;
+    use_bias_ = !bias.empty();
+    device_ready_ = false;
+    return Status::kSuccess;
+}
+
+void Conv2d::SetFusion(int act1, TensorNode* residual, int act2, float act_param) {
+    act1_ = act1;
+    residual_node_ = residual;
+    act2_ = act2;
+    act_param_ = act_param;
+}
+
+Status Conv2d::Deinit() {
+    weight_dev_.Free();
+    bias_dev_.Free();
+    device_ready_ = false;
+    return Status::kSuccess;
+}
+
+Status Conv2d::Validate() {
+    CHECK_STATUS(Layer::Validate());
+    CHECK_STATUS(ValidateShape(1, 1));
+    if (Status::kSuccess != ValidateFloat32()) {
+        LOG(ERROR) << "Conv2d::Validate fail [unsupport input/output data type]";
+        return Status::kUnsupport;
+    }
+    return Status::kSuccess;
+}
+
+SiConv2dDesc Conv2d::MakeDesc(const Tensor& input, const Tensor& output) const {
+    SiConv2dDesc d;
+    memset(&d, 0, sizeof(d));
+    Dims4 in, out;
+    GetDims4(input, in);
+    GetDims4(output, out);
+    d.n = in.n; d.ih = in.h; d.iw = in.w; d.ic = in.c; d.in_ld = input.PixelStride();
+    d.oh = out.h; d.ow = out.w; d.oc = out.c; d.out_ld = output.PixelStride();
+    d.kh = kernel_h_; d.kw = kernel_w_; d.sh = stride_h_; d.sw = stride_w_;
+    d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
+    d.groups = groups_;
+    d.has_bias = use_bias_ ? 1 : 0;
+    d.act1 = act1_; d.act2 = act2_; d.act_param = act_param_;
+    return d;
+}
+
+Status Conv2d::PrepareDevice() {
+    if (device_ready_) return Status::kSuccess;
+    CHECK_BOOL(groups_ > 0 && in_channels_ > 0 && out_channels_ > 0 && kernel_h_ > 0 && kernel_w_ > 0);
+    CHECK_BOOL(in_channels_ % groups_ == 0 && out_channels_ % groups_ == 0);
+    const size_t expect = (size_t)out_channels_ * (in_channels_ / groups_) * kernel_h_ * kernel_w_;
+    if (weight_.size() != expect) {
+        LOG(ERROR) << "Conv2d: weight has " << weight_.size() << " elements, expected " << expect;
+        return Status::kErrorShape;
+    }
+    if (use_bias_ && bias_.size() != (size_t)out_channels_) return Status::kErrorShape;
+
+    SiConv2dDesc d;
+    memset(&d, 0, sizeof(d));
+    d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
+    std::vector<float> packed(si_hip_conv2d_weight_elems(&d));
+    CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&d, weight_.data(), packed.data()), "pack weight"));
+    CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(float)), "upload weight"));
+    if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_.data(), bias_.size() * sizeof(float)), "upload bias"));
+    device_ready_ = true;
+    return Status::kSuccess;
+}
+
+Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& output) {
+    CHECK_STATUS(PrepareDevice());
+    Dims4 in, out;
+    if (!GetDims4(input, in) || !GetDims4(output, out)) return Status::kErrorShape;
+    if (in.c != in_channels_ || out.c != out_channels_ || in.n != out.n) {
+        LOG(ERROR) << "Conv2d: tensor channels/batch do not match the layer";
+        return Status::kErrorShape;
+    }
+    SiConv2dDesc d = MakeDesc(input, output);
+    if (residual) {
+        d.has_residual = 1;
+        d.res_ld = residual->PixelStride();
+    }
+    return CheckHip(si_hip_conv2d_f32(&d, input.Data<float>(), weight_dev_.As<float>(),
+                                      use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                      residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream()),
+                    "conv2d");
+}
+
+Status Conv2d::Forward(const Tensor& input, Tensor& output) {
+    std::vector<const Tensor*> ins{&input};
+    if (residual_node_) ins.push_back(&residual_node_->tensor);
+    return RunOnDevice(ins, {&output}, [this](const std::vector<Tensor>& in, std::vector<Tensor>& out) {
+        return Launch(in[0], in.size() > 1 ? &in[1] : nullptr, out[0]);
+    });
+}
+
+double Conv2d::Flops() const {
+    if (output_tensor_nodes_.empty() || groups_ <= 0) return 0.0;
+    const Tensor& o = output_tensor_nodes_[0]->tensor;
+    return 2.0 * (double)o.NumElements() * kernel_h_ * kernel_w_ * (in_channels_ / groups_);
+}
+
+double Conv2d::Bytes() const {
+    double b = Layer::Bytes() + (double)weight_.size() * sizeof(float);
+    if (residual_node_) b += (double)residual_node_->tensor.ByteSize();
+    return b;
+}
+
+}  // namespace SimpleInfer

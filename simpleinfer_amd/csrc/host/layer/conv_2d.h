@@ -1,0 +1,82 @@
+// layer/conv_2d.h -- nn.Conv2d on the MI355X.  Public configuration fields keep the reference's
+// names (src/layer/conv_2d.h:39-57) so layer tests that poke them still read the same; the three
+// CPU paths (Winograd23 / im2col / grouped im2col, src/layer/conv_2d.cpp:108-118) collapse into one
+// implicit-GEMM MFMA kernel (si_hip_conv2d_f32) with bias / activation / residual in its epilogue.
+#ifndef SIMPLE_INFER_SRC_LAYER_CONV_2D_H_
+#define SIMPLE_INFER_SRC_LAYER_CONV_2D_H_
+
+#include "layer.h"
+#include "layer_util.h"
+#include "si_hip.h"
+
+namespace SimpleInfer {
+
+class Conv2d : public Layer {
+public:
+    Conv2d();
+    virtual ~Conv2d() override;
+
+public:
+    virtual Status Init(const pnnx::Operator* op) override;
+
+    virtual Status Init(const std::map<std::string, pnnx::Parameter>& params,
+                        const std::map<std::string, pnnx::Attribute>& attrs) override;
+
+    virtual Status Deinit() override;
+
+    virtual Status Validate() override;
+
+    virtual Status Forward(const Tensor& input, Tensor& output) override;
+
+    virtual const char* KernelName() const override { return "conv_igemm_f32"; }
+    virtual double Flops() const override;
+    virtual double Bytes() const override;
+
+public:
+    // OIHW weights (the pnnx attribute layout) + optional bias; re-laid out to the kernel's
+    // [oc][kh][kw][ic/g padded] order and uploaded to HBM on the next Forward
+    Status SetWeights(const std::vector<float>& weight_oihw, const std::vector<float>& bias);
+
+    // engine fusion hook: y = act2(act1(conv + bias) + residual)
+    void SetFusion(int act1, TensorNode* residual, int act2, float act_param = 0.0f);
+
+    Status PrepareDevice();
+
+public:
+    enum class PaddingMode { kZeros = 0, kReplicate, kReflect } padding_mode_ = PaddingMode::kZeros;
+    int padding_t_    = 0;
+    int padding_b_    = 0;
+    int padding_l_    = 0;
+    int padding_r_    = 0;
+    int kernel_h_     = 0;
+    int kernel_w_     = 0;
+    int stride_h_     = 1;
+    int stride_w_     = 1;
+    int dilation_h_   = 1;
+    int dilation_w_   = 1;
+    int groups_       = 1;
+    int in_channels_  = 0;
+    int out_channels_ = 0;
+
+    bool use_bias_ = false;
+    std::vector<float> weight_;  // OIHW, host copy
+    std::vector<float> bias_;
+
+    // fused epilogue
+    int act1_ = SI_ACT_NONE;
+    int act2_ = SI_ACT_NONE;
+    float act_param_ = 0.0f;
+    TensorNode* residual_node_ = nullptr;
+
+private:
+    Status Launch(const Tensor& input, const Tensor* residual, Tensor& output);
+    SiConv2dDesc MakeDesc(const Tensor& input, const Tensor& output) const;
+
+    DeviceBuffer weight_dev_;
+    DeviceBuffer bias_dev_;
+    bool device_ready_ = false;
+};
+
+}  // namespace SimpleInfer
+
+#endif

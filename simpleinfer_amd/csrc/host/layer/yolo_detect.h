@@ -1,0 +1,50 @@
+// layer/yolo_detect.h -- models.yolo.Detect (YOLOv5 head).  Attribute names, level order and the
+// [H][W][anchor] row order are the reference's (src/layer/yolo_detect.h:27-41, yolo_detect.cpp:11-165
+// Init, :204-272 Forward).  Per level: 1x1 conv on the MFMA kernel, then one decode kernel
+// that applies sigmoid, the grid/anchor transforms and the concat into [N, rows, 85] in a single
+// pass (the reference makes a sigmoid pass plus two slice passes per level).
+#ifndef SIMPLE_INFER_SRC_LAYER_YOLO_DETECT_H_
+#define SIMPLE_INFER_SRC_LAYER_YOLO_DETECT_H_
+
+#include "conv_2d.h"
+#include "layer.h"
+#include "layer_util.h"
+
+namespace SimpleInfer {
+
+class YoloDetect : public Layer {
+public:
+    virtual Status Init(const pnnx::Operator* op) override;
+    virtual void SetContext(Context* context) override;
+    virtual Status Deinit() override;
+    virtual Status Validate() override;
+    virtual Status Forward(const std::vector<Tensor>& inputs, Tensor& output) override;
+    virtual const char* KernelName() const override { return "conv_igemm_f32+yolo_decode"; }
+    virtual double Flops() const override;
+
+public:
+    static const int num_spatial_sizes = 3;
+    static constexpr int anchor_index[num_spatial_sizes]{4, 2, 0};
+    static constexpr int grid_index[num_spatial_sizes]{6, 3, 1};
+
+    Conv2d conv_2d_layer_[num_spatial_sizes];
+    Tensor spatial_output[num_spatial_sizes];  // device, [N][H][W][na*ne]
+
+    std::vector<float> anchor_grids_[num_spatial_sizes];  // [H*W*na][2]
+    std::vector<float> grids_[num_spatial_sizes];
+    int level_h_[num_spatial_sizes] = {0, 0, 0};
+    int level_w_[num_spatial_sizes] = {0, 0, 0};
+    float strides_[num_spatial_sizes] = {8.f, 16.f, 32.f};
+
+    int num_elements_           = 255;
+    int num_anchor_grid_levels_ = 3;
+    int num_classes_info_       = 85;
+
+private:
+    DeviceBuffer grids_dev_[num_spatial_sizes], anchor_grids_dev_[num_spatial_sizes];
+    bool device_ready_ = false;
+};
+
+}  // namespace SimpleInfer
+
+#endif

@@ -1,0 +1,248 @@
+"""numpy-in / numpy-out wrappers over the kernel C-ABI (include/si_hip.h).
+
+Each helper uploads its operands to HBM, launches exactly one C-ABI kernel entry point and downloads
+the result, so the parity tests exercise the same symbols a C / cgo / JNI caller would bind.  No
+computation happens in Python; without a HIP device every call raises HipError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _native
+from ._native import SiConv2dDesc, SiPool2dDesc
+
+ACT = {"none": 0, "relu": 1, "silu": 2, "sigmoid": 3, "hardsigmoid": 4, "hardswish": 5, "leakyrelu": 6}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise HipError("%s: %s (code %d)" % (what, _native.hip().si_hip_error_string(rc).decode(), rc))
+
+
+class DeviceBuffer:
+    """HBM allocation owned by Python (hipMalloc / hipFree through the C-ABI)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _chk(_native.hip().si_hip_malloc(C.byref(p), max(self.nbytes, 16)), "si_hip_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray, stream=None) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        _chk(_native.hip().si_hip_memcpy_h2d(b.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes, stream), "h2d")
+        _chk(_native.hip().si_hip_stream_sync(stream), "sync")
+        return b
+
+    def to_numpy(self, shape, dtype=np.float32, stream=None) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= max(self.nbytes, 16)
+        _chk(_native.hip().si_hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes, stream), "d2h")
+        _chk(_native.hip().si_hip_stream_sync(stream), "sync")
+        return out
+
+    def fill(self, byte: int = 0):
+        _chk(_native.hip().si_hip_memset_async(self.ptr, byte, self.nbytes, None), "memset")
+        _chk(_native.hip().si_hip_stream_sync(None), "sync")
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            _native.hip().si_hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sync():
+    _chk(_native.hip().si_hip_device_sync(), "device sync")
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i4(shape: Sequence[int]):
+    return (C.c_int * 4)(*[int(s) for s in shape])
+
+
+def pad4(shape: Sequence[int]):
+    shape = list(shape)
+    if len(shape) >= 4:
+        return [int(np.prod(shape[:len(shape) - 3]))] + shape[-3:]
+    return [1] * (4 - len(shape)) + shape
+
+
+def conv_out_hw(ih, iw, k, s, p, d):
+    oh = (ih + 2 * p[0] - ((k[0] - 1) * d[0] + 1)) // s[0] + 1
+    ow = (iw + 2 * p[1] - ((k[1] - 1) * d[1] + 1)) // s[1] + 1
+    return oh, ow
+
+
+def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, act1="none",
+           residual=None, act2="none", act_param=0.0, in_ld: Optional[int] = None, out_ld: Optional[int] = None,
+           out_c_off: int = 0):
+    """si_hip_conv2d_f32.  in_ld/out_ld > C exercise the strided (concat-slice) addressing: the input is
+    embedded in / the output is written into a wider zero-filled buffer and sliced back."""
+    H = _native.hip()
+    x, w_oihw = _f32(x), _f32(w_oihw)
+    n, ih, iw, ic = x.shape
+    oc, _, kh, kw = w_oihw.shape
+    oh, ow = conv_out_hw(ih, iw, (kh, kw), stride, padding, dilation)
+    in_ld = in_ld or ic
+    out_ld = out_ld or oc
+    d = SiConv2dDesc(n, ih, iw, ic, in_ld, oh, ow, oc, out_ld, kh, kw, stride[0], stride[1], dilation[0], dilation[1],
+                     padding[0], padding[1], groups, 1 if bias is not None else 0, ACT[act1],
+                     1 if residual is not None else 0, oc, ACT[act2], float(act_param))
+    packed = np.zeros(H.si_hip_conv2d_weight_elems(C.byref(d)), np.float32)
+    _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)),
+         "pack weight")
+    if in_ld != ic:
+        xw = np.zeros((n, ih, iw, in_ld), np.float32)
+        xw[..., :ic] = x
+        x = xw
+    dx, dw = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(packed)
+    db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
+    dr = DeviceBuffer.from_numpy(_f32(residual)) if residual is not None else None
+    dy = DeviceBuffer(n * oh * ow * out_ld * 4)
+    dy.fill(0)
+    _chk(H.si_hip_conv2d_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dr.ptr if dr else None,
+                             dy.ptr + 4 * out_c_off, None), "si_hip_conv2d_f32")
+    y = dy.to_numpy((n, oh, ow, out_ld))
+    return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
+
+
+def linear(x, w, b=None):
+    H = _native.hip()
+    x, w = _f32(x), _f32(w)
+    dx, dw = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(w)
+    db = DeviceBuffer.from_numpy(_f32(b)) if b is not None else None
+    dy = DeviceBuffer(x.shape[0] * w.shape[0] * 4)
+    _chk(H.si_hip_linear_f32(dx.ptr, x.shape[0], x.shape[1], dw.ptr, db.ptr if db else None, w.shape[0], dy.ptr, None),
+         "si_hip_linear_f32")
+    return dy.to_numpy((x.shape[0], w.shape[0]))
+
+
+def maxpool2d(x, k, s, p, d=(1, 1)):
+    H = _native.hip()
+    x = _f32(x)
+    n, ih, iw, c = x.shape
+    oh, ow = conv_out_hw(ih, iw, k, s, p, d)
+    desc = SiPool2dDesc(n, ih, iw, c, c, oh, ow, c, k[0], k[1], s[0], s[1], d[0], d[1], p[0], p[1])
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(n * oh * ow * c * 4)
+    _chk(H.si_hip_maxpool2d_f32(C.byref(desc), dx.ptr, dy.ptr, None), "si_hip_maxpool2d_f32")
+    return dy.to_numpy((n, oh, ow, c))
+
+
+def adaptive_avgpool2d(x, out_hw):
+    H = _native.hip()
+    x = _f32(x)
+    n, ih, iw, c = x.shape
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(n * out_hw[0] * out_hw[1] * c * 4)
+    _chk(H.si_hip_adaptive_avgpool2d_f32(dx.ptr, n, ih, iw, c, c, dy.ptr, out_hw[0], out_hw[1], c, None),
+         "si_hip_adaptive_avgpool2d_f32")
+    return dy.to_numpy((n, out_hw[0], out_hw[1], c))
+
+
+def upsample_nearest(x, scale_h, scale_w, out_hw=None):
+    H = _native.hip()
+    x = _f32(x)
+    n, ih, iw, c = x.shape
+    oh, ow = out_hw if out_hw else (int(ih * scale_h), int(iw * scale_w))
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(n * oh * ow * c * 4)
+    _chk(H.si_hip_upsample_nearest_f32(dx.ptr, n, ih, iw, c, c, scale_h, scale_w, dy.ptr, oh, ow, c, None),
+         "si_hip_upsample_nearest_f32")
+    return dy.to_numpy((n, oh, ow, c))
+
+
+def cat(xs, axis):
+    H = _native.hip()
+    xs = [_f32(x) for x in xs]
+    shp = list(xs[0].shape)
+    shp[axis] = sum(x.shape[axis] for x in xs)
+    dy = DeviceBuffer(int(np.prod(shp)) * 4)
+    off = 0
+    for x in xs:
+        dx = DeviceBuffer.from_numpy(x)
+        if axis == 3:
+            _chk(H.si_hip_copy_channels_f32(dx.ptr, x.size // x.shape[3], x.shape[3], x.shape[3], dy.ptr + 4 * off,
+                                            shp[3], None), "si_hip_copy_channels_f32")
+        else:
+            _chk(H.si_hip_cat_axis_f32(dx.ptr, _i4(x.shape), dy.ptr, _i4(shp), axis, off, None), "si_hip_cat_axis_f32")
+        off += x.shape[axis]
+        sync()
+    return dy.to_numpy(shp)
+
+
+def binary_op(op, a, b, out_shape=None):
+    H = _native.hip()
+    a, b = _f32(a), _f32(b)
+    a4, b4 = pad4(a.shape), pad4(b.shape)
+    o4 = pad4(out_shape) if out_shape is not None else [max(x, y) for x, y in zip(a4, b4)]
+    da, db_, dy = DeviceBuffer.from_numpy(a), DeviceBuffer.from_numpy(b), DeviceBuffer(int(np.prod(o4)) * 4)
+    _chk(H.si_hip_binary_f32(op, da.ptr, _i4(a4), a4[3], db_.ptr, _i4(b4), b4[3], dy.ptr, _i4(o4), o4[3], None),
+         "si_hip_binary_f32")
+    return dy.to_numpy(o4).reshape(out_shape if out_shape is not None else o4)
+
+
+def activation(kind, x, param=0.0):
+    H = _native.hip()
+    x = _f32(x)
+    c = x.shape[-1]
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(x.nbytes)
+    _chk(H.si_hip_activation_f32(ACT[kind], param, dx.ptr, x.size // c, c, c, dy.ptr, c, None), "si_hip_activation_f32")
+    return dy.to_numpy(x.shape)
+
+
+def batchnorm2d(x, mean, var, gamma, beta, eps):
+    H = _native.hip()
+    x = _f32(x)
+    c = x.shape[-1]
+    bufs = [DeviceBuffer.from_numpy(_f32(v)) for v in (mean, var, gamma, beta)]
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(x.nbytes)
+    _chk(H.si_hip_batchnorm2d_f32(dx.ptr, x.size // c, c, c, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr, eps,
+                                  dy.ptr, c, None), "si_hip_batchnorm2d_f32")
+    return dy.to_numpy(x.shape)
+
+
+def flatten_nhwc(x):
+    H = _native.hip()
+    x = _f32(x)
+    n, h, w, c = x.shape
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(x.nbytes)
+    _chk(H.si_hip_nhwc_to_nchw_f32(dx.ptr, n, h, w, c, c, dy.ptr, None), "si_hip_nhwc_to_nchw_f32")
+    return dy.to_numpy((n, c * h * w))
+
+
+def yolo_detect(feats, weights, biases, grids, anchor_grids, strides, na=3):
+    """Detect head exactly as the YoloDetect layer runs it: per level 1x1 conv kernel + decode kernel."""
+    H = _native.hip()
+    feats = [_f32(f) for f in feats]
+    n = feats[0].shape[0]
+    ne = weights[0].shape[0] // na
+    rows_total = sum(f.shape[1] * f.shape[2] * na for f in feats)
+    dout = DeviceBuffer(n * rows_total * ne * 4)
+    off = 0
+    for f, w, b, g, a, s in zip(feats, weights, biases, grids, anchor_grids, strides):
+        _, h, wd, cin = f.shape
+        conv = conv2d(f, w, b)  # [n,h,w,na*ne]
+        g2 = _f32(np.transpose(_f32(g)[0], (1, 2, 0, 3)))   # [na,h,w,2] -> [h,w,na,2] (yolo_detect.cpp:75-79)
+        a2 = _f32(np.transpose(_f32(a)[0], (1, 2, 0, 3)))
+        dc, dg, da = DeviceBuffer.from_numpy(conv), DeviceBuffer.from_numpy(g2), DeviceBuffer.from_numpy(a2)
+        _chk(H.si_hip_yolo_decode_f32(dc.ptr, n, h, wd, na, ne, dg.ptr, da.ptr, float(s), dout.ptr, rows_total, off, None),
+             "si_hip_yolo_decode_f32")
+        sync()
+        off += h * wd * na
+    return dout.to_numpy((n, rows_total, ne))

@@ -1,0 +1,219 @@
+"""CPU: pins the oracle (oracle/si_oracle.c) before anything is compared with it.
+
+1. against the committed golden vectors (tests/golden/ops_golden.npz, torch-CPU float64 outputs);
+2. against the reference's own known-answer / in-test oracles, restated here with the reference's
+   tolerances (file:line cited per test).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import assert_exact, assert_parity, rng_uniform
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops_golden.npz"))
+
+CONV_CASES = ["conv_3x3_s1_p1", "conv_3x3_s1_p0", "conv_3x3_s2_p1", "conv_6x6_s2_p2", "conv_1x1", "conv_grouped",
+              "conv_depthwise", "conv_dilated", "conv_7x7_s2_p3"]
+
+
+def conv_case(name):
+    s, p, d, g = (int(v) for v in GOLD[name + "/cfg"])
+    b = GOLD[name + "/b"] if (name + "/b") in GOLD.files else None
+    return GOLD[name + "/x"], GOLD[name + "/w"], b, (s, s), (p, p), (d, d), g, GOLD[name + "/y"]
+
+
+@pytest.mark.parametrize("name", CONV_CASES)
+@pytest.mark.parametrize("path", ["auto", "im2col", "naive"])
+def test_conv_golden(orc, name, path):
+    x, w, b, s, p, d, g, y = conv_case(name)
+    got = orc.conv2d(x, w, b, s, p, d, g, path=path)
+    assert_parity(got, y, 2e-6, "%s/%s" % (name, path))
+
+
+def test_winograd_path_is_taken_and_matches(orc):
+    # 3x3 s1 p in {0,1} g1 -> ForwardWinograd23 (reference conv_2d.cpp:182-205)
+    for name in ("conv_3x3_s1_p1", "conv_3x3_s1_p0"):
+        x, w, b, s, p, d, g, y = conv_case(name)
+        got = orc.conv2d(x, w, b, s, p, d, g, path="winograd")
+        assert_parity(got, y, 2e-6, name)
+        assert_exact(got, orc.conv2d(x, w, b, s, p, d, g, path="auto"), name + " dispatch")
+    with pytest.raises(RuntimeError):
+        x, w, b, s, p, d, g, y = conv_case("conv_3x3_s2_p1")
+        orc.conv2d(x, w, b, s, p, d, g, path="winograd")
+
+
+# reference test/test_3rdparty/test_gemm.cpp:56-91: A = B = 1.0, GemmPack4F32 == GemmPack4F32Ref exactly
+GEMM_SHAPES = [(1, 1, 1), (4, 4, 4), (4, 12, 8), (13, 13, 13), (16, 24, 32), (97, 97, 97), (33, 129, 65),
+               (128, 64, 96), (1, 255, 7), (257, 3, 5), (1024, 128, 256)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_pack4_known_answer(orc, M, N, K):
+    A = np.ones((M, K), np.float32)
+    Bp = np.ones(((N + 3) // 4) * K * 4, np.float32)
+    c = orc.gemm_pack4(A, Bp, M, N, K)
+    assert_exact(c, orc.gemm_pack4(A, Bp, M, N, K, ref=True))
+    assert_exact(c, np.full((M, N), float(K), np.float32))
+
+
+def test_gemm_pack4_random_vs_float64(orc):
+    M, N, K = 37, 29, 131
+    A = rng_uniform(1, (M, K), -1, 1)
+    B = rng_uniform(2, (K, N), -1, 1)
+    Bp = np.zeros(((N + 3) // 4, K, 4), np.float32)
+    for n in range(N):
+        Bp[n // 4, :, n % 4] = B[:, n]
+    assert_parity(orc.gemm_pack4(A, Bp.ravel(), M, N, K), A.astype(np.float64) @ B.astype(np.float64), 1e-6)
+
+
+# reference test/test_layer/test_winograd.cpp:169-199: 4x4 spatial, these (ic, oc), pad in {0,1}, abs 2e-3
+WINO_CH = [(1, 1), (2, 1), (4, 1), (7, 1), (8, 1), (1, 2), (1, 4), (1, 7), (1, 8), (4, 4), (7, 7), (8, 8), (16, 16),
+           (128, 256), (256, 32), (32, 3)]
+
+
+@pytest.mark.parametrize("ic,oc", WINO_CH)
+@pytest.mark.parametrize("pad", [0, 1])
+def test_winograd_vs_reference_test_oracle(orc, ic, oc, pad):
+    x = rng_uniform(ic * 1000 + oc, (1, 4, 4, ic))
+    w = rng_uniform(ic * 1000 + oc + 1, (oc, ic, 3, 3))
+    b = rng_uniform(ic * 1000 + oc + 2, (oc,))
+    got = orc.conv2d(x, w, b, (1, 1), (pad, pad), path="winograd")
+    ref = orc.conv2d(x, w, b, (1, 1), (pad, pad), path="naive", acc64=False)  # the test's float loop (:101-131)
+    assert np.abs(got - ref).max() < 2e-3
+
+
+@pytest.mark.parametrize("h,w", [(5, 5), (6, 9), (7, 12), (9, 6), (12, 7), (13, 13)])
+@pytest.mark.parametrize("pad", [0, 1])
+def test_winograd_odd_sizes(orc, h, w, pad):
+    x = rng_uniform(h * 100 + w, (2, h, w, 6))
+    wt = rng_uniform(h * 100 + w + 1, (5, 6, 3, 3), -0.5, 0.5)
+    got = orc.conv2d(x, wt, None, (1, 1), (pad, pad), path="winograd")
+    assert_parity(got, orc.conv2d(x, wt, None, (1, 1), (pad, pad), path="naive"), 2e-6)
+
+
+def test_winograd_q1_bug_is_modelled(orc):
+    # tail tile-row dropped when pad=1 and the tail row index >= ow (winograd_helper.cpp:540)
+    x = rng_uniform(5, (1, 12, 7, 5))
+    w = rng_uniform(6, (6, 5, 3, 3))
+    good = orc.conv2d(x, w, None, (1, 1), (1, 1), path="winograd")
+    bad = orc.conv2d(x, w, None, (1, 1), (1, 1), path="winograd", q1_bug=True)
+    assert np.abs(good - bad).max() > 1.0
+    assert_exact(good[:, :10], bad[:, :10])  # only the last tile row (2 output rows) differs
+    # square maps (every YOLOv5s / ResNet18 layer) are unaffected
+    xs = rng_uniform(7, (1, 12, 12, 5))
+    assert_exact(orc.conv2d(xs, w, None, (1, 1), (1, 1), path="winograd"),
+                 orc.conv2d(xs, w, None, (1, 1), (1, 1), path="winograd", q1_bug=True))
+
+
+# reference test/test_layer/test_conv_2d.cpp: conv0 (:8-132) 1x128x128x32 -> 16 3x3 s1 p1; conv1 (:134-274)
+# groups=2; conv2 (:276-416) 1x640x640x3 -> 32 6x6 s2 p2 (run at 1/4 size); conv3 (:418-558) 1x10x10x256 -> 255
+# 1x1; tolerance abs 2e-4 against the float loop; those tests run the im2col path (InitWinograd not called)
+@pytest.mark.parametrize("shape,co,k,s,p,g", [((1, 128, 128, 32), 16, 3, 1, 1, 1), ((1, 128, 128, 32), 16, 3, 1, 1, 2),
+                                             ((1, 160, 160, 3), 32, 6, 2, 2, 1), ((1, 10, 10, 256), 255, 1, 1, 0, 1)])
+def test_conv_im2col_vs_reference_test_oracle(orc, shape, co, k, s, p, g):
+    x = rng_uniform(11, shape)
+    w = rng_uniform(12, (co, shape[3] // g, k, k))
+    b = rng_uniform(13, (co,))
+    got = orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, path="im2col")
+    ref = orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, path="naive", acc64=False)
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max() / 16)
+
+
+def test_pool_resample_shape_ops_golden(orc):
+    assert_exact(orc.maxpool2d(GOLD["maxpool_k5s1p2/x"], (5, 5), (1, 1), (2, 2)), GOLD["maxpool_k5s1p2/y"])
+    assert_exact(orc.maxpool2d(GOLD["maxpool_k3s2p1/x"], (3, 3), (2, 2), (1, 1)), GOLD["maxpool_k3s2p1/y"])
+    assert_parity(orc.adaptive_avgpool2d(GOLD["gap/x"], (1, 1)), GOLD["gap/y"], 1e-6)
+    assert_exact(orc.upsample_nearest(GOLD["upsample2/x"], 2.0, 2.0), GOLD["upsample2/y"])
+    assert_exact(orc.cat([GOLD["cat/x0"], GOLD["cat/x1"], GOLD["cat/x2"]], 3), GOLD["cat/y"])
+    assert_exact(orc.flatten_nhwc(GOLD["flatten/x"]), GOLD["flatten/y"])
+
+
+def test_elementwise_golden(orc):
+    x = GOLD["act/x"]
+    for kind in ("silu", "relu", "sigmoid", "hardsigmoid", "hardswish"):
+        assert_parity(orc.activation(kind, x), GOLD["act/" + kind], 1e-6, kind)
+    assert_exact(orc.binary_op(0, GOLD["binary/a"], GOLD["binary/b"]), GOLD["binary/add"])
+    assert_exact(orc.binary_op(2, GOLD["binary/a"], GOLD["binary/b"]), GOLD["binary/mul"])
+    assert_parity(orc.batchnorm2d(GOLD["bn/x"], GOLD["bn/mean"], GOLD["bn/var"], GOLD["bn/gamma"], GOLD["bn/beta"], 1e-5),
+                  GOLD["bn/y"], 1e-6)
+    assert_parity(orc.linear(GOLD["linear/x"], GOLD["linear/w"], GOLD["linear/b"]), GOLD["linear/y"], 1e-6)
+
+
+def test_upsample_index_rule(orc):
+    # reference upsample.cpp:85-92: src = clamp(int(float(dst) * (1/scale))); non-integer scale exercises it
+    x = np.arange(1 * 5 * 7 * 2, dtype=np.float32).reshape(1, 5, 7, 2)
+    y = orc.upsample_nearest(x, 1.5, 2.5, (7, 17))
+    for oy in range(7):
+        for ox in range(17):
+            sy = min(4, int(np.float32(oy) * (np.float32(1.0) / np.float32(1.5))))
+            sx = min(6, int(np.float32(ox) * (np.float32(1.0) / np.float32(2.5))))
+            assert_exact(y[0, oy, ox], x[0, sy, sx])
+
+
+def test_yolo_detect_row_order_and_decode(orc):
+    # rows are [H][W][anchor]; xy = (2s+grid)*stride, wh = (2s)^2*anchor (yolo_detect.cpp:252-266)
+    from simpleinfer_amd import modelgen as mg
+    n, na, ne = 2, 3, 8
+    feats, ws, bs, grids, anchors = [], [], [], [], []
+    for i, (h, c) in enumerate(((4, 8), (2, 16), (1, 32))):
+        feats.append(rng_uniform(20 + i, (n, h, h, c), -1, 1))
+        ws.append(rng_uniform(30 + i, (na * ne, c, 1, 1), -0.5, 0.5))
+        bs.append(rng_uniform(40 + i, (na * ne,), -0.5, 0.5))
+        gy, gx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="ij")
+        grids.append(np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, h, h, 2)).copy())
+        anchors.append(np.broadcast_to(rng_uniform(50 + i, (1, na, 1, 1, 2), 5, 50), (1, na, h, h, 2)).copy())
+    strides = [8.0, 16.0, 32.0]
+    out = orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na)
+    assert out.shape == (n, (16 + 4 + 1) * na, ne)
+    # independent numpy restatement in PyTorch order [a][h][w], permuted to the reference row order
+    off = 0
+    for f, w, b, g, a, s in zip(feats, ws, bs, grids, anchors, strides):
+        h = f.shape[1]
+        conv = np.einsum("nhwc,oc->nhwo", f.astype(np.float64), w[:, :, 0, 0].astype(np.float64)) + b
+        sig = 1.0 / (1.0 + np.exp(-conv.reshape(n, h, h, na, ne)))
+        g2, a2 = np.transpose(g[0], (1, 2, 0, 3)), np.transpose(a[0], (1, 2, 0, 3))
+        exp = sig.copy()
+        exp[..., 0:2] = (sig[..., 0:2] * 2 + g2) * s
+        exp[..., 2:4] = (sig[..., 2:4] * 2) ** 2 * a2
+        assert_parity(out[:, off:off + h * h * na], exp.reshape(n, h * h * na, ne), 1e-5)
+        off += h * h * na
+    assert mg is not None
+
+
+def test_graph_oracle_matches_torch_composition(orc, tmp_path):
+    """Whole-graph oracle (oracle/orc.py run_graph) vs an independent torch-CPU float64 evaluation of the
+    same synthesized toy classifier -- pins graph wiring, NCHW->NHWC handling and expression lowering."""
+    import torch
+    import torch.nn.functional as F
+    from simpleinfer_amd import modelgen as mg
+    b = mg.build_toy_classifier(2, 32)
+    pp, bp = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
+    b.save(pp, bp)
+    x = mg.synth_input((2, 32, 32, 3))
+    got = orc.run_graph(pp, bp, {"0": x})
+    (name, y), = got.items()
+    ops, shapes = orc.load_pnnx(pp, bp)
+    vals = {"0": torch.from_numpy(x).permute(0, 3, 1, 2).double()}
+    T = lambda a: torch.from_numpy(a).double()
+    for op in ops:
+        t, P, A = op.type, op.params, op.attrs
+        i = [vals[k] for k in op.inputs]
+        if t in ("pnnx.Input", "pnnx.Output"):
+            continue
+        if t == "nn.Conv2d":
+            o = F.conv2d(i[0], T(A["weight"]), T(A["bias"]) if P["bias"] else None, P["stride"], P["padding"],
+                         P["dilation"], P["groups"])
+        elif t == "nn.BatchNorm2d":
+            o = F.batch_norm(i[0], T(A["running_mean"]), T(A["running_var"]), T(A["weight"]), T(A["bias"]), False, 0.0, P["eps"])
+        elif t == "nn.Hardswish": o = F.hardswish(i[0])
+        elif t == "nn.Hardsigmoid": o = F.hardsigmoid(i[0])
+        elif t == "nn.ReLU": o = F.relu(i[0])
+        elif t == "nn.Sigmoid": o = torch.sigmoid(i[0])
+        elif t == "nn.AdaptiveAvgPool2d": o = F.adaptive_avg_pool2d(i[0], P["output_size"])
+        elif t == "pnnx.Expression": o = i[0] + i[1] if P["expr"].startswith("add") else i[0] * i[1]
+        elif t == "torch.flatten": o = torch.flatten(i[0], 1)
+        elif t == "nn.Linear": o = F.linear(i[0], T(A["weight"]), T(A["bias"]))
+        else: raise AssertionError(t)
+        vals[op.outputs[0]] = o
+    assert_parity(y, vals[name].float().numpy(), 1e-5)
