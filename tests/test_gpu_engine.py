@@ -1,0 +1,163 @@
+"""GPU: graph-level parity of the Engine (C++ host + HIP kernels, driven through include/si_engine.h)
+against the whole-graph CPU oracle (oracle/orc.py run_graph), plus the engine-only properties: fusion and
+concat aliasing change nothing, hipGraph replay changes nothing, batch sharding is bit-exact."""
+import numpy as np
+import pytest
+
+from util import assert_exact, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def si(gpu):
+    import simpleinfer_amd
+    return simpleinfer_amd
+
+
+def _save(tmp_path, builder, tag):
+    pp, bp = str(tmp_path / (tag + ".pnnx.param")), str(tmp_path / (tag + ".pnnx.bin"))
+    builder.save(pp, bp)
+    return pp, bp
+
+
+def _run(si, pp, bp, x, **opts):
+    e = si.Engine(**opts)
+    e.load_model(pp, bp)
+    (iname,), (oname,) = e.input_names(), e.output_names()
+    e.input(iname, x)
+    e.forward()
+    return e, oname, e.extract(oname)
+
+
+MODELS = {
+    "toy_yolo": (lambda mg: mg.build_toy_yolo(2, 64), (2, 64, 64, 3)),
+    "toy_classifier": (lambda mg: mg.build_toy_classifier(2, 32), (2, 32, 32, 3)),
+    "resnet18_small": (lambda mg: mg.build_resnet18(2, 64, num_classes=100, base=16), (2, 64, 64, 3)),
+    "yolov5s_160": (lambda mg: mg.build_yolov5s(2, 160), (2, 160, 160, 3)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MODELS))
+def test_graph_parity_vs_oracle(si, orc, tmp_path, name):
+    mk, shape = MODELS[name]
+    pp, bp = _save(tmp_path, mk(si.modelgen), name)
+    x = si.modelgen.synth_input(shape)
+    ref = orc.run_graph(pp, bp, {"0": x})
+    e, oname, got = _run(si, pp, bp, x)
+    assert_parity(got, ref[oname], what=name)
+    # plain schedule (no fusion, no aliasing: one launch per reference layer) gives the same numbers
+    _, _, plain = _run(si, pp, bp, x, fuse=0, alias_cat=0)
+    assert_parity(plain, ref[oname], what=name + " unfused")
+    assert_parity(got, plain, 1e-6, what=name + " fused vs unfused")
+
+
+def test_yolov5s_640_batch1_parity(si, orc, tmp_path):
+    """BASELINE.json configs[1]: YOLOv5s 1x3x640x640 fp32 parity vs the CPU outputs."""
+    pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(1, 640), "y1")
+    x = si.modelgen.synth_input((1, 640, 640, 3))
+    ref = orc.run_graph(pp, bp, {"0": x})
+    e, oname, got = _run(si, pp, bp, x)
+    assert got.shape == (1, 25200, 85)
+    assert_parity(got, ref[oname], what="yolov5s 640")
+    # known-answer style input of the reference's demo (test_yolo2.cpp:26 uses a constant image)
+    xc = np.full((1, 640, 640, 3), 0.5, np.float32)
+    e.input("0", xc)
+    e.forward()
+    assert_parity(e.extract(oname), orc.run_graph(pp, bp, {"0": xc})[oname], what="constant input")
+
+
+def test_schedule_fusion_and_aliasing(si, tmp_path):
+    pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(1, 64), "sched")
+    e = si.Engine()
+    e.load_model(pp, bp)
+    s = e.schedule()
+    # all 57 SiLUs and the 7 residual adds of YOLOv5s fold into conv epilogues
+    assert sum(n.startswith("silu_") for n in s["fused"]) == 57
+    assert sum(n.startswith("add_") for n in s["fused"]) == 7
+    assert not any(n.startswith("silu_") for n in s["run"])
+    assert len(s["alias"]) >= 20  # concat inputs written in place
+    e2 = si.Engine(fuse=0, alias_cat=0)
+    e2.load_model(pp, bp)
+    s2 = e2.schedule()
+    assert not s2["fused"] and not s2["alias"] and len(s2["run"]) == len(s["run"]) + 64
+
+
+def test_forward_is_repeatable_and_input_is_read_at_forward_time(si, tmp_path):
+    pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(2, 64), "rep")
+    x = si.modelgen.synth_input((2, 64, 64, 3))
+    e, oname, a = _run(si, pp, bp, x)
+    e.forward()
+    assert_exact(e.extract(oname), a)
+    # reference semantics: Input() borrows; the buffer is read when Forward() runs (bench_yolo.cpp:22-27)
+    buf = e._inputs["0"]
+    buf[...] = si.modelgen.synth_input((2, 64, 64, 3), seed=7)
+    e.forward()
+    b = e.extract(oname)
+    assert not np.array_equal(a, b)
+    e2, _, c = _run(si, pp, bp, buf.copy())
+    assert_exact(b, c)
+
+
+def test_hipgraph_replay_matches_eager(si, tmp_path):
+    pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(2, 64), "graph")
+    x = si.modelgen.synth_input((2, 64, 64, 3))
+    _, oname, eager = _run(si, pp, bp, x)
+    e = si.Engine(graph=1)
+    e.load_model(pp, bp)
+    e.input("0", x)
+    for _ in range(4):  # eager warm-up, capture, replay, replay
+        e.forward()
+        assert_exact(e.extract(oname), eager)
+
+
+def test_device_resident_io(si, tmp_path):
+    from simpleinfer_amd import hipops
+    pp, bp = _save(tmp_path, si.modelgen.build_toy_classifier(2, 32), "dev")
+    x = si.modelgen.synth_input((2, 32, 32, 3))
+    _, oname, ref = _run(si, pp, bp, x)
+    e = si.Engine(outputs_to_host=0)
+    e.load_model(pp, bp)
+    dx = hipops.DeviceBuffer.from_numpy(x)
+    e.input_device("0", dx.ptr)
+    e.forward()
+    ptr, on_dev = e.extract_ptr(oname)
+    assert on_dev and ptr
+    assert_exact(e.extract(oname), ref)
+
+
+def test_batch_sharding_is_bit_exact(si, tmp_path):
+    """section 8(e): the path shards by image with no halo -- a rank's slab equals the same rows of the full run."""
+    mg = si.modelgen
+    x = mg.synth_input((4, 64, 64, 3))
+    pp, bp = _save(tmp_path, mg.build_toy_yolo(4, 64), "b4")
+    _, oname, full = _run(si, pp, bp, x)
+    pp2, bp2 = _save(tmp_path, mg.build_toy_yolo(2, 64), "b2")
+    for r in range(2):
+        _, _, part = _run(si, pp2, bp2, x[2 * r:2 * r + 2])
+        assert_exact(part, full[2 * r:2 * r + 2])
+
+
+def test_errors_are_statuses(si, tmp_path):
+    e = si.Engine()
+    with pytest.raises(si.StatusError):
+        e.load_model(str(tmp_path / "missing.param"), str(tmp_path / "missing.bin"))
+    # an operator the reference does not register either -> kEmpty (engine_impl.cpp:247-250)
+    b = si.modelgen.PnnxBuilder()
+    x = b.input((1, 4, 8, 8))
+    y = b._unary("nn.GELU", "gelu", x)
+    b.output(y)
+    pp, bp = _save(tmp_path, b, "bad")
+    with pytest.raises(si.StatusError) as ei:
+        e.load_model(pp, bp)
+    assert ei.value.status == si.Status.kEmpty
+    pp, bp = _save(tmp_path, si.modelgen.build_toy_classifier(1, 16), "ok")
+    e.load_model(pp, bp)
+    with pytest.raises(si.StatusError):
+        e.forward()  # no input bound
+    with pytest.raises(si.StatusError):
+        e.input("nope", np.zeros((1, 16, 16, 3), np.float32))
+    with pytest.raises(si.StatusError):
+        e.input("0", np.zeros((1, 8, 8, 3), np.float32))
+    e.release()
+    assert e.input_names() == []

@@ -1,0 +1,227 @@
+"""GPU: per-operator parity of the HIP kernels (called through the C-ABI, include/si_hip.h) against the
+CPU oracle and the committed golden vectors.  Mirrors the reference's layer-test matrix
+(test/test_layer/*.cpp) with fixed seeds, and adds what it lacks: batch > 1,
+ragged channel counts, strided (concat-slice) tensors, fused epilogues.
+
+Tolerance: fp32 kernels 1e-4 relative to max|ref| (util.REL_TOL); index / copy / max ops bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import assert_exact, assert_parity, rng_uniform
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops_golden.npz"))
+CONV_CASES = ["conv_3x3_s1_p1", "conv_3x3_s1_p0", "conv_3x3_s2_p1", "conv_6x6_s2_p2", "conv_1x1", "conv_grouped",
+              "conv_depthwise", "conv_dilated", "conv_7x7_s2_p3"]
+
+
+@pytest.fixture(scope="module")
+def hops(gpu):
+    from simpleinfer_amd import hipops
+    return hipops
+
+
+@pytest.mark.parametrize("name", CONV_CASES)
+def test_conv_golden(hops, name):
+    s, p, d, g = (int(v) for v in GOLD[name + "/cfg"])
+    b = GOLD[name + "/b"] if (name + "/b") in GOLD.files else None
+    got = hops.conv2d(GOLD[name + "/x"], GOLD[name + "/w"], b, (s, s), (p, p), (d, d), g)
+    assert_parity(got, GOLD[name + "/y"], what=name)
+
+
+# (shape NHWC, oc, k, s, p, d, g): reference test_conv_2d.cpp conv0..conv3, then the YOLOv5s / ResNet18 layer
+# families of SURVEY.md 8(a) at reduced spatial size, then ragged / degenerate shapes
+CONV_SHAPES = [
+    ((1, 128, 128, 32), 16, 3, 1, 1, 1, 1),     # test_conv_2d.cpp:8-132
+    ((1, 128, 128, 32), 16, 3, 1, 1, 1, 2),     # :134-274 groups=2
+    ((1, 160, 160, 3), 32, 6, 2, 2, 1, 1),      # :276-416 stem (1/4 size)
+    ((1, 10, 10, 256), 255, 1, 1, 0, 1, 1),     # :418-558 Detect 1x1
+    ((2, 40, 40, 64), 64, 3, 1, 1, 1, 1),       # C3 bottleneck 3x3
+    ((2, 40, 40, 64), 128, 3, 2, 1, 1, 1),      # downsample 3x3 s2
+    ((2, 20, 20, 512), 256, 1, 1, 0, 1, 1),     # wide 1x1
+    ((2, 20, 20, 256), 512, 3, 2, 1, 1, 1),     # K = 2304
+    ((3, 56, 56, 3), 64, 7, 2, 3, 1, 1),        # ResNet stem
+    ((2, 14, 14, 128), 256, 1, 2, 0, 1, 1),     # ResNet 1x1 s2 downsample
+    ((1, 7, 9, 5), 7, 3, 1, 1, 1, 1),           # ragged everything
+    ((2, 5, 5, 6), 3, 3, 1, 0, 1, 1),
+    ((1, 1, 1, 4), 4, 1, 1, 0, 1, 1),           # single pixel
+    ((1, 3, 3, 1), 1, 3, 1, 1, 1, 1),           # single channel
+    ((1, 9, 9, 8), 8, 3, 1, 2, 2, 1),           # dilation
+    ((1, 12, 12, 12), 12, 3, 1, 1, 1, 12),      # depthwise
+    ((1, 12, 12, 12), 24, 3, 2, 1, 1, 3),       # grouped, oc/g = 8
+    ((5, 33, 17, 20), 36, 5, 3, 2, 1, 1),       # odd kernel/stride, M not a tile multiple
+]
+
+
+@pytest.mark.parametrize("shape,oc,k,s,p,d,g", CONV_SHAPES)
+def test_conv_vs_oracle(hops, orc, shape, oc, k, s, p, d, g):
+    seed = hash((shape, oc, k, s, p, d, g)) % 100000
+    x = rng_uniform(seed, shape)
+    w = rng_uniform(seed + 1, (oc, shape[3] // g, k, k), -0.5, 0.5)
+    b = rng_uniform(seed + 2, (oc,), -0.5, 0.5)
+    got = hops.conv2d(x, w, b, (s, s), (p, p), (d, d), g)
+    # reference dispatch (Winograd when eligible) is the parity target; the fp64 loop bounds both
+    assert_parity(got, orc.conv2d(x, w, b, (s, s), (p, p), (d, d), g, path="auto"), what="vs reference path")
+    assert_parity(got, orc.conv2d(x, w, b, (s, s), (p, p), (d, d), g, path="naive"), 2e-5, what="vs fp64")
+
+
+def test_conv_reference_test_tolerance(hops, orc):
+    """the reference's own criterion: abs < 2e-4 against its float loop, inputs U[0,1) (test_conv_2d.cpp:100-131)"""
+    x = rng_uniform(1, (1, 128, 128, 32))
+    w = rng_uniform(2, (16, 32, 3, 3))
+    b = rng_uniform(3, (16,))
+    got = hops.conv2d(x, w, b, (1, 1), (1, 1))
+    ref = orc.conv2d(x, w, b, (1, 1), (1, 1), path="naive", acc64=False)
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max() / 16)
+
+
+@pytest.mark.parametrize("act", ["relu", "silu", "sigmoid", "hardsigmoid", "hardswish", "leakyrelu"])
+def test_conv_fused_activation(hops, orc, act):
+    x = rng_uniform(4, (2, 12, 12, 16), -1, 1)
+    w = rng_uniform(5, (24, 16, 3, 3), -0.5, 0.5)
+    b = rng_uniform(6, (24,), -0.5, 0.5)
+    y = orc.conv2d(x, w, b, (1, 1), (1, 1), path="naive")
+    ref = np.where(y > 0, y, np.float32(0.1) * y) if act == "leakyrelu" else orc.activation(act, y)
+    assert_parity(hops.conv2d(x, w, b, (1, 1), (1, 1), act1=act, act_param=0.1), ref, what=act)
+
+
+def test_conv_fused_residual_orders(hops, orc):
+    x = rng_uniform(7, (2, 10, 10, 32), -1, 1)
+    w = rng_uniform(8, (32, 32, 3, 3), -0.3, 0.3)
+    b = rng_uniform(9, (32,), -0.5, 0.5)
+    r = rng_uniform(10, (2, 10, 10, 32), -1, 1)
+    y = orc.conv2d(x, w, b, (1, 1), (1, 1), path="naive")
+    # YOLOv5 bottleneck: x + silu(conv)      ResNet basic block: relu(conv + identity)
+    assert_parity(hops.conv2d(x, w, b, (1, 1), (1, 1), act1="silu", residual=r), orc.activation("silu", y) + r)
+    assert_parity(hops.conv2d(x, w, b, (1, 1), (1, 1), residual=r, act2="relu"), orc.activation("relu", y + r))
+
+
+def test_conv_strided_tensors(hops, orc):
+    """input read from / output written into a wider concat buffer (pixel stride > channels)"""
+    x = rng_uniform(11, (2, 9, 9, 16), -1, 1)
+    w = rng_uniform(12, (8, 16, 1, 1), -0.5, 0.5)
+    b = rng_uniform(13, (8,), -0.5, 0.5)
+    ref = orc.conv2d(x, w, b)
+    assert_parity(hops.conv2d(x, w, b, in_ld=40), ref, what="in_ld")
+    assert_parity(hops.conv2d(x, w, b, out_ld=24, out_c_off=12), ref, what="out_ld + offset")
+    assert_parity(hops.conv2d(x, w, b, in_ld=18, out_ld=11, out_c_off=3), ref, what="unaligned strides")
+
+
+def test_conv_batch_invariance_bit_exact(hops):
+    """an image's result must not depend on the batch it travels in (the data-parallel sharding contract)"""
+    x = rng_uniform(14, (6, 24, 24, 32), -1, 1)
+    w = rng_uniform(15, (64, 32, 3, 3), -0.5, 0.5)
+    b = rng_uniform(16, (64,), -0.5, 0.5)
+    full = hops.conv2d(x, w, b, (1, 1), (1, 1), act1="silu")
+    for i in (0, 3, 5):
+        assert_exact(hops.conv2d(x[i:i + 1], w, b, (1, 1), (1, 1), act1="silu")[0], full[i])
+
+
+def test_conv_linearity(hops):
+    x1, x2 = rng_uniform(17, (1, 16, 16, 8), -1, 1), rng_uniform(18, (1, 16, 16, 8), -1, 1)
+    w = rng_uniform(19, (16, 8, 3, 3), -0.5, 0.5)
+    a = hops.conv2d(x1 + x2, w, None, (1, 1), (1, 1))
+    assert_parity(a, hops.conv2d(x1, w, None, (1, 1), (1, 1)) + hops.conv2d(x2, w, None, (1, 1), (1, 1)), 1e-5)
+
+
+def test_linear(hops, orc):
+    assert_parity(hops.linear(GOLD["linear/x"], GOLD["linear/w"], GOLD["linear/b"]), GOLD["linear/y"])
+    x, w, b = rng_uniform(20, (1, 128)), rng_uniform(21, (64, 128)), rng_uniform(22, (64,))  # test_linear.cpp:8-65
+    assert np.abs(hops.linear(x, w, b) - orc.linear(x, w, b)).max() < 1e-4
+    x, w = rng_uniform(23, (64, 512), -1, 1), rng_uniform(24, (1000, 512), -0.1, 0.1)       # ResNet18 head
+    assert_parity(hops.linear(x, w, None), orc.linear(x, w, None))
+
+
+def test_maxpool_exact(hops, orc):
+    assert_exact(hops.maxpool2d(GOLD["maxpool_k5s1p2/x"], (5, 5), (1, 1), (2, 2)), GOLD["maxpool_k5s1p2/y"])
+    assert_exact(hops.maxpool2d(GOLD["maxpool_k3s2p1/x"], (3, 3), (2, 2), (1, 1)), GOLD["maxpool_k3s2p1/y"])
+    x = rng_uniform(25, (1, 8, 8, 3), -1, 1)                                      # test_max_pool_2d.cpp:7-73
+    assert_exact(hops.maxpool2d(x, (2, 2), (2, 2), (0, 0)), orc.maxpool2d(x, (2, 2), (2, 2), (0, 0)))
+    x = rng_uniform(26, (8, 20, 20, 256), -1, 1)                                  # :75-150 SPPF
+    assert_exact(hops.maxpool2d(x, (5, 5), (1, 1), (2, 2)), orc.maxpool2d(x, (5, 5), (1, 1), (2, 2)))
+    x = -rng_uniform(27, (1, 6, 6, 4), 1, 2)                                      # all-negative: padding must be lowest()
+    assert_exact(hops.maxpool2d(x, (3, 3), (1, 1), (1, 1)), orc.maxpool2d(x, (3, 3), (1, 1), (1, 1)))
+
+
+def test_avgpool(hops, orc):
+    assert_parity(hops.adaptive_avgpool2d(GOLD["gap/x"], (1, 1)), GOLD["gap/y"], 1e-6)
+    x = rng_uniform(28, (1, 8, 8, 3))                                             # test_adaptive_avg_pool_2d.cpp:7-52
+    assert np.abs(hops.adaptive_avgpool2d(x, (1, 1)) - orc.adaptive_avgpool2d(x, (1, 1))).max() < 1e-6
+    x = rng_uniform(29, (2, 12, 8, 5))
+    assert_parity(hops.adaptive_avgpool2d(x, (3, 4)), orc.adaptive_avgpool2d(x, (3, 4)), 1e-6)
+    with pytest.raises(hops.HipError):
+        hops.adaptive_avgpool2d(x, (5, 3))  # not divisible: kUnsupport in the reference (:78-84)
+
+
+def test_upsample_exact(hops, orc):
+    assert_exact(hops.upsample_nearest(GOLD["upsample2/x"], 2.0, 2.0), GOLD["upsample2/y"])
+    x = rng_uniform(30, (1, 16, 16, 3))                                           # test_upsample.cpp:8-54
+    assert_exact(hops.upsample_nearest(x, 2.0, 2.0), orc.upsample_nearest(x, 2.0, 2.0))
+    x = rng_uniform(31, (4, 10, 10, 128))                                         # :56-102
+    assert_exact(hops.upsample_nearest(x, 2.0, 2.0), orc.upsample_nearest(x, 2.0, 2.0))
+    x = rng_uniform(32, (1, 5, 7, 2))
+    assert_exact(hops.upsample_nearest(x, 1.5, 2.5, (7, 17)), orc.upsample_nearest(x, 1.5, 2.5, (7, 17)))
+
+
+def test_cat_exact(hops, orc):
+    xs = [GOLD["cat/x0"], GOLD["cat/x1"], GOLD["cat/x2"]]                         # test_cat.cpp:7-65 (C = 3, 2, 4)
+    assert_exact(hops.cat(xs, 3), GOLD["cat/y"])
+    a, b = rng_uniform(33, (2, 3, 4, 8)), rng_uniform(34, (2, 5, 4, 8))
+    assert_exact(hops.cat([a, b], 1), orc.cat([a, b], 1))
+    a, b = rng_uniform(35, (2, 3, 4, 8)), rng_uniform(36, (2, 3, 6, 8))
+    assert_exact(hops.cat([a, b], 2), orc.cat([a, b], 2))
+    a, b = rng_uniform(37, (20, 20, 20, 256)), rng_uniform(38, (20, 20, 20, 256))
+    assert_exact(hops.cat([a, b], 3), np.concatenate([a, b], 3))
+
+
+def test_activations(hops, orc):
+    x = GOLD["act/x"]
+    for kind in ("silu", "relu", "sigmoid", "hardsigmoid", "hardswish"):
+        assert_parity(hops.activation(kind, x), GOLD["act/" + kind], what=kind)
+    x = rng_uniform(39, (1, 128, 128, 3), -4, 4)                                  # test_silu.cpp etc: abs 1e-6
+    for kind in ("silu", "sigmoid", "hardsigmoid", "hardswish"):
+        assert np.abs(hops.activation(kind, x) - orc.activation(kind, x)).max() < 2e-6, kind
+    assert_exact(hops.activation("relu", x), orc.activation("relu", x))
+    big = np.array([[-100.0, -20.0, 0.0, 20.0, 100.0, 1e-30, -1e-30, 88.0]], np.float32).reshape(1, 1, 2, 4)
+    assert_parity(hops.activation("silu", big), orc.activation("silu", big), 1e-6)
+
+
+def test_binary(hops, orc):
+    a, b = rng_uniform(40, (1, 128, 128, 3)), rng_uniform(41, (1, 128, 128, 3))    # test_binary_op.cpp:7-87
+    assert_exact(hops.binary_op(0, a, b), a + b)
+    assert_exact(hops.binary_op(2, a, b), a * b)
+    assert_exact(hops.binary_op(0, GOLD["binary/a"], GOLD["binary/b"]), GOLD["binary/add"])
+    assert_exact(hops.binary_op(2, GOLD["binary/a"], GOLD["binary/b"]), GOLD["binary/mul"])
+    a, b = rng_uniform(42, (2, 6, 6, 16)), rng_uniform(43, (2, 1, 1, 16))          # SE-style broadcast
+    assert_exact(hops.binary_op(2, a, b), orc.binary_op(2, a, b))
+    a, b = rng_uniform(44, (1, 3, 1, 4)), rng_uniform(45, (2, 3, 5, 1))            # both sides broadcast
+    assert_exact(hops.binary_op(0, a, b), orc.binary_op(0, a, b))
+    with pytest.raises(hops.HipError):
+        hops.binary_op(1, a, a)  # sub: unsupported by the reference layer too (binary_op.cpp:27-30)
+
+
+def test_batchnorm_flatten(hops, orc):
+    g = GOLD
+    assert_parity(hops.batchnorm2d(g["bn/x"], g["bn/mean"], g["bn/var"], g["bn/gamma"], g["bn/beta"], 1e-5), g["bn/y"], 1e-5)
+    assert_exact(hops.flatten_nhwc(g["flatten/x"]), g["flatten/y"])
+    x = rng_uniform(46, (1, 2, 2, 128))                                            # test_flatten.cpp:7-45
+    assert_exact(hops.flatten_nhwc(x), orc.flatten_nhwc(x))
+
+
+def test_yolo_detect_head(hops, orc):
+    n, na, ne = 2, 3, 85
+    feats, ws, bs, grids, anchors = [], [], [], [], []
+    for i, (h, c) in enumerate(((8, 32), (4, 64), (2, 128))):
+        feats.append(rng_uniform(50 + i, (n, h, h, c), -1, 1))
+        ws.append(rng_uniform(60 + i, (na * ne, c, 1, 1), -0.3, 0.3))
+        bs.append(rng_uniform(70 + i, (na * ne,), -0.5, 0.5))
+        gy, gx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="ij")
+        grids.append(np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, h, h, 2)).copy())
+        anchors.append(np.broadcast_to(rng_uniform(80 + i, (1, na, 1, 1, 2), 5, 300), (1, na, h, h, 2)).copy())
+    strides = [8.0, 16.0, 32.0]
+    assert_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na),
+                  orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na))
