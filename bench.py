@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of Engine::Forward() for YOLOv5s 640x640 fp32 on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A step is one Engine::Forward() over one batch of synthetic images (the reference's bench harness,
+bench/bench_yolo.cpp:7-34, times exactly that) plus, for N > 1, the all-gather of the output slabs.
+Per-GPU batch is fixed (32) as N grows: weak scaling, global batch 32*N (N = 8 is BASELINE.json's
+"batch=256 sharded across 8 MI355X").  Inputs are resident in HBM before the timed region; weights are
+random-init (portable splitmix64 stream), data is synthetic.
+
+One JSON line on stdout from rank 0.  Besides the contract's fields it carries
+  roofline     -- the dominant kernel (conv implicit-GEMM instantiation with the largest total time):
+                  algorithmic direct-conv FLOPs per launch / average launch duration, measured live with HIP
+                  events on the engine's stream in an instrumented pass right after the timed region
+                  (peak: 157.3 TFLOP/s fp32 MFMA); `traffic` from profiles/ when a PMC pass was recorded.
+  cpu_baseline -- the CPU oracle (restatement of SimpleInfer's Eigen/highway path, kind "port") timed on
+                  this box's host cores on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (images per Forward)")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--model", default="yolov5s", choices=["yolov5s", "resnet18"])
+    ap.add_argument("--graph", type=int, default=0, help="replay Forward() as a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (reference uses 16 intra-op)")
+    ap.add_argument("--profile-passes", type=int, default=3)
+    ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
+    return ap.parse_args()
+
+
+def build_model(mg, name, batch, size):
+    if name == "yolov5s":
+        return mg.build_yolov5s(batch, size), (batch, size, size, 3)
+    return mg.build_resnet18(batch, 224 if size == 640 else size), (batch, 224 if size == 640 else size, 224 if size == 640 else size, 3)
+
+
+def cpu_baseline(args, mg, td):
+    """oracle timed on the host cores: N images of the same workload, one Forward each (batch-1 model)."""
+    from oracle import orc
+    orc.lib().orc_set_num_threads(args.cpu_threads)
+    b, shape = build_model(mg, args.model, 1, args.size)
+    pp, bp = os.path.join(td, "cpu.pnnx.param"), os.path.join(td, "cpu.pnnx.bin")
+    b.save(pp, bp)
+    x = mg.synth_input(shape)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_images):
+        orc.run_graph(pp, bp, {"0": x})
+    dt = time.perf_counter() - t0
+    return {"value": round(args.cpu_images / dt, 4), "unit": "images/sec", "cores": int(orc.lib().orc_num_threads()),
+            "kind": "port",
+            "sample": "%d x %s %dx%d fp32 batch-1 forward, CPU restatement of SimpleInfer's Eigen/highway path "
+                      "(Winograd F(2,3)+pack4 GEMM for 3x3 s1, im2col GEMM otherwise, unfused passes), %.1f s, host %s"
+                      % (args.cpu_images, args.model, shape[1], shape[2], dt, _cpu_name())}
+
+
+def _cpu_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip() + " x%d threads" % os.cpu_count()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def roofline_from_profile(passes):
+    """passes: list of per-layer profile lists (same schedule).  Groups conv launches by kernel instantiation."""
+    agg = {}
+    for layers in passes:
+        for L in layers:
+            if not L["kernel"].startswith("conv_igemm") or L["flops"] <= 0 or L["type"] == "models.yolo.Detect":
+                continue
+            a = agg.setdefault(L["kernel"], {"ms": 0.0, "flops": 0.0, "launches": 0})
+            a["ms"] += L["ms"]
+            a["flops"] += L["flops"]
+            a["launches"] += 1
+    if not agg:
+        return None, agg
+    name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = a["ms"] / a["launches"]
+    flops_per_launch = a["flops"] / a["launches"]
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(name)
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "launches_per_step": a["launches"] // max(len(passes), 1), "avg_launch_ms": round(avg_ms, 4),
+            "gflop_per_launch": round(flops_per_launch / 1e9, 3)}, agg
+
+
+def main():
+    args = parse()
+    import simpleinfer_amd as si
+    from simpleinfer_amd import distributed as sd, hipops, _native
+
+    rank, world, local_rank = sd.env_rank_world()
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    H = _native.hip()
+    ndev = si.device_count()
+    if ndev <= 0:
+        sys.exit("bench.py: no HIP device (the product has no CPU fallback)")
+    dev = local_rank % ndev
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # plumbing only: process group, barrier, the RCCL all-gather
+        torch.cuda.set_device(dev)
+        dist = sd.init_process_group("nccl")
+    H.si_hip_set_device(dev)
+
+    mg = si.modelgen
+    with tempfile.TemporaryDirectory(prefix="si_bench_r%d_" % rank) as td:
+        builder, shape = build_model(mg, args.model, args.batch, args.size)
+        pp, bp = os.path.join(td, "m.pnnx.param"), os.path.join(td, "m.pnnx.bin")
+        builder.save(pp, bp)
+        flops_step = mg.conv_flops(builder)
+
+        e = si.Engine(device=dev, outputs_to_host=0, graph=args.graph)
+        e.load_model(pp, bp)
+        iname, oname = e.input_names()[0], e.output_names()[0]
+        # global batch = per-GPU batch * world; this rank's slab gets its own seed (distinct images)
+        x = mg.synth_input(shape, seed=1 + rank)
+        dx = hipops.DeviceBuffer.from_numpy(x)
+        e.input_device(iname, dx.ptr)
+        oshape = e.operand_shape(oname)
+
+        gathered = local_view = None
+        if world > 1:
+            e.forward()
+            optr, _ = e.extract_ptr(oname)
+            local_view = sd.as_torch(optr, oshape, dev)
+            gathered = torch.empty((world * oshape[0],) + tuple(oshape[1:]), dtype=torch.float32, device="cuda:%d" % dev)
+
+        def step():
+            e.forward()  # synchronous: kernels of this step are done when it returns
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, local_view)
+
+        def fence():
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+            H.si_hip_device_sync()
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        fwd_ms = 0.0
+        for _ in range(args.steps):
+            step()
+            fwd_ms += e.last_forward_ms()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+
+        roof, agg, layers = None, {}, None
+        if rank == 0:
+            passes = [e.profile() for _ in range(max(args.profile_passes, 1))]
+            layers = passes[-1]
+            roof, agg = roofline_from_profile(passes)
+            if args.layers:
+                for L in layers:
+                    tf = L["flops"] / (L["ms"] * 1e-3) / 1e12 if L["ms"] > 0 else 0
+                    gb = L["bytes"] / (L["ms"] * 1e-3) / 1e9 if L["ms"] > 0 else 0
+                    print("%-28s %-22s %-48s %8.3f ms %7.1f TF/s %8.1f GB/s" % (L["name"], L["type"], L["kernel"], L["ms"], tf, gb),
+                          file=sys.stderr)
+                print("sum of layer times %.3f ms" % sum(L["ms"] for L in layers), file=sys.stderr)
+
+        cpu = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, mg, td)
+
+        if world > 1:
+            dist.barrier()
+
+    if rank != 0:
+        return
+    imgs = args.batch * world * args.steps
+    value = imgs / dt
+    ceiling = PEAK_FP32_MFMA_TFLOPS * 1e12 / (flops_step / args.batch)  # images/s/GPU at the fp32 MFMA peak
+    out = {
+        "metric": "images/sec %s %dx%d fp32 batch=%d per GPU, Engine::Forward()" % (
+            "YOLOv5s" if args.model == "yolov5s" else "ResNet18", shape[1], shape[2], args.batch),
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %dx%d fp32 forward, batch %d per GPU (global %d), random-init weights, "
+                               "inputs resident in HBM%s" % (args.model, shape[1], shape[2], args.batch,
+                                                            args.batch * world,
+                                                            ", outputs all-gathered over RCCL" if world > 1 else ""),
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "hipgraph": bool(args.graph)},
+        "forward_kernel_ms_per_step": round(fwd_ms / args.steps, 3),
+        "gflop_per_image": round(flops_step / args.batch / 1e9, 3),
+        "frac_of_mfma_ceiling": round(value / world / ceiling, 4),
+        "roofline": roof,
+        "conv_kernels": {k: {"ms_per_step": round(v["ms"] / max(args.profile_passes, 1), 3),
+                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0}
+                         for k, v in agg.items()},
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -112,6 +112,9 @@ size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d);
 int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* w_packed);
 int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
                       const float* residual, float* out, si_stream_t stream);
+/* name of the kernel instantiation si_hip_conv2d_f32 would launch for this problem (as rocprofv3 prints
+ * it, minus the namespace), so profiles can be joined with per-layer timings */
+const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);
 
 /* ---- Linear ------------------------------------------------------------ */
 /* y[n,out] = x[n,in] W[out,in]^T + b   (src/layer/linear.cpp:74-117) */

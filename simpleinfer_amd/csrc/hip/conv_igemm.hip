@@ -256,6 +256,24 @@ inline int round_up4(int v) { return (v + 3) & ~3; }
 
 }  // namespace
 
+// tile choice: widest N tile the layer fills; drop to 64-row tiles when a 128-row grid would leave
+// most of the 256 CUs idle.  0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
+static int conv_variant(const SiConv2dDesc* d) {
+    const int ocg = d->oc / d->groups;
+    const long long M = (long long)d->n * d->oh * d->ow;
+    const long long wg128 = ((M + 127) / 128) * ((ocg + 127) / 128) * d->groups;
+    if (ocg > 32) {
+        if (wg128 < 192 && M > 64) return 2;
+        return ocg > 64 ? 0 : 1;
+    }
+    return 3;
+}
+
+static bool conv_vec_a(const SiConv2dDesc* d, const float* in) {
+    const int icg = d->ic / d->groups;
+    return (icg % 4 == 0) && (d->in_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+}
+
 extern "C" size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d) {
     if (!d || d->groups <= 0) return 0;
     const int icg = d->ic / d->groups;
@@ -305,20 +323,23 @@ extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const f
     a.m_tiles = a.n_tiles = 0;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
 
-    const bool vec_a = (a.icg % 4 == 0) && (d->in_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+    const bool vec_a = conv_vec_a(d, in);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int G = d->groups;
+    switch (conv_variant(d)) {
+        case 0: return launch<128, 128, 2, 2>(a, G, vec_a, s);
+        case 1: return launch<128, 64, 2, 2>(a, G, vec_a, s);
+        case 2: return launch<64, 64, 2, 2>(a, G, vec_a, s);
+        default: return launch<128, 32, 4, 1>(a, G, vec_a, s);
+    }
+}
 
-    // tile choice: widest N tile the layer fills; drop to 64-row tiles when a
-    // 128-row grid would leave most of the 256 CUs idle.
-    const long long wg128 = (long long)((a.M + 127) / 128) * ((a.ocg + 127) / 128) * G;
-    if (a.ocg > 64) {
-        if (wg128 < 192 && a.M > 64) return launch<64, 64, 2, 2>(a, G, vec_a, s);
-        return launch<128, 128, 2, 2>(a, G, vec_a, s);
-    }
-    if (a.ocg > 32) {
-        if (wg128 < 192 && a.M > 64) return launch<64, 64, 2, 2>(a, G, vec_a, s);
-        return launch<128, 64, 2, 2>(a, G, vec_a, s);
-    }
-    return launch<128, 32, 4, 1>(a, G, vec_a, s);
+extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in) {
+    if (!d || d->groups <= 0) return "invalid";
+    static const char* names[4][2] = {
+        {"conv_igemm_f32_kernel<128, 128, 2, 2, false>", "conv_igemm_f32_kernel<128, 128, 2, 2, true>"},
+        {"conv_igemm_f32_kernel<128, 64, 2, 2, false>", "conv_igemm_f32_kernel<128, 64, 2, 2, true>"},
+        {"conv_igemm_f32_kernel<64, 64, 2, 2, false>", "conv_igemm_f32_kernel<64, 64, 2, 2, true>"},
+        {"conv_igemm_f32_kernel<128, 32, 4, 1, false>", "conv_igemm_f32_kernel<128, 32, 4, 1, true>"}};
+    return names[conv_variant(d)][conv_vec_a(d, in) ? 1 : 0];
 }

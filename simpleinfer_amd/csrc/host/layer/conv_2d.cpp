@@ -183,6 +183,15 @@ Status Conv2d::Forward(const Tensor& input, Tensor& output) {
     });
 }
 
+const char* Conv2d::KernelName() const {
+    if (input_tensor_nodes_.empty() || output_tensor_nodes_.empty()) return "conv_igemm_f32";
+    const Tensor& in = input_tensor_nodes_[0]->tensor;
+    const Tensor& out = output_tensor_nodes_[0]->tensor;
+    if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
+    const SiConv2dDesc d = MakeDesc(in, out);
+    return si_hip_conv2d_kernel_name(&d, in.Data<float>());
+}
+
 double Conv2d::Flops() const {
     if (output_tensor_nodes_.empty() || groups_ <= 0) return 0.0;
     const Tensor& o = output_tensor_nodes_[0]->tensor;

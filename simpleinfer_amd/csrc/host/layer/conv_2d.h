@@ -28,7 +28,7 @@ public:
 
     virtual Status Forward(const Tensor& input, Tensor& output) override;
 
-    virtual const char* KernelName() const override { return "conv_igemm_f32"; }
+    virtual const char* KernelName() const override;
     virtual double Flops() const override;
     virtual double Bytes() const override;
 

@@ -1,0 +1,62 @@
+"""Batch (data) parallelism over the GPUs of one node: one process per GPU, torch.distributed.
+
+The path shards by image with no halo and no reduction: every rank runs an independent
+Engine on its contiguous slab of the global batch; the only exchange is ONE all-gather of the output
+slabs [B/G, rows, 85] into [B, rows, 85] at the end of a step (RCCL over xGMI on the GPU box, gloo in the
+CPU tests).  Nothing here computes.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous slab [begin, end) of the global batch owned by `rank`; requires even division, because
+    batch is baked into a pnnx model file (reference src/pnnx/ir.cpp:597-651) and every rank loads the
+    same per-rank-batch model."""
+    if global_batch % world != 0:
+        raise ValueError("global batch %d is not divisible by world size %d" % (global_batch, world))
+    per = global_batch // world
+    return rank * per, (rank + 1) * per
+
+
+def init_process_group(backend: str):
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend)
+    return dist
+
+
+def all_gather_slabs(local, gathered=None, group=None):
+    """all-gather `local` [b, ...] into `gathered` [world*b, ...] (rank r's slab at rows r*b..); in place into
+    a preallocated `gathered` when given.  One collective, bucket = the whole slab."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if gathered is None:
+        gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if world == 1:
+        gathered.copy_(local)
+        return gathered
+    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    return gathered
+
+
+class DeviceArrayView:
+    """Zero-copy handle that lets torch wrap an engine-owned device buffer (`__cuda_array_interface__`)."""
+
+    def __init__(self, ptr: int, shape, typestr: str = "<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(int(s) for s in shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2, "strides": None}
+
+
+def as_torch(ptr: int, shape, device_index: int):
+    import torch
+    return torch.as_tensor(DeviceArrayView(ptr, shape), device="cuda:%d" % device_index)
