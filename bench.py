@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--model", default="yolov5s", choices=["yolov5s", "resnet18"])
     ap.add_argument("--graph", type=int, default=0, help="replay Forward() as a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=2, help="images in the CPU baseline sample")
+    ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (reference uses 16 intra-op)")
     ap.add_argument("--profile-passes", type=int, default=3)
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""tools/conv_bench.py -- times si_hip_conv2d_f32 on the distinct conv shapes of a synthesized model
+(default: YOLOv5s 640x640, batch 32) with HIP events, back-to-back launches per shape.
+
+    python tools/conv_bench.py [--batch 32] [--reps 20] [--model yolov5s] [--only 3x3]
+
+Prints one line per distinct shape: count in the graph, kernel instantiation, ms, TFLOP/s, algorithmic GB/s,
+and the share of the model's conv time.  Development tool; not part of the product or the tests.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from simpleinfer_amd import _native, hipops, modelgen as mg  # noqa: E402
+from simpleinfer_amd._native import SiConv2dDesc  # noqa: E402
+
+
+def conv_shapes(builder):
+    shapes = {}
+    for ln in builder.lines:
+        t = ln.split()
+        if t[0] != "nn.Conv2d":
+            continue
+        kv = dict(x.split("=", 1) for x in t[4 + int(t[2]) + int(t[3]):] if "=" in x)
+        n, ci, ih, iw = builder.shapes[t[4]]
+        _, co, oh, ow = builder.shapes[t[5]]
+        k = tuple(int(v) for v in kv["kernel_size"].strip("()").split(","))
+        s = tuple(int(v) for v in kv["stride"].strip("()").split(","))
+        p = tuple(int(v) for v in kv["padding"].strip("()").split(","))
+        key = (n, ih, iw, ci, oh, ow, co, k, s, p, int(kv["groups"]))
+        shapes[key] = shapes.get(key, 0) + 1
+    return shapes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--model", default="yolov5s")
+    ap.add_argument("--only", default="")
+    ap.add_argument("--act", default="silu")
+    args = ap.parse_args()
+    H = _native.hip()
+    b = mg.build_yolov5s(args.batch, args.size) if args.model == "yolov5s" else mg.build_resnet18(args.batch, 224)
+    shapes = conv_shapes(b)
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    H.si_hip_event_create(C.byref(ev0))
+    H.si_hip_event_create(C.byref(ev1))
+    rows = []
+    for key, count in shapes.items():
+        n, ih, iw, ci, oh, ow, co, k, s, p, g = key
+        tag = "%dx%d" % k
+        if args.only and args.only != tag:
+            continue
+        d = SiConv2dDesc(n, ih, iw, ci, ci, oh, ow, co, co, k[0], k[1], s[0], s[1], 1, 1, p[0], p[1], g, 1,
+                         hipops.ACT[args.act], 0, co, 0, 0.0)
+        wn = H.si_hip_conv2d_weight_elems(C.byref(d))
+        rng = np.random.default_rng(0)
+        dx = hipops.DeviceBuffer.from_numpy(rng.random((n, ih, iw, ci), dtype=np.float32))
+        dw = hipops.DeviceBuffer.from_numpy((rng.random(wn, dtype=np.float32) - 0.5) * 0.1)
+        db = hipops.DeviceBuffer.from_numpy(rng.random(co, dtype=np.float32))
+        dy = hipops.DeviceBuffer(n * oh * ow * co * 4)
+        for _ in range(2):
+            rc = H.si_hip_conv2d_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr, None, dy.ptr, None)
+            assert rc == 0, rc
+        H.si_hip_device_sync()
+        H.si_hip_event_record(ev0, None)
+        for _ in range(args.reps):
+            H.si_hip_conv2d_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr, None, dy.ptr, None)
+        H.si_hip_event_record(ev1, None)
+        H.si_hip_event_sync(ev1)
+        ms = C.c_float()
+        H.si_hip_event_elapsed_ms(ev0, ev1, C.byref(ms))
+        ms = ms.value / args.reps
+        flops = 2.0 * n * oh * ow * co * k[0] * k[1] * (ci // g)
+        byts = 4.0 * (n * ih * iw * ci + n * oh * ow * co + wn)
+        name = H.si_hip_conv2d_kernel_name(C.byref(d), dx.ptr).decode().replace("conv_igemm_f32_kernel", "")
+        rows.append((key, count, name, ms, flops / ms / 1e9, byts / ms / 1e6, flops))
+        for buf in (dx, dw, db, dy):
+            buf.free()
+    total = sum(r[3] * r[1] for r in rows)
+    print("%-34s %3s %-24s %8s %8s %9s %6s" % ("in(HxWxC)->out(HxWxC) k/s", "cnt", "kernel", "ms", "TF/s", "GB/s", "share"))
+    for key, count, name, ms, tf, gb, fl in sorted(rows, key=lambda r: -r[3] * r[1]):
+        n, ih, iw, ci, oh, ow, co, k, s, p, g = key
+        print("%-34s %3d %-24s %8.4f %8.1f %9.1f %5.1f%%" % (
+            "%dx%dx%d->%dx%dx%d k%ds%d" % (ih, iw, ci, oh, ow, co, k[0], s[0]), count, name, ms, tf, gb, 100 * ms * count / total))
+    tot_fl = sum(r[6] * r[1] for r in rows)
+    print("total conv time %.3f ms per forward (batch %d) = %.1f TF/s = %.0f img/s conv-only" % (
+        total, args.batch, tot_fl / total / 1e9, args.batch / total * 1e3))
+
+
+if __name__ == "__main__":
+    main()
