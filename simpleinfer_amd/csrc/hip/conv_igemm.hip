@@ -30,6 +30,8 @@
 // tile, not a different sum).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "si_hip.h"
 #include "si_hip_internal.h"
 
@@ -54,6 +56,9 @@ struct ConvArgs {
     int m_tiles, n_tiles;
     int act1, act2;
     float act_param;
+    int cb_major;               // K order: 0 = (tap, c), 1 = (c/32, tap, c%32)
+    int ntaps;                  // kh*kw
+    unsigned in_bytes, w_bytes; // buffer-resource extents for the fast path (tensor < 4 GB)
 };
 
 __device__ __forceinline__ float apply_act(int act, float v, float p) {
@@ -65,6 +70,67 @@ __device__ __forceinline__ float apply_act(int act, float v, float p) {
         case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;
         default: return v;
+    }
+}
+
+// ---- epilogue shared by the kernels.  32x32 C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+// Each store instruction writes two 128-byte row segments (lanes 0-31 / 32-63).  The activation switch
+// is resolved once per workgroup, not per element.
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v, float p) {
+    if (ACT == SI_ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == SI_ACT_SILU) return v / (1.0f + __expf(-v));
+    if (ACT == SI_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
+    if (ACT == SI_ACT_HARDSIGMOID) return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+    if (ACT == SI_ACT_HARDSWISH) return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+    if (ACT == SI_ACT_LEAKYRELU) return v > 0.0f ? v : v * p;
+    return v;
+}
+
+template <int TM, int TN, int ACT1, bool GENERIC>
+__device__ __forceinline__ void epilogue_impl(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0) {
+    const bool has_bias = a.bias != nullptr;
+    const bool has_res = a.res != nullptr;
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = ocol0 + u * 32;  // channel inside the group
+        if (o >= a.ocg) continue;
+        const int oc_abs = g * a.ocg + o;
+        const float bv = has_bias ? a.bias[oc_abs] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int mb = mrow0 + t * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < a.M) {
+                    float v = acc[t][u][e] + bv;
+                    if (GENERIC) {
+                        v = apply_act(a.act1, v, a.act_param);
+                        if (has_res) v += a.res[(size_t)m * a.res_ld + oc_abs];
+                        v = apply_act(a.act2, v, a.act_param);
+                    } else {
+                        v = act_fn<ACT1>(v, a.act_param);
+                        if (has_res) v += a.res[(size_t)m * a.res_ld + oc_abs];
+                    }
+                    a.out[(size_t)m * a.out_ld + oc_abs] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0) {
+    // the two shapes the YOLOv5 / ResNet graphs produce get straight-line code; the rest is generic
+    if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_SILU) {
+        epilogue_impl<TM, TN, SI_ACT_SILU, false>(a, acc, g, mrow0, ocol0);
+    } else if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_NONE) {
+        epilogue_impl<TM, TN, SI_ACT_NONE, false>(a, acc, g, mrow0, ocol0);
+    } else if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_RELU) {
+        epilogue_impl<TM, TN, SI_ACT_RELU, false>(a, acc, g, mrow0, ocol0);
+    } else {
+        epilogue_impl<TM, TN, SI_ACT_NONE, true>(a, acc, g, mrow0, ocol0);
     }
 }
 
@@ -124,8 +190,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
 
     auto load_tile = [&](int kt) {
         const int k = kt * BK + kv * 4;
-        const int tap = k / a.icg_pad;
-        const int c = k - tap * a.icg_pad;
+        int tap, c;
+        if (a.cb_major) {  // k = (cb * ntaps + tap) * 32 + c%32
+            const int blk = k >> 5;
+            const int cb = blk / a.ntaps;
+            tap = blk - cb * a.ntaps;
+            c = cb * 32 + (k & 31);
+        } else {
+            tap = k / a.icg_pad;
+            c = k - tap * a.icg_pad;
+        }
         const int ky = tap / a.kw;
         const int kx = tap - ky * a.kw;
         const bool kvalid = k < a.Kp;
@@ -211,31 +285,174 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue.  32x32 C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    const bool has_bias = a.bias != nullptr;
-    const bool has_res = a.res != nullptr;
+    epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31);
+}
+
+// ---- fast path: ic/groups a multiple of 32, 16-byte aligned tensors smaller than 4 GB -------------------
+// * K runs channel-block major, (c/32, kh, kw, c%32): all taps of one 32-channel block are consumed
+//   back to back, so the 3x3 halo re-reads of a pixel's 128-byte line come 1..3 K-tiles apart and hit L2
+//   instead of 4..12 tiles apart (they were thrashing the 4 MiB XCD L2: 40-60 % hit rate measured).
+// * the tap walk (cb, ky, kx) is wave-uniform scalar code; per row the thread only adds a scalar delta to a
+//   fixed byte offset and looks its tap up in a 64-bit validity mask computed once.
+// * loads are raw buffer loads: an out-of-image tap (or a row past M / past OC) is an out-of-range offset
+//   and the hardware returns zeros -- no branches around the loads.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB_A = 0xFFFFFF00u;  // >= any legal num_records
+constexpr unsigned OOB_B = 0x80000000u;  // weights are < 2 GB; + kt*128 cannot wrap
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int A_IT = BM / 32;
+    constexpr int B_IT = BN / 32;
+
+    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_LD];
+
+    const int g = blockIdx.y;
+    const int per_chunk = 8 * a.n_tiles;
+    const int chunk = blockIdx.x / per_chunk;
+    const int r = blockIdx.x - chunk * per_chunk;
+    const int m_tile = chunk * 8 + (r & 7);
+    const int n_tile = r >> 3;
+    if (m_tile >= a.m_tiles) return;
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * BN;
+
+    const int tid = threadIdx.x;
+    const int kv = tid & 7;
+    const int r0 = tid >> 3;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.in + (size_t)g * a.icg), 0, a.in_bytes - (unsigned)g * a.icg * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w + (size_t)g * a.ocg * a.Kp), 0, (unsigned)a.ocg * a.Kp * 4u, 0x00020000);
+
+    // per-thread A rows: byte offset of (tap 0, channel kv*4) and the tap validity mask
+    unsigned a_off[A_IT];
+    unsigned long long a_mask[A_IT];
 #pragma unroll
-    for (int u = 0; u < TN; ++u) {
-        const int o = n0 + (wn * TN + u) * 32 + l31;  // channel inside the group
-        if (o >= a.ocg) continue;
-        const int oc_abs = g * a.ocg + o;
-        const float bv = has_bias ? a.bias[oc_abs] : 0.0f;
-#pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            const int mb = m0 + (wm * TM + t) * 32 + 4 * lh;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m < a.M) {
-                    float v = acc[t][u][e] + bv;
-                    v = apply_act(a.act1, v, a.act_param);
-                    if (has_res) v += a.res[(size_t)m * a.res_ld + oc_abs];
-                    v = apply_act(a.act2, v, a.act_param);
-                    a.out[(size_t)m * a.out_ld + oc_abs] = v;
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        a_off[i] = 0;
+        a_mask[i] = 0ull;
+        if (m < a.M) {
+            const int img = m / a.ohow;
+            const int rem = m - img * a.ohow;
+            const int oy = rem / a.ow;
+            const int ox = rem - oy * a.ow;
+            const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
+            // modulo-2^32 arithmetic: (tap-0 pixel may lie before the tensor start; adding the tap delta brings
+            // every VALID tap back into [0, in_bytes))
+            a_off[i] = (unsigned)((img * a.ih + y0) * a.iw + x0) * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16);
+            unsigned long long mk = 0ull;
+            for (int ky = 0; ky < a.kh; ++ky)
+                for (int kx = 0; kx < a.kw; ++kx) {
+                    const int y = y0 + ky * a.dh, x = x0 + kx * a.dw;
+                    if ((unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw) mk |= 1ull << (ky * a.kw + kx);
                 }
-            }
+            a_mask[i] = mk;
         }
     }
+    unsigned b_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int o = n0 + r0 + 32 * i;
+        b_off[i] = o < a.ocg ? (unsigned)(o * a.Kp * 4 + kv * 16) : OOB_B;
+    }
+
+    u32x4 pa[A_IT], pb[B_IT];
+    // wave-uniform K walk
+    int cb = 0, ky = 0, kx = 0;
+
+    auto load_tile = [&](int kt) {
+        const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * 32) * 4u;
+        const int tapbit = ky * a.kw + kx;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const bool ok = (a_mask[i] >> tapbit) & 1ull;
+            const unsigned off = ok ? a_off[i] + delta : OOB_A;
+            pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+        }
+        const unsigned kb = (unsigned)kt * (BK * 4);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i] + kb, 0, 0);
+        if (++kx == a.kw) {
+            kx = 0;
+            if (++ky == a.kh) {
+                ky = 0;
+                ++cb;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* As = lds[buf];
+        float* Bs = lds[buf] + BM * LDS_LD;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * LDS_LD + kv * 4) = pa[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * LDS_LD + kv * 4) = pb[i];
+    };
+
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.0f;
+
+    const int nk = a.Kp / BK;  // icg_pad % 32 == 0
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+
+        const float* As = lds[cur] + (wm * TM * 32 + l31) * LDS_LD + lh * 4;
+        const float* Bs = lds[cur] + BM * LDS_LD + (wn * TN * 32 + l31) * LDS_LD + lh * 4;
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f32x4*>(As + t * 32 * LDS_LD + q * 8);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f32x4*>(Bs + u * 32 * LDS_LD + q * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int u = 0; u < TN; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[u][j], acc[t][u], 0, 0, 0);
+        }
+
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
+    ConvArgs b = a;
+    b.m_tiles = (a.M + BM - 1) / BM;
+    b.n_tiles = (a.ocg + BN - 1) / BN;
+    const int chunks = (b.m_tiles + 7) / 8;
+    dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
+    hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, b);
+    return (int)hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -259,6 +476,11 @@ inline int round_up4(int v) { return (v + 3) & ~3; }
 // tile choice: widest N tile the layer fills; drop to 64-row tiles when a 128-row grid would leave
 // most of the 256 CUs idle.  0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
 static int conv_variant(const SiConv2dDesc* d) {
+    static const int forced = [] {
+        const char* e = getenv("SI_CONV_VARIANT");  // development override: 0..3
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0 && forced <= 3) return forced;
     const int ocg = d->oc / d->groups;
     const long long M = (long long)d->n * d->oh * d->ow;
     const long long wg128 = ((M + 127) / 128) * ((ocg + 127) / 128) * d->groups;
@@ -267,6 +489,21 @@ static int conv_variant(const SiConv2dDesc* d) {
         return ocg > 64 ? 0 : 1;
     }
     return 3;
+}
+
+// K order is a property of the weight buffer, so it depends on the layer shape only
+static bool conv_cb_major(const SiConv2dDesc* d) {
+    const int icg = d->ic / d->groups;
+    return (icg % 32 == 0) && (d->kh * d->kw > 1);
+}
+
+static bool conv_fast_ok(const SiConv2dDesc* d, const float* in) {
+    const int icg = d->ic / d->groups;
+    if (icg % 32 != 0 || d->in_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
+    if (d->kh * d->kw > 64) return false;
+    const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull;
+    const unsigned long long w_bytes = (unsigned long long)d->oc * d->kh * d->kw * icg * 4ull;
+    return in_bytes < 0xFFFFFF00ull && w_bytes < 0x40000000ull;
 }
 
 static bool conv_vec_a(const SiConv2dDesc* d, const float* in) {
@@ -283,12 +520,17 @@ extern "C" size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d) {
 extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* w_packed) {
     if (!d || !w_oihw || !w_packed || d->groups <= 0) return SI_E_BADARG;
     const int icg = d->ic / d->groups, icp = round_up4(icg);
+    const int ntaps = d->kh * d->kw;
+    const bool cbm = conv_cb_major(d);
     for (int o = 0; o < d->oc; ++o)
         for (int y = 0; y < d->kh; ++y)
             for (int x = 0; x < d->kw; ++x) {
-                float* dst = w_packed + (((size_t)o * d->kh + y) * d->kw + x) * icp;
-                for (int c = 0; c < icp; ++c)
-                    dst[c] = c < icg ? w_oihw[(((size_t)o * icg + c) * d->kh + y) * d->kw + x] : 0.0f;
+                const int tap = y * d->kw + x;
+                for (int c = 0; c < icp; ++c) {
+                    const float v = c < icg ? w_oihw[(((size_t)o * icg + c) * d->kh + y) * d->kw + x] : 0.0f;
+                    const size_t k = cbm ? ((size_t)(c >> 5) * ntaps + tap) * 32 + (c & 31) : (size_t)tap * icp + c;
+                    w_packed[(size_t)o * ntaps * icp + k] = v;
+                }
             }
     return 0;
 }
@@ -322,6 +564,20 @@ extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const f
     a.ohow = d->oh * d->ow;
     a.m_tiles = a.n_tiles = 0;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
+    a.cb_major = conv_cb_major(d) ? 1 : 0;
+    a.ntaps = d->kh * d->kw;
+    a.in_bytes = 0; a.w_bytes = 0;
+
+    if (conv_fast_ok(d, in)) {
+        a.in_bytes = (unsigned)((unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull);
+        hipStream_t fs = static_cast<hipStream_t>(stream);
+        switch (conv_variant(d)) {
+            case 0: return launch_fast<128, 128, 2, 2>(a, d->groups, fs);
+            case 1: return launch_fast<128, 64, 2, 2>(a, d->groups, fs);
+            case 2: return launch_fast<64, 64, 2, 2>(a, d->groups, fs);
+            default: return launch_fast<128, 32, 4, 1>(a, d->groups, fs);
+        }
+    }
 
     const bool vec_a = conv_vec_a(d, in);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -341,5 +597,8 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         {"conv_igemm_f32_kernel<128, 64, 2, 2, false>", "conv_igemm_f32_kernel<128, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<64, 64, 2, 2, false>", "conv_igemm_f32_kernel<64, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<128, 32, 4, 1, false>", "conv_igemm_f32_kernel<128, 32, 4, 1, true>"}};
+    static const char* fast_names[4] = {"conv_igemm_f32_fast_kernel<128, 128, 2, 2>", "conv_igemm_f32_fast_kernel<128, 64, 2, 2>",
+                                        "conv_igemm_f32_fast_kernel<64, 64, 2, 2>", "conv_igemm_f32_fast_kernel<128, 32, 4, 1>"};
+    if (conv_fast_ok(d, in)) return fast_names[conv_variant(d)];
     return names[conv_variant(d)][conv_vec_a(d, in) ? 1 : 0];
 }
