@@ -59,6 +59,7 @@ struct ConvArgs {
     int cb_major;               // K order: 0 = (tap, c), 1 = (c/32, tap, c%32)
     int ntaps;                  // kh*kw
     unsigned in_bytes, w_bytes; // buffer-resource extents for the fast path (tensor < 4 GB)
+    int ablate;                 // timing experiments only (SI_CONV_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
 };
 
 __device__ __forceinline__ float apply_act(int act, float v, float p) {
@@ -300,15 +301,18 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB_A = 0xFFFFFF00u;  // >= any legal num_records
 constexpr unsigned OOB_B = 0x80000000u;  // weights are < 2 GB; + kt*128 cannot wrap
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBUF>
 __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int A_IT = BM / 32;
     constexpr int B_IT = BN / 32;
 
-    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDS_LD];
+    // NBUF = 2: one barrier per K-tile.  NBUF = 1: half the LDS (more workgroups per CU), two barriers
+    // per K-tile; the other resident workgroups cover them.
+    __shared__ __attribute__((aligned(16))) float lds[NBUF][(BM + BN) * LDS_LD];
 
     const int g = blockIdx.y;
     const int per_chunk = 8 * a.n_tiles;
@@ -416,8 +420,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        const int cur = NBUF == 2 ? (kt & 1) : 0;
+        if (kt + 1 < nk && !(a.ablate & 1)) load_tile(kt + 1);
 
         const float* As = lds[cur] + (wm * TM * 32 + l31) * LDS_LD + lh * 4;
         const float* Bs = lds[cur] + BM * LDS_LD + (wn * TN * 32 + l31) * LDS_LD + lh * 4;
@@ -437,21 +441,29 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[u][j], acc[t][u], 0, 0, 0);
         }
 
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
+        if (NBUF == 2) {
+            if (kt + 1 < nk && !(a.ablate & 2)) store_tile(cur ^ 1);
+            if (!(a.ablate & 4)) __syncthreads();
+        } else {
+            __syncthreads();  // everyone is done reading tile kt
+            if (kt + 1 < nk) {
+                store_tile(0);
+                __syncthreads();
+            }
+        }
     }
 
     epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NBUF>
 int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
     ConvArgs b = a;
     b.m_tiles = (a.M + BM - 1) / BM;
     b.n_tiles = (a.ocg + BN - 1) / BN;
     const int chunks = (b.m_tiles + 7) / 8;
     dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
-    hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, b);
+    hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), 0, s, b);
     return (int)hipGetLastError();
 }
 
@@ -473,22 +485,22 @@ inline int round_up4(int v) { return (v + 3) & ~3; }
 
 }  // namespace
 
-// tile choice: widest N tile the layer fills; drop to 64-row tiles when a 128-row grid would leave
-// most of the 256 CUs idle.  0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32
+// Tile choice.  Measured on MI355X over every YOLOv5s / ResNet18 conv shape at batch 32
+// (tools/conv_bench.py, SI_CONV_VARIANT sweep, profiles/r01_conv_variants.txt): the fp32 MFMA is slow
+// enough (64 cycles per 32x32x2) that operand reuse is not the limit -- residency is.  A 64x64 tile with
+// ONE LDS stage (18 KB) lets 7-8 workgroups share a CU, which hides HBM/L2 latency and evens out the tail
+// when a layer only has a few hundred tiles; it beats the 128x128 double-buffered tile on every shape
+// (6.7 ms vs 10.6 ms summed over the net).  Layers with <= 32 output channels use 128x32.
+//   id: 0 128x128x2  1 128x64x2  2 64x64x2  3 128x32x2  4 64x64x1  5 64x128x1  6 128x64x1  7 128x128x1
+//       8 64x128x2  10 128x32x1        (BM x BN x LDS stages)
 static int conv_variant(const SiConv2dDesc* d) {
     static const int forced = [] {
-        const char* e = getenv("SI_CONV_VARIANT");  // development override: 0..3
+        const char* e = getenv("SI_CONV_VARIANT");  // development override
         return e ? atoi(e) : -1;
     }();
-    if (forced >= 0 && forced <= 3) return forced;
+    if (forced >= 0 && forced <= 10) return forced;
     const int ocg = d->oc / d->groups;
-    const long long M = (long long)d->n * d->oh * d->ow;
-    const long long wg128 = ((M + 127) / 128) * ((ocg + 127) / 128) * d->groups;
-    if (ocg > 32) {
-        if (wg128 < 192 && M > 64) return 2;
-        return ocg > 64 ? 0 : 1;
-    }
-    return 3;
+    return ocg <= 32 ? 10 : 4;
 }
 
 // K order is a property of the weight buffer, so it depends on the layer shape only
@@ -567,15 +579,26 @@ extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const f
     a.cb_major = conv_cb_major(d) ? 1 : 0;
     a.ntaps = d->kh * d->kw;
     a.in_bytes = 0; a.w_bytes = 0;
+    static const int ablate = [] {
+        const char* e = getenv("SI_CONV_ABLATE");
+        return e ? atoi(e) : 0;
+    }();
+    a.ablate = ablate;
 
     if (conv_fast_ok(d, in)) {
         a.in_bytes = (unsigned)((unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull);
         hipStream_t fs = static_cast<hipStream_t>(stream);
         switch (conv_variant(d)) {
-            case 0: return launch_fast<128, 128, 2, 2>(a, d->groups, fs);
-            case 1: return launch_fast<128, 64, 2, 2>(a, d->groups, fs);
-            case 2: return launch_fast<64, 64, 2, 2>(a, d->groups, fs);
-            default: return launch_fast<128, 32, 4, 1>(a, d->groups, fs);
+            case 0: return launch_fast<128, 128, 2, 2, 2>(a, d->groups, fs);
+            case 1: return launch_fast<128, 64, 2, 2, 2>(a, d->groups, fs);
+            case 2: return launch_fast<64, 64, 2, 2, 2>(a, d->groups, fs);
+            case 3: return launch_fast<128, 32, 4, 1, 2>(a, d->groups, fs);
+            case 4: return launch_fast<64, 64, 2, 2, 1>(a, d->groups, fs);
+            case 5: return launch_fast<64, 128, 2, 2, 1>(a, d->groups, fs);
+            case 6: return launch_fast<128, 64, 2, 2, 1>(a, d->groups, fs);
+            case 7: return launch_fast<128, 128, 2, 2, 1>(a, d->groups, fs);
+            case 8: return launch_fast<64, 128, 2, 2, 2>(a, d->groups, fs);
+            default: return launch_fast<128, 32, 4, 1, 1>(a, d->groups, fs);
         }
     }
 
@@ -583,9 +606,9 @@ extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const f
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int G = d->groups;
     switch (conv_variant(d)) {
-        case 0: return launch<128, 128, 2, 2>(a, G, vec_a, s);
-        case 1: return launch<128, 64, 2, 2>(a, G, vec_a, s);
-        case 2: return launch<64, 64, 2, 2>(a, G, vec_a, s);
+        case 0: case 7: return launch<128, 128, 2, 2>(a, G, vec_a, s);
+        case 1: case 6: return launch<128, 64, 2, 2>(a, G, vec_a, s);
+        case 2: case 4: case 5: case 8: return launch<64, 64, 2, 2>(a, G, vec_a, s);
         default: return launch<128, 32, 4, 1>(a, G, vec_a, s);
     }
 }
@@ -597,8 +620,15 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         {"conv_igemm_f32_kernel<128, 64, 2, 2, false>", "conv_igemm_f32_kernel<128, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<64, 64, 2, 2, false>", "conv_igemm_f32_kernel<64, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<128, 32, 4, 1, false>", "conv_igemm_f32_kernel<128, 32, 4, 1, true>"}};
-    static const char* fast_names[4] = {"conv_igemm_f32_fast_kernel<128, 128, 2, 2>", "conv_igemm_f32_fast_kernel<128, 64, 2, 2>",
-                                        "conv_igemm_f32_fast_kernel<64, 64, 2, 2>", "conv_igemm_f32_fast_kernel<128, 32, 4, 1>"};
-    if (conv_fast_ok(d, in)) return fast_names[conv_variant(d)];
-    return names[conv_variant(d)][conv_vec_a(d, in) ? 1 : 0];
+    static const char* fast_names[11] = {
+        "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 2>", "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 2>",
+        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 2>",   "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 2>",
+        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1>",   "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 1>",
+        "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 1>",  "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 1>",
+        "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 2>",  "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>",
+        "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>"};
+    const int v = conv_variant(d);
+    if (conv_fast_ok(d, in)) return fast_names[v];
+    static const int generic_of[11] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3};
+    return names[generic_of[v]][conv_vec_a(d, in) ? 1 : 0];
 }

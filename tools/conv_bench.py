@@ -46,10 +46,17 @@ def main():
     ap.add_argument("--model", default="yolov5s")
     ap.add_argument("--only", default="")
     ap.add_argument("--act", default="silu")
+    ap.add_argument("--shape", action="append", default=[], help="n,h,w,ci,co,k,s,p (repeatable): custom shapes instead of a model")
     args = ap.parse_args()
     H = _native.hip()
     b = mg.build_yolov5s(args.batch, args.size) if args.model == "yolov5s" else mg.build_resnet18(args.batch, 224)
     shapes = conv_shapes(b)
+    if args.shape:
+        shapes = {}
+        for sp in args.shape:
+            n, h, w, ci, co, k, st, pd = (int(v) for v in sp.split(","))
+            oh, ow = (h + 2 * pd - k) // st + 1, (w + 2 * pd - k) // st + 1
+            shapes[(n, h, w, ci, oh, ow, co, (k, k), (st, st), (pd, pd), 1)] = 1
     ev0, ev1 = C.c_void_p(), C.c_void_p()
     H.si_hip_event_create(C.byref(ev0))
     H.si_hip_event_create(C.byref(ev1))
