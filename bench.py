@@ -131,7 +131,10 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    # SI_BENCH_FORCE_DIST=1 runs the N>1 code path (process group, zero-copy wrap of the engine's output buffer,
+    # RCCL all-gather) even at world size 1, so that path can be exercised on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("SI_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch  # plumbing only: process group, barrier, the RCCL all-gather
         torch.cuda.set_device(dev)
         dist = sd.init_process_group("nccl")
@@ -154,7 +157,7 @@ def main():
         oshape = e.operand_shape(oname)
 
         gathered = local_view = None
-        if world > 1:
+        if use_dist:
             e.forward()
             optr, _ = e.extract_ptr(oname)
             local_view = sd.as_torch(optr, oshape, dev)
@@ -162,11 +165,11 @@ def main():
 
         def step():
             e.forward()  # synchronous: kernels of this step are done when it returns
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(gathered, local_view)
 
         def fence():
-            if world > 1:
+            if use_dist:
                 dist.barrier()
                 torch.cuda.synchronize()
             H.si_hip_device_sync()
@@ -181,7 +184,11 @@ def main():
             fwd_ms += e.last_forward_ms()
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
+            # the gathered buffer must hold this rank's slab at its rank offset, bit for bit
+            b0 = rank * oshape[0]
+            if not torch.equal(gathered[b0:b0 + oshape[0]], local_view):
+                sys.exit("bench.py: all-gather result does not match the local output slab")
             tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -203,7 +210,7 @@ def main():
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args, mg, td)
 
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     if rank != 0:

@@ -38,6 +38,12 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// conv_smallc.hip: stem kernel for 1..3 input channels
+bool si_conv_smallc_ok(const SiConv2dDesc* d);
+const char* si_conv_smallc_name(const SiConv2dDesc* d);
+int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                          const float* residual, float* out, hipStream_t s);
+
 namespace {
 
 struct ConvArgs {
@@ -557,6 +563,12 @@ extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const f
     if ((long long)d->n * d->oh * d->ow > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     if ((long long)d->n * d->ih * d->iw > 0x7fffffffLL) return SI_E_UNSUPPORTED;
 
+    static const bool no_smallc = getenv("SI_CONV_NO_SMALLC") != nullptr;  // development switch
+    if (!no_smallc && si_conv_smallc_ok(d)) {
+        const int rc = si_conv_smallc_launch(d, in, w_packed, bias, residual, out, static_cast<hipStream_t>(stream));
+        if (rc != SI_E_UNSUPPORTED) return rc;
+    }
+
     ConvArgs a;
     a.in = in;
     a.w = w_packed;
@@ -628,6 +640,8 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 2>",  "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>",
         "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>"};
     const int v = conv_variant(d);
+    static const bool no_smallc = getenv("SI_CONV_NO_SMALLC") != nullptr;
+    if (!no_smallc && si_conv_smallc_ok(d)) return si_conv_smallc_name(d);
     if (conv_fast_ok(d, in)) return fast_names[v];
     static const int generic_of[11] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3};
     return names[generic_of[v]][conv_vec_a(d, in) ? 1 : 0];
