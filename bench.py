@@ -89,7 +89,7 @@ def roofline_from_profile(passes):
     agg = {}
     for layers in passes:
         for L in layers:
-            if not L["kernel"].startswith("conv_igemm") or L["flops"] <= 0 or L["type"] == "models.yolo.Detect":
+            if not L["kernel"].startswith("conv_") or L["flops"] <= 0 or L["type"] == "models.yolo.Detect":
                 continue
             a = agg.setdefault(L["kernel"], {"ms": 0.0, "flops": 0.0, "launches": 0})
             a["ms"] += L["ms"]
@@ -137,7 +137,7 @@ def main():
     if use_dist:
         import torch  # plumbing only: process group, barrier, the RCCL all-gather
         torch.cuda.set_device(dev)
-        dist = sd.init_process_group("nccl")
+        dist = sd.init_process_group("nccl", device_index=dev)
     H.si_hip_set_device(dev)
 
     mg = si.modelgen
@@ -213,6 +213,8 @@ def main():
         if use_dist:
             dist.barrier()
 
+    if use_dist:
+        dist.destroy_process_group()
     if rank != 0:
         return
     imgs = args.batch * world * args.steps

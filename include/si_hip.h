@@ -116,6 +116,20 @@ int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_pac
  * it, minus the namespace), so profiles can be joined with per-layer timings */
 const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);
 
+/* Detect level in one launch: conv (normally the 1x1 of YoloDetect, src/layer/yolo_detect.cpp:214) with the sigmoid /
+ * grid / anchor decode of si_hip_yolo_decode_f32 and the concat into detect_out [n][rows_total][ne] done in the
+ * conv epilogue -- the conv output never goes to HBM.  d->oc must equal na*ne; d->out_ld is ignored.  Returns
+ * SI_E_UNSUPPORTED when the shape is not eligible for the fast kernel (caller then runs conv + decode). */
+typedef struct SiYoloLevel {
+    int na, ne;       /* anchors per cell, elements per anchor (85) */
+    int rows_total;   /* rows of the detect tensor per image (25200) */
+    int row_off;      /* first row of this level */
+    float stride;
+} SiYoloLevel;
+int si_hip_conv2d_yolo_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                           const SiYoloLevel* level, const float* grid_hwa2, const float* anchor_hwa2,
+                           float* detect_out, si_stream_t stream);
+
 /* ---- Linear ------------------------------------------------------------ */
 /* y[n,out] = x[n,in] W[out,in]^T + b   (src/layer/linear.cpp:74-117) */
 int si_hip_linear_f32(const float* x, int n, int in_features, const float* w, const float* bias, int out_features,

@@ -35,6 +35,10 @@ class SiConv2dDesc(C.Structure):
                  "pt", "pl", "groups", "has_bias", "act1", "has_residual", "res_ld", "act2")] + [("act_param", C.c_float)]
 
 
+class SiYoloLevel(C.Structure):
+    _fields_ = [("na", C.c_int), ("ne", C.c_int), ("rows_total", C.c_int), ("row_off", C.c_int), ("stride", C.c_float)]
+
+
 class SiPool2dDesc(C.Structure):
     _fields_ = [(k, C.c_int) for k in
                 ("n", "ih", "iw", "c", "in_ld", "oh", "ow", "out_ld", "kh", "kw", "sh", "sw", "dh", "dw", "pt", "pl")]
@@ -79,6 +83,7 @@ def hip():
         "si_hip_conv2d_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
+        "si_hip_conv2d_yolo_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),
         "si_hip_conv2d_kernel_name": (C.c_char_p, [C.POINTER(SiConv2dDesc), vp]),
         "si_hip_linear_f32": (i, [vp, i, i, vp, vp, i, vp, vp]),
         "si_hip_maxpool2d_f32": (i, [C.POINTER(SiPool2dDesc), vp, vp, vp]),

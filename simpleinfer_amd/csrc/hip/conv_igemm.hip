@@ -66,6 +66,11 @@ struct ConvArgs {
     int ntaps;                  // kh*kw
     unsigned in_bytes, w_bytes; // buffer-resource extents for the fast path (tensor < 4 GB)
     int ablate;                 // timing experiments only (SI_CONV_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
+    // YOLOv5 Detect decode fused into the epilogue (ymode != 0): out is the [N][rows_total][ne] detect tensor
+    int ymode, yna, yne, yrows_total, yrow_off;
+    float ystride;
+    const float* ygrid;         // [oh*ow*na][2]
+    const float* yanchor;       // [oh*ow*na][2]
 };
 
 __device__ __forceinline__ float apply_act(int act, float v, float p) {
@@ -127,8 +132,52 @@ __device__ __forceinline__ void epilogue_impl(const ConvArgs& a, f32x16 (&acc)[T
     }
 }
 
+// Detect head: sigmoid, grid / anchor decode and the concat into [N][rows_total][ne] in the conv epilogue
+// (reference src/layer/yolo_detect.cpp:223-266).  Output channel o = anchor*ne + e; pixel (y,x) of level rows
+// [H][W][anchor], so one pixel's na*ne outputs are contiguous: offset = ((img*rows_total + row_off + pix*na)*ne + o.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_yolo(const ConvArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int ocol0) {
+    const int per_pix = a.yna * a.yne;
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = ocol0 + u * 32;
+        if (o >= a.ocg) continue;
+        const float bv = a.bias ? a.bias[o] : 0.0f;
+        const int anc = o / a.yne;
+        const int e_ = o - anc * a.yne;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int mb = mrow0 + t * 32;
+            const int img0 = mb / a.ohow;
+            const int pix0 = mb - img0 * a.ohow;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dm = (e & 3) + 8 * (e >> 2);
+                if (mb + dm < a.M) {
+                    int pix = pix0 + dm, img = img0;
+                    if (pix >= a.ohow) { pix -= a.ohow; ++img; }
+                    const float sg = 1.0f / (1.0f + __expf(-(acc[t][u][e] + bv)));
+                    const size_t row = (size_t)pix * a.yna + anc;
+                    float v = sg;
+                    if (e_ < 2) {
+                        v = (sg * 2.0f + a.ygrid[row * 2 + e_]) * a.ystride;
+                    } else if (e_ < 4) {
+                        const float t2 = sg * 2.0f;
+                        v = t2 * t2 * a.yanchor[row * 2 + (e_ - 2)];
+                    }
+                    a.out[((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix * per_pix + o] = v;
+                }
+            }
+        }
+    }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0) {
+    if (a.ymode) {
+        epilogue_yolo<TM, TN>(a, acc, mrow0, ocol0);
+        return;
+    }
     // the two shapes the YOLOv5 / ResNet graphs produce get straight-line code; the rest is generic
     if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_SILU) {
         epilogue_impl<TM, TN, SI_ACT_SILU, false>(a, acc, g, mrow0, ocol0);
@@ -553,8 +602,9 @@ extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float
     return 0;
 }
 
-extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
-                                 const float* residual, float* out, si_stream_t stream) {
+static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                           const float* residual, float* out, si_stream_t stream, const SiYoloLevel* yolo,
+                           const float* ygrid, const float* yanchor) {
     if (!d || !in || !w_packed || !out) return SI_E_BADARG;
     if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return SI_E_BADARG;
     if (d->n <= 0 || d->oh <= 0 || d->ow <= 0) return SI_E_BADARG;
@@ -564,7 +614,7 @@ extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const f
     if ((long long)d->n * d->ih * d->iw > 0x7fffffffLL) return SI_E_UNSUPPORTED;
 
     static const bool no_smallc = getenv("SI_CONV_NO_SMALLC") != nullptr;  // development switch
-    if (!no_smallc && si_conv_smallc_ok(d)) {
+    if (!yolo && !no_smallc && si_conv_smallc_ok(d)) {
         const int rc = si_conv_smallc_launch(d, in, w_packed, bias, residual, out, static_cast<hipStream_t>(stream));
         if (rc != SI_E_UNSUPPORTED) return rc;
     }
@@ -596,6 +646,13 @@ extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const f
         return e ? atoi(e) : 0;
     }();
     a.ablate = ablate;
+    a.ymode = 0; a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.f; a.ygrid = a.yanchor = nullptr;
+    if (yolo) {
+        // the decode epilogue lives in the fast kernel only; the layer falls back to conv + decode otherwise
+        if (!conv_fast_ok(d, in) || d->groups != 1 || d->has_residual || yolo->na * yolo->ne != d->oc) return SI_E_UNSUPPORTED;
+        a.ymode = 1; a.yna = yolo->na; a.yne = yolo->ne; a.yrows_total = yolo->rows_total; a.yrow_off = yolo->row_off;
+        a.ystride = yolo->stride; a.ygrid = ygrid; a.yanchor = yanchor;
+    }
 
     if (conv_fast_ok(d, in)) {
         a.in_bytes = (unsigned)((unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull);
@@ -623,6 +680,18 @@ extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const f
         case 2: case 4: case 5: case 8: return launch<64, 64, 2, 2>(a, G, vec_a, s);
         default: return launch<128, 32, 4, 1>(a, G, vec_a, s);
     }
+}
+
+extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                                 const float* residual, float* out, si_stream_t stream) {
+    return conv2d_dispatch(d, in, w_packed, bias, residual, out, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int si_hip_conv2d_yolo_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                                      const SiYoloLevel* level, const float* grid_hwa2, const float* anchor_hwa2,
+                                      float* detect_out, si_stream_t stream) {
+    if (!level || !grid_hwa2 || !anchor_hwa2 || level->ne < 4 || level->na <= 0) return SI_E_BADARG;
+    return conv2d_dispatch(d, in, w_packed, bias, nullptr, detect_out, stream, level, grid_hwa2, anchor_hwa2);
 }
 
 extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in) {

@@ -6,6 +6,7 @@
 #include "layer/binary_op.h"
 #include "layer/cat.h"
 #include "layer/conv_2d.h"
+#include "layer/yolo_detect.h"
 #include "layer_registry.h"
 #include "logger.h"
 #include "pnnx/expand_expression.h"
@@ -204,6 +205,7 @@ Status EngineImpl::CreateLayers() {
             return ret;
         }
         layer->SetContext(context_);
+        if (YoloDetect* yd = dynamic_cast<YoloDetect*>(layer)) yd->fuse_decode_ = opt_fuse_;
 
         std::vector<TensorNode*> ins, outs;
         for (pnnx::Operand* r : op->inputs) {

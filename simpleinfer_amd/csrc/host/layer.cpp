@@ -111,8 +111,9 @@ Status Layer::RunOnDevice(const std::vector<const Tensor*>& inputs, const std::v
             continue;
         }
         if (nullptr == t.RawData()) return Status::kEmpty;
-        din[i] = Tensor(t.GetDataType(), t.Shape(), MemoryType::kDevice, true);
-        if (nullptr == din[i].RawData()) return Status::kFail;
+        // Tensor assignment aliases (reference semantics), so allocate in place: din[i] must own the staging buffer
+        din[i] = Tensor(t.GetDataType(), t.Shape(), MemoryType::kDevice, false);
+        CHECK_STATUS(din[i].Allocate());
         CHECK_STATUS(CheckHip(si_hip_memcpy_h2d(din[i].RawData(), t.RawData(), t.ByteSize(), s), "h2d"));
     }
     for (size_t i = 0; i < outputs.size(); ++i) {
@@ -122,8 +123,8 @@ Status Layer::RunOnDevice(const std::vector<const Tensor*>& inputs, const std::v
             continue;
         }
         if (nullptr == t.RawData()) return Status::kEmpty;
-        dout[i] = Tensor(t.GetDataType(), t.Shape(), MemoryType::kDevice, true);
-        if (nullptr == dout[i].RawData()) return Status::kFail;
+        dout[i] = Tensor(t.GetDataType(), t.Shape(), MemoryType::kDevice, false);
+        CHECK_STATUS(dout[i].Allocate());
     }
     CHECK_STATUS(fn(din, dout));
     for (size_t i = 0; i < outputs.size(); ++i) {

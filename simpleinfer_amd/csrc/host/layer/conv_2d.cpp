@@ -175,6 +175,22 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
                     "conv2d");
 }
 
+// Detect-head variant: device tensors only (called by YoloDetect inside its own RunOnDevice scope)
+Status Conv2d::ForwardYolo(const Tensor& input, const SiYoloLevel& level, const float* grid_dev, const float* anchor_dev,
+                           Tensor& detect_out) {
+    CHECK_STATUS(PrepareDevice());
+    Dims4 in;
+    if (!GetDims4(input, in) || in.c != in_channels_) return Status::kErrorShape;
+    if (input.GetMemoryType() != MemoryType::kDevice || detect_out.GetMemoryType() != MemoryType::kDevice) return Status::kUnsupport;
+    Tensor conv_out(DataType::kFloat32, {in.n, in.h, in.w, out_channels_}, MemoryType::kDevice, false);  // shape only
+    SiConv2dDesc d = MakeDesc(input, conv_out);
+    d.act1 = d.act2 = SI_ACT_NONE;
+    const int rc = si_hip_conv2d_yolo_f32(&d, input.Data<float>(), weight_dev_.As<float>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                          &level, grid_dev, anchor_dev, detect_out.Data<float>(), Stream());
+    if (rc == SI_E_UNSUPPORTED) return Status::kUnsupport;
+    return CheckHip(rc, "conv2d+yolo");
+}
+
 Status Conv2d::Forward(const Tensor& input, Tensor& output) {
     std::vector<const Tensor*> ins{&input};
     if (residual_node_) ins.push_back(&residual_node_->tensor);

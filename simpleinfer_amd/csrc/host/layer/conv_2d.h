@@ -42,6 +42,10 @@ public:
 
     Status PrepareDevice();
 
+    // conv + YOLOv5 decode epilogue, writing into the Detect output (kUnsupport: shape not eligible)
+    Status ForwardYolo(const Tensor& input, const SiYoloLevel& level, const float* grid_dev, const float* anchor_dev,
+                       Tensor& detect_out);
+
 public:
     enum class PaddingMode { kZeros = 0, kReplicate, kReflect } padding_mode_ = PaddingMode::kZeros;
     int padding_t_    = 0;

@@ -138,6 +138,18 @@ Status YoloDetect::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
         for (int i = 0; i < num_spatial_sizes; ++i) {
             Dims4 d;
             if (!GetDims4(in[i], d) || d.h != level_h_[i] || d.w != level_w_[i]) return Status::kErrorShape;
+            if (fuse_decode_) {
+                // one launch: 1x1 conv with the decode + concat in its epilogue
+                SiYoloLevel lv;
+                lv.na = num_anchor_grid_levels_; lv.ne = num_classes_info_; lv.rows_total = rows_total; lv.row_off = row_off;
+                lv.stride = strides_[i];
+                const Status fs = conv_2d_layer_[i].ForwardYolo(in[i], lv, grids_dev_[i].As<float>(), anchor_grids_dev_[i].As<float>(), out[0]);
+                if (fs == Status::kSuccess) {
+                    row_off += d.h * d.w * num_anchor_grid_levels_;
+                    continue;
+                }
+                if (fs != Status::kUnsupport) return fs;
+            }
             CHECK_STATUS(spatial_output[i].Allocate(DataType::kFloat32, {d.n, d.h, d.w, num_elements_}));
             CHECK_STATUS(conv_2d_layer_[i].Forward(in[i], spatial_output[i]));
             CHECK_STATUS(CheckHip(si_hip_yolo_decode_f32(spatial_output[i].Data<float>(), d.n, d.h, d.w, num_anchor_grid_levels_,

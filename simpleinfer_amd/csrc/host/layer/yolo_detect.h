@@ -19,7 +19,7 @@ public:
     virtual Status Deinit() override;
     virtual Status Validate() override;
     virtual Status Forward(const std::vector<Tensor>& inputs, Tensor& output) override;
-    virtual const char* KernelName() const override { return "conv_igemm_f32+yolo_decode"; }
+    virtual const char* KernelName() const override { return fuse_decode_ ? "conv_igemm_f32(yolo epilogue)" : "conv_igemm_f32+yolo_decode"; }
     virtual double Flops() const override;
 
 public:
@@ -39,6 +39,8 @@ public:
     int num_elements_           = 255;
     int num_anchor_grid_levels_ = 3;
     int num_classes_info_       = 85;
+
+    bool fuse_decode_ = true;  // decode + concat in the conv epilogue (engine option "fuse")
 
 private:
     DeviceBuffer grids_dev_[num_spatial_sizes], anchor_grids_dev_[num_spatial_sizes];

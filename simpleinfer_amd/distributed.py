@@ -25,12 +25,16 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
-def init_process_group(backend: str):
+def init_process_group(backend: str, device_index: int = None):
+    import torch
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend)
+        kw = {}
+        if backend == "nccl" and device_index is not None:
+            kw["device_id"] = torch.device("cuda", device_index)
+        dist.init_process_group(backend=backend, **kw)
     return dist
 
 

@@ -226,9 +226,12 @@ def flatten_nhwc(x):
     return dy.to_numpy((n, c * h * w))
 
 
-def yolo_detect(feats, weights, biases, grids, anchor_grids, strides, na=3):
-    """Detect head exactly as the YoloDetect layer runs it: per level 1x1 conv kernel + decode kernel."""
+def yolo_detect(feats, weights, biases, grids, anchor_grids, strides, na=3, fused=False):
+    """Detect head exactly as the YoloDetect layer runs it: per level 1x1 conv kernel + decode kernel, or (fused)
+    si_hip_conv2d_yolo_f32 -- the conv with the decode + concat in its epilogue."""
     H = _native.hip()
+    if fused:
+        return _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na)
     feats = [_f32(f) for f in feats]
     n = feats[0].shape[0]
     ne = weights[0].shape[0] // na
@@ -243,6 +246,33 @@ def yolo_detect(feats, weights, biases, grids, anchor_grids, strides, na=3):
         dc, dg, da = DeviceBuffer.from_numpy(conv), DeviceBuffer.from_numpy(g2), DeviceBuffer.from_numpy(a2)
         _chk(H.si_hip_yolo_decode_f32(dc.ptr, n, h, wd, na, ne, dg.ptr, da.ptr, float(s), dout.ptr, rows_total, off, None),
              "si_hip_yolo_decode_f32")
+        sync()
+        off += h * wd * na
+    return dout.to_numpy((n, rows_total, ne))
+
+
+def _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na):
+    from ._native import SiYoloLevel
+    H = _native.hip()
+    feats = [_f32(f) for f in feats]
+    n = feats[0].shape[0]
+    ne = weights[0].shape[0] // na
+    rows_total = sum(f.shape[1] * f.shape[2] * na for f in feats)
+    dout = DeviceBuffer(n * rows_total * ne * 4)
+    dout.fill(0)
+    off = 0
+    for f, w, b, g, a, s in zip(feats, weights, biases, grids, anchor_grids, strides):
+        _, h, wd, cin = f.shape
+        w = _f32(w)
+        d = SiConv2dDesc(n, h, wd, cin, cin, h, wd, na * ne, na * ne, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, na * ne, 0, 0.0)
+        packed = np.zeros(H.si_hip_conv2d_weight_elems(C.byref(d)), np.float32)
+        _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack")
+        g2 = _f32(np.transpose(_f32(g)[0], (1, 2, 0, 3)))
+        a2 = _f32(np.transpose(_f32(a)[0], (1, 2, 0, 3)))
+        bufs = [DeviceBuffer.from_numpy(v) for v in (f, packed, _f32(b), g2, a2)]
+        lv = SiYoloLevel(na, ne, rows_total, off, float(s))
+        _chk(H.si_hip_conv2d_yolo_f32(C.byref(d), bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, C.byref(lv), bufs[3].ptr, bufs[4].ptr,
+                                      dout.ptr, None), "si_hip_conv2d_yolo_f32")
         sync()
         off += h * wd * na
     return dout.to_numpy((n, rows_total, ne))

@@ -223,5 +223,6 @@ def test_yolo_detect_head(hops, orc):
         grids.append(np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, h, h, 2)).copy())
         anchors.append(np.broadcast_to(rng_uniform(80 + i, (1, na, 1, 1, 2), 5, 300), (1, na, h, h, 2)).copy())
     strides = [8.0, 16.0, 32.0]
-    assert_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na),
-                  orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na))
+    ref = orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na)
+    assert_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na), ref, what="conv + decode kernels")
+    assert_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na, fused=True), ref, what="decode fused in conv epilogue")
