@@ -104,7 +104,11 @@ typedef struct SiConv2dDesc {
 /* Weight layout expected by the kernels: [oc][kh][kw][icg_pad] ("OHWI",
  * K = kh*kw*icg_pad contiguous per output channel), icg_pad = ic/groups
  * rounded up to a multiple of 4 when ic/groups is not one (zero filled), so
- * that every 16-byte K-vector stays inside one (kh,kw) tap.
+ * that every 16-byte K-vector stays inside one (kh,kw) tap.  (Stem shapes -- 1..3 input channels, see
+ * csrc/hip/conv_smallc.hip -- use a transposed [kh][kw*ic padded][oc padded] image instead; callers never
+ * need to know: always size with si_hip_conv2d_weight_elems and fill with si_hip_conv2d_pack_weight_host, passing
+ * a descriptor whose ic, oc, kh, kw, sh, sw, dh, dw, groups equal the ones used at launch -- the layout is a function
+ * of exactly those fields.)
  * si_hip_conv2d_weight_elems returns the element count of that layout and
  * si_hip_conv2d_pack_weight_host re-lays an OIHW host tensor (the pnnx
  * attribute layout; replaces the OIHW->HWIO shuffle of conv_2d.cpp:126-150). */

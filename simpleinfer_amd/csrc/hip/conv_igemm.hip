@@ -40,6 +40,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // conv_smallc.hip: stem kernel for 1..3 input channels
 bool si_conv_smallc_ok(const SiConv2dDesc* d);
+size_t si_conv_smallc_weight_elems(const SiConv2dDesc* d);
+void si_conv_smallc_pack(const SiConv2dDesc* d, const float* w_oihw, float* w_packed);
 const char* si_conv_smallc_name(const SiConv2dDesc* d);
 int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
                           const float* residual, float* out, hipStream_t s);
@@ -155,7 +157,11 @@ __device__ __forceinline__ void epilogue_yolo(const ConvArgs& a, f32x16 (&acc)[T
                 const int dm = (e & 3) + 8 * (e >> 2);
                 if (mb + dm < a.M) {
                     int pix = pix0 + dm, img = img0;
-                    if (pix >= a.ohow) { pix -= a.ohow; ++img; }
+                    if (pix >= a.ohow) {  // tile rows may span several images when the level is tiny (2x2, 4x4 maps)
+                        const int adv = pix / a.ohow;
+                        pix -= adv * a.ohow;
+                        img += adv;
+                    }
                     const float sg = 1.0f / (1.0f + __expf(-(acc[t][u][e] + bv)));
                     const size_t row = (size_t)pix * a.yna + anc;
                     float v = sg;
@@ -580,12 +586,17 @@ static bool conv_vec_a(const SiConv2dDesc* d, const float* in) {
 
 extern "C" size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d) {
     if (!d || d->groups <= 0) return 0;
+    if (si_conv_smallc_ok(d)) return si_conv_smallc_weight_elems(d);  // stem layout, see conv_smallc.hip
     const int icg = d->ic / d->groups;
     return (size_t)d->oc * d->kh * d->kw * round_up4(icg);
 }
 
 extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* w_packed) {
     if (!d || !w_oihw || !w_packed || d->groups <= 0) return SI_E_BADARG;
+    if (si_conv_smallc_ok(d)) {
+        si_conv_smallc_pack(d, w_oihw, w_packed);
+        return 0;
+    }
     const int icg = d->ic / d->groups, icp = round_up4(icg);
     const int ntaps = d->kh * d->kw;
     const bool cbm = conv_cb_major(d);
@@ -613,10 +624,10 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     if ((long long)d->n * d->oh * d->ow > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     if ((long long)d->n * d->ih * d->iw > 0x7fffffffLL) return SI_E_UNSUPPORTED;
 
-    static const bool no_smallc = getenv("SI_CONV_NO_SMALLC") != nullptr;  // development switch
-    if (!yolo && !no_smallc && si_conv_smallc_ok(d)) {
-        const int rc = si_conv_smallc_launch(d, in, w_packed, bias, residual, out, static_cast<hipStream_t>(stream));
-        if (rc != SI_E_UNSUPPORTED) return rc;
+    // 1..3 input channels: the stem kernel (its weight layout is its own, so there is no falling through)
+    if (si_conv_smallc_ok(d)) {
+        if (yolo) return SI_E_UNSUPPORTED;
+        return si_conv_smallc_launch(d, in, w_packed, bias, residual, out, static_cast<hipStream_t>(stream));
     }
 
     ConvArgs a;
@@ -709,8 +720,7 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 2>",  "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>",
         "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>"};
     const int v = conv_variant(d);
-    static const bool no_smallc = getenv("SI_CONV_NO_SMALLC") != nullptr;
-    if (!no_smallc && si_conv_smallc_ok(d)) return si_conv_smallc_name(d);
+    if (si_conv_smallc_ok(d)) return si_conv_smallc_name(d);
     if (conv_fast_ok(d, in)) return fast_names[v];
     static const int generic_of[11] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3};
     return names[generic_of[v]][conv_vec_a(d, in) ? 1 : 0];

@@ -1,19 +1,20 @@
-// conv_smallc.hip -- first-layer ("stem") convolution: very few input channels (RGB), large kernel, stride 2.
+// conv_smallc.hip -- first-layer ("stem") convolution: 1..3 input channels (RGB), large kernel, stride 2.
 //
 // YOLOv5s conv0 is 640x640x3 -> 320x320x32, 6x6 s2 p2 (reference shape: test/test_layer/test_conv_2d.cpp:279-293);
 // ResNet18 conv1 is 224x224x3 -> 112x112x64, 7x7 s2 p3.  With 3 channels the im2col row of one tap is 12 bytes, so
-// the implicit-GEMM kernel's 16-byte channel vectors do not apply and its scalar gather ran at 37 TFLOP/s.
+// the implicit-GEMM kernel's 16-byte channel vectors do not apply (its scalar gather ran at 37 TFLOP/s).
 //
-// Here the NHWC layout is exploited the other way round: for one output pixel and one kernel row, the KW taps x C
-// channels are KW*C CONTIGUOUS floats of the input row, and neighbouring output pixels overlap in all but
-// stride*C of them.  So a workgroup
-//   1. stages the KH (+ stride per extra output row) input rows that its output pixels need into LDS with
-//      perfectly coalesced dword loads (each input byte is fetched ~1.5x instead of KH*KW/stride^2 = 9x),
-//   2. stages the layer's weights transposed to [K][OC] (B operand: lanes = output channels, conflict free),
-//   3. runs 32x32x2 MFMAs whose A operand is read straight from the staged rows:
-//        A[m][k] = row[kh][(m*sw)*C + (kw*C + c)],   k = (kh, kw, c)
-//      -- no im2col tile is ever formed, in HBM or in LDS.
-// One wave owns 32 consecutive output pixels of one output row and all (<= 64) output channels.
+// Here NHWC is exploited the other way round: for one output pixel and one kernel ROW, the KW taps x C channels are
+// KW*C CONTIGUOUS floats of the input row, and neighbouring output pixels overlap in all but stride*C of them.
+// A persistent workgroup walks over (image, output-row block, column tile) items and for each one
+//   1. has the KH + (RB-1)*stride input rows it needs in LDS, staged with coalesced loads (each input byte is
+//      fetched ~1.5x instead of KH*KW/stride^2 = 9x); the loads for item i+1 are issued before the MFMAs of item i
+//      (register prefetch, committed to LDS after the MFMAs), and the stores of item i drain while item i+1 computes;
+//   2. runs 32x32x2 MFMAs whose A operand is read straight from the staged rows,
+//        A[m][k] = row[ky][(m*sw)*C + j],  j = kx*C + c,  k = (ky, j)   -- no im2col tile anywhere,
+//      and whose B operand comes from a pre-transposed weight image [ky][j][oc] through the vector L1 (13.8 KB for
+//      the YOLOv5 stem: every wave of the CU reads the same lines).
+// One wave owns 32 consecutive output pixels of one output row and NT*32 output channels.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -27,28 +28,26 @@ namespace {
 
 struct SmallCArgs {
     const float* in;
-    const float* w;     // packed [oc][kh*kw][cpad] (the layout si_hip_conv2d_pack_weight_host produces)
+    const float* w;     // transposed image [kh][2*HP][ocp], rows j >= kw*c are zero (see si_conv_smallc_pack)
     const float* bias;
     const float* res;
     float* out;
     int n, ih, iw, c, in_ld;
-    int oh, ow, oc, out_ld, res_ld;
+    int oh, ow, oc, ocp, out_ld, res_ld;
     int kh, kw, sh, sw, pt, pl;
-    int cpad;           // channel padding of the packed weights
-    int K;              // kh*kw*c
     int row_len;        // floats staged per input row
-    int w_tiles;        // ceil(ow / (32*NW))
-    unsigned magic_per_oc;  // ceil(2^32 / (kh*kw*4))
-    unsigned magic_kw;      // ceil(2^32 / kw)
+    int n_in_rows;
+    int w_tiles, oc_tiles, row_blocks;
+    int items;          // n * row_blocks * w_tiles * oc_tiles
+    unsigned in_bytes;  // extent of the input tensor for the buffer resource (< 4 GB)
     int act1, act2;
     float act_param;
-    int ablate;  // timing experiments (SI_CONV_ABLATE): 1 no input staging, 2 no weight staging, 4 no MFMA loop, 8 no stores
 };
 
 __device__ __forceinline__ float act_any(int act, float v, float p) {
     switch (act) {
         case SI_ACT_RELU: return fmaxf(v, 0.0f);
-        case SI_ACT_SILU: return v / (1.0f + __expf(-v));
+        case SI_ACT_SILU: return __fdividef(v, 1.0f + __expf(-v));
         case SI_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
         case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
@@ -57,151 +56,245 @@ __device__ __forceinline__ float act_any(int act, float v, float p) {
     }
 }
 
-// NW waves per workgroup (32*NW output pixels along W), NT 32-wide output-channel tiles per wave,
-// RB output rows per workgroup (amortises the weight staging and the vertical halo).
-// HP = (kw*c rounded up to even)/2 = MFMA steps per kernel row, a compile-time constant so the step loop unrolls
-// into HP independent LDS reads followed by HP back-to-back MFMAs (9 for 6x6x3, 11 for 7x7x3).
-template <int NW, int NT, int RB, int HP>
+// NW waves per workgroup (32*NW output pixels along W), NT 32-wide output-channel tiles per wave, RB output rows per
+// item, HP = (kw*c rounded up to even)/2 MFMA steps per kernel row (compile time: 9 for 6x6x3, 11 for 7x7x3),
+// PF = prefetch registers per thread (>= n_in_rows*row_len / (64*NW)).
+template <int NW, int NT, int RB, int HP, int PF>
 __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTHR = NW * 64;
     constexpr int TOW = 32 * NW;
-    constexpr int OCW = 32 * NT;        // output channels handled by this workgroup
-    constexpr int WLD = OCW + 1;        // +1: conflict-free transposing store
-    const int n_in_rows = (RB - 1) * a.sh + a.kh;
-    float* rows = smem;                                   // [n_in_rows][row_len]
-    float* wl = smem + n_in_rows * a.row_len;             // [kh][2*HP][WLD]; rows j >= kw*c are zero
+    const int buf_len = a.n_in_rows * a.row_len;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-    const int tile_w = blockIdx.x % a.w_tiles;
-    const int oc0 = (blockIdx.x / a.w_tiles) * OCW;
-    const int oy0 = blockIdx.y * RB;
-    const int img = blockIdx.z;
-    const int ox0 = tile_w * TOW;
-    const int ix0 = ox0 * a.sw - a.pl;   // first staged input pixel (may be negative)
-    const int iy0 = oy0 * a.sh - a.pt;
 
-    // ---- stage input rows (zero outside the image).  The input is dense (in_ld == c), so a staged row is one
-    // contiguous span of the image row: no pixel/channel decomposition, consecutive lanes -> consecutive dwords.
-    {
-        const int lo = ix0 < 0 ? -ix0 * a.c : 0;                 // first valid element of the span
-        const int hi = min(a.row_len, (a.iw - ix0) * a.c);       // one past the last valid element
-        for (int r = 0; r < n_in_rows && !(a.ablate & 1); ++r) {
+    float pre[PF];
+
+    // item -> coordinates (oc tile fastest, then column tile, row block, image)
+    auto decode = [&](int item, int& img, int& oy0, int& ox0, int& oc0) {
+        int t = item;
+        const int ot = t % a.oc_tiles; t /= a.oc_tiles;
+        const int wt = t % a.w_tiles; t /= a.w_tiles;
+        const int rbk = t % a.row_blocks; t /= a.row_blocks;
+        img = t; oy0 = rbk * RB; ox0 = wt * TOW; oc0 = ot * 32 * NT;
+    };
+
+    // issue the global loads of one item's input rows into registers (zero outside the image)
+    // register q holds element e = tid + (q % PER_ROW) * NTHR of staged row r = q / PER_ROW (no divisions at run time)
+    constexpr int PER_ROW = 4;   // ceil(row_len / NTHR) <= 4 for every instantiated shape (checked at launch)
+    constexpr int MAX_ROWS = PF / PER_ROW;
+    // Raw buffer loads: an element outside the image gets an out-of-range offset and the hardware returns 0, so the
+    // loaded value is not touched (no select, hence no wait) until it is committed to LDS after the MFMAs.
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+    auto prefetch = [&](int item) {
+        int img, oy0, ox0, oc0;
+        decode(item, img, oy0, ox0, oc0);
+        const int ix0 = ox0 * a.sw - a.pl, iy0 = oy0 * a.sh - a.pt;
+        const int lo = ix0 < 0 ? -ix0 * a.c : 0;
+        const int hi = min(a.row_len, (a.iw - ix0) * a.c);
+        const bool dense = a.in_ld == a.c;
+#pragma unroll
+        for (int r = 0; r < MAX_ROWS; ++r) {
             const int y = iy0 + r;
-            const bool yok = (unsigned)y < (unsigned)a.ih;
-            const float* src = a.in + ((size_t)(img * a.ih + (yok ? y : 0)) * a.iw) * a.c + (ptrdiff_t)ix0 * a.c;
-            float* dst = rows + r * a.row_len;
-            for (int e = tid; e < a.row_len; e += NW * 64) dst[e] = (yok && e >= lo && e < hi) ? src[e] : 0.0f;
+            const bool yok = r < a.n_in_rows && (unsigned)y < (unsigned)a.ih;
+            // byte offset of staged element 0 of this row, modulo 2^32 (ix0 may be negative; valid elements land in range)
+            const unsigned row_off = ((unsigned)((img * a.ih + (yok ? y : 0)) * a.iw + ix0)) * (unsigned)(a.in_ld * 4);
+#pragma unroll
+            for (int p = 0; p < PER_ROW; ++p) {
+                const int e = tid + p * NTHR;
+                unsigned off;
+                if (dense) {
+                    off = row_off + (unsigned)e * 4u;
+                } else {
+                    const int px = e / a.c, ch = e - px * a.c;
+                    off = row_off + (unsigned)(px * a.in_ld + ch) * 4u;
+                }
+                if (!(yok && e >= lo && e < hi)) off = 0xFFFFFF00u;
+                pre[r * PER_ROW + p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0));
+            }
         }
-    }
-    // ---- stage weights transposed: wl[ky*2HP + j][o] = w[oc0+o][ky][kx][ch], j = kx*c + ch.  cpad == 4 for c <= 4.
+    };
+    auto commit = [&](float* buf) {
+#pragma unroll
+        for (int r = 0; r < MAX_ROWS; ++r)
+#pragma unroll
+            for (int p = 0; p < PER_ROW; ++p) {
+                const int e = tid + p * NTHR;
+                if (r < a.n_in_rows && e < a.row_len) buf[r * a.row_len + e] = pre[r * PER_ROW + p];
+            }
+    };
+
+    int item = blockIdx.x;
+    if (item >= a.items) return;
+    prefetch(item);
+    commit(smem);
+    // the layer's weight image (all output channels), once per persistent workgroup: straight 16-byte copy
+    float* wl = smem + buf_len;
     {
-        const int RL = a.kw * a.c;
-        for (int i = tid; i < a.kh * 2 * HP * WLD; i += NW * 64) wl[i] = 0.0f;
-        __syncthreads();
-        const int per_oc = a.kh * a.kw * 4;
-        const int total = OCW * per_oc;
-        for (int i = tid; i < total && !(a.ablate & 2); i += NW * 64) {
-            const int o = (int)__umulhi((unsigned)i, a.magic_per_oc);  // i / per_oc, exact for i*per_oc < 2^32
-            const int rem = i - o * per_oc;
-            const int tap = rem >> 2, ch = rem & 3;
-            const int ky = (int)__umulhi((unsigned)tap, a.magic_kw);
-            const int kx = tap - ky * a.kw;
-            if (ch < a.c && oc0 + o < a.oc) wl[(ky * 2 * HP + kx * a.c + ch) * WLD + o] = a.w[(size_t)(oc0 + o) * per_oc + rem];
-        }
-        (void)RL;
+        const int nvec = a.kh * 2 * HP * a.ocp / 4;
+        const float4* src = reinterpret_cast<const float4*>(a.w);
+        float4* dst = reinterpret_cast<float4*>(wl);
+        for (int i = tid; i < nvec; i += NTHR) dst[i] = src[i];
     }
     __syncthreads();
 
-    const int px_off = (wave * 32 + l31) * a.sw * a.c + lh;   // lane half h reads element 2*jj + h of the kernel row
+    const int px_off = (wave * 32 + l31) * a.sw * a.c + lh;  // lane half h reads element 2*jj + h of a kernel row
+    for (; item < a.items; item += gridDim.x) {
+        const int next = item + gridDim.x;
+        if (next < a.items) prefetch(next);
+
+        int img, oy0, ox0, oc0;
+        decode(item, img, oy0, ox0, oc0);
+        const float* rows = smem;
 
 #pragma unroll 1
-    for (int rb = 0; rb < RB; ++rb) {
-        const int oy = oy0 + rb;
-        if (oy >= a.oh) break;
-        f32x16 acc[NT];
+        for (int rb = 0; rb < RB; ++rb) {
+            const int oy = oy0 + rb;
+            if (oy >= a.oh) break;
+            f32x16 acc[NT];
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
+            for (int u = 0; u < NT; ++u)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[u][e] = 0.0f;
+                for (int e = 0; e < 16; ++e) acc[u][e] = 0.0f;
 
-        const float* rbase = rows + rb * a.sh * a.row_len + px_off;
-        const float* wbase = wl + lh * WLD + l31;
-        for (int ky = 0; ky < a.kh && !(a.ablate & 4); ++ky) {
-            float av[HP], bv[HP][NT];
+            const float* rbase = rows + rb * a.sh * a.row_len + px_off;
+            const float* wbase = wl + lh * a.ocp + oc0 + l31;
+            for (int ky = 0; ky < a.kh; ++ky) {
+                float av[HP], bv[HP][NT];
 #pragma unroll
-            for (int jj = 0; jj < HP; ++jj) {
-                av[jj] = rbase[2 * jj];  // elements past kw*c belong to the next pixels: finite, and their weights are 0
+                for (int jj = 0; jj < HP; ++jj) {
+                    av[jj] = rbase[2 * jj];  // elements past kw*c belong to the next pixel: finite, and their weights are 0
 #pragma unroll
-                for (int u = 0; u < NT; ++u) bv[jj][u] = wbase[2 * jj * WLD + u * 32];
+                    for (int u = 0; u < NT; ++u) bv[jj][u] = wbase[(2 * jj) * a.ocp + u * 32];
+                }
+#pragma unroll
+                for (int jj = 0; jj < HP; ++jj)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u)
+                        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], bv[jj][u], acc[u], 0, 0, 0);
+                rbase += a.row_len;
+                wbase += 2 * HP * a.ocp;
             }
-#pragma unroll
-            for (int jj = 0; jj < HP; ++jj)
-#pragma unroll
-                for (int u = 0; u < NT; ++u)
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], bv[jj][u], acc[u], 0, 0, 0);
-            rbase += a.row_len;
-            wbase += 2 * HP * WLD;
-        }
 
-        // ---- epilogue: C/D map col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel)
+            // ---- epilogue: C/D map col = lane&31 (channel), row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel).
+            // The activation dispatch is hoisted out of the element loop (SiLU-only and ReLU-only stems are the cases).
+            const bool simple = a.res == nullptr && a.act2 == SI_ACT_NONE;
+            const size_t mrow = (size_t)(img * a.oh + oy) * a.ow;
+            const int oxb = ox0 + wave * 32 + 4 * lh;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const int o = oc0 + u * 32 + l31;
-            if (o >= a.oc) continue;
-            const float bv = a.bias ? a.bias[o] : 0.0f;
+            for (int u = 0; u < NT; ++u) {
+                const int o = oc0 + u * 32 + l31;
+                if (o >= a.oc) continue;
+                const float bvv = a.bias ? a.bias[o] : 0.0f;
+                float* orow = a.out + mrow * a.out_ld + o;
+                if (simple && a.act1 == SI_ACT_SILU) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ox = ox0 + wave * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
-                if (ox < a.ow && !(a.ablate & 8)) {
-                    const size_t m = (size_t)(img * a.oh + oy) * a.ow + ox;
-                    float v = acc[u][e] + bv;
-                    v = act_any(a.act1, v, a.act_param);
-                    if (a.res) v += a.res[m * a.res_ld + o];
-                    v = act_any(a.act2, v, a.act_param);
-                    a.out[m * a.out_ld + o] = v;
+                    for (int e = 0; e < 16; ++e) {
+                        const int ox = oxb + (e & 3) + 8 * (e >> 2);
+                        const float v = acc[u][e] + bvv;
+                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = __fdividef(v, 1.0f + __expf(-v));
+                    }
+                } else if (simple && a.act1 == SI_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ox = oxb + (e & 3) + 8 * (e >> 2);
+                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = fmaxf(acc[u][e] + bvv, 0.0f);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ox = oxb + (e & 3) + 8 * (e >> 2);
+                        if (ox < a.ow) {
+                            float v = acc[u][e] + bvv;
+                            v = act_any(a.act1, v, a.act_param);
+                            if (a.res) v += a.res[(mrow + ox) * a.res_ld + o];
+                            v = act_any(a.act2, v, a.act_param);
+                            orow[(size_t)ox * a.out_ld] = v;
+                        }
+                    }
                 }
             }
         }
+
+        if (next < a.items) {
+            __syncthreads();  // every wave is done reading this item's rows
+            commit(smem);
+            __syncthreads();
+        }
     }
 }
 
-template <int NW, int NT, int RB, int HP>
+template <int NW, int NT, int RB, int HP, int PF>
 int launch_smallc(SmallCArgs a, hipStream_t s) {
     constexpr int TOW = 32 * NW;
     a.w_tiles = (a.ow + TOW - 1) / TOW;
+    a.oc_tiles = (a.oc + 32 * NT - 1) / (32 * NT);
+    a.row_blocks = (a.oh + RB - 1) / RB;
     a.row_len = ((TOW - 1) * a.sw + a.kw) * a.c + 2;  // +2: the even-padded kernel row may read one element past
-    const int n_in_rows = (RB - 1) * a.sh + a.kh;
-    const size_t lds = ((size_t)n_in_rows * a.row_len + 2 + (size_t)a.kh * 2 * HP * (32 * NT + 1)) * sizeof(float);
+    a.n_in_rows = (RB - 1) * a.sh + a.kh;
+    if (a.n_in_rows > PF / 4 || a.row_len > 4 * NW * 64) return SI_E_UNSUPPORTED;
+    const long long items = (long long)a.n * a.row_blocks * a.w_tiles * a.oc_tiles;
+    if (items > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    a.items = (int)items;
+    // one row buffer (padded so the weight image behind it is 16-byte aligned) + the weight image
+    while ((a.n_in_rows * a.row_len) % 4 != 0) a.row_len += 1;
+    const size_t lds = ((size_t)a.n_in_rows * a.row_len + (size_t)a.kh * 2 * HP * a.ocp) * sizeof(float);
     if (lds > 160 * 1024) return SI_E_UNSUPPORTED;
-    const int oc_tiles = (a.oc + 32 * NT - 1) / (32 * NT);
-    dim3 grid(a.w_tiles * oc_tiles, (a.oh + RB - 1) / RB, a.n);
-    auto kern = conv_smallc_rows_kernel<NW, NT, RB, HP>;
-    if (lds > 64 * 1024) {
+    auto kern = conv_smallc_rows_kernel<NW, NT, RB, HP, PF>;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+        attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+    // persistent grid: as many workgroups as stay resident (LDS-limited), never more than there are items
+    const int per_cu = (int)((160 * 1024) / lds);
+    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    if ((long long)grid > items) grid = (int)items;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
+inline int smallc_hp(const SiConv2dDesc* d) { return (d->kw * d->ic + 1) / 2; }
+
 }  // namespace
 
-// eligibility: dense small-channel input, no groups / dilation, kernel rows fit comfortably in LDS
+// Shape-only eligibility (it also decides the weight layout, so it must not depend on pointers or strides):
+// 1..3 input channels, no groups / dilation, stride <= 2, and one of the instantiated kernel-row lengths.
 bool si_conv_smallc_ok(const SiConv2dDesc* d) {
     if (d->groups != 1 || d->dh != 1 || d->dw != 1) return false;
-    if (d->ic > 4 || d->ic % 4 == 0) return false;  // 1..3 channels (4 takes the vector path)
-    if (d->in_ld != d->ic) return false;            // staged rows must be contiguous spans
-    if (d->kh * d->kw * d->ic > 512) return false;
-    if (d->n > 65535 || d->oh > 65535) return false;
-    const int hp = (d->kw * d->ic + 1) / 2;
-    return hp == 9 || hp == 11;  // instantiated row lengths: 6x6x3 (YOLOv5 stem), 7x7x3 (ResNet stem)
+    if (d->ic < 1 || d->ic > 3) return false;
+    if (d->sh < 1 || d->sh > 2 || d->sw < 1 || d->sw > 2 || d->kh > 7 || d->kw > 7) return false;
+    const int hp = smallc_hp(d);
+    return hp == 9 || hp == 11;  // 6x6x3 (YOLOv5 stem), 7x7x3 (ResNet stem)
+}
+
+size_t si_conv_smallc_weight_elems(const SiConv2dDesc* d) {
+    const int ocp = (d->oc + 31) / 32 * 32;
+    return (size_t)d->kh * 2 * smallc_hp(d) * ocp;
+}
+
+// OIHW -> [ky][j = kx*c + ch, padded to 2*HP][ocp], zero filled
+void si_conv_smallc_pack(const SiConv2dDesc* d, const float* w_oihw, float* w_packed) {
+    const int hp2 = 2 * smallc_hp(d);
+    const int ocp = (d->oc + 31) / 32 * 32;
+    const size_t total = si_conv_smallc_weight_elems(d);
+    for (size_t i = 0; i < total; ++i) w_packed[i] = 0.0f;
+    for (int o = 0; o < d->oc; ++o)
+        for (int c = 0; c < d->ic; ++c)
+            for (int ky = 0; ky < d->kh; ++ky)
+                for (int kx = 0; kx < d->kw; ++kx)
+                    w_packed[((size_t)ky * hp2 + kx * d->ic + c) * ocp + o] =
+                        w_oihw[(((size_t)o * d->ic + c) * d->kh + ky) * d->kw + kx];
 }
 
 const char* si_conv_smallc_name(const SiConv2dDesc* d) {
-    const int hp = (d->kw * d->ic + 1) / 2;
-    if (hp == 9) return d->oc > 32 ? "conv_smallc_rows_kernel<4, 2, 2, 9>" : (d->ow % 160 == 0 ? "conv_smallc_rows_kernel<5, 1, 2, 9>" : "conv_smallc_rows_kernel<4, 1, 2, 9>");
-    return d->oc > 32 ? "conv_smallc_rows_kernel<4, 2, 2, 11>" : "conv_smallc_rows_kernel<4, 1, 2, 11>";
+    const int hp = smallc_hp(d);
+    if (hp == 9)
+        return d->oc > 32 ? "conv_smallc_rows_kernel<4, 2, 2, 9, 36>"
+                          : ((d->ow % 160 == 0 || d->ow > 128) ? "conv_smallc_rows_kernel<5, 1, 1, 9, 28>" : "conv_smallc_rows_kernel<4, 1, 1, 9, 28>");
+    return d->oc > 32 ? "conv_smallc_rows_kernel<4, 2, 2, 11, 36>" : "conv_smallc_rows_kernel<4, 1, 2, 11, 36>";
 }
 
 int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
@@ -210,22 +303,20 @@ int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w
     a.in = in; a.w = w_packed; a.bias = d->has_bias ? bias : nullptr; a.res = d->has_residual ? residual : nullptr;
     a.out = out;
     a.n = d->n; a.ih = d->ih; a.iw = d->iw; a.c = d->ic; a.in_ld = d->in_ld;
-    a.oh = d->oh; a.ow = d->ow; a.oc = d->oc; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
+    a.oh = d->oh; a.ow = d->ow; a.oc = d->oc; a.ocp = (d->oc + 31) / 32 * 32; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
     a.kh = d->kh; a.kw = d->kw; a.sh = d->sh; a.sw = d->sw; a.pt = d->pt; a.pl = d->pl;
-    a.cpad = (d->ic + 3) & ~3;
-    a.K = d->kh * d->kw * d->ic;
-    a.row_len = 0; a.w_tiles = 0;
-    a.magic_per_oc = (unsigned)((0x100000000ull + (unsigned long long)(d->kh * d->kw * 4) - 1) / (unsigned long long)(d->kh * d->kw * 4));
-    a.magic_kw = (unsigned)((0x100000000ull + (unsigned long long)d->kw - 1) / (unsigned long long)d->kw);
+    a.row_len = a.n_in_rows = a.w_tiles = a.oc_tiles = a.row_blocks = a.items = 0;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
-    static const int ablate = [] { const char* e = getenv("SI_CONV_ABLATE"); return e ? atoi(e) : 0; }();
-    a.ablate = ablate;
-    const int hp = (d->kw * d->ic + 1) / 2;
-    if (hp == 9) {
-        if (d->oc > 32) return launch_smallc<4, 2, 2, 9>(a, s);
-        if (d->ow % 160 == 0) return launch_smallc<5, 1, 2, 9>(a, s);
-        return launch_smallc<4, 1, 2, 9>(a, s);
+    const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull;
+    if (in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;  // > 4 GB input image tensor
+    a.in_bytes = (unsigned)in_bytes;
+    // Variants measured on the YOLOv5s stem at batch 32 (MI355X): 5 waves x 1 output row per item (37 KB LDS, 4 resident
+    // workgroups per CU) 0.40 ms; 2 rows per item 0.63 ms; 4 waves 0.45 ms.  Residency beats halo reuse here too.
+    if (smallc_hp(d) == 9) {
+        if (d->oc > 32) return launch_smallc<4, 2, 2, 9, 36>(a, s);
+        if (d->ow % 160 == 0 || d->ow > 128) return launch_smallc<5, 1, 1, 9, 28>(a, s);
+        return launch_smallc<4, 1, 1, 9, 28>(a, s);
     }
-    if (d->oc > 32) return launch_smallc<4, 2, 2, 11>(a, s);
-    return launch_smallc<4, 1, 2, 11>(a, s);
+    if (d->oc > 32) return launch_smallc<4, 2, 2, 11, 36>(a, s);
+    return launch_smallc<4, 1, 2, 11, 36>(a, s);
 }

@@ -145,9 +145,12 @@ Status Conv2d::PrepareDevice() {
     }
     if (use_bias_ && bias_.size() != (size_t)out_channels_) return Status::kErrorShape;
 
+    // the weight layout is chosen from the layer's static shape (channels, kernel, stride, dilation, groups), so the
+    // descriptor used for packing must carry all of those, exactly as the launch descriptor will
     SiConv2dDesc d;
     memset(&d, 0, sizeof(d));
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
+    d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
     std::vector<float> packed(si_hip_conv2d_weight_elems(&d));
     CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&d, weight_.data(), packed.data()), "pack weight"));
     CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(float)), "upload weight"));

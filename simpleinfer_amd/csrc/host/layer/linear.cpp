@@ -56,7 +56,7 @@ Status Linear::PrepareDevice() {
     CHECK_BOOL(weight_.size() == (size_t)in_features_ * out_features_);
     SiConv2dDesc d;
     memset(&d, 0, sizeof(d));
-    d.ic = in_features_; d.oc = out_features_; d.kh = d.kw = 1; d.groups = 1;
+    d.ic = in_features_; d.oc = out_features_; d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1; d.groups = 1;
     std::vector<float> packed(si_hip_conv2d_weight_elems(&d));
     CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&d, weight_.data(), packed.data()), "pack weight"));
     CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(float)), "upload weight"));

@@ -212,10 +212,12 @@ def test_batchnorm_flatten(hops, orc):
     assert_exact(hops.flatten_nhwc(x), orc.flatten_nhwc(x))
 
 
-def test_yolo_detect_head(hops, orc):
-    n, na, ne = 2, 3, 85
+@pytest.mark.parametrize("n,levels", [(2, ((8, 32), (4, 64), (2, 128))), (5, ((4, 32), (2, 64), (1, 96)))])
+def test_yolo_detect_head(hops, orc, n, levels):
+    # the second case has maps smaller than a 32-row MFMA tile and batch > 2: one tile spans several images
+    na, ne = 3, 85
     feats, ws, bs, grids, anchors = [], [], [], [], []
-    for i, (h, c) in enumerate(((8, 32), (4, 64), (2, 128))):
+    for i, (h, c) in enumerate(levels):
         feats.append(rng_uniform(50 + i, (n, h, h, c), -1, 1))
         ws.append(rng_uniform(60 + i, (na * ne, c, 1, 1), -0.3, 0.3))
         bs.append(rng_uniform(70 + i, (na * ne,), -0.5, 0.5))
