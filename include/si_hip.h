@@ -120,6 +120,13 @@ int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_pac
  * it, minus the namespace), so profiles can be joined with per-layer timings */
 const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);
 
+/* Two convolutions that read the SAME input with the same geometry (YOLOv5 C3: cv1 and cv2, both 1x1) run as one launch:
+ * the weights / biases are concatenated along oc by the caller (d->oc = oc_a + oc_b); output channels [0, split_oc)
+ * are written to `out` (stride d->out_ld) and [split_oc, d->oc) to `out2` (stride out2_ld).  split_oc must be a
+ * multiple of 32; groups == 1; no residual.  Replaces two Conv2d::Forward calls (src/layer/conv_2d.cpp:108-118). */
+int si_hip_conv2d_split_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                            float* out, int split_oc, float* out2, int out2_ld, si_stream_t stream);
+
 /* Detect level in one launch: conv (normally the 1x1 of YoloDetect, src/layer/yolo_detect.cpp:214) with the sigmoid /
  * grid / anchor decode of si_hip_yolo_decode_f32 and the concat into detect_out [n][rows_total][ne] done in the
  * conv epilogue -- the conv output never goes to HBM.  d->oc must equal na*ne; d->out_ld is ignored.  Returns

@@ -68,6 +68,9 @@ struct ConvArgs {
     int ntaps;                  // kh*kw
     unsigned in_bytes, w_bytes; // buffer-resource extents for the fast path (tensor < 4 GB)
     int ablate;                 // timing experiments only (SI_CONV_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
+    // split output (two sibling convs on one input fused along oc): channels >= split go to out2 (stride out2_ld)
+    float* out2;
+    int out2_ld, split;
     // YOLOv5 Detect decode fused into the epilogue (ymode != 0): out is the [N][rows_total][ne] detect tensor
     int ymode, yna, yne, yrows_total, yrow_off;
     float ystride;
@@ -93,7 +96,7 @@ __device__ __forceinline__ float apply_act(int act, float v, float p) {
 template <int ACT>
 __device__ __forceinline__ float act_fn(float v, float p) {
     if (ACT == SI_ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == SI_ACT_SILU) return v / (1.0f + __expf(-v));
+    if (ACT == SI_ACT_SILU) return __fdividef(v, 1.0f + __expf(-v));
     if (ACT == SI_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
     if (ACT == SI_ACT_HARDSIGMOID) return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
     if (ACT == SI_ACT_HARDSWISH) return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
@@ -111,6 +114,10 @@ __device__ __forceinline__ void epilogue_impl(const ConvArgs& a, f32x16 (&acc)[T
         if (o >= a.ocg) continue;
         const int oc_abs = g * a.ocg + o;
         const float bv = has_bias ? a.bias[oc_abs] : 0.0f;
+        // split output: the boundary is a multiple of 32, so a 32-wide column tile goes to one destination
+        const bool second = a.out2 != nullptr && oc_abs >= a.split;
+        float* const obase = second ? a.out2 + (oc_abs - a.split) : a.out + oc_abs;
+        const int old = second ? a.out2_ld : a.out_ld;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int mb = mrow0 + t * 32;
@@ -127,7 +134,7 @@ __device__ __forceinline__ void epilogue_impl(const ConvArgs& a, f32x16 (&acc)[T
                         v = act_fn<ACT1>(v, a.act_param);
                         if (has_res) v += a.res[(size_t)m * a.res_ld + oc_abs];
                     }
-                    a.out[(size_t)m * a.out_ld + oc_abs] = v;
+                    obase[(size_t)m * old] = v;
                 }
             }
         }
@@ -613,9 +620,14 @@ extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float
     return 0;
 }
 
+struct SplitOut {
+    float* out2;
+    int out2_ld, split;
+};
+
 static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
                            const float* residual, float* out, si_stream_t stream, const SiYoloLevel* yolo,
-                           const float* ygrid, const float* yanchor) {
+                           const float* ygrid, const float* yanchor, const SplitOut* split = nullptr) {
     if (!d || !in || !w_packed || !out) return SI_E_BADARG;
     if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return SI_E_BADARG;
     if (d->n <= 0 || d->oh <= 0 || d->ow <= 0) return SI_E_BADARG;
@@ -626,7 +638,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
 
     // 1..3 input channels: the stem kernel (its weight layout is its own, so there is no falling through)
     if (si_conv_smallc_ok(d)) {
-        if (yolo) return SI_E_UNSUPPORTED;
+        if (yolo || split) return SI_E_UNSUPPORTED;
         return si_conv_smallc_launch(d, in, w_packed, bias, residual, out, static_cast<hipStream_t>(stream));
     }
 
@@ -658,6 +670,11 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     }();
     a.ablate = ablate;
     a.ymode = 0; a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.f; a.ygrid = a.yanchor = nullptr;
+    a.out2 = nullptr; a.out2_ld = 0; a.split = 0;
+    if (split) {
+        if (d->groups != 1 || split->split <= 0 || split->split >= d->oc || split->split % 32 != 0 || !split->out2) return SI_E_BADARG;
+        a.out2 = split->out2; a.out2_ld = split->out2_ld; a.split = split->split;
+    }
     if (yolo) {
         // the decode epilogue lives in the fast kernel only; the layer falls back to conv + decode otherwise
         if (!conv_fast_ok(d, in) || d->groups != 1 || d->has_residual || yolo->na * yolo->ne != d->oc) return SI_E_UNSUPPORTED;
@@ -696,6 +713,13 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
 extern "C" int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
                                  const float* residual, float* out, si_stream_t stream) {
     return conv2d_dispatch(d, in, w_packed, bias, residual, out, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int si_hip_conv2d_split_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                                       float* out, int split_oc, float* out2, int out2_ld, si_stream_t stream) {
+    if (!d || d->has_residual) return SI_E_BADARG;
+    SplitOut sp{out2, out2_ld, split_oc};
+    return conv2d_dispatch(d, in, w_packed, bias, nullptr, out, stream, nullptr, nullptr, nullptr, &sp);
 }
 
 extern "C" int si_hip_conv2d_yolo_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,

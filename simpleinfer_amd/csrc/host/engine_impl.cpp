@@ -287,7 +287,10 @@ Status EngineImpl::CreatePipeline() {
         }
     }
 
-    if (opt_fuse_) CHECK_STATUS(FuseEpilogues(order));
+    if (opt_fuse_) {
+        CHECK_STATUS(FuseEpilogues(order));
+        CHECK_STATUS(FuseSiblingConvs(order));
+    }
     plan_ = order;
     if (opt_alias_cat_) CHECK_STATUS(AliasConcats());
     return Status::kSuccess;
@@ -300,6 +303,7 @@ Status EngineImpl::DestroyPipeline() {
     captured_input_ptrs_.clear();
     plan_.clear();
     fused_ops_.clear();
+    sibling_ops_.clear();
     dead_operands_.clear();
     aliases_.clear();
     return Status::kSuccess;
@@ -384,6 +388,36 @@ Status EngineImpl::FuseEpilogues(std::vector<Step>& order) {
         }
     }
 
+    std::vector<Step> out;
+    for (size_t i = 0; i < order.size(); ++i)
+        if (!removed[i]) out.push_back(order[i]);
+    order.swap(out);
+    return Status::kSuccess;
+}
+
+// Two 1x1 convs reading the same operand with the same geometry (YOLOv5 C3: cv1 and cv2) become one launch with
+// twice the output channels and a split destination: the input is read once and the launch has twice the tiles.
+Status EngineImpl::FuseSiblingConvs(std::vector<Step>& order) {
+    std::vector<bool> removed(order.size(), false);
+    for (size_t i = 0; i < order.size(); ++i) {
+        if (removed[i]) continue;
+        Conv2d* a = dynamic_cast<Conv2d*>(order[i].layer);
+        if (!a || order[i].op->type != "nn.Conv2d" || a->InputNodes().size() != 1 || a->OutputNodes().size() != 1) continue;
+        for (size_t j = i + 1; j < order.size(); ++j) {
+            if (removed[j]) continue;
+            Conv2d* b = dynamic_cast<Conv2d*>(order[j].layer);
+            if (!b || order[j].op->type != "nn.Conv2d" || b->InputNodes().size() != 1 || b->OutputNodes().size() != 1) continue;
+            if (a->InputNodes()[0] != b->InputNodes()[0] || !a->CanFuseSibling(*b)) continue;
+            const std::vector<int>& sa = a->OutputNodes()[0]->tensor.Shape();
+            const std::vector<int>& sb = b->OutputNodes()[0]->tensor.Shape();
+            if (sa.size() != 4 || sb.size() != 4 || sa[0] != sb[0] || sa[1] != sb[1] || sa[2] != sb[2]) continue;
+            a->SetSibling(b);
+            a->SetOutputNodes({a->OutputNodes()[0], b->OutputNodes()[0]});
+            removed[j] = true;
+            sibling_ops_.insert(order[j].op->name);
+            break;
+        }
+    }
     std::vector<Step> out;
     for (size_t i = 0; i < order.size(); ++i)
         if (!removed[i]) out.push_back(order[i]);
@@ -642,7 +676,11 @@ std::vector<std::string> EngineImpl::ScheduledOps() const {
     return out;
 }
 
-std::vector<std::string> EngineImpl::FusedOps() const { return std::vector<std::string>(fused_ops_.begin(), fused_ops_.end()); }
+std::vector<std::string> EngineImpl::FusedOps() const {
+    std::vector<std::string> out(fused_ops_.begin(), fused_ops_.end());
+    out.insert(out.end(), sibling_ops_.begin(), sibling_ops_.end());
+    return out;
+}
 
 std::vector<std::string> EngineImpl::AliasedOperands() const {
     std::vector<std::string> out;

@@ -80,6 +80,7 @@ private:
     };
 
     Status FuseEpilogues(std::vector<Step>& order);
+    Status FuseSiblingConvs(std::vector<Step>& order);
     Status AliasConcats();
     Status UploadInputs();
     Status LaunchAll();
@@ -102,6 +103,7 @@ private:
 
     std::vector<Step> plan_;
     std::set<std::string> fused_ops_;        // operator names folded into a conv epilogue
+    std::set<std::string> sibling_ops_;      // convs computed by a sibling conv's launch
     std::set<std::string> dead_operands_;    // operands that no longer exist after fusion
     struct Alias {
         TensorNode* parent = nullptr;

@@ -101,6 +101,21 @@ void Conv2d::SetFusion(int act1, TensorNode* residual, int act2, float act_param
     act_param_ = act_param;
 }
 
+bool Conv2d::CanFuseSibling(const Conv2d& o) const {
+    auto plain1x1 = [](const Conv2d& c) {
+        return c.kernel_h_ == 1 && c.kernel_w_ == 1 && c.stride_h_ == 1 && c.stride_w_ == 1 && c.dilation_h_ == 1 &&
+               c.dilation_w_ == 1 && c.padding_t_ == 0 && c.padding_l_ == 0 && c.groups_ == 1 && c.residual_node_ == nullptr &&
+               c.act2_ == SI_ACT_NONE && c.sibling_ == nullptr;
+    };
+    return this != &o && plain1x1(*this) && plain1x1(o) && in_channels_ == o.in_channels_ && act1_ == o.act1_ &&
+           act_param_ == o.act_param_ && use_bias_ == o.use_bias_ && out_channels_ % 32 == 0 && in_channels_ % 32 == 0;
+}
+
+void Conv2d::SetSibling(Conv2d* other) {
+    sibling_ = other;
+    device_ready_ = false;
+}
+
 Status Conv2d::Deinit() {
     weight_dev_.Free();
     bias_dev_.Free();
@@ -153,10 +168,37 @@ Status Conv2d::PrepareDevice() {
     d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
     std::vector<float> packed(si_hip_conv2d_weight_elems(&d));
     CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&d, weight_.data(), packed.data()), "pack weight"));
+    std::vector<float> bias_all = bias_;
+    if (sibling_) {
+        // [oc][K] layouts with the same K: the fused weight is the two images one after the other
+        SiConv2dDesc ds = d;
+        ds.oc = sibling_->out_channels_;
+        CHECK_BOOL(sibling_->weight_.size() == (size_t)ds.oc * in_channels_);
+        std::vector<float> packed2(si_hip_conv2d_weight_elems(&ds));
+        CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&ds, sibling_->weight_.data(), packed2.data()), "pack sibling weight"));
+        packed.insert(packed.end(), packed2.begin(), packed2.end());
+        if (use_bias_) bias_all.insert(bias_all.end(), sibling_->bias_.begin(), sibling_->bias_.end());
+    }
     CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(float)), "upload weight"));
-    if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_.data(), bias_.size() * sizeof(float)), "upload bias"));
+    if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_all.data(), bias_all.size() * sizeof(float)), "upload bias"));
     device_ready_ = true;
     return Status::kSuccess;
+}
+
+Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
+    if (!sibling_ || outputs.size() != 2) return Status::kUnsupport;
+    return RunOnDevice({&input}, {&outputs[0], &outputs[1]}, [this](const std::vector<Tensor>& in, std::vector<Tensor>& out) {
+        CHECK_STATUS(PrepareDevice());
+        Dims4 di, d0, d1;
+        if (!GetDims4(in[0], di) || !GetDims4(out[0], d0) || !GetDims4(out[1], d1)) return Status::kErrorShape;
+        if (di.c != in_channels_ || d0.c != out_channels_ || d1.c != sibling_->out_channels_ || d0.pixels() != d1.pixels()) return Status::kErrorShape;
+        SiConv2dDesc d = MakeDesc(in[0], out[0]);
+        d.oc = out_channels_ + sibling_->out_channels_;
+        return CheckHip(si_hip_conv2d_split_f32(&d, in[0].Data<float>(), weight_dev_.As<float>(),
+                                                use_bias_ ? bias_dev_.As<float>() : nullptr, out[0].Data<float>(), out_channels_,
+                                                out[1].Data<float>(), out[1].PixelStride(), Stream()),
+                        "conv2d (fused siblings)");
+    });
 }
 
 Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& output) {
@@ -207,18 +249,21 @@ const char* Conv2d::KernelName() const {
     const Tensor& in = input_tensor_nodes_[0]->tensor;
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
-    const SiConv2dDesc d = MakeDesc(in, out);
+    SiConv2dDesc d = MakeDesc(in, out);
+    if (sibling_) d.oc += sibling_->out_channels_;
     return si_hip_conv2d_kernel_name(&d, in.Data<float>());
 }
 
 double Conv2d::Flops() const {
     if (output_tensor_nodes_.empty() || groups_ <= 0) return 0.0;
-    const Tensor& o = output_tensor_nodes_[0]->tensor;
-    return 2.0 * (double)o.NumElements() * kernel_h_ * kernel_w_ * (in_channels_ / groups_);
+    double elems = 0.0;
+    for (auto* n : output_tensor_nodes_) elems += (double)n->tensor.NumElements();
+    return 2.0 * elems * kernel_h_ * kernel_w_ * (in_channels_ / groups_);
 }
 
 double Conv2d::Bytes() const {
     double b = Layer::Bytes() + (double)weight_.size() * sizeof(float);
+    if (sibling_) b += (double)sibling_->weight_.size() * sizeof(float);
     if (residual_node_) b += (double)residual_node_->tensor.ByteSize();
     return b;
 }

@@ -28,6 +28,9 @@ public:
 
     virtual Status Forward(const Tensor& input, Tensor& output) override;
 
+    // two outputs: this conv and its fused sibling (see SetSibling)
+    virtual Status Forward(const Tensor& input, std::vector<Tensor>& outputs) override;
+
     virtual const char* KernelName() const override;
     virtual double Flops() const override;
     virtual double Bytes() const override;
@@ -39,6 +42,12 @@ public:
 
     // engine fusion hook: y = act2(act1(conv + bias) + residual)
     void SetFusion(int act1, TensorNode* residual, int act2, float act_param = 0.0f);
+
+    // engine fusion hook: `other` reads the same input with the same 1x1 geometry (YOLOv5 C3 cv1 / cv2); this layer
+    // then computes both (weights concatenated along oc) and writes other's result to its second output node
+    bool CanFuseSibling(const Conv2d& other) const;
+    void SetSibling(Conv2d* other);
+    Conv2d* Sibling() const { return sibling_; }
 
     Status PrepareDevice();
 
@@ -71,6 +80,7 @@ public:
     int act2_ = SI_ACT_NONE;
     float act_param_ = 0.0f;
     TensorNode* residual_node_ = nullptr;
+    Conv2d* sibling_ = nullptr;
 
 private:
     Status Launch(const Tensor& input, const Tensor* residual, Tensor& output);

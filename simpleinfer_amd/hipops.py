@@ -124,6 +124,32 @@ def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
     return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
 
 
+def conv2d_split(x, w_a, b_a, w_b, b_b, act1="none", out2_ld=None, out2_c_off=0):
+    """si_hip_conv2d_split_f32: two 1x1 convs on the same input in one launch; returns (y_a, y_b)."""
+    H = _native.hip()
+    x, w_a, w_b = _f32(x), _f32(w_a), _f32(w_b)
+    n, ih, iw, ic = x.shape
+    oa, ob = w_a.shape[0], w_b.shape[0]
+    out2_ld = out2_ld or ob
+
+    def packed(w):
+        d = SiConv2dDesc(n, ih, iw, ic, ic, ih, iw, w.shape[0], w.shape[0], 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 0.0)
+        buf = np.zeros(H.si_hip_conv2d_weight_elems(C.byref(d)), np.float32)
+        _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p)), "pack")
+        return buf
+
+    wcat = np.concatenate([packed(w_a), packed(w_b)])
+    bcat = np.concatenate([_f32(b_a), _f32(b_b)])
+    d = SiConv2dDesc(n, ih, iw, ic, ic, ih, iw, oa + ob, oa, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, ACT[act1], 0, 0, 0, 0.0)
+    dx, dw, db = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(wcat), DeviceBuffer.from_numpy(bcat)
+    dya, dyb = DeviceBuffer(n * ih * iw * oa * 4), DeviceBuffer(n * ih * iw * out2_ld * 4)
+    dyb.fill(0)
+    _chk(H.si_hip_conv2d_split_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr, dya.ptr, oa, dyb.ptr + 4 * out2_c_off, out2_ld, None),
+         "si_hip_conv2d_split_f32")
+    yb = dyb.to_numpy((n, ih, iw, out2_ld))
+    return dya.to_numpy((n, ih, iw, oa)), yb[..., out2_c_off:out2_c_off + ob].copy()
+
+
 def linear(x, w, b=None):
     H = _native.hip()
     x, w = _f32(x), _f32(w)

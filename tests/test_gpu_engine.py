@@ -68,7 +68,7 @@ def test_yolov5s_640_batch1_parity(si, orc, tmp_path):
 
 
 def test_schedule_fusion_and_aliasing(si, tmp_path):
-    pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(1, 64), "sched")
+    pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(1, 64), "sched")  # full-width YOLOv5s at 64x64
     e = si.Engine()
     e.load_model(pp, bp)
     s = e.schedule()
@@ -77,10 +77,13 @@ def test_schedule_fusion_and_aliasing(si, tmp_path):
     assert sum(n.startswith("add_") for n in s["fused"]) == 7
     assert not any(n.startswith("silu_") for n in s["run"])
     assert len(s["alias"]) >= 20  # concat inputs written in place
+    # the 8 C3 blocks: cv2 is computed by cv1's launch (same input, same 1x1 geometry)
+    siblings = [n for n in s["fused"] if n.startswith("conv_")]
+    assert len(siblings) == 8
     e2 = si.Engine(fuse=0, alias_cat=0)
     e2.load_model(pp, bp)
     s2 = e2.schedule()
-    assert not s2["fused"] and not s2["alias"] and len(s2["run"]) == len(s["run"]) + 64
+    assert not s2["fused"] and not s2["alias"] and len(s2["run"]) == len(s["run"]) + 64 + 8
 
 
 def test_forward_is_repeatable_and_input_is_read_at_forward_time(si, tmp_path):

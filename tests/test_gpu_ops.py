@@ -111,6 +111,19 @@ def test_conv_strided_tensors(hops, orc):
     assert_parity(hops.conv2d(x, w, b, in_ld=18, out_ld=11, out_c_off=3), ref, what="unaligned strides")
 
 
+def test_conv_split_siblings(hops, orc):
+    """YOLOv5 C3: cv1 and cv2 (both 1x1 + SiLU on the same x) as one launch with a split destination"""
+    x = rng_uniform(60, (2, 20, 20, 64), -1, 1)
+    wa, wb = rng_uniform(61, (32, 64, 1, 1), -0.5, 0.5), rng_uniform(62, (64, 64, 1, 1), -0.5, 0.5)
+    ba, bb = rng_uniform(63, (32,), -0.5, 0.5), rng_uniform(64, (64,), -0.5, 0.5)
+    ya, yb = hops.conv2d_split(x, wa, ba, wb, bb, act1="silu", out2_ld=160, out2_c_off=96)
+    assert_parity(ya, orc.activation("silu", orc.conv2d(x, wa, ba)), what="first sibling")
+    assert_parity(yb, orc.activation("silu", orc.conv2d(x, wb, bb)), what="second sibling (strided slice)")
+    # identical bits to the two separate launches
+    assert_exact(ya, hops.conv2d(x, wa, ba, act1="silu"))
+    assert_exact(yb, hops.conv2d(x, wb, bb, act1="silu"))
+
+
 def test_conv_batch_invariance_bit_exact(hops):
     """an image's result must not depend on the batch it travels in (the data-parallel sharding contract)"""
     x = rng_uniform(14, (6, 24, 24, 32), -1, 1)
