@@ -105,7 +105,8 @@ def roofline_from_profile(passes):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(name)
+            rec = json.load(open(tpath)).get(name)
+            traffic = rec.get("hbm_bytes_per_launch") if isinstance(rec, dict) else rec
         except Exception:
             traffic = None
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
