@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--model", default="yolov5s", choices=["yolov5s", "resnet18"])
     ap.add_argument("--graph", type=int, default=0, help="replay Forward() as a hipGraph")
+    ap.add_argument("--winograd", type=int, default=1, help="fused Winograd F(2,3) for 3x3 s1 convs (0: implicit GEMM everywhere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (reference uses 16 intra-op)")
@@ -148,7 +149,7 @@ def main():
         builder.save(pp, bp)
         flops_step = mg.conv_flops(builder)
 
-        e = si.Engine(device=dev, outputs_to_host=0, graph=args.graph)
+        e = si.Engine(device=dev, outputs_to_host=0, graph=args.graph, winograd=args.winograd)
         e.load_model(pp, bp)
         iname, oname = e.input_names()[0], e.output_names()[0]
         # global batch = per-GPU batch * world; this rank's slab gets its own seed (distinct images)
@@ -232,7 +233,7 @@ def main():
                                                             args.batch * world,
                                                             ", outputs all-gathered over RCCL" if world > 1 else ""),
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "hipgraph": bool(args.graph)},
+                   "hipgraph": bool(args.graph), "winograd_f23_for_3x3s1": bool(args.winograd)},
         "forward_kernel_ms_per_step": round(fwd_ms / args.steps, 3),
         "gflop_per_image": round(flops_step / args.batch / 1e9, 3),
         "frac_of_mfma_ceiling": round(value / world / ceiling, 4),

@@ -61,6 +61,8 @@ public:
     //   "device"          HIP device ordinal (default: current device)
     //   "fuse"            1/0  fold activation / residual add into the conv epilogue (default 1)
     //   "alias_cat"       1/0  producers write straight into torch.cat outputs (default 1)
+    //   "winograd"        1/0  3x3 stride-1 convs run the fused Winograd F(2,3) kernel, as the reference does on the
+    //                          CPU (default 1); 0 = implicit GEMM everywhere
     //   "graph"           1/0  replay Forward() as a captured hipGraph (default 0)
     //   "outputs_to_host" 1/0  copy outputs to pinned host memory in Forward() (default 1);
     //                          with 0, Extract() returns device tensors

@@ -120,6 +120,25 @@ int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_pac
  * it, minus the namespace), so profiles can be joined with per-layer timings */
 const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);
 
+/* ---- Winograd F(2x2,3x3) for 3x3 stride-1 convolutions --------------------------------------------------------
+ * One fused kernel replacing the reference's four-pass Conv2d::ForwardWinograd23 (src/layer/conv_2d.cpp:382-487):
+ * Conv3x3s1Winograd23TransformInput (src/layer/simd/winograd_helper.cpp:413-580), the 16 GemmPack4F32 calls
+ * (src/layer/simd/gemm.cpp:295-385), Conv3x3s1Winograd23TransformOutput (:806-874) and AddBiasNHWC
+ * (src/layer/simd/binary.cpp:38-53) -- plus the fused activation / residual epilogue of si_hip_conv2d_f32.  The
+ * transformed tensors live in LDS / registers only.  Same arithmetic as the reference path (same B, G, A matrices
+ * and evaluation order), 2.25x fewer MFMA flops than the direct kernel.
+ * Eligibility (shape only): 3x3, stride 1, dilation 1, groups 1, pad 0 or 1 on all sides (the reference's condition,
+ * conv_2d.cpp:183-187) and ic % 16 == 0, oc % 32 == 0.  The filter is pre-transformed once with
+ * si_hip_conv2d_wino23_pack_weight_host into U = G g G^T laid out [16][ic][oc] (replaces
+ * Conv3x3s1Winograd23TransformKernelPack4, winograd_helper.cpp:40-143). */
+int si_hip_conv2d_wino23_eligible(const SiConv2dDesc* d);
+/* eligible AND measured faster than si_hip_conv2d_f32 on MI355X (currently: ic >= 128) */
+int si_hip_conv2d_wino23_preferred(const SiConv2dDesc* d);
+size_t si_hip_conv2d_wino23_weight_elems(const SiConv2dDesc* d);
+int si_hip_conv2d_wino23_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* u);
+int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, const float* u, const float* bias,
+                             const float* residual, float* out, si_stream_t stream);
+
 /* Two convolutions that read the SAME input with the same geometry (YOLOv5 C3: cv1 and cv2, both 1x1) run as one launch:
  * the weights / biases are concatenated along oc by the caller (d->oc = oc_a + oc_b); output channels [0, split_oc)
  * are written to `out` (stride d->out_ld) and [split_oc, d->oc) to `out2` (stride out2_ld).  split_oc must be a

@@ -83,6 +83,11 @@ def hip():
         "si_hip_conv2d_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
+        "si_hip_conv2d_wino23_eligible": (i, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_wino23_preferred": (i, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_wino23_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_wino23_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
+        "si_hip_conv2d_wino23_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_split_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_yolo_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),
         "si_hip_conv2d_kernel_name": (C.c_char_p, [C.POINTER(SiConv2dDesc), vp]),

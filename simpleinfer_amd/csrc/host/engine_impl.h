@@ -92,6 +92,7 @@ private:
     bool opt_alias_cat_ = true;
     bool opt_graph_ = false;
     bool opt_outputs_to_host_ = true;
+    bool opt_winograd_ = true;
 
     Context* context_ = nullptr;
     pnnx::Graph* graph_ = nullptr;

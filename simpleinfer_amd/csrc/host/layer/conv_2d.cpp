@@ -166,8 +166,20 @@ Status Conv2d::PrepareDevice() {
     memset(&d, 0, sizeof(d));
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
     d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
-    std::vector<float> packed(si_hip_conv2d_weight_elems(&d));
-    CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&d, weight_.data(), packed.data()), "pack weight"));
+    use_winograd_ = false;
+    if (!sibling_ && ((algo_ == Algo::kAuto && si_hip_conv2d_wino23_preferred(&d)) ||
+                      (algo_ == Algo::kWinograd23 && si_hip_conv2d_wino23_eligible(&d))))
+        use_winograd_ = true;
+    if (algo_ == Algo::kWinograd23 && !use_winograd_) {
+        LOG(ERROR) << "Conv2d: Winograd F(2,3) requested for a shape it does not support";
+        return Status::kUnsupport;
+    }
+    std::vector<float> packed(use_winograd_ ? si_hip_conv2d_wino23_weight_elems(&d) : si_hip_conv2d_weight_elems(&d));
+    if (use_winograd_) {
+        CHECK_STATUS(CheckHip(si_hip_conv2d_wino23_pack_weight_host(&d, weight_.data(), packed.data()), "winograd filter transform"));
+    } else {
+        CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&d, weight_.data(), packed.data()), "pack weight"));
+    }
     std::vector<float> bias_all = bias_;
     if (sibling_) {
         // [oc][K] layouts with the same K: the fused weight is the two images one after the other
@@ -214,6 +226,16 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
         d.has_residual = 1;
         d.res_ld = residual->PixelStride();
     }
+    if (use_winograd_) {
+        const int rc = si_hip_conv2d_wino23_f32(&d, input.Data<float>(), weight_dev_.As<float>(),
+                                                use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream());
+        if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (winograd)");
+        // an unaligned / oversized tensor view: re-pack for the implicit-GEMM kernel once and stay there
+        algo_ = Algo::kImplicitGemm;
+        device_ready_ = false;
+        CHECK_STATUS(PrepareDevice());
+    }
     return CheckHip(si_hip_conv2d_f32(&d, input.Data<float>(), weight_dev_.As<float>(),
                                       use_bias_ ? bias_dev_.As<float>() : nullptr,
                                       residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream()),
@@ -251,6 +273,9 @@ const char* Conv2d::KernelName() const {
     if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
     SiConv2dDesc d = MakeDesc(in, out);
     if (sibling_) d.oc += sibling_->out_channels_;
+    if (!sibling_ && ((algo_ == Algo::kAuto && si_hip_conv2d_wino23_preferred(&d)) ||
+                      (algo_ == Algo::kWinograd23 && si_hip_conv2d_wino23_eligible(&d))))
+        return "conv_wino23_kernel";
     return si_hip_conv2d_kernel_name(&d, in.Data<float>());
 }
 

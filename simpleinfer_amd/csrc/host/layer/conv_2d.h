@@ -75,6 +75,11 @@ public:
     std::vector<float> weight_;  // OIHW, host copy
     std::vector<float> bias_;
 
+    // algorithm: the reference picks Winograd F(2,3) for every eligible 3x3 s1 conv (InitWinograd, conv_2d.cpp:182-205);
+    // here kAuto does the same when the fused Winograd kernel supports the channel counts, else implicit GEMM
+    enum class Algo { kAuto = 0, kImplicitGemm, kWinograd23 } algo_ = Algo::kAuto;
+    bool use_winograd_ = false;  // resolved at PrepareDevice (same name as the reference's flag, conv_2d.h:60)
+
     // fused epilogue
     int act1_ = SI_ACT_NONE;
     int act2_ = SI_ACT_NONE;

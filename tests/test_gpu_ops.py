@@ -111,6 +111,42 @@ def test_conv_strided_tensors(hops, orc):
     assert_parity(hops.conv2d(x, w, b, in_ld=18, out_ld=11, out_c_off=3), ref, what="unaligned strides")
 
 
+# (n, h, w, ic, oc, pad): YOLOv5s / ResNet18 3x3 s1 families, odd sizes (clipped 2x2 stores), every tile-block shape
+# (4x8, 8x4, 16x2 tiles), blocks spanning images, oc = 32 (one MFMA column tile) and 96 (ragged column block)
+WINO_SHAPES = [(2, 40, 40, 64, 64, 1), (1, 80, 80, 32, 32, 1), (3, 20, 20, 128, 128, 1), (5, 10, 10, 256, 64, 1),
+               (2, 13, 17, 16, 32, 1), (2, 12, 12, 32, 96, 0), (1, 7, 5, 16, 32, 1), (4, 4, 4, 32, 64, 1),
+               (1, 56, 56, 64, 64, 1)]
+
+
+@pytest.mark.parametrize("n,h,w,ic,oc,pad", WINO_SHAPES)
+def test_winograd_vs_reference_path(hops, orc, n, h, w, ic, oc, pad):
+    x = rng_uniform(n * 1000 + h, (n, h, w, ic), -1, 1)
+    wt = rng_uniform(n * 1000 + h + 1, (oc, ic, 3, 3), -0.5, 0.5)
+    b = rng_uniform(n * 1000 + h + 2, (oc,), -0.5, 0.5)
+    got = hops.conv2d_winograd(x, wt, b, (pad, pad))
+    # parity target: the reference's own Winograd F(2,3) pipeline (oracle restatement), bounded by the fp64 loop
+    assert_parity(got, orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="winograd"), what="vs reference Winograd")
+    assert_parity(got, orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="naive"), 2e-5, what="vs fp64")
+    # the reference test's own criterion (test/test_layer/test_winograd.cpp:130): abs 2e-3
+    assert np.abs(got - orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="naive", acc64=False)).max() < 2e-3
+
+
+def test_winograd_fused_epilogue_and_strides(hops, orc):
+    x = rng_uniform(71, (2, 20, 20, 32), -1, 1)
+    wt = rng_uniform(72, (64, 32, 3, 3), -0.3, 0.3)
+    b = rng_uniform(73, (64,), -0.5, 0.5)
+    r = rng_uniform(74, (2, 20, 20, 64), -1, 1)
+    y = orc.conv2d(x, wt, b, (1, 1), (1, 1), path="naive")
+    assert_parity(hops.conv2d_winograd(x, wt, b, act1="silu", residual=r), orc.activation("silu", y) + r, what="silu + residual")
+    assert_parity(hops.conv2d_winograd(x, wt, b, residual=r, act2="relu"), orc.activation("relu", y + r), what="residual + relu")
+    assert_parity(hops.conv2d_winograd(x, wt, b, in_ld=48, out_ld=160, out_c_off=32), y, what="strided tensors")
+    # batch invariance: bit-identical per image
+    full = hops.conv2d_winograd(x, wt, b, act1="silu")
+    assert_exact(hops.conv2d_winograd(x[1:2], wt, b, act1="silu")[0], full[1])
+    with pytest.raises(hops.HipError):
+        hops.conv2d_winograd(rng_uniform(75, (1, 8, 8, 12), -1, 1), rng_uniform(76, (32, 12, 3, 3)), None)  # ic % 16 != 0
+
+
 def test_conv_split_siblings(hops, orc):
     """YOLOv5 C3: cv1 and cv2 (both 1x1 + SiLU on the same x) as one launch with a split destination"""
     x = rng_uniform(60, (2, 20, 20, 64), -1, 1)
