@@ -73,10 +73,13 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     constexpr int PW = 2 * TBW + 2;          // staged pixels per slot row
     constexpr int PWP = PW;                  // even row pitch: every patch row of a tile starts 8-byte aligned (ds_read_b64)
     constexpr int SLOTS = 4 * TBH;           // slot = j * TBH + tr  (j = patch row 0..3)
-    constexpr int PLANE = SLOTS * PWP;       // floats per staged channel
+    // floats per staged channel, padded to 2 (mod 8): the commit writes the four channels of a 16-byte vector to four
+    // planes (4*PLANE apart = 8 banks apart), conflict free within a 32-lane group
+    constexpr int PLANE = ((SLOTS * PWP + 5) / 8) * 8 + 2;
     constexpr int NVEC = SLOTS * PW * (CB / 4);
     constexpr int PFV = (NVEC + 255) / 256;  // 16-byte vectors per thread per block
     static_assert(CB * PLANE >= 4 * 16 * 64, "patch buffer doubles as the 16 KB exchange buffer");
+    static_assert(PLANE % 2 == 0, "8-byte aligned patch rows");
 
     __shared__ float patch[CB * PLANE];
 
@@ -179,26 +182,33 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     load_b(bcur, 0, 0);
     __syncthreads();
 
+    // software pipeline: the patch rows of step s+1 are read from LDS before the MFMAs of step s are issued, and within a
+    // block the filter loads are issued BEFORE the (slower, HBM) patch prefetch so that waiting for the filter values
+    // never waits for the patch (vmcnt retires in order)
+    float2 da[2], db[2];
+    auto read_d = [&](int s) {
+        const float2* qa = reinterpret_cast<const float2*>(pa + (2 * s) * PLANE);
+        const float2* qb = reinterpret_cast<const float2*>(pb + (2 * s) * PLANE);
+        da[0] = qa[0]; da[1] = qa[1]; db[0] = qb[0]; db[1] = qb[1];
+    };
     for (int cb = 0; cb < ncb; ++cb) {
-        if (cb + 1 < ncb) prefetch(cb + 1);
+        read_d(0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            // filter values of the next half block are in flight during this half's 16 MFMAs
             if (half == 0) {
                 load_b(bnxt, cb, 1);
+                if (cb + 1 < ncb) prefetch(cb + 1);
             } else if (cb + 1 < ncb) {
                 load_b(bnxt, cb + 1, 0);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int s = half * 4 + k;
-                const float2* qa = reinterpret_cast<const float2*>(pa + (2 * s) * PLANE);
-                const float2* qb = reinterpret_cast<const float2*>(pb + (2 * s) * PLANE);
-                const float2 a01 = qa[0], a23 = qa[1], b01 = qb[0], b23 = qb[1];
-                const float t0 = a01.x + sg * b01.x;
-                const float t1 = a01.y + sg * b01.y;
-                const float t2 = a23.x + sg * b23.x;
-                const float t3 = a23.y + sg * b23.y;
+                const float t0 = da[0].x + sg * db[0].x;
+                const float t1 = da[0].y + sg * db[0].y;
+                const float t2 = da[1].x + sg * db[1].x;
+                const float t3 = da[1].y + sg * db[1].y;
+                if (s + 1 < CB / 2) read_d(s + 1);
                 float v[4];
                 v[0] = t0 - t2;
                 v[1] = t1 + t2;
@@ -320,11 +330,13 @@ extern "C" int si_hip_conv2d_wino23_eligible(const SiConv2dDesc* d) {
     return 1;
 }
 
-// Measured on MI355X (YOLOv5s batch 32, in-network): the fused kernel beats the implicit-GEMM kernel from 128 input
-// channels up (0.114 vs 0.150 ms at 40x40x128, 0.103 vs 0.141 ms at 80x80x... see DESIGN.md); with 32-64 channels there
-// are only 2-4 channel blocks per workgroup and its prologue / exchange epilogue dominate, so direct wins there.
+// Measured on MI355X (YOLOv5s batch 32, in-network): the fused kernel beats the implicit-GEMM kernel from 64 input
+// channels up (0.125 vs 0.144 ms at 80x80x64, 0.114 vs 0.150 ms at 40x40x128, 0.105 vs 0.157 ms at 20x20x256); at 32
+// channels there are only 2 channel blocks per workgroup, its prologue / exchange epilogue dominate and direct wins
+// (0.184 vs 0.174 ms at 160x160x32).
 extern "C" int si_hip_conv2d_wino23_preferred(const SiConv2dDesc* d) {
-    return si_hip_conv2d_wino23_eligible(d) && d->ic >= 128;
+    static const int min_ic = [] { const char* e = getenv("SI_WINO_MIN_IC"); return e ? atoi(e) : 64; }();  // dev override
+    return si_hip_conv2d_wino23_eligible(d) && d->ic >= min_ic;
 }
 
 extern "C" size_t si_hip_conv2d_wino23_weight_elems(const SiConv2dDesc* d) {
