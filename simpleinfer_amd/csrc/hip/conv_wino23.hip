@@ -45,7 +45,7 @@ struct WinoArgs {
     int pad;
     int th, tw;          // tiles per image column / row
     int rows_total;      // n * th
-    int col_blocks, oc_blocks;
+    int col_blocks, oc_blocks, spatial_blocks;
     unsigned in_bytes;
     int act1, act2;
     float act_param;
@@ -85,9 +85,17 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-    const int ocb = blockIdx.x % a.oc_blocks;
-    const int bc = blockIdx.x / a.oc_blocks;
-    const int row0 = blockIdx.y * TBH;       // first flattened tile row of the block
+    // block id -> (spatial block, oc block): the oc blocks of one spatial block share blockIdx % 8, i.e. one XCD and its
+    // L2, because they all stage the same input patches (placement is a speed hint only)
+    const int per_chunk = 8 * a.oc_blocks;
+    const int chunk = blockIdx.x / per_chunk;
+    const int rr = blockIdx.x - chunk * per_chunk;
+    const int sb = chunk * 8 + (rr & 7);
+    const int ocb = rr >> 3;
+    if (sb >= a.spatial_blocks) return;
+    const int by = sb / a.col_blocks;
+    const int bc = sb - by * a.col_blocks;
+    const int row0 = by * TBH;               // first flattened tile row of the block
     const int col0 = bc * TBW;               // first tile column
     const int oc0 = ocb * (32 * NT);
 
@@ -292,8 +300,10 @@ int launch_wino(WinoArgs a, hipStream_t s) {
     a.col_blocks = (a.tw + TBW - 1) / TBW;
     a.oc_blocks = (a.oc + 32 * NT - 1) / (32 * NT);
     const int row_blocks = (a.rows_total + TBH - 1) / TBH;
-    if (row_blocks > 65535) return SI_E_UNSUPPORTED;
-    dim3 grid(a.col_blocks * a.oc_blocks, row_blocks, 1);
+    a.spatial_blocks = a.col_blocks * row_blocks;
+    const long long nblocks = (long long)((a.spatial_blocks + 7) / 8) * 8 * a.oc_blocks;
+    if (nblocks > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    dim3 grid((unsigned)nblocks, 1, 1);
     hipLaunchKernelGGL((conv_wino23_kernel<NT, LOG_TBW>), grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
@@ -398,7 +408,7 @@ extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, 
     a.pad = d->pt;
     a.th = (d->oh + 1) / 2; a.tw = (d->ow + 1) / 2;
     a.rows_total = d->n * a.th;
-    a.col_blocks = a.oc_blocks = 0;
+    a.col_blocks = a.oc_blocks = a.spatial_blocks = 0;
     a.in_bytes = (unsigned)in_bytes;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
 
