@@ -215,6 +215,32 @@ int si_hip_yolo_decode_f32(const float* conv, int n, int h, int w, int na, int n
                            const float* anchor_hwa2, float stride, float* out, int rows_total, int row_off,
                            si_stream_t stream);
 
+/* ---- the steps either side of Forward() in the reference's application ----------------------- */
+/* Letterbox geometry of PreProcess (test/test_yolo/test_yolo.cpp:194-213, 234-241): aspect-preserving resize target,
+ * scale, and the top / left padding (Adjust, :18-22).  Host-only arithmetic, no device work. */
+void si_letterbox_geometry(int height_origin, int width_origin, int height_new, int width_new, int* height_resize,
+                           int* width_resize, float* scale, int* padding_t, int* padding_l);
+/* The rest of PreProcess after cv::resize (test_yolo.cpp:220-259): BGR u8 [height_resize][width_resize][3] ->
+ * reverse to RGB, pad to [height_new][width_new] with 114, cast to float, divide by 255; written to one image slot
+ * `out` of the NHWC input tensor.  (The bilinear resize itself lives in the absent simpleocv submodule and stays
+ * with the caller.) */
+int si_hip_letterbox_u8_f32(const unsigned char* resized_bgr, int height_resize, int width_resize, float* out,
+                            int height_new, int width_new, int padding_t, int padding_l, si_stream_t stream);
+/* Detection post-processing of test_yolo.cpp:337-428 on the device, for all images of a batch:
+ *   confidence = pred[.,4] * max_k pred[.,5+k] (first maximum), kept when >= prob_threshold (:341-377);
+ *   sorted by confidence, descending (:380; equal confidences are ordered by element index here, by an unstable
+ *   quicksort in the reference); greedy NMS against every box picked so far, same label only unless `agnostic`
+ *   (:68-104, IoU > nms_threshold suppresses); then, when `adjust` != NULL, the un-letterbox + clip of :390-416.
+ * pred [n][rows][ne] fp32 on the device (the Detect output).  adjust: NULL or device [n][5] floats
+ * {padding_l, padding_t, scale, image cols, image rows}.  dets: device [n][max_det][6] floats
+ * {x, y, width, height, confidence, label}, in picked order.  counts: device [n] ints = number of boxes picked (the
+ * reference has no cap: when counts[b] > max_det only the first max_det were stored).  workspace: device scratch of
+ * si_hip_yolo_postprocess_workspace_bytes(n, rows, ne) bytes. */
+size_t si_hip_yolo_postprocess_workspace_bytes(int n, int rows, int ne);
+int si_hip_yolo_postprocess_f32(const float* pred, int n, int rows, int ne, float prob_threshold, float nms_threshold,
+                                int agnostic, const float* adjust, float* dets, int* counts, int max_det,
+                                void* workspace, size_t workspace_bytes, si_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,6 +218,41 @@ def yolo_detect(feats, weights, biases, grids, anchor_grids, strides, na=3):
     return out
 
 
+def letterbox_geometry(height_origin, width_origin, height_new, width_new):
+    hr, wr, pt, pl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    sc = C.c_float()
+    lib().orc_letterbox_geometry(height_origin, width_origin, height_new, width_new, C.byref(hr), C.byref(wr),
+                                 C.byref(sc), C.byref(pt), C.byref(pl))
+    return hr.value, wr.value, sc.value, pt.value, pl.value
+
+
+def letterbox(resized_bgr, height_new, width_new, padding_t, padding_l):
+    src = np.ascontiguousarray(resized_bgr, dtype=np.uint8)
+    out = np.empty((height_new, width_new, 3), np.float32)
+    lib().orc_letterbox_u8(src.ctypes.data_as(C.c_void_p), int(src.shape[0]), int(src.shape[1]), _p(out), height_new,
+                           width_new, padding_t, padding_l)
+    return out
+
+
+def yolo_postprocess(pred, prob_threshold=0.25, nms_threshold=0.45, agnostic=False, adjust=None, max_det=None):
+    """test_yolo.cpp:337-428 per image; returns (list of [k][6] arrays, counts)."""
+    pred = _f32(pred)
+    n, rows, ne = pred.shape
+    if max_det is None:
+        max_det = max(rows, 1)
+    L = lib()
+    L.orc_yolo_postprocess.restype = C.c_int
+    outs, cnts = [], np.zeros((n,), np.int32)
+    for b in range(n):
+        dets = np.zeros((max(max_det, 1), 6), np.float32)
+        adj = _f32(adjust[b]) if adjust is not None else None
+        k = L.orc_yolo_postprocess(_p(pred[b]), rows, ne, C.c_float(prob_threshold), C.c_float(nms_threshold),
+                                   int(bool(agnostic)), _p(adj), _p(dets), max_det)
+        cnts[b] = k
+        outs.append(dets[:min(k, max_det)].copy())
+    return outs, cnts
+
+
 # ---------------------------------------------------------------------------
 # independent .pnnx.param/.bin reader + graph walk
 # ---------------------------------------------------------------------------

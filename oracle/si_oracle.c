@@ -641,3 +641,152 @@ void orc_yolo_detect_level(const float* feat, int n, int h, int w, int cin,
         }
     free(conv);
 }
+
+/* ---- letterbox + detection post-processing (test/test_yolo/test_yolo.cpp) ------------------- */
+void orc_letterbox_geometry(int height_origin, int width_origin, int height_new, int width_new, int* height_resize,
+                            int* width_resize, float* scale, int* padding_t, int* padding_l) {
+    /* test_yolo.cpp:194-213 */
+    int hr = height_new, wr = width_new;
+    float s = 1.0f;
+    if (height_new * width_origin < width_new * height_origin) {
+        s = (float)height_new / (float)height_origin;
+        wr = (int)(width_origin * s);
+    } else {
+        s = (float)width_new / (float)width_origin;
+        hr = (int)(height_origin * s);
+    }
+    /* :234-241 */
+    *height_resize = hr;
+    *width_resize = wr;
+    *scale = s;
+    *padding_t = (height_new - hr) / 2;
+    *padding_l = (width_new - wr) / 2;
+}
+
+void orc_letterbox_u8(const unsigned char* src, int hr, int wr, float* out, int H, int W, int pt, int pl) {
+    /* :220-252: reverse channel dim, pad with 114, cast<float>, / 255.0f */
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int c = 0; c < 3; ++c) {
+                const int sy = y - pt, sx = x - pl;
+                unsigned char v = 114;
+                if (sy >= 0 && sy < hr && sx >= 0 && sx < wr) v = src[((size_t)sy * wr + sx) * 3 + (2 - c)];
+                out[((size_t)y * W + x) * 3 + c] = (float)v / 255.0f;
+            }
+}
+
+typedef struct {
+    float x, y, w, h;
+    int label;
+    float prob;
+} OrcObject;
+
+/* test_yolo.cpp:28-59 */
+static void orc_qsort_descent(OrcObject* o, int left, int right) {
+    int i = left, j = right;
+    const float p = o[(left + right) / 2].prob;
+    while (i <= j) {
+        while (o[i].prob > p) i++;
+        while (o[j].prob < p) j--;
+        if (i <= j) {
+            const OrcObject t = o[i];
+            o[i] = o[j];
+            o[j] = t;
+            i++;
+            j--;
+        }
+    }
+    if (left < j) orc_qsort_descent(o, left, j);
+    if (i < right) orc_qsort_descent(o, i, right);
+}
+
+/* cv::Rect_<float> a & b, then area() (simpleocv) */
+static float orc_intersection_area(const OrcObject* a, const OrcObject* b) {
+    const float x1 = a->x > b->x ? a->x : b->x;
+    const float y1 = a->y > b->y ? a->y : b->y;
+    const float ax2 = a->x + a->w, bx2 = b->x + b->w;
+    const float ay2 = a->y + a->h, by2 = b->y + b->h;
+    const float w = (ax2 < bx2 ? ax2 : bx2) - x1;
+    const float h = (ay2 < by2 ? ay2 : by2) - y1;
+    if (w <= 0.0f || h <= 0.0f) return 0.0f;
+    return w * h;
+}
+
+static float orc_clipf(float v, float lo, float hi) {
+    const float m = v < hi ? v : hi;
+    return lo > m ? lo : m;
+}
+
+int orc_yolo_postprocess(const float* pred, int rows, int ne, float prob_threshold, float nms_threshold, int agnostic,
+                         const float* adjust, float* dets, int max_det) {
+    const int num_class = ne - 5;
+    OrcObject* objs = (OrcObject*)malloc(sizeof(OrcObject) * (size_t)(rows > 0 ? rows : 1));
+    int n = 0;
+    /* :341-377 */
+    for (int e = 0; e < rows; ++e) {
+        const float* r = pred + (size_t)e * ne;
+        const float box_score = r[4];
+        int class_index = -1;
+        float class_score = -FLT_MAX;
+        for (int k = 0; k < num_class; ++k) {
+            const float score = r[k + 5];
+            if (score > class_score) {
+                class_index = k;
+                class_score = score;
+            }
+        }
+        const float confidence = box_score * class_score;
+        if (confidence >= prob_threshold) {
+            const float x0 = r[0] - r[2] * 0.5f, y0 = r[1] - r[3] * 0.5f;
+            const float x1 = r[0] + r[2] * 0.5f, y1 = r[1] + r[3] * 0.5f;
+            objs[n].x = x0;
+            objs[n].y = y0;
+            objs[n].w = x1 - x0;
+            objs[n].h = y1 - y0;
+            objs[n].label = class_index;
+            objs[n].prob = confidence;
+            ++n;
+        }
+    }
+    /* :380 */
+    if (n > 0) orc_qsort_descent(objs, 0, n - 1);
+    /* :68-104 */
+    int* picked = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    float* areas = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    int np_ = 0;
+    for (int i = 0; i < n; ++i) areas[i] = objs[i].w * objs[i].h;
+    for (int i = 0; i < n; ++i) {
+        int keep = 1;
+        for (int j = 0; j < np_; ++j) {
+            const OrcObject* b = &objs[picked[j]];
+            if (!agnostic && objs[i].label != b->label) continue;
+            const float inter_area = orc_intersection_area(&objs[i], b);
+            const float union_area = areas[i] + areas[picked[j]] - inter_area;
+            if (inter_area / union_area > nms_threshold) keep = 0;
+        }
+        if (keep) picked[np_++] = i;
+    }
+    /* :386-416 */
+    for (int i = 0; i < np_ && i < max_det; ++i) {
+        const OrcObject* o = &objs[picked[i]];
+        float* d = dets + (size_t)i * 6;
+        if (adjust) {
+            const float pl = adjust[0], pt = adjust[1], sc = adjust[2];
+            float x0 = (o->x - pl) / sc, y0 = (o->y - pt) / sc;
+            float x1 = (o->x + o->w - pl) / sc, y1 = (o->y + o->h - pt) / sc;
+            x0 = orc_clipf(x0, 0.0f, adjust[3] - 1.0f);
+            y0 = orc_clipf(y0, 0.0f, adjust[4] - 1.0f);
+            x1 = orc_clipf(x1, 0.0f, adjust[3] - 1.0f);
+            y1 = orc_clipf(y1, 0.0f, adjust[4] - 1.0f);
+            d[0] = x0; d[1] = y0; d[2] = x1 - x0; d[3] = y1 - y0;
+        } else {
+            d[0] = o->x; d[1] = o->y; d[2] = o->w; d[3] = o->h;
+        }
+        d[4] = o->prob;
+        d[5] = (float)o->label;
+    }
+    free(areas);
+    free(picked);
+    free(objs);
+    return np_;
+}

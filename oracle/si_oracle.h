@@ -149,6 +149,22 @@ void orc_yolo_detect_level(const float* feat, int n, int h, int w, int cin,
                            const float* anchor_attr, float stride, float* out,
                            int rows_total, int row_off);
 
+/* Letterbox of PreProcess after cv::resize (test/test_yolo/test_yolo.cpp:194-259): geometry (:194-213, 234-241) and
+ * the reverse(bgr->rgb) / pad(114) / cast / divide-by-255 expression (:220-252) for one image. */
+void orc_letterbox_geometry(int height_origin, int width_origin, int height_new, int width_new, int* height_resize,
+                            int* width_resize, float* scale, int* padding_t, int* padding_l);
+void orc_letterbox_u8(const unsigned char* resized_bgr, int hr, int wr, float* out, int height_new, int width_new,
+                      int padding_t, int padding_l);
+
+/* Detection post-processing of ONE image exactly as test_yolo.cpp:337-428 does it: confidence filter (:341-377),
+ * qsort_descent_inplace (:28-66, the same unstable quicksort), nms_sorted_bboxes (:68-104; rect intersection as
+ * simpleocv's `a & b`, an absent ncnn-derived submodule: empty when width <= 0 or height <= 0), and -- when adjust !=
+ * NULL {padding_l, padding_t, scale, cols, rows} -- the un-letterbox + clip of :390-416.
+ * pred [rows][ne]; dets [max_det][6] = {x, y, w, h, prob, label}.  Returns the number of boxes picked (only the
+ * first max_det are stored). */
+int orc_yolo_postprocess(const float* pred, int rows, int ne, float prob_threshold, float nms_threshold, int agnostic,
+                         const float* adjust, float* dets, int max_det);
+
 int orc_num_threads(void);
 void orc_set_num_threads(int n);
 

@@ -102,6 +102,10 @@ def hip():
         "si_hip_binary_f32": (i, [i, vp, ip, i, vp, ip, i, vp, ip, i, vp]),
         "si_hip_batchnorm2d_f32": (i, [vp, sz, i, i, vp, vp, vp, vp, f, vp, i, vp]),
         "si_hip_yolo_decode_f32": (i, [vp, i, i, i, i, i, vp, vp, f, vp, i, i, vp]),
+        "si_letterbox_geometry": (None, [i, i, i, i, ip, ip, C.POINTER(f), ip, ip]),
+        "si_hip_letterbox_u8_f32": (i, [vp, i, i, vp, i, i, i, i, vp]),
+        "si_hip_yolo_postprocess_workspace_bytes": (sz, [i, i, i]),
+        "si_hip_yolo_postprocess_f32": (i, [vp, i, i, i, f, f, i, vp, vp, vp, i, vp, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = header/library mismatch, which tests check

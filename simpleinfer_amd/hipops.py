@@ -333,3 +333,50 @@ def _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na)
         sync()
         off += h * wd * na
     return dout.to_numpy((n, rows_total, ne))
+
+
+def letterbox_geometry(height_origin, width_origin, height_new, width_new):
+    """(height_resize, width_resize, scale, padding_t, padding_l) of PreProcess (test_yolo.cpp:194-241)."""
+    hr, wr, pt, pl = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    sc = C.c_float()
+    _native.hip().si_letterbox_geometry(height_origin, width_origin, height_new, width_new, C.byref(hr), C.byref(wr),
+                                        C.byref(sc), C.byref(pt), C.byref(pl))
+    return hr.value, wr.value, sc.value, pt.value, pl.value
+
+
+def letterbox(resized_bgr, height_new, width_new, padding_t, padding_l):
+    """u8 BGR [hr][wr][3] -> float RGB [height_new][width_new][3], padded with 114, / 255 (test_yolo.cpp:220-259)."""
+    H = _native.hip()
+    src = np.ascontiguousarray(resized_bgr, dtype=np.uint8)
+    hr, wr = int(src.shape[0]), int(src.shape[1])
+    dsrc = DeviceBuffer.from_numpy(src)
+    dout = DeviceBuffer(height_new * width_new * 3 * 4)
+    _chk(H.si_hip_letterbox_u8_f32(dsrc.ptr, hr, wr, dout.ptr, height_new, width_new, padding_t, padding_l, None),
+         "si_hip_letterbox_u8_f32")
+    return dout.to_numpy((height_new, width_new, 3))
+
+
+def yolo_postprocess(pred, prob_threshold=0.25, nms_threshold=0.45, agnostic=False, adjust=None, max_det=None,
+                     pred_dev=None):
+    """Device post-processing of test_yolo.cpp:337-428.  pred [n][rows][ne] -> list (one per image) of float arrays
+    [k][6] = {x, y, w, h, confidence, label} in picked order.  adjust: None or [n][5]
+    {padding_l, padding_t, scale, image cols, image rows}."""
+    H = _native.hip()
+    pred = _f32(pred)
+    n, rows, ne = (int(v) for v in pred.shape)
+    if max_det is None:
+        max_det = max(rows, 1)
+    dpred = pred_dev if pred_dev is not None else DeviceBuffer.from_numpy(pred)
+    dadj = DeviceBuffer.from_numpy(_f32(adjust).reshape(n, 5)) if adjust is not None else None
+    wsb = H.si_hip_yolo_postprocess_workspace_bytes(n, rows, ne)
+    dws = DeviceBuffer(wsb)
+    ddets = DeviceBuffer(max(n * max_det * 6 * 4, 16))
+    dcnt = DeviceBuffer(max(n * 4, 16))
+    _chk(H.si_hip_yolo_postprocess_f32(dpred.ptr, n, rows, ne, float(prob_threshold), float(nms_threshold),
+                                       int(bool(agnostic)), dadj.ptr if dadj else None, ddets.ptr, dcnt.ptr, max_det,
+                                       dws.ptr, wsb, None), "si_hip_yolo_postprocess_f32")
+    if n == 0:
+        return [], np.zeros((0,), np.int32)
+    cnt = dcnt.to_numpy((n,), np.int32)
+    dets = ddets.to_numpy((n, max_det, 6)) if max_det > 0 else np.zeros((n, 0, 6), np.float32)
+    return [dets[b, :min(int(cnt[b]), max_det)].copy() for b in range(n)], cnt

@@ -277,3 +277,49 @@ def test_yolo_detect_head(hops, orc, n, levels):
     ref = orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na)
     assert_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na), ref, what="conv + decode kernels")
     assert_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na, fused=True), ref, what="decode fused in conv epilogue")
+
+
+# ---- letterbox + detection post-processing (test/test_yolo/test_yolo.cpp:194-259, 337-428) ----
+def test_letterbox_exact(hops, orc):
+    assert hops.letterbox_geometry(1080, 810, 640, 640) == orc.letterbox_geometry(1080, 810, 640, 640)
+    assert hops.letterbox_geometry(375, 500, 640, 640) == orc.letterbox_geometry(375, 500, 640, 640)
+    r = np.random.Generator(np.random.Philox(5))
+    hr, wr, sc, pt, pl = hops.letterbox_geometry(375, 500, 640, 640)
+    img = r.integers(0, 256, (hr, wr, 3), dtype=np.uint8)
+    assert_exact(hops.letterbox(img, 640, 640, pt, pl), orc.letterbox(img, 640, 640, pt, pl), "letterbox")
+
+
+@pytest.mark.parametrize("n,rows,nc,thr,agnostic,hot", [
+    (3, 25200, 80, 0.25, False, 0.03),     # the application's shape and thresholds
+    (2, 25200, 80, 0.25, True, 0.03),
+    (5, 1000, 3, 0.10, False, 0.30),       # rows not a multiple of the staging block, few classes, dense overlaps
+    (2, 700, 20, -1.0, False, 0.20),       # every row survives the filter
+    (2, 300, 20, 2.0, False, 0.20),        # nothing survives
+    (1, 64, 1, 0.25, False, 0.50),
+])
+def test_yolo_postprocess_matches_oracle(hops, orc, n, rows, nc, thr, agnostic, hot):
+    from util import synthetic_predictions
+    pred = synthetic_predictions(100 + rows + nc, n, rows, nc=nc, n_gt=5, hot_frac=hot)
+    adjust = np.array([[80, 0, 0.5925926, 810, 1080], [0, 80, 1.0, 640, 480], [10, 20, 1.7, 300, 200]] * 2,
+                      np.float32)[:n]
+    for adj in (None, adjust):
+        got, gcnt = hops.yolo_postprocess(pred, thr, 0.45, agnostic, adj)
+        ref, rcnt = orc.yolo_postprocess(pred, thr, 0.45, agnostic, adj)
+        assert_exact(gcnt, rcnt, "counts")
+        for b in range(n):
+            assert_exact(got[b], ref[b], "image %d" % b)
+    if thr == 0.25:
+        assert all(0 < c < rows for c in rcnt)
+
+
+def test_yolo_postprocess_cap_and_empty(hops, orc):
+    from util import synthetic_predictions
+    pred = synthetic_predictions(7, 2, 2000, nc=10, n_gt=8, hot_frac=0.2)
+    ref, rcnt = orc.yolo_postprocess(pred, 0.25, 0.45)
+    got, gcnt = hops.yolo_postprocess(pred, 0.25, 0.45, max_det=5)
+    assert_exact(gcnt, rcnt, "counts report every pick even past the cap")
+    for b in range(2):
+        assert rcnt[b] > 5
+        assert_exact(got[b], ref[b][:5], "first max_det picks")
+    got, gcnt = hops.yolo_postprocess(np.zeros((2, 0, 85), np.float32), 0.25, 0.45)
+    assert list(gcnt) == [0, 0] and all(len(g) == 0 for g in got)

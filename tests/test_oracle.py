@@ -217,3 +217,35 @@ def test_graph_oracle_matches_torch_composition(orc, tmp_path):
         else: raise AssertionError(t)
         vals[op.outputs[0]] = o
     assert_parity(y, vals[name].float().numpy(), 1e-5)
+
+
+# ---- letterbox + detection post-processing (test/test_yolo/test_yolo.cpp) ---------------------
+def test_letterbox_geometry_and_packing(orc):
+    # wide image: width limits; tall image: height limits (test_yolo.cpp:204-213)
+    assert orc.letterbox_geometry(480, 640, 640, 640) == (480, 640, 1.0, 80, 0)
+    hr, wr, sc, pt, pl = orc.letterbox_geometry(1080, 810, 640, 640)
+    assert (hr, wr, pt, pl) == (640, 480, 0, 80) and abs(sc - 640.0 / 1080.0) < 1e-7
+    img = (np.arange(5 * 7 * 3) % 251).astype(np.uint8).reshape(5, 7, 3)
+    out = orc.letterbox(img, 9, 10, 2, 1)
+    exp = np.full((9, 10, 3), np.float32(114) / np.float32(255), np.float32)
+    exp[2:7, 1:8, :] = img[:, :, ::-1].astype(np.float32) / np.float32(255)
+    assert_exact(out, exp, "letterbox")
+
+
+@pytest.mark.parametrize("agnostic", [False, True])
+def test_postprocess_oracle_matches_independent_numpy(orc, agnostic):
+    from util import numpy_postprocess, synthetic_predictions
+    pred = synthetic_predictions(11, 2, 1500, nc=12, n_gt=4, hot_frac=0.08)
+    adjust = np.array([[0, 80, 1.0, 640, 480], [80, 0, 0.5925926, 810, 1080]], np.float32)
+    outs, cnts = orc.yolo_postprocess(pred, 0.25, 0.45, agnostic, adjust)
+    ref = numpy_postprocess(pred, 0.25, 0.45, agnostic, adjust)
+    for b in range(2):
+        assert 0 < cnts[b] < 400 and cnts[b] == len(ref[b])
+        assert_exact(outs[b], ref[b], "image %d" % b)
+    # no survivors / everything survives
+    outs, cnts = orc.yolo_postprocess(pred, 2.0, 0.45, agnostic)
+    assert list(cnts) == [0, 0]
+    outs, cnts = orc.yolo_postprocess(pred[:, :300], -1.0, 0.45, agnostic)
+    ref = numpy_postprocess(pred[:, :300], -1.0, 0.45, agnostic)
+    for b in range(2):
+        assert_exact(outs[b], ref[b], "all rows, image %d" % b)

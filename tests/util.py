@@ -34,3 +34,79 @@ def rng_uniform(seed, shape, lo=0.0, hi=1.0):
     """Deterministic U[lo,hi) float32 (the reference tests use Eigen setRandom(): U[0,1), unseeded)."""
     r = np.random.Generator(np.random.Philox(seed))
     return (lo + (hi - lo) * r.random(shape, dtype=np.float32)).astype(np.float32)
+
+
+def synthetic_predictions(seed, n, rows, nc=80, n_gt=6, hot_frac=0.05, img=640.0):
+    """Detect-like predictions [n][rows][5+nc] in (0,1) scores / pixel boxes: a few ground-truth boxes per image, a
+    `hot_frac` share of the rows jittered around them with high scores (so NMS has real work), the rest cold."""
+    r = np.random.Generator(np.random.Philox(seed))
+    pred = np.empty((n, rows, 5 + nc), np.float32)
+    for b in range(n):
+        gt = np.stack([r.uniform(80, img - 80, n_gt), r.uniform(80, img - 80, n_gt), r.uniform(30, 200, n_gt),
+                       r.uniform(30, 200, n_gt)], 1)
+        gl = r.integers(0, nc, n_gt)
+        p = pred[b]
+        p[:, 0:2] = r.uniform(0, img, (rows, 2))
+        p[:, 2:4] = r.uniform(4, 300, (rows, 2))
+        p[:, 4] = r.uniform(0.0, 0.3, rows)
+        p[:, 5:] = r.uniform(0.0, 0.6, (rows, nc))
+        hot = r.random(rows) < hot_frac
+        k = int(hot.sum())
+        if k:
+            g = r.integers(0, n_gt, k)
+            p[hot, 0:4] = gt[g] * r.uniform(0.9, 1.1, (k, 4))
+            p[hot, 4] = r.uniform(0.5, 1.0, k)
+            cls = p[hot, 5:]
+            cls[np.arange(k), gl[g]] = r.uniform(0.6, 1.0, k)
+            p[hot, 5:] = cls
+    return pred
+
+
+def numpy_postprocess(pred, prob_threshold, nms_threshold, agnostic=False, adjust=None):
+    """Independent float32 statement of the post-processing semantics (filter, stable sort by confidence, greedy
+    NMS vs all picked, un-letterbox + clip) used to cross-check the C oracle."""
+    f = np.float32
+    outs = []
+    for b in range(pred.shape[0]):
+        p = pred[b].astype(np.float32)
+        cls = p[:, 5:]
+        lab = cls.argmax(1) if cls.shape[1] else np.zeros(len(p), np.int64)
+        conf = (p[:, 4] * cls[np.arange(len(p)), lab]).astype(np.float32)
+        keep = np.nonzero(conf >= f(prob_threshold))[0]
+        half_w, half_h = p[keep, 2] * f(0.5), p[keep, 3] * f(0.5)
+        x0, y0 = p[keep, 0] - half_w, p[keep, 1] - half_h
+        x1, y1 = p[keep, 0] + half_w, p[keep, 1] + half_h
+        w, h = x1 - x0, y1 - y0
+        order = np.argsort(-conf[keep], kind="stable")
+        x0, y0, w, h, lb, cf = x0[order], y0[order], w[order], h[order], lab[keep][order], conf[keep][order]
+        area = (w * h).astype(np.float32)
+        picked = []
+        for i in range(len(cf)):
+            ok = True
+            for j in picked:
+                if not agnostic and lb[i] != lb[j]:
+                    continue
+                ix = max(x0[i], x0[j]); iy = max(y0[i], y0[j])
+                iw = min(f(x0[i] + w[i]), f(x0[j] + w[j])) - ix
+                ih = min(f(y0[i] + h[i]), f(y0[j] + h[j])) - iy
+                ia = f(0.0) if (iw <= 0 or ih <= 0) else f(f(iw) * f(ih))
+                ua = f(f(area[i] + area[j]) - ia)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    if f(ia) / ua > f(nms_threshold):
+                        ok = False
+            if ok:
+                picked.append(i)
+        d = np.zeros((len(picked), 6), np.float32)
+        for k, i in enumerate(picked):
+            if adjust is not None:
+                pl, pt, sc, cols, rows_ = (f(v) for v in adjust[b])
+                ax0 = np.clip(f(x0[i] - pl) / sc, f(0), cols - f(1)); ay0 = np.clip(f(y0[i] - pt) / sc, f(0), rows_ - f(1))
+                ax1 = np.clip(f(f(x0[i] + w[i]) - pl) / sc, f(0), cols - f(1))
+                ay1 = np.clip(f(f(y0[i] + h[i]) - pt) / sc, f(0), rows_ - f(1))
+                d[k, :4] = [ax0, ay0, f(ax1 - ax0), f(ay1 - ay0)]
+            else:
+                d[k, :4] = [x0[i], y0[i], w[i], h[i]]
+            d[k, 4] = cf[i]
+            d[k, 5] = lb[i]
+        outs.append(d)
+    return outs
