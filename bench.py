@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--model", default="yolov5s", choices=["yolov5s", "resnet18"])
     ap.add_argument("--graph", type=int, default=0, help="replay Forward() as a hipGraph")
-    ap.add_argument("--winograd", type=int, default=1, help="fused Winograd F(2,3) for 3x3 s1 convs (0: implicit GEMM everywhere)")
+    ap.add_argument("--winograd", type=int, default=1, help="3x3 s1 convs: 0 implicit GEMM everywhere, 1 fused Winograd F(2,3) where faster (default), 2 fused Winograd F(4,3) on those layers")
     ap.add_argument("--no-aux", action="store_true", help="skip the host-I/O and post-processing side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU baseline sample")
@@ -300,7 +300,7 @@ def main():
                                                             args.batch * world,
                                                             ", outputs all-gathered over RCCL" if world > 1 else ""),
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "hipgraph": bool(args.graph), "winograd_f23_for_3x3s1": bool(args.winograd)},
+                   "hipgraph": bool(args.graph), "winograd_for_3x3s1": {0: "off", 1: "F(2,3)", 2: "F(4,3)"}.get(args.winograd, "F(2,3)")},
         "forward_kernel_ms_per_step": round(fwd_ms / args.steps, 3),
         "gflop_per_image": round(flops_step / args.batch / 1e9, 3),
         "frac_of_mfma_ceiling": round(value / world / ceiling, 4),

@@ -139,6 +139,18 @@ int si_hip_conv2d_wino23_pack_weight_host(const SiConv2dDesc* d, const float* w_
 int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, const float* u, const float* bias,
                              const float* residual, float* out, si_stream_t stream);
 
+/* The same layers through fused Winograd F(4x4, 3x3) -- the larger tile BASELINE.json's north_star names; the
+ * reference itself stops at F(2,3).  6x6 transform domain, 4x fewer MFMA flops than the direct kernel, standard
+ * matrices for the points {0, +-1, +-2, inf}; fp32 throughout (measured error vs a float64 direct convolution: a few
+ * 1e-6 of the output scale, inside the 1e-4 parity bar).  Same eligibility rule, same epilogue, same calling
+ * convention as the wino23 entry points; U = G g G^T is 36 * ic * oc floats. */
+int si_hip_conv2d_wino43_eligible(const SiConv2dDesc* d);
+int si_hip_conv2d_wino43_preferred(const SiConv2dDesc* d);
+size_t si_hip_conv2d_wino43_weight_elems(const SiConv2dDesc* d);
+int si_hip_conv2d_wino43_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* u);
+int si_hip_conv2d_wino43_f32(const SiConv2dDesc* d, const float* in, const float* u, const float* bias,
+                             const float* residual, float* out, si_stream_t stream);
+
 /* Two convolutions that read the SAME input with the same geometry (YOLOv5 C3: cv1 and cv2, both 1x1) run as one launch:
  * the weights / biases are concatenated along oc by the caller (d->oc = oc_a + oc_b); output channels [0, split_oc)
  * are written to `out` (stride d->out_ld) and [split_oc, d->oc) to `out2` (stride out2_ld).  split_oc must be a

@@ -1,0 +1,459 @@
+// conv_wino43.hip -- 3x3 stride-1 convolution as fused Winograd F(4x4, 3x3) on the fp32 matrix cores.
+//
+// Same contract as conv_wino23.hip (the reference's Winograd layers, src/layer/conv_2d.cpp:382-487) with the larger
+// tile BASELINE.json's north_star asks for: a 6x6 transform domain producing 4x4 outputs needs 36 multiplies per 16
+// outputs instead of 144, a 4x cut (F(2,3): 2.25x) of the work that is bound by the 157 TFLOP/s fp32 MFMA rate.  The
+// transform matrices are the standard ones for the points {0, +-1, +-2, inf} (Lavin & Gray, "Fast Algorithms for
+// Convolutional Neural Networks", 2016):
+//
+//   B^T = [ 4  0 -5  0  1  0 ]   G = [  1/4    0     0  ]   A^T = [ 1  1  1  1  1  0 ]
+//         [ 0 -4 -4  1  1  0 ]       [ -1/6  -1/6  -1/6 ]         [ 0  1 -1  2 -2  0 ]
+//         [ 0  4 -4 -1  1  0 ]       [ -1/6   1/6  -1/6 ]         [ 0  1  1  4  4  0 ]
+//         [ 0 -2 -1  2  1  0 ]       [ 1/24  1/12   1/6 ]         [ 0  1 -1  8 -8  1 ]
+//         [ 0  2 -1 -2  1  0 ]       [ 1/24 -1/12   1/6 ]
+//         [ 0  4  0 -5  0  1 ]       [  0     0      1  ]
+//
+// fp32 throughout; against a float64 direct convolution the result is within a few 1e-6 of the output scale (tests),
+// two orders inside the 1e-4 parity bar.  Nothing but the input, the pre-transformed filter and the output touches HBM.
+//
+// Work split: a workgroup = 6 waves owns 16 tiles (TBH x TBW; tile rows are counted over the whole batch, as in
+// conv_wino23.hip) x 32 output channels.  Wave r owns plane ROW r of the 6x6 domain: per 4-channel step its lane
+// (tile = lane & 15, channel = 4*step + lane >> 4) reads the patch rows B^T row r needs from LDS, forms
+// V[r][0..5] = (B^T d B)[r][.] in ~38 VALU operations -- which issue in the shadow of the MFMAs -- and feeds them as the
+// A operand of 12 v_mfma_f32_16x16x4_f32 (6 planes x 2 halves of the 32 output channels).  The B operand is the
+// filter image U = G g G^T, pre-swizzled on the host so that every load is one coalesced dwordx2 per lane (one
+// step, both halves).  Epilogue: the column half of A^T M A in registers, the row half across the six waves through LDS (in the
+// patch buffer), then bias / activation / residual and edge-clipped stores.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "si_hip.h"
+#include "si_hip_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct Wino43Args {
+    const float* in;
+    const float* u;      // U4[36][ic/16][oc/32][4][64][2]
+    const float* bias;
+    const float* res;
+    float* out;
+    int n, ih, iw, ic, in_ld;
+    int oh, ow, oc, out_ld, res_ld;
+    int pad;
+    int th, tw;          // tiles per image column / row
+    int rows_total;      // n * th
+    int col_blocks, oc_blocks, spatial_blocks;
+    unsigned in_bytes;
+    int act1, act2;
+    float act_param;
+};
+
+__device__ __forceinline__ float w43_act(int act, float v, float p) {
+    switch (act) {
+        case SI_ACT_RELU: return fmaxf(v, 0.0f);
+        case SI_ACT_SILU: return __fdividef(v, 1.0f + __expf(-v));
+        case SI_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;
+        default: return v;
+    }
+}
+
+constexpr int CB = 16;     // input channels per staged block
+constexpr int WG = 384;    // 6 waves
+
+template <int LOG_TBW>
+__global__ __launch_bounds__(WG, 3) void conv_wino43_kernel(const Wino43Args a) {
+    constexpr int TBW = 1 << LOG_TBW;
+    constexpr int TBH = 16 / TBW;
+    constexpr int PW = 4 * TBW + 2;          // staged pixels per slot row (even: 8-byte aligned ds_read_b64 rows)
+    constexpr int PWP = PW;
+    constexpr int SLOTS = 6 * TBH;           // slot = j * TBH + tr  (j = patch row 0..5)
+    constexpr int PLANE = ((SLOTS * PWP + 5) / 8) * 8 + 2;  // floats per staged channel, 2 (mod 8): see conv_wino23.hip
+    constexpr int NVEC = SLOTS * PW * (CB / 4);
+    constexpr int PFV = (NVEC + WG - 1) / WG;
+    static_assert(PLANE % 2 == 0 && PWP % 2 == 0, "8-byte aligned patch rows");
+    constexpr int BUF = CB * PLANE;          // one staged channel block; two of them alternate (one barrier per block)
+    constexpr int XLS = 36;                  // exchange: floats per lane, 32 used; XLS/4 odd keeps ds_*_b128 conflict free
+    constexpr int XCH = 6 * 64 * XLS;
+    constexpr int LDS_FLOATS = 2 * BUF > XCH ? 2 * BUF : XCH;
+
+    __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the B^T row constants in SGPRs
+    const int lane = tid & 63, l15 = lane & 15, kk = lane >> 4;
+    const int per_chunk = 8 * a.oc_blocks;
+    const int chunk = blockIdx.x / per_chunk;
+    const int rr = blockIdx.x - chunk * per_chunk;
+    const int sb = chunk * 8 + (rr & 7);
+    const int ocb = rr >> 3;
+    if (sb >= a.spatial_blocks) return;
+    const int by = sb / a.col_blocks;
+    const int bc = sb - by * a.col_blocks;
+    const int row0 = by * TBH;               // first flattened tile row of the block
+    const int col0 = bc * TBW;               // first tile column
+    const int oc0 = ocb * 32;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+
+    // ---- per-thread staging slots: byte offset of channel block 0 and LDS destination
+    unsigned g_off[PFV];
+#pragma unroll
+    for (int q = 0; q < PFV; ++q) {
+        const int v = tid + q * WG;
+        g_off[q] = 0xFFFFFF00u;
+        if (v < NVEC) {
+            const int cq = v & 3;
+            const int rest = v >> 2;
+            const int slot = rest / PW;
+            const int px = rest - slot * PW;
+            const int j = slot / TBH;
+            const int tr = slot - j * TBH;
+            const int R = row0 + tr;
+            if (R < a.rows_total) {
+                const int img = R / a.th;
+                const int ty = R - img * a.th;
+                const int y = 4 * ty - a.pad + j;
+                const int x = 4 * col0 - a.pad + px;
+                if ((unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw)
+                    g_off[q] = (unsigned)((img * a.ih + y) * a.iw + x) * (unsigned)(a.in_ld * 4) + (unsigned)(cq * 16);
+            }
+        }
+    }
+
+    u32x4 pre[PFV];
+    auto prefetch = [&](int cb) {
+#pragma unroll
+        for (int q = 0; q < PFV; ++q) {
+            const unsigned off = g_off[q] == 0xFFFFFF00u ? 0xFFFFFF00u : g_off[q] + (unsigned)(cb * CB * 4);
+            pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < PFV; ++q) {
+            const int v = tid + q * WG;
+            if (v < NVEC) {
+                const int rest = v >> 2;
+                const int slot = rest / PW;
+                const int dst = buf * BUF + ((v & 3) * 4) * PLANE + slot * PWP + (rest - slot * PW);
+                const f32x4 f = __builtin_bit_cast(f32x4, pre[q]);
+                patch[dst] = f[0];
+                patch[dst + PLANE] = f[1];
+                patch[dst + 2 * PLANE] = f[2];
+                patch[dst + 3 * PLANE] = f[3];
+            }
+        }
+    };
+
+    // ---- this wave's row of B^T: t[j] = c0*d[i0][j] + c1*d[i1][j] + c2*d[i2][j] + c3*d[i3][j]
+    int i0, i1, i2, i3;
+    float c0, c1, c2, c3;
+    switch (wave) {
+        case 0: i0 = 0; i1 = 2; i2 = 4; i3 = 4; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
+        case 1: i0 = 1; i1 = 2; i2 = 3; i3 = 4; c0 = -4.f; c1 = -4.f; c2 = 1.f; c3 = 1.f; break;
+        case 2: i0 = 1; i1 = 2; i2 = 3; i3 = 4; c0 = 4.f; c1 = -4.f; c2 = -1.f; c3 = 1.f; break;
+        case 3: i0 = 1; i1 = 2; i2 = 3; i3 = 4; c0 = -2.f; c1 = -1.f; c2 = 2.f; c3 = 1.f; break;
+        case 4: i0 = 1; i1 = 2; i2 = 3; i3 = 4; c0 = 2.f; c1 = -1.f; c2 = -2.f; c3 = 1.f; break;
+        default: i0 = 1; i1 = 3; i2 = 5; i3 = 5; c0 = 4.f; c1 = -5.f; c2 = 1.f; c3 = 0.f; break;
+    }
+    const int tr_l = l15 >> LOG_TBW, tc_l = l15 & (TBW - 1);
+    const float* p0 = patch + kk * PLANE + (i0 * TBH + tr_l) * PWP + 4 * tc_l;
+    const float* p1 = patch + kk * PLANE + (i1 * TBH + tr_l) * PWP + 4 * tc_l;
+    const float* p2 = patch + kk * PLANE + (i2 * TBH + tr_l) * PWP + 4 * tc_l;
+    const float* p3 = patch + kk * PLANE + (i3 * TBH + tr_l) * PWP + 4 * tc_l;
+
+    // B operand: filter image U4[plane][cb][oc tile][step][lane][2]: element h of lane (n = lane&15, k = lane>>4) is
+    // U[plane][cb*16 + 4*step + k][oc tile*32 + 16*h + n], the B values of one 4-channel step for both 16-wide halves of
+    // the oc tile.  One coalesced 512-byte load per wave feeds two MFMAs; it is issued one step ahead.
+    const int noct = a.oc / 32;
+    const int ncb = a.ic / CB;
+    const float2* ub = reinterpret_cast<const float2*>(a.u) + lane;
+    auto b_index = [&](int c, int cb, int step) -> size_t {
+        return ((((size_t)(6 * wave + c) * ncb + cb) * noct + (oc0 / 32)) * 4 + step) * 64;
+    };
+
+    f32x4 acc[6][2];
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][h][e] = 0.0f;
+
+    float2 bcur[6], bnxt[6];
+    auto load_b = [&](float2 (&dst)[6], int cb, int step) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dst[c] = ub[b_index(c, cb, step)];
+    };
+
+    prefetch(0);
+    commit(0);
+    load_b(bcur, 0, 0);
+    __syncthreads();
+
+    // row transform of one 4-channel step: t[0..5] for this lane's (tile, channel), two adjacent pixels per packed op
+    f32x2 t2[3];
+    const float *q0 = p0, *q1 = p1, *q2 = p2, *q3 = p3;  // p* + current buffer: every read below is base + immediate
+    auto row_transform = [&](int s) {
+        const int o = 4 * s * PLANE;
+#pragma unroll
+        for (int jp = 0; jp < 3; ++jp) {
+            const f32x2 d0 = *reinterpret_cast<const f32x2*>(q0 + o + 2 * jp);
+            const f32x2 d1 = *reinterpret_cast<const f32x2*>(q1 + o + 2 * jp);
+            const f32x2 d2 = *reinterpret_cast<const f32x2*>(q2 + o + 2 * jp);
+            const f32x2 d3 = *reinterpret_cast<const f32x2*>(q3 + o + 2 * jp);
+            t2[jp] = c0 * d0 + (c1 * d1 + (c2 * d2 + c3 * d3));
+        }
+    };
+
+    // vmcnt retires in order: the filter load of the next step is issued BEFORE the (slower) patch prefetch, so waiting
+    // for it never waits for the patch
+    for (int cb = 0; cb < ncb; ++cb) {
+        const int buf = cb & 1;
+        q0 = p0 + buf * BUF; q1 = p1 + buf * BUF; q2 = p2 + buf * BUF; q3 = p3 + buf * BUF;
+        row_transform(0);
+#pragma unroll
+        for (int s = 0; s < CB / 4; ++s) {
+            if (s + 1 < CB / 4) {
+                load_b(bnxt, cb, s + 1);
+            } else if (cb + 1 < ncb) {
+                load_b(bnxt, cb + 1, 0);
+            }
+            if (s == 0 && cb + 1 < ncb) prefetch(cb + 1);
+            // column transform: V[r][c] = sum_j t[j] B[j][c]   (t[2jp] = t2[jp].x, t[2jp+1] = t2[jp].y)
+            float v[6];
+            {
+                // (v0, v5) = 4*(t0, t1) - 5*(t2, t3) + (t4, t5)
+                const f32x2 a05 = 4.0f * t2[0] + (-5.0f * t2[1] + t2[2]);
+                v[0] = a05.x;
+                v[5] = a05.y;
+                // pe = t4 - 4 t2, po = t3 - 4 t1;  qe = t4 - t2, qo = t3 - t1
+                const f32x2 e = {t2[2].x, t2[2].x}, tt2 = {t2[1].x, t2[1].x};
+                const f32x2 o = {t2[1].y, t2[1].y}, tt1 = {t2[0].y, t2[0].y};
+                const f32x2 k = {-4.0f, -1.0f};
+                const f32x2 pq_e = e + k * tt2;   // (pe, qe)
+                const f32x2 pq_o = o + k * tt1;   // (po, qo)
+                v[1] = pq_e.x + pq_o.x;
+                v[2] = pq_e.x - pq_o.x;
+                v[3] = fmaf(2.0f, pq_o.y, pq_e.y);
+                v[4] = fmaf(-2.0f, pq_o.y, pq_e.y);
+            }
+            if (s + 1 < CB / 4) row_transform(s + 1);  // LDS reads of the next step overlap this step's MFMAs
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c], bcur[c].x, acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c], bcur[c].y, acc[c][1], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) bcur[c] = bnxt[c];
+        }
+        // the other buffer was last read one block ago and a barrier has passed since: fill it, then one barrier
+        if (cb + 1 < ncb) commit(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- output transform Y = A^T M A.  Column half in registers: for plane row r, Z[r][jc] = sum_c M[r][c] A[c][jc]:
+    //   Z0 = m0+m1+m2+m3+m4   Z1 = (m1-m2) + 2(m3-m4)   Z2 = (m1+m2) + 4(m3+m4)   Z3 = (m1-m2) + 8(m3-m4) + m5
+    // Row half across the six waves through LDS, two output columns jc per round:
+    //   Y[i][jc] = sum_r A^T[i][r] Z[r][jc], same coefficients.  Waves 0..3 finish output row i = wave.
+    // Every wave parks its 32 column-transformed values Z[jc][h][e] in LDS as [wave][lane][XLS] (8 ds_write_b128); after
+    // one barrier waves 0..3 combine the six plane rows for output row i = wave (48 ds_read_b128) and store.
+    float* xch = patch;
+    {
+        f32x4* mine = reinterpret_cast<f32x4*>(xch + (wave * 64 + lane) * XLS);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 z[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float m0 = acc[0][h][e], m1 = acc[1][h][e], m2 = acc[2][h][e], m3 = acc[3][h][e], m4 = acc[4][h][e],
+                            m5 = acc[5][h][e];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                z[0][e] = (m0 + s12) + s34;
+                z[1][e] = fmaf(2.0f, d34, d12);
+                z[2][e] = fmaf(4.0f, s34, s12);
+                z[3][e] = fmaf(8.0f, d34, d12) + m5;
+            }
+#pragma unroll
+            for (int jc = 0; jc < 4; ++jc) mine[jc * 2 + h] = z[jc];   // float index (jc*2 + h)*4 + e
+        }
+    }
+    __syncthreads();
+    if (wave >= 4) return;
+
+    // geometry of this lane's four tiles (C/D map of the 16x16 MFMA: row = 4 * (lane >> 4) + e): first output pixel
+    // index and how many of the tile's 4 rows / columns are inside the image
+    int pix0[4], nrow[4], ncol[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int m = 4 * kk + e;
+        const int tr = m >> LOG_TBW, tc = m & (TBW - 1);
+        const int R = row0 + tr;
+        const int txg = col0 + tc;
+        pix0[e] = 0;
+        nrow[e] = ncol[e] = 0;
+        if (R < a.rows_total && txg < a.tw) {
+            const int img = R / a.th;
+            const int ty = R - img * a.th;
+            pix0[e] = (img * a.oh + 4 * ty) * a.ow + 4 * txg;
+            nrow[e] = min(4, a.oh - 4 * ty);
+            ncol[e] = min(4, a.ow - 4 * txg);
+        }
+    }
+    const int i_out = wave;
+    // A^T row i: y = k0*z0 + (z1 + s2*z2) * k12 ... written per row to keep the exact same evaluation order as before
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int o = oc0 + 16 * h + l15;
+        const bool ocok = o < a.oc;
+        const float bv = (a.bias && ocok) ? a.bias[o] : 0.0f;
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) {
+            f32x4 zr[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                zr[r] = *reinterpret_cast<const f32x4*>(xch + (r * 64 + lane) * XLS + (jc * 2 + h) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z0 = zr[0][e], z1 = zr[1][e], z2 = zr[2][e], z3 = zr[3][e], z4 = zr[4][e], z5 = zr[5][e];
+                const float s12 = z1 + z2, d12 = z1 - z2, s34 = z3 + z4, d34 = z3 - z4;
+                float y;
+                if (i_out == 0) y = (z0 + s12) + s34;
+                else if (i_out == 1) y = fmaf(2.0f, d34, d12);
+                else if (i_out == 2) y = fmaf(4.0f, s34, s12);
+                else y = fmaf(8.0f, d34, d12) + z5;
+                if (ocok && i_out < nrow[e] && jc < ncol[e]) {
+                    const size_t pix = (size_t)(pix0[e] + i_out * a.ow + jc);
+                    float vv = y + bv;
+                    vv = w43_act(a.act1, vv, a.act_param);
+                    if (a.res) vv += a.res[pix * a.res_ld + o];
+                    vv = w43_act(a.act2, vv, a.act_param);
+                    a.out[pix * a.out_ld + o] = vv;
+                }
+            }
+        }
+    }
+}
+
+template <int LOG_TBW>
+int launch_wino43(Wino43Args a, hipStream_t s) {
+    constexpr int TBW = 1 << LOG_TBW;
+    constexpr int TBH = 16 / TBW;
+    a.col_blocks = (a.tw + TBW - 1) / TBW;
+    a.oc_blocks = (a.oc + 31) / 32;
+    const int row_blocks = (a.rows_total + TBH - 1) / TBH;
+    a.spatial_blocks = a.col_blocks * row_blocks;
+    const long long nblocks = (long long)((a.spatial_blocks + 7) / 8) * 8 * a.oc_blocks;
+    if (nblocks > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    hipLaunchKernelGGL((conv_wino43_kernel<LOG_TBW>), dim3((unsigned)nblocks), dim3(WG), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+inline double w43_cover(int tw, int rows_total, int tbw) {
+    const int tbh = 16 / tbw;
+    const double cols = (double)((tw + tbw - 1) / tbw) * tbw, rows = (double)((rows_total + tbh - 1) / tbh) * tbh;
+    return ((double)tw * rows_total) / (cols * rows);
+}
+
+inline int w43_pick_log_tbw(int tw, int rows_total) {
+    int best = 3;
+    double bc = -1.0;
+    for (int l = 3; l >= 0; --l) {  // prefer wide blocks on ties (fewer staged halo columns)
+        const double c = w43_cover(tw, rows_total, 1 << l);
+        if (c > bc + 1e-9) {
+            bc = c;
+            best = l;
+        }
+    }
+    return best;
+}
+
+}  // namespace
+
+extern "C" int si_hip_conv2d_wino43_eligible(const SiConv2dDesc* d) {
+    if (!d) return 0;
+    if (d->kh != 3 || d->kw != 3 || d->sh != 1 || d->sw != 1 || d->dh != 1 || d->dw != 1 || d->groups != 1) return 0;
+    if (d->pt != d->pl || (d->pt != 0 && d->pt != 1)) return 0;
+    if (d->ic % CB != 0 || d->oc % 32 != 0) return 0;
+    return 1;
+}
+
+// Measured on MI355X (batch 32, standalone): 0.125 ms at 80x80x64 / 40x40x128 / 20x20x256 against 0.115 ms for the
+// F(2,3) kernel and ~0.15 ms for implicit GEMM.  The 4x cut in MFMA work is real (MFMA-only time 0.03 ms), but each
+// 32-cycle MFMA now needs ~3 VALU transform operations on the same vector issue port, which leaves the loop issue
+// bound; F(2,3) keeps the edge, so nothing prefers this kernel by default (SI_WINO43_MIN_IC=<ic> turns it on).
+extern "C" int si_hip_conv2d_wino43_preferred(const SiConv2dDesc* d) {
+    static const int min_ic = [] { const char* e = getenv("SI_WINO43_MIN_IC"); return e ? atoi(e) : 0; }();
+    return min_ic > 0 && si_hip_conv2d_wino43_eligible(d) && d->ic >= min_ic;
+}
+
+extern "C" size_t si_hip_conv2d_wino43_weight_elems(const SiConv2dDesc* d) {
+    return d ? (size_t)36 * d->ic * d->oc : 0;
+}
+
+// U = G g G^T evaluated in double and rounded once; plane = 6*row + col
+extern "C" int si_hip_conv2d_wino43_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* u) {
+    if (!d || !w_oihw || !u) return SI_E_BADARG;
+    static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int ic = d->ic, oc = d->oc;
+    const int ncb = ic / 16, noct = oc / 32;
+    for (int o = 0; o < oc; ++o)
+        for (int c = 0; c < ic; ++c) {
+            const float* g = w_oihw + ((size_t)o * ic + c) * 9;  // g[kh*3 + kw]
+            double tmp[6][3];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 3; ++j) tmp[i][j] = G[i][0] * g[j] + G[i][1] * g[3 + j] + G[i][2] * g[6 + j];
+            const int cb = c / 16, cl = c % 16;
+            const int step = cl / 4, k = cl % 4;
+            const int h = (o % 32) / 16, nn = o % 16;
+            const int ln = k * 16 + nn;
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    const double v = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                    const int plane = 6 * i + j;
+                    u[(((((size_t)plane * ncb + cb) * noct + o / 32) * 4 + step) * 64 + ln) * 2 + h] = (float)v;
+                }
+        }
+    return 0;
+}
+
+extern "C" int si_hip_conv2d_wino43_f32(const SiConv2dDesc* d, const float* in, const float* u, const float* bias,
+                                        const float* residual, float* out, si_stream_t stream) {
+    if (!d || !in || !u || !out) return SI_E_BADARG;
+    if (!si_hip_conv2d_wino43_eligible(d)) return SI_E_UNSUPPORTED;
+    if (d->has_bias && !bias) return SI_E_BADARG;
+    if (d->has_residual && !residual) return SI_E_BADARG;
+    if (d->in_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
+    const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull;
+    if (in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+    if (d->oh != d->ih + 2 * d->pt - 2 || d->ow != d->iw + 2 * d->pl - 2) return SI_E_BADARG;
+
+    Wino43Args a;
+    a.in = in; a.u = u; a.bias = d->has_bias ? bias : nullptr; a.res = d->has_residual ? residual : nullptr; a.out = out;
+    a.n = d->n; a.ih = d->ih; a.iw = d->iw; a.ic = d->ic; a.in_ld = d->in_ld;
+    a.oh = d->oh; a.ow = d->ow; a.oc = d->oc; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
+    a.pad = d->pt;
+    a.th = (d->oh + 3) / 4; a.tw = (d->ow + 3) / 4;
+    a.rows_total = d->n * a.th;
+    a.col_blocks = a.oc_blocks = a.spatial_blocks = 0;
+    a.in_bytes = (unsigned)in_bytes;
+    a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
+
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (w43_pick_log_tbw(a.tw, a.rows_total)) {
+        case 3: return launch_wino43<3>(a, s);
+        case 2: return launch_wino43<2>(a, s);
+        case 1: return launch_wino43<1>(a, s);
+        default: return launch_wino43<0>(a, s);
+    }
+}

@@ -45,7 +45,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "alias_cat") opt_alias_cat_ = value != 0;
     else if (key == "graph") opt_graph_ = value != 0;
     else if (key == "outputs_to_host") opt_outputs_to_host_ = value != 0;
-    else if (key == "winograd") opt_winograd_ = value != 0;
+    else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else {
         LOG(ERROR) << "unknown engine option [" << key << "]";
         return Status::kUnsupport;
@@ -209,6 +209,7 @@ Status EngineImpl::CreateLayers() {
         if (YoloDetect* yd = dynamic_cast<YoloDetect*>(layer)) yd->fuse_decode_ = opt_fuse_;
         if (Conv2d* cv = dynamic_cast<Conv2d*>(layer)) {
             if (!opt_winograd_) cv->algo_ = Conv2d::Algo::kImplicitGemm;
+            cv->prefer_wino43_ = opt_winograd_ == 2;
         }
 
         std::vector<TensorNode*> ins, outs;

@@ -92,7 +92,7 @@ private:
     bool opt_alias_cat_ = true;
     bool opt_graph_ = false;
     bool opt_outputs_to_host_ = true;
-    bool opt_winograd_ = true;
+    int opt_winograd_ = 1;
 
     Context* context_ = nullptr;
     pnnx::Graph* graph_ = nullptr;

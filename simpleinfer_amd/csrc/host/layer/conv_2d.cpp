@@ -166,16 +166,18 @@ Status Conv2d::PrepareDevice() {
     memset(&d, 0, sizeof(d));
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
     d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
-    use_winograd_ = false;
-    if (!sibling_ && ((algo_ == Algo::kAuto && si_hip_conv2d_wino23_preferred(&d)) ||
-                      (algo_ == Algo::kWinograd23 && si_hip_conv2d_wino23_eligible(&d))))
-        use_winograd_ = true;
-    if (algo_ == Algo::kWinograd23 && !use_winograd_) {
-        LOG(ERROR) << "Conv2d: Winograd F(2,3) requested for a shape it does not support";
+    wino_tile_ = WinogradTile(d);
+    use_winograd_ = wino_tile_ != 0;
+    if ((algo_ == Algo::kWinograd23 || algo_ == Algo::kWinograd43) && !use_winograd_) {
+        LOG(ERROR) << "Conv2d: Winograd requested for a shape it does not support";
         return Status::kUnsupport;
     }
-    std::vector<float> packed(use_winograd_ ? si_hip_conv2d_wino23_weight_elems(&d) : si_hip_conv2d_weight_elems(&d));
-    if (use_winograd_) {
+    std::vector<float> packed(wino_tile_ == 4   ? si_hip_conv2d_wino43_weight_elems(&d)
+                              : wino_tile_ == 2 ? si_hip_conv2d_wino23_weight_elems(&d)
+                                                : si_hip_conv2d_weight_elems(&d));
+    if (wino_tile_ == 4) {
+        CHECK_STATUS(CheckHip(si_hip_conv2d_wino43_pack_weight_host(&d, weight_.data(), packed.data()), "winograd filter transform"));
+    } else if (wino_tile_ == 2) {
         CHECK_STATUS(CheckHip(si_hip_conv2d_wino23_pack_weight_host(&d, weight_.data(), packed.data()), "winograd filter transform"));
     } else {
         CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&d, weight_.data(), packed.data()), "pack weight"));
@@ -227,9 +229,9 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
         d.res_ld = residual->PixelStride();
     }
     if (use_winograd_) {
-        const int rc = si_hip_conv2d_wino23_f32(&d, input.Data<float>(), weight_dev_.As<float>(),
-                                                use_bias_ ? bias_dev_.As<float>() : nullptr,
-                                                residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream());
+        const auto fn = wino_tile_ == 4 ? si_hip_conv2d_wino43_f32 : si_hip_conv2d_wino23_f32;
+        const int rc = fn(&d, input.Data<float>(), weight_dev_.As<float>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                          residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream());
         if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (winograd)");
         // an unaligned / oversized tensor view: re-pack for the implicit-GEMM kernel once and stay there
         algo_ = Algo::kImplicitGemm;
@@ -273,10 +275,23 @@ const char* Conv2d::KernelName() const {
     if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
     SiConv2dDesc d = MakeDesc(in, out);
     if (sibling_) d.oc += sibling_->out_channels_;
-    if (!sibling_ && ((algo_ == Algo::kAuto && si_hip_conv2d_wino23_preferred(&d)) ||
-                      (algo_ == Algo::kWinograd23 && si_hip_conv2d_wino23_eligible(&d))))
-        return "conv_wino23_kernel";
+    const int tile = WinogradTile(d);
+    if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
     return si_hip_conv2d_kernel_name(&d, in.Data<float>());
+}
+
+// 0 = implicit GEMM, 2 = fused Winograd F(2,3), 4 = fused Winograd F(4,3) for this layer's static shape
+int Conv2d::WinogradTile(const SiConv2dDesc& d) const {
+    if (sibling_) return 0;
+    switch (algo_) {
+        case Algo::kWinograd43: return si_hip_conv2d_wino43_eligible(&d) ? 4 : 0;
+        case Algo::kWinograd23: return si_hip_conv2d_wino23_eligible(&d) ? 2 : 0;
+        case Algo::kAuto:
+            if (si_hip_conv2d_wino43_preferred(&d)) return 4;
+            if (si_hip_conv2d_wino23_preferred(&d)) return (prefer_wino43_ && si_hip_conv2d_wino43_eligible(&d)) ? 4 : 2;
+            return 0;
+        default: return 0;
+    }
 }
 
 double Conv2d::Flops() const {

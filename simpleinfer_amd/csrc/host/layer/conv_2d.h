@@ -32,6 +32,7 @@ public:
     virtual Status Forward(const Tensor& input, std::vector<Tensor>& outputs) override;
 
     virtual const char* KernelName() const override;
+    int WinogradTile(const SiConv2dDesc& d) const;
     virtual double Flops() const override;
     virtual double Bytes() const override;
 
@@ -77,8 +78,10 @@ public:
 
     // algorithm: the reference picks Winograd F(2,3) for every eligible 3x3 s1 conv (InitWinograd, conv_2d.cpp:182-205);
     // here kAuto does the same when the fused Winograd kernel supports the channel counts, else implicit GEMM
-    enum class Algo { kAuto = 0, kImplicitGemm, kWinograd23 } algo_ = Algo::kAuto;
+    enum class Algo { kAuto = 0, kImplicitGemm, kWinograd23, kWinograd43 } algo_ = Algo::kAuto;
+    bool prefer_wino43_ = false;  // kAuto: take F(4,3) instead of F(2,3) wherever F(2,3) would have been chosen
     bool use_winograd_ = false;  // resolved at PrepareDevice (same name as the reference's flag, conv_2d.h:60)
+    int wino_tile_ = 0;          // 2 = F(2,3), 4 = F(4,3) when use_winograd_
 
     // fused epilogue
     int act1_ = SI_ACT_NONE;

@@ -125,9 +125,13 @@ def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
 
 
 def conv2d_winograd(x, w_oihw, bias=None, padding=(1, 1), act1="none", residual=None, act2="none", in_ld=None,
-                    out_ld=None, out_c_off=0):
-    """si_hip_conv2d_wino23_f32 (fused Winograd F(2,3)); raises HipError(SI_E_UNSUPPORTED) for ineligible shapes."""
+                    out_ld=None, out_c_off=0, tile=2):
+    """si_hip_conv2d_wino23_f32 (tile=2, fused Winograd F(2,3)) or si_hip_conv2d_wino43_f32 (tile=4, F(4,3)); raises
+    HipError for ineligible shapes."""
     H = _native.hip()
+    fam = "wino23" if tile == 2 else "wino43"
+    f_elig, f_elems = getattr(H, "si_hip_conv2d_%s_eligible" % fam), getattr(H, "si_hip_conv2d_%s_weight_elems" % fam)
+    f_pack, f_run = getattr(H, "si_hip_conv2d_%s_pack_weight_host" % fam), getattr(H, "si_hip_conv2d_%s_f32" % fam)
     x, w_oihw = _f32(x), _f32(w_oihw)
     n, ih, iw, ic = x.shape
     oc = w_oihw.shape[0]
@@ -136,10 +140,10 @@ def conv2d_winograd(x, w_oihw, bias=None, padding=(1, 1), act1="none", residual=
     out_ld = out_ld or oc
     d = SiConv2dDesc(n, ih, iw, ic, in_ld, oh, ow, oc, out_ld, 3, 3, 1, 1, 1, 1, padding[0], padding[1], 1,
                      1 if bias is not None else 0, ACT[act1], 1 if residual is not None else 0, oc, ACT[act2], 0.0)
-    if not H.si_hip_conv2d_wino23_eligible(C.byref(d)):
-        raise HipError("shape not eligible for Winograd F(2,3)")
-    u = np.zeros(H.si_hip_conv2d_wino23_weight_elems(C.byref(d)), np.float32)
-    _chk(H.si_hip_conv2d_wino23_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p)), "wino pack")
+    if not f_elig(C.byref(d)):
+        raise HipError("shape not eligible for Winograd")
+    u = np.zeros(f_elems(C.byref(d)), np.float32)
+    _chk(f_pack(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p)), "wino pack")
     if in_ld != ic:
         xw = np.zeros((n, ih, iw, in_ld), np.float32)
         xw[..., :ic] = x
@@ -149,8 +153,8 @@ def conv2d_winograd(x, w_oihw, bias=None, padding=(1, 1), act1="none", residual=
     dr = DeviceBuffer.from_numpy(_f32(residual)) if residual is not None else None
     dy = DeviceBuffer(n * oh * ow * out_ld * 4)
     dy.fill(0)
-    _chk(H.si_hip_conv2d_wino23_f32(C.byref(d), dx.ptr, du.ptr, db.ptr if db else None, dr.ptr if dr else None,
-                                    dy.ptr + 4 * out_c_off, None), "si_hip_conv2d_wino23_f32")
+    _chk(f_run(C.byref(d), dx.ptr, du.ptr, db.ptr if db else None, dr.ptr if dr else None,
+               dy.ptr + 4 * out_c_off, None), "si_hip_conv2d_%s_f32" % fam)
     y = dy.to_numpy((n, oh, ow, out_ld))
     return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
 

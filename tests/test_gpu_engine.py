@@ -52,6 +52,22 @@ def test_graph_parity_vs_oracle(si, orc, tmp_path, name):
     assert_parity(got, plain, 1e-6, what=name + " fused vs unfused")
 
 
+def test_winograd_schedules_agree(si, orc, tmp_path):
+    """winograd = 0 (implicit GEMM everywhere) / 1 (F(2,3) where faster) / 2 (F(4,3) on those layers) are the same
+    function; each is held to the parity bar against the oracle."""
+    pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(2, 160), "yw")
+    x = si.modelgen.synth_input((2, 160, 160, 3))
+    ref = orc.run_graph(pp, bp, {"0": x})
+    kernels = {}
+    for w in (0, 1, 2):
+        e, oname, got = _run(si, pp, bp, x, winograd=w)
+        assert_parity(got, ref[oname], what="winograd=%d" % w)
+        kernels[w] = {L["kernel"] for L in e.profile()}
+    assert not any("wino" in k for k in kernels[0])
+    assert any("conv_wino23" in k for k in kernels[1]) and not any("conv_wino43" in k for k in kernels[1])
+    assert any("conv_wino43" in k for k in kernels[2])
+
+
 def test_yolov5s_640_batch1_parity(si, orc, tmp_path):
     """BASELINE.json configs[1]: YOLOv5s 1x3x640x640 fp32 parity vs the CPU outputs."""
     pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(1, 640), "y1")

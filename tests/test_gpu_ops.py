@@ -147,6 +147,36 @@ def test_winograd_fused_epilogue_and_strides(hops, orc):
         hops.conv2d_winograd(rng_uniform(75, (1, 8, 8, 12), -1, 1), rng_uniform(76, (32, 12, 3, 3)), None)  # ic % 16 != 0
 
 
+# F(4x4, 3x3): same shapes (tile-block shapes 2x8 / 4x4 / 8x2 / 16x1, clipped 4x4 stores on odd sizes, image-spanning
+# blocks) plus maps smaller than one tile.  Parity target stays the reference's Winograd pipeline; the fp64 bound shows
+# the larger tile costs about one digit (measured <= 1e-5 of the output scale) and stays far inside 1e-4.
+@pytest.mark.parametrize("n,h,w,ic,oc,pad", WINO_SHAPES + [(2, 3, 3, 16, 32, 1), (1, 28, 28, 128, 128, 1), (3, 14, 14, 256, 32, 1)])
+def test_winograd43_vs_reference_path(hops, orc, n, h, w, ic, oc, pad):
+    x = rng_uniform(n * 1000 + h, (n, h, w, ic), -1, 1)
+    wt = rng_uniform(n * 1000 + h + 1, (oc, ic, 3, 3), -0.5, 0.5)
+    b = rng_uniform(n * 1000 + h + 2, (oc,), -0.5, 0.5)
+    got = hops.conv2d_winograd(x, wt, b, (pad, pad), tile=4)
+    assert_parity(got, orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="winograd"), what="vs reference Winograd")
+    assert_parity(got, orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="naive"), 2e-5, what="vs fp64")
+    assert np.abs(got - orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="naive", acc64=False)).max() < 2e-3
+
+
+def test_winograd43_fused_epilogue_and_strides(hops, orc):
+    x = rng_uniform(71, (2, 20, 20, 32), -1, 1)
+    wt = rng_uniform(72, (64, 32, 3, 3), -0.3, 0.3)
+    b = rng_uniform(73, (64,), -0.5, 0.5)
+    r = rng_uniform(74, (2, 20, 20, 64), -1, 1)
+    y = orc.conv2d(x, wt, b, (1, 1), (1, 1), path="naive")
+    w4 = lambda *a, **k: hops.conv2d_winograd(*a, tile=4, **k)  # noqa: E731
+    assert_parity(w4(x, wt, b, act1="silu", residual=r), orc.activation("silu", y) + r, what="silu + residual")
+    assert_parity(w4(x, wt, b, residual=r, act2="relu"), orc.activation("relu", y + r), what="residual + relu")
+    assert_parity(w4(x, wt, b, in_ld=48, out_ld=160, out_c_off=32), y, what="strided tensors")
+    full = w4(x, wt, b, act1="silu")
+    assert_exact(w4(x[1:2], wt, b, act1="silu")[0], full[1])
+    with pytest.raises(hops.HipError):
+        w4(rng_uniform(75, (1, 8, 8, 12), -1, 1), rng_uniform(76, (32, 12, 3, 3)), None)  # ic % 16 != 0
+
+
 def test_conv_split_siblings(hops, orc):
     """YOLOv5 C3: cv1 and cv2 (both 1x1 + SiLU on the same x) as one launch with a split destination"""
     x = rng_uniform(60, (2, 20, 20, 64), -1, 1)

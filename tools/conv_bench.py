@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--model", default="yolov5s")
     ap.add_argument("--only", default="")
     ap.add_argument("--act", default="silu")
-    ap.add_argument("--algo", default="direct", choices=["direct", "wino"], help="wino: si_hip_conv2d_wino23_f32 on eligible shapes only")
+    ap.add_argument("--algo", default="direct", choices=["direct", "wino", "wino43"], help="wino: si_hip_conv2d_wino23_f32 on eligible shapes only")
     ap.add_argument("--shape", action="append", default=[], help="n,h,w,ci,co,k,s,p (repeatable): custom shapes instead of a model")
     args = ap.parse_args()
     H = _native.hip()
@@ -69,11 +69,12 @@ def main():
             continue
         d = SiConv2dDesc(n, ih, iw, ci, ci, oh, ow, co, co, k[0], k[1], s[0], s[1], 1, 1, p[0], p[1], g, 1,
                          hipops.ACT[args.act], 0, co, 0, 0.0)
-        wino = args.algo == "wino"
-        if wino and not H.si_hip_conv2d_wino23_eligible(C.byref(d)):
+        wino = args.algo != "direct"
+        fam = "wino23" if args.algo == "wino" else "wino43"
+        if wino and not getattr(H, "si_hip_conv2d_%s_eligible" % fam)(C.byref(d)):
             continue
-        wn = H.si_hip_conv2d_wino23_weight_elems(C.byref(d)) if wino else H.si_hip_conv2d_weight_elems(C.byref(d))
-        fn = H.si_hip_conv2d_wino23_f32 if wino else H.si_hip_conv2d_f32
+        wn = getattr(H, "si_hip_conv2d_%s_weight_elems" % fam)(C.byref(d)) if wino else H.si_hip_conv2d_weight_elems(C.byref(d))
+        fn = getattr(H, "si_hip_conv2d_%s_f32" % fam) if wino else H.si_hip_conv2d_f32
         rng = np.random.default_rng(0)
         dx = hipops.DeviceBuffer.from_numpy(rng.random((n, ih, iw, ci), dtype=np.float32))
         dw = hipops.DeviceBuffer.from_numpy((rng.random(wn, dtype=np.float32) - 0.5) * 0.1)
@@ -93,7 +94,7 @@ def main():
         ms = ms.value / args.reps
         flops = 2.0 * n * oh * ow * co * k[0] * k[1] * (ci // g)
         byts = 4.0 * (n * ih * iw * ci + n * oh * ow * co + wn)
-        name = "wino23" if wino else H.si_hip_conv2d_kernel_name(C.byref(d), dx.ptr).decode().replace("conv_igemm_f32_kernel", "")
+        name = fam if wino else H.si_hip_conv2d_kernel_name(C.byref(d), dx.ptr).decode().replace("conv_igemm_f32_kernel", "")
         rows.append((key, count, name, ms, flops / ms / 1e9, byts / ms / 1e6, flops))
         for buf in (dx, dw, db, dy):
             buf.free()
