@@ -6,7 +6,7 @@
 // fp32 MFMA rate (157 TFLOP/s) is the bound for these layers, so the 2.25x cut in multiplies is worth having -- but
 // only if the transformed tensors (4x the activation size) never touch HBM.  This kernel keeps everything on chip:
 //
-//   * a workgroup owns 32 Winograd tiles (TBH x TBW, rows of tiles counted across the whole batch) x NT*32 output
+//   * a workgroup owns 32 Winograd tiles (TBH x TBW, rows of tiles counted across the whole batch) x 32 output
 //     channels.  Per 16-channel block it stages the raw input patches of its tiles in LDS (channel-major, so the MFMA
 //     operand reads below are plain ds_read_b32 with immediate offsets);
 //   * wave r (0..3) owns plane ROW r of the 4x4 transform domain: for its tile (lane&31) and channel (2*step + lane>>5)
@@ -65,8 +65,8 @@ __device__ __forceinline__ float wino_act(int act, float v, float p) {
 
 constexpr int CB = 16;  // input channels per staged block
 
-// NT: 32-wide output-channel tiles per wave (workgroup covers NT*32 channels).  LOG_TBW: log2 of tiles per block row.
-template <int NT, int LOG_TBW>
+// LOG_TBW: log2 of tiles per block row (the workgroup's 32 tiles form a TBH x TBW block).
+template <int LOG_TBW>
 __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     constexpr int TBW = 1 << LOG_TBW;
     constexpr int TBH = 32 / TBW;
@@ -78,13 +78,17 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     constexpr int PLANE = ((SLOTS * PWP + 5) / 8) * 8 + 2;
     constexpr int NVEC = SLOTS * PW * (CB / 4);
     constexpr int PFV = (NVEC + 255) / 256;  // 16-byte vectors per thread per block
-    static_assert(CB * PLANE >= 4 * 16 * 64, "patch buffer doubles as the 16 KB exchange buffer");
     static_assert(PLANE % 2 == 0, "8-byte aligned patch rows");
+    constexpr int BUF = CB * PLANE;          // one staged channel block; two alternate, so a block costs ONE barrier
+    constexpr int XLS = 36;                  // exchange: floats per lane (32 used); XLS/4 odd keeps ds_*_b128 conflict free
+    constexpr int XCH = 4 * 64 * XLS;
+    constexpr int LDS_FLOATS = 2 * BUF > XCH ? 2 * BUF : XCH;
 
-    __shared__ float patch[CB * PLANE];
+    __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     // block id -> (spatial block, oc block): the oc blocks of one spatial block share blockIdx % 8, i.e. one XCD and its
     // L2, because they all stage the same input patches (placement is a speed hint only)
     const int per_chunk = 8 * a.oc_blocks;
@@ -97,18 +101,16 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     const int bc = sb - by * a.col_blocks;
     const int row0 = by * TBH;               // first flattened tile row of the block
     const int col0 = bc * TBW;               // first tile column
-    const int oc0 = ocb * (32 * NT);
+    const int oc0 = ocb * 32;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
 
-    // ---- per-thread staging slots: byte offset of channel block 0 and LDS destination
+    // ---- per-thread staging slots: byte offset of channel block 0 (the LDS destination is recomputed at commit time)
     unsigned g_off[PFV];
-    int l_dst[PFV];
 #pragma unroll
     for (int q = 0; q < PFV; ++q) {
         const int v = tid + q * 256;
         g_off[q] = 0xFFFFFF00u;
-        l_dst[q] = -1;
         if (v < NVEC) {
             const int cq = v & 3;
             const int rest = v >> 2;
@@ -117,7 +119,6 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
             const int j = slot / TBH;
             const int tr = slot - j * TBH;
             const int R = row0 + tr;
-            l_dst[q] = (cq * 4) * PLANE + slot * PWP + px;
             if (R < a.rows_total) {
                 const int img = R / a.th;
                 const int ty = R - img * a.th;
@@ -137,15 +138,19 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
             pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < PFV; ++q) {
-            if (l_dst[q] >= 0) {
+            const int v = tid + q * 256;
+            if (v < NVEC) {
+                const int rest = v >> 2;
+                const int slot = rest / PW;
+                const int dst = buf * BUF + ((v & 3) * 4) * PLANE + slot * PWP + (rest - slot * PW);
                 const f32x4 f = __builtin_bit_cast(f32x4, pre[q]);
-                patch[l_dst[q]] = f[0];
-                patch[l_dst[q] + PLANE] = f[1];
-                patch[l_dst[q] + 2 * PLANE] = f[2];
-                patch[l_dst[q] + 3 * PLANE] = f[3];
+                patch[dst] = f[0];
+                patch[dst + PLANE] = f[1];
+                patch[dst + 2 * PLANE] = f[2];
+                patch[dst + 3 * PLANE] = f[3];
             }
         }
     };
@@ -156,8 +161,8 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     const int jb = (wave == 0 || wave == 1) ? 2 : ((wave == 2) ? 1 : 3);
     const float sg = (wave == 1) ? 1.0f : -1.0f;
     const int tr_l = l31 >> LOG_TBW, tc_l = l31 & (TBW - 1);
-    const float* pa = patch + lh * PLANE + (ja * TBH + tr_l) * PWP + 2 * tc_l;
-    const float* pb = patch + lh * PLANE + (jb * TBH + tr_l) * PWP + 2 * tc_l;
+    const float* pa0 = patch + lh * PLANE + (ja * TBH + tr_l) * PWP + 2 * tc_l;
+    const float* pb0 = patch + lh * PLANE + (jb * TBH + tr_l) * PWP + 2 * tc_l;
 
     // B operand: filter image U2[plane][cb][oc tile][half][oc%32][lane half][4]: for one (plane, 16-channel block, 32-wide
     // oc tile, half) the 64 lanes' float4s are 1 KB contiguous; element k of lane (o, h) is U[plane][cb*16 + (half*4+k)*2 + h][o],
@@ -165,28 +170,24 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     const int noct = a.oc / 32;
     const int ncb = a.ic / CB;
     const f32x4* ub = reinterpret_cast<const f32x4*>(a.u) + l31 * 2 + lh;
-    auto b_index = [&](int q, int cb, int u, int half) -> size_t {
-        return ((((size_t)(4 * wave + q) * ncb + cb) * noct + (oc0 / 32 + u)) * 2 + half) * 64;
+    auto b_index = [&](int q, int cb, int half) -> size_t {
+        return ((((size_t)(4 * wave + q) * ncb + cb) * noct + (oc0 / 32)) * 2 + half) * 64;
     };
 
-    f32x16 acc[4][NT];
+    f32x16 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[q][u][e] = 0.0f;
+        for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
 
-    f32x4 bcur[4][NT], bnxt[4][NT];
-    auto load_b = [&](f32x4 (&dst)[4][NT], int cb, int half) {
+    f32x4 bcur[4], bnxt[4];
+    auto load_b = [&](f32x4 (&dst)[4], int cb, int half) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) dst[q][u] = ub[b_index(q, cb, u, half)];
+        for (int q = 0; q < 4; ++q) dst[q] = ub[b_index(q, cb, half)];
     };
 
     prefetch(0);
-    commit();
+    commit(0);
     load_b(bcur, 0, 0);
     __syncthreads();
 
@@ -194,12 +195,16 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     // block the filter loads are issued BEFORE the (slower, HBM) patch prefetch so that waiting for the filter values
     // never waits for the patch (vmcnt retires in order)
     float2 da[2], db[2];
+    const float *pa = pa0, *pb = pb0;
     auto read_d = [&](int s) {
         const float2* qa = reinterpret_cast<const float2*>(pa + (2 * s) * PLANE);
         const float2* qb = reinterpret_cast<const float2*>(pb + (2 * s) * PLANE);
         da[0] = qa[0]; da[1] = qa[1]; db[0] = qb[0]; db[1] = qb[1];
     };
     for (int cb = 0; cb < ncb; ++cb) {
+        const int buf = cb & 1;
+        pa = pa0 + buf * BUF;
+        pb = pb0 + buf * BUF;
         read_d(0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -224,87 +229,84 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
                 v[3] = t1 - t3;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int u = 0; u < NT; ++u)
-                        acc[q][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], bcur[q][u][k], acc[q][u], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], bcur[q][k], acc[q], 0, 0, 0);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int u = 0; u < NT; ++u) bcur[q][u] = bnxt[q][u];
+            for (int q = 0; q < 4; ++q) bcur[q] = bnxt[q];
         }
-        __syncthreads();  // everyone is done reading this block's patch
-        if (cb + 1 < ncb) {
-            commit();
-            __syncthreads();
-        }
+        // the other buffer was last read one block ago and a barrier has passed since: fill it, then one barrier
+        if (cb + 1 < ncb) commit(buf ^ 1);
+        __syncthreads();
     }
 
     // ---- output transform.  Column half in registers (winograd_helper.cpp:582-590): Z0 = m0+m1+m2, Z1 = m1-m2-m3.
-    // Row half across the four waves through LDS (:592-615): Y0 = Z(r0)+Z(r1)+Z(r2), Y1 = Z(r1)-Z(r2)-Z(r3).
-    float* xch = patch;  // [4 waves][16 e][64 lanes]
+    // Every wave parks its Z[jc][e] (32 values) in LDS as [wave][lane][XLS] with 8 ds_write_b128; after ONE barrier wave w
+    // finishes output row i = w & 1 of output column jc = w >> 1 for every tile: the row half across the four plane rows
+    // (:592-615), Y0 = Z(r0)+Z(r1)+Z(r2), Y1 = Z(r1)-Z(r2)-Z(r3), then bias / activation / residual.
+    float* xch = patch;
+    {
+        f32x4* mine = reinterpret_cast<f32x4*>(xch + (wave * 64 + lane) * XLS);
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-#pragma unroll
-        for (int jc = 0; jc < 2; ++jc) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float z = (jc == 0) ? (acc[0][u][e] + acc[1][u][e]) + acc[2][u][e]
-                                          : (acc[1][u][e] - acc[2][u][e]) - acc[3][u][e];
-                xch[(wave * 16 + e) * 64 + lane] = z;
-            }
-            __syncthreads();
-            // wave w finishes accumulator elements e = 4w .. 4w+3 of every lane
-            const int o = oc0 + u * 32 + l31;
-            const float bv = (a.bias && o < a.oc) ? a.bias[o] : 0.0f;
+        for (int g = 0; g < 4; ++g) {
+            f32x4 z0, z1;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int e = wave * 4 + k;
-                const float z0 = xch[(0 * 16 + e) * 64 + lane];
-                const float z1 = xch[(1 * 16 + e) * 64 + lane];
-                const float z2 = xch[(2 * 16 + e) * 64 + lane];
-                const float z3 = xch[(3 * 16 + e) * 64 + lane];
-                const float y[2] = {(z0 + z1) + z2, (z1 - z2) - z3};
-                // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh
-                const int m = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const int tr = m >> LOG_TBW, tc = m & (TBW - 1);
-                const int R = row0 + tr;
-                const int txg = col0 + tc;
-                if (R < a.rows_total && txg < a.tw && o < a.oc) {
-                    const int img = R / a.th;
-                    const int ty = R - img * a.th;
-                    const int ox = 2 * txg + jc;
+                const int e = 4 * g + k;
+                z0[k] = (acc[0][e] + acc[1][e]) + acc[2][e];
+                z1[k] = (acc[1][e] - acc[2][e]) - acc[3][e];
+            }
+            mine[g] = z0;       // float index jc*16 + e
+            mine[4 + g] = z1;
+        }
+    }
+    __syncthreads();
+    const int i_out = wave & 1, jc = wave >> 1;
+    const int o = oc0 + l31;
+    const bool ocok = o < a.oc;
+    const float bv = (a.bias && ocok) ? a.bias[o] : 0.0f;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int oy = 2 * ty + i;
-                        if (oy < a.oh && ox < a.ow) {
-                            const size_t pix = (size_t)(img * a.oh + oy) * a.ow + ox;
-                            float vv = y[i] + bv;
-                            vv = wino_act(a.act1, vv, a.act_param);
-                            if (a.res) vv += a.res[pix * a.res_ld + o];
-                            vv = wino_act(a.act2, vv, a.act_param);
-                            a.out[pix * a.out_ld + o] = vv;
-                        }
-                    }
+    for (int g = 0; g < 4; ++g) {
+        f32x4 zr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zr[r] = *reinterpret_cast<const f32x4*>(xch + (r * 64 + lane) * XLS + jc * 16 + 4 * g);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = 4 * g + k;
+            const float y = (i_out == 0) ? (zr[0][k] + zr[1][k]) + zr[2][k] : (zr[1][k] - zr[2][k]) - zr[3][k];
+            // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int tr = m >> LOG_TBW, tc = m & (TBW - 1);
+            const int R = row0 + tr;
+            const int txg = col0 + tc;
+            if (R < a.rows_total && txg < a.tw && ocok) {
+                const int img = R / a.th;
+                const int ty = R - img * a.th;
+                const int oy = 2 * ty + i_out, ox = 2 * txg + jc;
+                if (oy < a.oh && ox < a.ow) {
+                    const size_t pix = (size_t)(img * a.oh + oy) * a.ow + ox;
+                    float vv = y + bv;
+                    vv = wino_act(a.act1, vv, a.act_param);
+                    if (a.res) vv += a.res[pix * a.res_ld + o];
+                    vv = wino_act(a.act2, vv, a.act_param);
+                    a.out[pix * a.out_ld + o] = vv;
                 }
             }
-            __syncthreads();
         }
     }
 }
 
-template <int NT, int LOG_TBW>
+template <int LOG_TBW>
 int launch_wino(WinoArgs a, hipStream_t s) {
     constexpr int TBW = 1 << LOG_TBW;
     constexpr int TBH = 32 / TBW;
     a.col_blocks = (a.tw + TBW - 1) / TBW;
-    a.oc_blocks = (a.oc + 32 * NT - 1) / (32 * NT);
+    a.oc_blocks = (a.oc + 31) / 32;
     const int row_blocks = (a.rows_total + TBH - 1) / TBH;
     a.spatial_blocks = a.col_blocks * row_blocks;
     const long long nblocks = (long long)((a.spatial_blocks + 7) / 8) * 8 * a.oc_blocks;
     if (nblocks > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     dim3 grid((unsigned)nblocks, 1, 1);
-    hipLaunchKernelGGL((conv_wino23_kernel<NT, LOG_TBW>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW>), grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -414,15 +416,7 @@ extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, 
 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int l = wino_pick_log_tbw(a.tw, a.rows_total);
-    // NT = 2 (64 channels per workgroup) needs 276 registers per lane -> one wave per SIMD; NT = 1 keeps three.
-    static const bool force_wide = [] { const char* e = getenv("SI_WINO_NT"); return e && atoi(e) == 2; }();  // dev only
-    const bool wide = force_wide && d->oc >= 64;
-    if (wide) {
-        if (l == 3) return launch_wino<2, 3>(a, s);
-        if (l == 2) return launch_wino<2, 2>(a, s);
-        return launch_wino<2, 1>(a, s);
-    }
-    if (l == 3) return launch_wino<1, 3>(a, s);
-    if (l == 2) return launch_wino<1, 2>(a, s);
-    return launch_wino<1, 1>(a, s);
+    if (l == 3) return launch_wino<3>(a, s);
+    if (l == 2) return launch_wino<2>(a, s);
+    return launch_wino<1>(a, s);
 }
