@@ -253,6 +253,40 @@ int si_hip_yolo_postprocess_f32(const float* pred, int n, int rows, int ne, floa
                                 int agnostic, const float* adjust, float* dets, int* counts, int max_det,
                                 void* workspace, size_t workspace_bytes, si_stream_t stream);
 
+/* ---- fp16 storage path (BASELINE.json configs[3]; the reference is fp32 only, so these have no reference routine --
+ * they are the fp32 entry points above with half-precision activations / weights and fp32 accumulation) ------------- */
+/* host-side conversions (round to nearest even), used to prepare weights and by the tests */
+int si_hip_f32_to_f16_host(const float* src, void* dst, size_t n);
+int si_hip_f16_to_f32_host(const void* src, float* dst, size_t n);
+/* 0: no fp16 kernel for this shape; 1: implicit GEMM on v_mfma_f32_32x32x16_f16 (needs ic/groups % 32 == 0);
+ * 2: stem (ic <= 3): fp32 input image and fp32-packed weights (si_hip_conv2d_pack_weight_host), fp16 output */
+int si_hip_conv2d_f16_supported(const SiConv2dDesc* d);
+size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d);
+/* OIHW fp32 -> [oc][K] fp16, K order (c/32, kh, kw, c%32) */
+int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
+/* as si_hip_conv2d_f32; in / residual / out fp16 (strides in elements), bias fp32; out_is_f32 != 0 stores fp32 (graph
+ * outputs) */
+int si_hip_conv2d_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
+                      void* out, int out_is_f32, si_stream_t stream);
+int si_hip_conv2d_stem_f16(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias, void* out,
+                           si_stream_t stream);
+int si_hip_conv2d_split_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, void* out,
+                            int split_oc, void* out2, int out2_ld, si_stream_t stream);
+/* fp16 features in, fp32 [n][rows_total][ne] detections out */
+int si_hip_conv2d_yolo_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias,
+                           const SiYoloLevel* level, const float* grid_hwa2, const float* anchor_hwa2, float* detect_out,
+                           si_stream_t stream);
+int si_hip_activation_f16(int act, float act_param, const void* in, size_t pixels, int c, int in_ld, void* out, int out_ld,
+                          si_stream_t stream);
+/* same-shape add (op 0) / mul (op 2) */
+int si_hip_binary_same_f16(int op, const void* a, int a_ld, const void* b, int b_ld, void* out, int out_ld, size_t pixels,
+                           int c, si_stream_t stream);
+int si_hip_maxpool2d_f16(const SiPool2dDesc* d, const void* in, void* out, si_stream_t stream);
+int si_hip_adaptive_avgpool2d_f16(const void* in, int n, int ih, int iw, int c, int in_ld, void* out, int oh, int ow,
+                                  int out_ld, si_stream_t stream);
+int si_hip_convert_f32_f16(const float* in, size_t pixels, int c, int in_ld, void* out, int out_ld, si_stream_t stream);
+int si_hip_convert_f16_f32(const void* in, size_t pixels, int c, int in_ld, float* out, int out_ld, si_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

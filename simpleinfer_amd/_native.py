@@ -107,6 +107,21 @@ def hip():
         "si_hip_binary_f32": (i, [i, vp, ip, i, vp, ip, i, vp, ip, i, vp]),
         "si_hip_batchnorm2d_f32": (i, [vp, sz, i, i, vp, vp, vp, vp, f, vp, i, vp]),
         "si_hip_yolo_decode_f32": (i, [vp, i, i, i, i, i, vp, vp, f, vp, i, i, vp]),
+        "si_hip_f32_to_f16_host": (i, [vp, vp, sz]),
+        "si_hip_f16_to_f32_host": (i, [vp, vp, sz]),
+        "si_hip_conv2d_f16_supported": (i, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_f16_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_f16_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
+        "si_hip_conv2d_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, i, vp]),
+        "si_hip_conv2d_stem_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp]),
+        "si_hip_conv2d_split_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, i, vp, i, vp]),
+        "si_hip_conv2d_yolo_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),
+        "si_hip_activation_f16": (i, [i, f, vp, sz, i, i, vp, i, vp]),
+        "si_hip_binary_same_f16": (i, [i, vp, i, vp, i, vp, i, sz, i, vp]),
+        "si_hip_maxpool2d_f16": (i, [C.POINTER(SiPool2dDesc), vp, vp, vp]),
+        "si_hip_adaptive_avgpool2d_f16": (i, [vp, i, i, i, i, i, vp, i, i, i, vp]),
+        "si_hip_convert_f32_f16": (i, [vp, sz, i, i, vp, i, vp]),
+        "si_hip_convert_f16_f32": (i, [vp, sz, i, i, vp, i, vp]),
         "si_letterbox_geometry": (None, [i, i, i, i, ip, ip, C.POINTER(f), ip, ip]),
         "si_hip_letterbox_u8_f32": (i, [vp, i, i, vp, i, i, i, i, vp]),
         "si_hip_yolo_postprocess_workspace_bytes": (sz, [i, i, i]),

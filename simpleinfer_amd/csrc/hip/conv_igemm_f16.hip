@@ -1,0 +1,444 @@
+// conv_igemm_f16.hip -- NHWC fp16 convolution as an implicit GEMM on v_mfma_f32_32x32x16_f16 (fp32 accumulate).
+//
+// BASELINE.json configs[3] (YOLOv5s batch 32 fp16): the reference is fp32 only, so this path has no reference parity
+// target; it keeps the fp32 path's contract (same descriptor, same fused epilogues: bias + activation + residual, split
+// destination for sibling convs, YOLOv5 Detect decode) with fp16 storage for activations and weights.  Bias, the
+// accumulators and all epilogue arithmetic stay fp32; the Detect epilogue writes fp32.
+//
+// At 2.5 PFLOP/s the matrix cores are 16x faster than in fp32 while HBM is not, so every YOLOv5s layer is now bound by
+// memory or latency.  The kernel is therefore the fp32 fast kernel's structure with the cheapest possible tile
+// (conv_igemm.hip): raw buffer loads of 16-byte (8-channel) vectors with out-of-image taps as out-of-range offsets, a
+// wave-uniform tap walk over the channel-block-major K order (c/32, kh, kw, c%32), ONE LDS stage of [row][32+8] halves
+// (80-byte rows: the 16 lanes of a ds_read_b128 phase land on 16 disjoint 4-bank groups) and many resident workgroups.
+// One ds_read_b128 per operand feeds one 32x32x16 MFMA (lane l holds k = 8*(l>>5) .. +7 of row l&31, A and W alike).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "si_hip.h"
+#include "si_hip_internal.h"
+
+typedef _Float16 half_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// conv_smallc.hip: stem kernel (fp32 input, fp16 or fp32 output)
+bool si_conv_smallc_ok(const SiConv2dDesc* d);
+int si_conv_smallc_launch_f16out(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                                 void* out, hipStream_t s);
+
+namespace {
+
+struct ConvArgsH {
+    const half_t* in;
+    const half_t* w;
+    const float* bias;
+    const half_t* res;
+    void* out;                  // half, or float when ymode / out_f32
+    int ih, iw, in_ld;
+    int oh, ow, out_ld, res_ld;
+    int kh, kw, sh, sw, dh, dw, pt, pl;
+    int icg, ocg, oc;
+    int Kp;                     // kh*kw*icg
+    int M, ohow;
+    int m_tiles, n_tiles;
+    int act1, act2;
+    float act_param;
+    unsigned in_bytes;
+    int out_f32;                // plain epilogue writing fp32 (graph outputs)
+    half_t* out2;               // split output (sibling convs): channels >= split go to out2
+    int out2_ld, split;
+    int ymode, yna, yne, yrows_total, yrow_off;
+    float ystride;
+    const float* ygrid;
+    const float* yanchor;
+};
+
+__device__ __forceinline__ float act_h(int act, float v, float p) {
+    switch (act) {
+        case SI_ACT_RELU: return fmaxf(v, 0.0f);
+        case SI_ACT_SILU: return __fdividef(v, 1.0f + __expf(-v));
+        case SI_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;
+        default: return v;
+    }
+}
+
+// 32x32 C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+template <int TM, int TN, typename OutT>
+__device__ __forceinline__ void epilogue_plain(const ConvArgsH& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0) {
+    const bool has_res = a.res != nullptr;
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = ocol0 + u * 32;
+        if (o >= a.ocg) continue;
+        const int oc_abs = g * a.ocg + o;
+        const float bv = a.bias ? a.bias[oc_abs] : 0.0f;
+        const bool second = a.out2 != nullptr && oc_abs >= a.split;
+        OutT* const obase = second ? reinterpret_cast<OutT*>(a.out2) + (oc_abs - a.split) : static_cast<OutT*>(a.out) + oc_abs;
+        const int old = second ? a.out2_ld : a.out_ld;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int mb = mrow0 + t * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < a.M) {
+                    float v = acc[t][u][e] + bv;
+                    v = act_h(a.act1, v, a.act_param);
+                    if (has_res) v += (float)a.res[(size_t)m * a.res_ld + oc_abs];
+                    v = act_h(a.act2, v, a.act_param);
+                    obase[(size_t)m * old] = (OutT)v;
+                }
+            }
+        }
+    }
+}
+
+// Detect decode in the epilogue, fp32 out (same as conv_igemm.hip epilogue_yolo; src/layer/yolo_detect.cpp:223-266)
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_yolo_h(const ConvArgsH& a, f32x16 (&acc)[TM][TN], int mrow0, int ocol0) {
+    const int per_pix = a.yna * a.yne;
+    float* out = static_cast<float*>(a.out);
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = ocol0 + u * 32;
+        if (o >= a.ocg) continue;
+        const float bv = a.bias ? a.bias[o] : 0.0f;
+        const int anc = o / a.yne;
+        const int e_ = o - anc * a.yne;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int mb = mrow0 + t * 32;
+            const int img0 = mb / a.ohow;
+            const int pix0 = mb - img0 * a.ohow;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dm = (e & 3) + 8 * (e >> 2);
+                if (mb + dm < a.M) {
+                    int pix = pix0 + dm, img = img0;
+                    if (pix >= a.ohow) {
+                        const int adv = pix / a.ohow;
+                        pix -= adv * a.ohow;
+                        img += adv;
+                    }
+                    const float sg = 1.0f / (1.0f + __expf(-(acc[t][u][e] + bv)));
+                    const size_t row = (size_t)pix * a.yna + anc;
+                    float v = sg;
+                    if (e_ < 2) {
+                        v = (sg * 2.0f + a.ygrid[row * 2 + e_]) * a.ystride;
+                    } else if (e_ < 4) {
+                        const float t2 = sg * 2.0f;
+                        v = t2 * t2 * a.yanchor[row * 2 + (e_ - 2)];
+                    }
+                    out[((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix * per_pix + o] = v;
+                }
+            }
+        }
+    }
+}
+
+constexpr int BKH = 32;       // channels per K-tile (one tap of one 32-channel block)
+constexpr int LDH = BKH + 8;  // halves per LDS row
+constexpr unsigned OOB_A = 0xFFFFFF00u;
+constexpr unsigned OOB_B = 0x80000000u;
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int A_IT = BM / 64;  // 16-byte vectors per thread per K-tile (4 vectors per 64-byte row, 64 rows per pass)
+    constexpr int B_IT = BN / 64;
+    static_assert(TM >= 1 && TN >= 1 && A_IT >= 1 && B_IT >= 1, "tile too small");
+
+    __shared__ __attribute__((aligned(16))) half_t lds[(BM + BN) * LDH];
+
+    const int g = blockIdx.y;
+    const int per_chunk = 8 * a.n_tiles;
+    const int chunk = blockIdx.x / per_chunk;
+    const int r = blockIdx.x - chunk * per_chunk;
+    const int m_tile = chunk * 8 + (r & 7);
+    const int n_tile = r >> 3;
+    if (m_tile >= a.m_tiles) return;
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * BN;
+
+    const int tid = threadIdx.x;
+    const int kv = tid & 3;
+    const int r0 = tid >> 2;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(a.in + (size_t)g * a.icg), 0, a.in_bytes - (unsigned)g * a.icg * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(a.w + (size_t)g * a.ocg * a.Kp), 0, (unsigned)a.ocg * a.Kp * 2u, 0x00020000);
+
+    unsigned a_off[A_IT];
+    unsigned long long a_mask[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + 64 * i;
+        a_off[i] = 0;
+        a_mask[i] = 0ull;
+        if (m < a.M) {
+            const int img = m / a.ohow;
+            const int rem = m - img * a.ohow;
+            const int oy = rem / a.ow;
+            const int ox = rem - oy * a.ow;
+            const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
+            a_off[i] = (unsigned)((img * a.ih + y0) * a.iw + x0) * (unsigned)(a.in_ld * 2) + (unsigned)(kv * 16);
+            unsigned long long mk = 0ull;
+            for (int ky = 0; ky < a.kh; ++ky)
+                for (int kx = 0; kx < a.kw; ++kx) {
+                    const int y = y0 + ky * a.dh, x = x0 + kx * a.dw;
+                    if ((unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw) mk |= 1ull << (ky * a.kw + kx);
+                }
+            a_mask[i] = mk;
+        }
+    }
+    unsigned b_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int o = n0 + r0 + 64 * i;
+        b_off[i] = o < a.ocg ? (unsigned)(o * a.Kp * 2 + kv * 16) : OOB_B;
+    }
+
+    u32x4 pa[A_IT], pb[B_IT];
+    int cb = 0, ky = 0, kx = 0;  // wave-uniform K walk
+    auto load_tile = [&](int kt) {
+        const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * 32) * 2u;
+        const int tapbit = ky * a.kw + kx;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const bool ok = (a_mask[i] >> tapbit) & 1ull;
+            pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
+        }
+        const unsigned kb = (unsigned)kt * (BKH * 2);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i] + kb, 0, 0);
+        if (++kx == a.kw) {
+            kx = 0;
+            if (++ky == a.kh) {
+                ky = 0;
+                ++cb;
+            }
+        }
+    };
+    auto store_tile = [&]() {
+        half_t* As = lds;
+        half_t* Bs = lds + BM * LDH;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 64 * i) * LDH + kv * 8) = pa[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4*>(Bs + (r0 + 64 * i) * LDH + kv * 8) = pb[i];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.0f;
+
+    const int nk = a.Kp / BKH;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    const half_t* As = lds + (wm * TM * 32 + l31) * LDH + lh * 8;
+    const half_t* Bs = lds + BM * LDH + (wn * TN * 32 + l31) * LDH + lh * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int q = 0; q < BKH / 16; ++q) {
+            f16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f16x8*>(As + t * 32 * LDH + q * 16);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f16x8*>(Bs + u * 32 * LDH + q * 16);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t], fb[u], acc[t][u], 0, 0, 0);
+        }
+        __syncthreads();  // everyone is done reading tile kt
+        if (kt + 1 < nk) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    const int mrow0 = m0 + wm * TM * 32 + 4 * lh, ocol0 = n0 + wn * TN * 32 + l31;
+    if (a.ymode) epilogue_yolo_h<TM, TN>(a, acc, mrow0, ocol0);
+    else if (a.out_f32) epilogue_plain<TM, TN, float>(a, acc, g, mrow0, ocol0);
+    else epilogue_plain<TM, TN, half_t>(a, acc, g, mrow0, ocol0);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_h(const ConvArgsH& a, int groups, hipStream_t s) {
+    ConvArgsH b = a;
+    b.m_tiles = (a.M + BM - 1) / BM;
+    b.n_tiles = (a.ocg + BN - 1) / BN;
+    const int chunks = (b.m_tiles + 7) / 8;
+    dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
+    hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, b);
+    return (int)hipGetLastError();
+}
+
+struct SplitOutH {
+    half_t* out2;
+    int out2_ld, split;
+};
+
+bool f16_shape_ok(const SiConv2dDesc* d) {
+    if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return false;
+    const int icg = d->ic / d->groups;
+    return icg % 32 == 0 && d->kh * d->kw <= 64;
+}
+
+// 0: 64x64, 1: 128x64, 2: 128x128 (SI_CONV_F16_VARIANT overrides, development only)
+int f16_variant(const SiConv2dDesc* d) {
+    static const int forced = [] { const char* e = getenv("SI_CONV_F16_VARIANT"); return e ? atoi(e) : -1; }();
+    if (forced >= 0 && forced <= 2) return forced;
+    return 0;
+}
+
+int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
+               void* out, int out_f32, si_stream_t stream, const SiYoloLevel* yolo, const float* ygrid, const float* yanchor,
+               const SplitOutH* split) {
+    if (!d || !in || !w_packed || !out) return SI_E_BADARG;
+    if (d->n <= 0 || d->oh <= 0 || d->ow <= 0) return SI_E_BADARG;
+    if (d->has_bias && !bias) return SI_E_BADARG;
+    if (d->has_residual && !residual) return SI_E_BADARG;
+    if (!f16_shape_ok(d)) return SI_E_UNSUPPORTED;
+    if (d->in_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
+    if ((long long)d->n * d->oh * d->ow > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 2ull;
+    const unsigned long long w_bytes = (unsigned long long)d->oc * d->kh * d->kw * (d->ic / d->groups) * 2ull;
+    if (in_bytes >= 0xFFFFFF00ull || w_bytes >= 0x40000000ull) return SI_E_UNSUPPORTED;
+
+    ConvArgsH a;
+    a.in = static_cast<const half_t*>(in);
+    a.w = static_cast<const half_t*>(w_packed);
+    a.bias = d->has_bias ? bias : nullptr;
+    a.res = d->has_residual ? static_cast<const half_t*>(residual) : nullptr;
+    a.out = out;
+    a.ih = d->ih; a.iw = d->iw; a.in_ld = d->in_ld;
+    a.oh = d->oh; a.ow = d->ow; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
+    a.kh = d->kh; a.kw = d->kw; a.sh = d->sh; a.sw = d->sw; a.dh = d->dh; a.dw = d->dw;
+    a.pt = d->pt; a.pl = d->pl;
+    a.icg = d->ic / d->groups;
+    a.ocg = d->oc / d->groups;
+    a.oc = d->oc;
+    a.Kp = d->kh * d->kw * a.icg;
+    a.M = d->n * d->oh * d->ow;
+    a.ohow = d->oh * d->ow;
+    a.m_tiles = a.n_tiles = 0;
+    a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
+    a.in_bytes = (unsigned)in_bytes;
+    a.out_f32 = out_f32;
+    a.out2 = nullptr; a.out2_ld = 0; a.split = 0;
+    a.ymode = 0; a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.f; a.ygrid = a.yanchor = nullptr;
+    if (split) {
+        if (d->groups != 1 || out_f32 || split->split <= 0 || split->split >= d->oc || split->split % 32 != 0 || !split->out2)
+            return SI_E_BADARG;
+        a.out2 = split->out2; a.out2_ld = split->out2_ld; a.split = split->split;
+    }
+    if (yolo) {
+        if (d->groups != 1 || d->has_residual || yolo->na * yolo->ne != d->oc) return SI_E_UNSUPPORTED;
+        a.ymode = 1; a.yna = yolo->na; a.yne = yolo->ne; a.yrows_total = yolo->rows_total; a.yrow_off = yolo->row_off;
+        a.ystride = yolo->stride; a.ygrid = ygrid; a.yanchor = yanchor;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (f16_variant(d)) {
+        case 1: return launch_h<128, 64, 2, 2>(a, d->groups, s);
+        case 2: return launch_h<128, 128, 2, 2>(a, d->groups, s);
+        default: return launch_h<64, 64, 2, 2>(a, d->groups, s);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int si_hip_f32_to_f16_host(const float* src, void* dst, size_t n) {
+    if ((!src || !dst) && n) return SI_E_BADARG;
+    half_t* d = static_cast<half_t*>(dst);
+    for (size_t i = 0; i < n; ++i) d[i] = (half_t)src[i];  // round to nearest even
+    return 0;
+}
+
+int si_hip_f16_to_f32_host(const void* src, float* dst, size_t n) {
+    if ((!src || !dst) && n) return SI_E_BADARG;
+    const half_t* s = static_cast<const half_t*>(src);
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)s[i];
+    return 0;
+}
+
+int si_hip_conv2d_f16_supported(const SiConv2dDesc* d) {
+    if (!d) return 0;
+    if (si_conv_smallc_ok(d)) return 2;  // stem: fp32 input, fp32 weights (si_hip_conv2d_pack_weight_host), fp16 output
+    return f16_shape_ok(d) ? 1 : 0;
+}
+
+size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d) {
+    if (!d || !f16_shape_ok(d)) return 0;
+    return (size_t)d->oc * d->kh * d->kw * (d->ic / d->groups);
+}
+
+int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed) {
+    if (!d || !w_oihw || !w_packed) return SI_E_BADARG;
+    if (!f16_shape_ok(d)) return SI_E_UNSUPPORTED;
+    const int icg = d->ic / d->groups;
+    const int ntaps = d->kh * d->kw;
+    half_t* w = static_cast<half_t*>(w_packed);
+    for (int o = 0; o < d->oc; ++o)
+        for (int y = 0; y < d->kh; ++y)
+            for (int x = 0; x < d->kw; ++x) {
+                const int tap = y * d->kw + x;
+                for (int c = 0; c < icg; ++c) {
+                    const float v = w_oihw[(((size_t)o * icg + c) * d->kh + y) * d->kw + x];
+                    const size_t k = ((size_t)(c >> 5) * ntaps + tap) * 32 + (c & 31);  // (c/32, kh, kw, c%32)
+                    w[(size_t)o * ntaps * icg + k] = (half_t)v;
+                }
+            }
+    return 0;
+}
+
+int si_hip_conv2d_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
+                      void* out, int out_is_f32, si_stream_t stream) {
+    return dispatch_h(d, in, w_packed, bias, residual, out, out_is_f32 ? 1 : 0, stream, nullptr, nullptr, nullptr, nullptr);
+}
+
+int si_hip_conv2d_stem_f16(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias, void* out,
+                           si_stream_t stream) {
+    if (!d || !in || !w_packed || !out) return SI_E_BADARG;
+    if (!si_conv_smallc_ok(d) || d->has_residual) return SI_E_UNSUPPORTED;
+    return si_conv_smallc_launch_f16out(d, in, w_packed, d->has_bias ? bias : nullptr, out, static_cast<hipStream_t>(stream));
+}
+
+int si_hip_conv2d_split_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, void* out,
+                            int split_oc, void* out2, int out2_ld, si_stream_t stream) {
+    if (!d || d->has_residual) return SI_E_BADARG;
+    SplitOutH sp{static_cast<half_t*>(out2), out2_ld, split_oc};
+    return dispatch_h(d, in, w_packed, bias, nullptr, out, 0, stream, nullptr, nullptr, nullptr, &sp);
+}
+
+int si_hip_conv2d_yolo_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias,
+                           const SiYoloLevel* level, const float* grid_hwa2, const float* anchor_hwa2, float* detect_out,
+                           si_stream_t stream) {
+    if (!level || !grid_hwa2 || !anchor_hwa2 || level->ne < 4 || level->na <= 0) return SI_E_BADARG;
+    return dispatch_h(d, in, w_packed, bias, nullptr, detect_out, 0, stream, level, grid_hwa2, anchor_hwa2, nullptr);
+}
+
+}  // extern "C"

@@ -31,7 +31,7 @@ struct SmallCArgs {
     const float* w;     // transposed image [kh][2*HP][ocp], rows j >= kw*c are zero (see si_conv_smallc_pack)
     const float* bias;
     const float* res;
-    float* out;
+    void* out;          // OutT (float, or _Float16 for the fp16 engine path)
     int n, ih, iw, c, in_ld;
     int oh, ow, oc, ocp, out_ld, res_ld;
     int kh, kw, sh, sw, pt, pl;
@@ -59,7 +59,7 @@ __device__ __forceinline__ float act_any(int act, float v, float p) {
 // NW waves per workgroup (32*NW output pixels along W), NT 32-wide output-channel tiles per wave, RB output rows per
 // item, HP = (kw*c rounded up to even)/2 MFMA steps per kernel row (compile time: 9 for 6x6x3, 11 for 7x7x3),
 // PF = prefetch registers per thread (>= n_in_rows*row_len / (64*NW)).
-template <int NW, int NT, int RB, int HP, int PF>
+template <int NW, int NT, int RB, int HP, int PF, typename OutT = float>
 __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTHR = NW * 64;
@@ -187,19 +187,19 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
                 const int o = oc0 + u * 32 + l31;
                 if (o >= a.oc) continue;
                 const float bvv = a.bias ? a.bias[o] : 0.0f;
-                float* orow = a.out + mrow * a.out_ld + o;
+                OutT* orow = static_cast<OutT*>(a.out) + mrow * a.out_ld + o;
                 if (simple && a.act1 == SI_ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int ox = oxb + (e & 3) + 8 * (e >> 2);
                         const float v = acc[u][e] + bvv;
-                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = __fdividef(v, 1.0f + __expf(-v));
+                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = (OutT)__fdividef(v, 1.0f + __expf(-v));
                     }
                 } else if (simple && a.act1 == SI_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int ox = oxb + (e & 3) + 8 * (e >> 2);
-                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = fmaxf(acc[u][e] + bvv, 0.0f);
+                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = (OutT)fmaxf(acc[u][e] + bvv, 0.0f);
                     }
                 } else {
 #pragma unroll
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
                             v = act_any(a.act1, v, a.act_param);
                             if (a.res) v += a.res[(mrow + ox) * a.res_ld + o];
                             v = act_any(a.act2, v, a.act_param);
-                            orow[(size_t)ox * a.out_ld] = v;
+                            orow[(size_t)ox * a.out_ld] = (OutT)v;
                         }
                     }
                 }
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
     }
 }
 
-template <int NW, int NT, int RB, int HP, int PF>
+template <int NW, int NT, int RB, int HP, int PF, typename OutT = float>
 int launch_smallc(SmallCArgs a, hipStream_t s) {
     constexpr int TOW = 32 * NW;
     a.w_tiles = (a.ow + TOW - 1) / TOW;
@@ -241,7 +241,7 @@ int launch_smallc(SmallCArgs a, hipStream_t s) {
     while ((a.n_in_rows * a.row_len) % 4 != 0) a.row_len += 1;
     const size_t lds = ((size_t)a.n_in_rows * a.row_len + (size_t)a.kh * 2 * HP * a.ocp) * sizeof(float);
     if (lds > 160 * 1024) return SI_E_UNSUPPORTED;
-    auto kern = conv_smallc_rows_kernel<NW, NT, RB, HP, PF>;
+    auto kern = conv_smallc_rows_kernel<NW, NT, RB, HP, PF, OutT>;
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -297,8 +297,9 @@ const char* si_conv_smallc_name(const SiConv2dDesc* d) {
     return d->oc > 32 ? "conv_smallc_rows_kernel<4, 2, 2, 11, 36>" : "conv_smallc_rows_kernel<4, 1, 2, 11, 36>";
 }
 
-int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
-                          const float* residual, float* out, hipStream_t s) {
+template <typename OutT>
+static int smallc_launch_t(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                           const float* residual, void* out, hipStream_t s) {
     SmallCArgs a;
     a.in = in; a.w = w_packed; a.bias = d->has_bias ? bias : nullptr; a.res = d->has_residual ? residual : nullptr;
     a.out = out;
@@ -313,10 +314,21 @@ int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w
     // Variants measured on the YOLOv5s stem at batch 32 (MI355X): 5 waves x 1 output row per item (37 KB LDS, 4 resident
     // workgroups per CU) 0.40 ms; 2 rows per item 0.63 ms; 4 waves 0.45 ms.  Residency beats halo reuse here too.
     if (smallc_hp(d) == 9) {
-        if (d->oc > 32) return launch_smallc<4, 2, 2, 9, 36>(a, s);
-        if (d->ow % 160 == 0 || d->ow > 128) return launch_smallc<5, 1, 1, 9, 28>(a, s);
-        return launch_smallc<4, 1, 1, 9, 28>(a, s);
+        if (d->oc > 32) return launch_smallc<4, 2, 2, 9, 36, OutT>(a, s);
+        if (d->ow % 160 == 0 || d->ow > 128) return launch_smallc<5, 1, 1, 9, 28, OutT>(a, s);
+        return launch_smallc<4, 1, 1, 9, 28, OutT>(a, s);
     }
-    if (d->oc > 32) return launch_smallc<4, 2, 2, 11, 36>(a, s);
-    return launch_smallc<4, 1, 2, 11, 36>(a, s);
+    if (d->oc > 32) return launch_smallc<4, 2, 2, 11, 36, OutT>(a, s);
+    return launch_smallc<4, 1, 2, 11, 36, OutT>(a, s);
+}
+
+int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                          const float* residual, float* out, hipStream_t s) {
+    return smallc_launch_t<float>(d, in, w_packed, bias, residual, out, s);
+}
+
+// fp16 engine path: same kernel (fp32 input image, fp32 MFMA), activations leave as fp16
+int si_conv_smallc_launch_f16out(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                                 void* out, hipStream_t s) {
+    return smallc_launch_t<_Float16>(d, in, w_packed, bias, nullptr, out, s);
 }

@@ -384,3 +384,151 @@ def yolo_postprocess(pred, prob_threshold=0.25, nms_threshold=0.45, agnostic=Fal
     cnt = dcnt.to_numpy((n,), np.int32)
     dets = ddets.to_numpy((n, max_det, 6)) if max_det > 0 else np.zeros((n, 0, 6), np.float32)
     return [dets[b, :min(int(cnt[b]), max_det)].copy() for b in range(n)], cnt
+
+
+# ---------------------------------------------------------------------------
+# fp16 storage path (include/si_hip.h "fp16 storage path").  Activations travel as numpy float16 (IEEE binary16, the
+# device's _Float16); results come back as float16 unless noted.
+# ---------------------------------------------------------------------------
+def _f16(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float16)
+
+
+def conv2d_f16(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, act1="none",
+               residual=None, act2="none", act_param=0.0, in_ld=None, out_ld=None, out_c_off=0, out_f32=False):
+    """si_hip_conv2d_f16, or si_hip_conv2d_stem_f16 when the shape is a stem (fp32 image in, fp16 out)."""
+    H = _native.hip()
+    w_oihw = _f32(w_oihw)
+    n, ih, iw, ic = x.shape
+    oc, _, kh, kw = w_oihw.shape
+    oh, ow = conv_out_hw(ih, iw, (kh, kw), stride, padding, dilation)
+    in_ld = in_ld or ic
+    out_ld = out_ld or oc
+    d = SiConv2dDesc(n, ih, iw, ic, in_ld, oh, ow, oc, out_ld, kh, kw, stride[0], stride[1], dilation[0], dilation[1],
+                     padding[0], padding[1], groups, 1 if bias is not None else 0, ACT[act1],
+                     1 if residual is not None else 0, oc, ACT[act2], float(act_param))
+    kind = H.si_hip_conv2d_f16_supported(C.byref(d))
+    if kind == 0:
+        raise HipError("no fp16 conv kernel for this shape")
+    db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
+    osz = 4 if out_f32 else 2
+    dy = DeviceBuffer(n * oh * ow * out_ld * osz)
+    dy.fill(0)
+    if kind == 2:
+        packed = np.zeros(H.si_hip_conv2d_weight_elems(C.byref(d)), np.float32)
+        _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack")
+        dx, dw = DeviceBuffer.from_numpy(_f32(x)), DeviceBuffer.from_numpy(packed)
+        _chk(H.si_hip_conv2d_stem_f16(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dy.ptr + 2 * out_c_off, None),
+             "si_hip_conv2d_stem_f16")
+        y = dy.to_numpy((n, oh, ow, out_ld), np.float16)
+        return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
+    packed = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d)), np.float16)
+    _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack f16")
+    x = _f16(x)
+    if in_ld != ic:
+        xw = np.zeros((n, ih, iw, in_ld), np.float16)
+        xw[..., :ic] = x
+        x = xw
+    dx, dw = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(packed)
+    dr = DeviceBuffer.from_numpy(_f16(residual)) if residual is not None else None
+    _chk(H.si_hip_conv2d_f16(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dr.ptr if dr else None,
+                             dy.ptr + osz * out_c_off, 1 if out_f32 else 0, None), "si_hip_conv2d_f16")
+    y = dy.to_numpy((n, oh, ow, out_ld), np.float32 if out_f32 else np.float16)
+    return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
+
+
+def conv2d_split_f16(x, w_a, b_a, w_b, b_b, act1="none"):
+    H = _native.hip()
+    x = _f16(x)
+    n, h, w, ic = x.shape
+    oa, ob = w_a.shape[0], w_b.shape[0]
+    wcat = _f32(np.concatenate([w_a, w_b], 0))
+    bcat = _f32(np.concatenate([b_a, b_b], 0))
+    d = SiConv2dDesc(n, h, w, ic, ic, h, w, oa + ob, oa, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, ACT[act1], 0, oa, 0, 0.0)
+    packed = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d)), np.float16)
+    _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d), wcat.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack f16")
+    dx, dw, db = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(packed), DeviceBuffer.from_numpy(bcat)
+    dy, dy2 = DeviceBuffer(n * h * w * oa * 2), DeviceBuffer(n * h * w * ob * 2)
+    _chk(H.si_hip_conv2d_split_f16(C.byref(d), dx.ptr, dw.ptr, db.ptr, dy.ptr, oa, dy2.ptr, ob, None), "si_hip_conv2d_split_f16")
+    return dy.to_numpy((n, h, w, oa), np.float16), dy2.to_numpy((n, h, w, ob), np.float16)
+
+
+def maxpool2d_f16(x, k, s, p, d=(1, 1)):
+    H = _native.hip()
+    x = _f16(x)
+    n, ih, iw, c = x.shape
+    oh, ow = conv_out_hw(ih, iw, k, s, p, d)
+    desc = SiPool2dDesc(n, ih, iw, c, c, oh, ow, c, k[0], k[1], s[0], s[1], d[0], d[1], p[0], p[1])
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(n * oh * ow * c * 2)
+    _chk(H.si_hip_maxpool2d_f16(C.byref(desc), dx.ptr, dy.ptr, None), "si_hip_maxpool2d_f16")
+    return dy.to_numpy((n, oh, ow, c), np.float16)
+
+
+def adaptive_avgpool2d_f16(x, out_hw):
+    H = _native.hip()
+    x = _f16(x)
+    n, ih, iw, c = x.shape
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(n * out_hw[0] * out_hw[1] * c * 2)
+    _chk(H.si_hip_adaptive_avgpool2d_f16(dx.ptr, n, ih, iw, c, c, dy.ptr, out_hw[0], out_hw[1], c, None),
+         "si_hip_adaptive_avgpool2d_f16")
+    return dy.to_numpy((n, out_hw[0], out_hw[1], c), np.float16)
+
+
+def activation_f16(kind, x, param=0.0):
+    H = _native.hip()
+    x = _f16(x)
+    c = x.shape[-1]
+    pixels = x.size // c
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(x.nbytes)
+    _chk(H.si_hip_activation_f16(ACT[kind], float(param), dx.ptr, pixels, c, c, dy.ptr, c, None), "si_hip_activation_f16")
+    return dy.to_numpy(x.shape, np.float16)
+
+
+def binary_same_f16(op, a, b):
+    H = _native.hip()
+    a, b = _f16(a), _f16(b)
+    c = a.shape[-1]
+    pixels = a.size // c
+    da, db, dy = DeviceBuffer.from_numpy(a), DeviceBuffer.from_numpy(b), DeviceBuffer(a.nbytes)
+    _chk(H.si_hip_binary_same_f16({"add": 0, "mul": 2}[op], da.ptr, c, db.ptr, c, dy.ptr, c, pixels, c, None),
+         "si_hip_binary_same_f16")
+    return dy.to_numpy(a.shape, np.float16)
+
+
+def convert_roundtrip_f16(x):
+    """fp32 -> fp16 -> fp32 on the device (si_hip_convert_f32_f16 / si_hip_convert_f16_f32)."""
+    H = _native.hip()
+    x = _f32(x)
+    c = x.shape[-1]
+    pixels = x.size // c
+    dx, dh, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(x.size * 2), DeviceBuffer(x.nbytes)
+    _chk(H.si_hip_convert_f32_f16(dx.ptr, pixels, c, c, dh.ptr, c, None), "si_hip_convert_f32_f16")
+    half = dh.to_numpy(x.shape, np.float16)
+    _chk(H.si_hip_convert_f16_f32(dh.ptr, pixels, c, c, dy.ptr, c, None), "si_hip_convert_f16_f32")
+    return half, dy.to_numpy(x.shape)
+
+
+def yolo_detect_f16(feats, weights, biases, grids, anchor_grids, strides, na=3):
+    """si_hip_conv2d_yolo_f16 per level: fp16 features, fp32 [n][rows_total][ne] detections."""
+    H = _native.hip()
+    feats = [_f16(f) for f in feats]
+    n = feats[0].shape[0]
+    ne = weights[0].shape[0] // na
+    rows_total = sum(f.shape[1] * f.shape[2] * na for f in feats)
+    dout = DeviceBuffer(n * rows_total * ne * 4)
+    off = 0
+    for f, w, b, g, a, s in zip(feats, weights, biases, grids, anchor_grids, strides):
+        _, h, wd, cin = f.shape
+        w = _f32(w)
+        d = SiConv2dDesc(n, h, wd, cin, cin, h, wd, na * ne, na * ne, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, na * ne, 0, 0.0)
+        packed = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d)), np.float16)
+        _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d), w.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack")
+        g2 = _f32(np.transpose(_f32(g)[0], (1, 2, 0, 3)))
+        a2 = _f32(np.transpose(_f32(a)[0], (1, 2, 0, 3)))
+        bufs = [DeviceBuffer.from_numpy(v) for v in (f, packed, _f32(b), g2, a2)]
+        lv = _native.SiYoloLevel(na, ne, rows_total, off, float(s))
+        _chk(H.si_hip_conv2d_yolo_f16(C.byref(d), bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, C.byref(lv), bufs[3].ptr, bufs[4].ptr,
+                                      dout.ptr, None), "si_hip_conv2d_yolo_f16")
+        sync()
+        off += h * wd * na
+    return dout.to_numpy((n, rows_total, ne))

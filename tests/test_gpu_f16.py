@@ -1,0 +1,124 @@
+"""GPU: the fp16 storage path (BASELINE.json configs[3]).  The reference is fp32 only, so the yardstick is the fp32
+oracle evaluated on the SAME fp16-rounded inputs and weights: what is left is fp32 accumulation order plus one rounding
+of the result to fp16 (relative 2^-11 = 4.9e-4), hence the 1e-3 bound on max|diff| / max|ref|; copies, pooling maxima
+and conversions are exact."""
+import numpy as np
+import pytest
+
+from util import assert_exact, assert_parity, rng_uniform
+
+pytestmark = pytest.mark.gpu
+
+F16_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def hops(gpu):
+    from simpleinfer_amd import hipops
+    return hipops
+
+
+def h(a):
+    """round to fp16 and come back: the value the device actually sees"""
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+CONV_CASES = [
+    # n, ih, iw, ic, oc, k, s, p, d, g
+    (2, 20, 20, 64, 64, 1, 1, 0, 1, 1),
+    (2, 20, 20, 32, 64, 3, 1, 1, 1, 1),
+    (2, 21, 19, 64, 128, 3, 2, 1, 1, 1),
+    (1, 12, 12, 256, 96, 3, 1, 1, 1, 1),     # long K, ragged 32-wide column tile
+    (3, 9, 9, 64, 48, 3, 1, 2, 2, 1),        # dilation, oc not a multiple of 32
+    (2, 10, 10, 64, 64, 3, 1, 1, 1, 2),      # grouped (32 channels per group)
+    (5, 4, 4, 128, 256, 1, 1, 0, 1, 1),
+    (1, 40, 40, 32, 32, 5, 1, 2, 1, 1),
+]
+
+
+@pytest.mark.parametrize("n,ih,iw,ic,oc,k,s,p,d,g", CONV_CASES)
+def test_conv_f16_vs_oracle_on_rounded_operands(hops, orc, n, ih, iw, ic, oc, k, s, p, d, g):
+    x = h(rng_uniform(ih * 7 + ic, (n, ih, iw, ic), -1, 1))
+    w = h(rng_uniform(ih * 7 + ic + 1, (oc, ic // g, k, k), -0.3, 0.3))
+    b = rng_uniform(ih * 7 + ic + 2, (oc,), -0.5, 0.5)
+    ref = orc.conv2d(x, w, b, (s, s), (p, p), (d, d), g, path="naive")
+    got = hops.conv2d_f16(x, w, b, (s, s), (p, p), (d, d), g)
+    assert got.dtype == np.float16
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="fp16 conv")
+    # fp32 store of the same accumulators: only the accumulation order is left
+    assert_parity(hops.conv2d_f16(x, w, b, (s, s), (p, p), (d, d), g, out_f32=True), ref, 2e-5, what="fp16 conv, fp32 out")
+
+
+def test_conv_f16_fused_epilogue_strides_and_batch_invariance(hops, orc):
+    x = h(rng_uniform(1, (2, 16, 16, 64), -1, 1))
+    w = h(rng_uniform(2, (64, 64, 3, 3), -0.2, 0.2))
+    b = rng_uniform(3, (64,), -0.5, 0.5)
+    r = h(rng_uniform(4, (2, 16, 16, 64), -1, 1))
+    y = orc.conv2d(x, w, b, (1, 1), (1, 1), path="naive")
+    got = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), act1="silu", residual=r).astype(np.float32)
+    assert_parity(got, orc.activation("silu", y) + r, F16_TOL, what="silu + residual")
+    got = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), residual=r, act2="relu").astype(np.float32)
+    assert_parity(got, orc.activation("relu", y + r), F16_TOL, what="residual + relu")
+    got = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), in_ld=96, out_ld=160, out_c_off=32).astype(np.float32)
+    assert_parity(got, y, F16_TOL, what="strided tensors")
+    full = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), act1="silu")
+    assert_exact(hops.conv2d_f16(x[1:2], w, b, (1, 1), (1, 1), act1="silu")[0], full[1], "an image's result does not depend on the batch")
+    with pytest.raises(hops.HipError):
+        hops.conv2d_f16(h(rng_uniform(5, (1, 8, 8, 24), -1, 1)), h(rng_uniform(6, (32, 24, 3, 3))), None)  # ic % 32 != 0
+
+
+@pytest.mark.parametrize("k,s,p,oc,size", [(6, 2, 2, 32, 64), (7, 2, 3, 64, 56)])
+def test_stem_f16_output(hops, orc, k, s, p, oc, size):
+    x = rng_uniform(10 + k, (2, size, size, 3), 0, 1)            # the stem reads the fp32 image
+    w = rng_uniform(11 + k, (oc, 3, k, k), -0.3, 0.3)
+    b = rng_uniform(12 + k, (oc,), -0.5, 0.5)
+    ref = orc.activation("silu", orc.conv2d(x, w, b, (s, s), (p, p), path="naive"))
+    got = hops.conv2d_f16(x, w, b, (s, s), (p, p), act1="silu")
+    assert got.dtype == np.float16
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="stem")
+
+
+def test_conv_split_f16(hops, orc):
+    x = h(rng_uniform(20, (2, 12, 12, 64), -1, 1))
+    wa, wb = h(rng_uniform(21, (32, 64, 1, 1), -0.3, 0.3)), h(rng_uniform(22, (64, 64, 1, 1), -0.3, 0.3))
+    ba, bb = rng_uniform(23, (32,), -0.5, 0.5), rng_uniform(24, (64,), -0.5, 0.5)
+    ya, yb = hops.conv2d_split_f16(x, wa, ba, wb, bb, act1="silu")
+    assert_parity(ya.astype(np.float32), orc.activation("silu", orc.conv2d(x, wa, ba, path="naive")), F16_TOL, what="first sibling")
+    assert_parity(yb.astype(np.float32), orc.activation("silu", orc.conv2d(x, wb, bb, path="naive")), F16_TOL, what="second sibling")
+
+
+@pytest.mark.parametrize("n,levels", [(2, ((8, 32), (4, 64), (2, 128))), (5, ((4, 32), (2, 64), (1, 96)))])
+def test_yolo_detect_head_f16(hops, orc, n, levels):
+    na, ne = 3, 85
+    feats, ws, bs, grids, anchors = [], [], [], [], []
+    for i, (hh, c) in enumerate(levels):
+        feats.append(h(rng_uniform(50 + i, (n, hh, hh, c), -1, 1)))
+        ws.append(h(rng_uniform(60 + i, (na * ne, c, 1, 1), -0.3, 0.3)))
+        bs.append(rng_uniform(70 + i, (na * ne,), -0.5, 0.5))
+        gy, gx = np.meshgrid(np.arange(hh, dtype=np.float32), np.arange(hh, dtype=np.float32), indexing="ij")
+        grids.append(np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, hh, hh, 2)).copy())
+        anchors.append(np.broadcast_to(rng_uniform(80 + i, (1, na, 1, 1, 2), 5, 300), (1, na, hh, hh, 2)).copy())
+    strides = [8.0, 16.0, 32.0]
+    ref = orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na)
+    got = hops.yolo_detect_f16(feats, ws, bs, grids, anchors, strides, na)
+    assert got.dtype == np.float32
+    assert_parity(got, ref, 1e-4, what="fp16 features, fp32 decode")   # output is fp32: the fp32 bar applies
+
+
+def test_pool_activation_binary_convert_f16(hops, orc):
+    x = h(rng_uniform(30, (2, 20, 20, 64), -2, 2))
+    assert_exact(hops.maxpool2d_f16(x, (5, 5), (1, 1), (2, 2)).astype(np.float32), orc.maxpool2d(x, (5, 5), (1, 1), (2, 2)), "maxpool k5")
+    x3 = h(rng_uniform(31, (2, 15, 15, 12), -2, 2))                       # c % 8 != 0: scalar path
+    assert_exact(hops.maxpool2d_f16(x3, (3, 3), (2, 2), (1, 1)).astype(np.float32), orc.maxpool2d(x3, (3, 3), (2, 2), (1, 1)), "maxpool k3s2")
+    xa = h(rng_uniform(32, (2, 7, 7, 64), -1, 1))
+    assert_parity(hops.adaptive_avgpool2d_f16(xa, (1, 1)).astype(np.float32), orc.adaptive_avgpool2d(xa, (1, 1)), F16_TOL, what="avgpool")
+    for kind in ("relu", "silu", "sigmoid", "hardswish", "hardsigmoid"):
+        assert_parity(hops.activation_f16(kind, x).astype(np.float32), orc.activation(kind, x), F16_TOL, what=kind)
+    y = h(rng_uniform(33, (2, 20, 20, 64), -2, 2))
+    assert_exact(hops.binary_same_f16("add", x, y), (x + y).astype(np.float16), "add rounds once")
+    assert_exact(hops.binary_same_f16("mul", x, y), (x * y).astype(np.float16), "mul rounds once")
+    z = rng_uniform(34, (3, 5, 5, 10), -70000, 70000)
+    half, back = hops.convert_roundtrip_f16(z)
+    with np.errstate(over="ignore"):
+        assert_exact(half, z.astype(np.float16), "fp32 -> fp16 is round-to-nearest-even (overflow to inf)")
+    assert_exact(back, half.astype(np.float32), "fp16 -> fp32 is exact")
