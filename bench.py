@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--model", default="yolov5s", choices=["yolov5s", "resnet18"])
     ap.add_argument("--graph", type=int, default=0, help="replay Forward() as a hipGraph")
     ap.add_argument("--winograd", type=int, default=1, help="3x3 s1 convs: 0 implicit GEMM everywhere, 1 fused Winograd F(2,3) where faster (default), 2 fused Winograd F(4,3) on those layers")
+    ap.add_argument("--fp16", type=int, default=0, help="1: fp16 storage / fp16 MFMA path (BASELINE.json configs[3]); the headline metric is fp32 (default 0)")
     ap.add_argument("--no-aux", action="store_true", help="skip the host-I/O and post-processing side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=64, help="images in the CPU baseline sample")
@@ -88,16 +89,24 @@ def _cpu_name():
     return "unknown"
 
 
-def roofline_from_profile(passes):
-    """passes: list of per-layer profile lists (same schedule).  Groups conv launches by kernel instantiation."""
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E
+
+
+def roofline_from_profile(passes, fp16=False):
+    """passes: list of per-layer profile lists (same schedule).  Groups conv launches by kernel instantiation.
+    fp32: the dominant kernel is priced against the fp32 MFMA peak with direct-conv FLOPs.  fp16: the matrix cores are
+    16x faster and every YOLOv5s layer is bound by memory, so the dominant kernel is priced against HBM with its
+    algorithmic bytes (input + output + weights of each launch)."""
     agg = {}
     for layers in passes:
         for L in layers:
             if not L["kernel"].startswith("conv_") or L["flops"] <= 0 or L["type"] == "models.yolo.Detect":
                 continue
-            a = agg.setdefault(L["kernel"], {"ms": 0.0, "flops": 0.0, "launches": 0})
+            a = agg.setdefault(L["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
             a["ms"] += L["ms"]
             a["flops"] += L["flops"]
+            a["bytes"] += L["bytes"]
             a["launches"] += 1
     if not agg:
         return None, agg
@@ -113,6 +122,14 @@ def roofline_from_profile(passes):
             traffic = rec.get("hbm_bytes_per_launch") if isinstance(rec, dict) else rec
         except Exception:
             traffic = None
+    if fp16:
+        bytes_per_launch = a["bytes"] / a["launches"]
+        gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+                "launches_per_step": a["launches"] // max(len(passes), 1), "avg_launch_ms": round(avg_ms, 4),
+                "mbytes_per_launch": round(bytes_per_launch / 1e6, 2), "tflops": round(achieved, 1),
+                "frac_of_f16_mfma_peak": round(achieved / PEAK_F16_MFMA_TFLOPS, 4)}, agg
     return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
             "launches_per_step": a["launches"] // max(len(passes), 1), "avg_launch_ms": round(avg_ms, 4),
@@ -127,7 +144,7 @@ def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x):
     import ctypes as C
     aux = {}
     steps = max(3, min(args.steps, 5))
-    e2 = si.Engine(device=dev, outputs_to_host=1, graph=args.graph, winograd=args.winograd)
+    e2 = si.Engine(device=dev, outputs_to_host=1, graph=args.graph, winograd=args.winograd, fp16=args.fp16)
     e2.load_model(pp, bp)
     e2.input(e2.input_names()[0], x)
     e2.forward()
@@ -212,7 +229,7 @@ def main():
         builder.save(pp, bp)
         flops_step = mg.conv_flops(builder)
 
-        e = si.Engine(device=dev, outputs_to_host=0, graph=args.graph, winograd=args.winograd)
+        e = si.Engine(device=dev, outputs_to_host=0, graph=args.graph, winograd=args.winograd, fp16=args.fp16)
         e.load_model(pp, bp)
         iname, oname = e.input_names()[0], e.output_names()[0]
         # global batch = per-GPU batch * world; this rank's slab gets its own seed (distinct images)
@@ -262,7 +279,7 @@ def main():
         if rank == 0:
             passes = [e.profile() for _ in range(max(args.profile_passes, 1))]
             layers = passes[-1]
-            roof, agg = roofline_from_profile(passes)
+            roof, agg = roofline_from_profile(passes, fp16=bool(args.fp16))
             if args.layers:
                 for L in layers:
                     tf = L["flops"] / (L["ms"] * 1e-3) / 1e12 if L["ms"] > 0 else 0
@@ -288,15 +305,16 @@ def main():
         return
     imgs = args.batch * world * args.steps
     value = imgs / dt
-    ceiling = PEAK_FP32_MFMA_TFLOPS * 1e12 / (flops_step / args.batch)  # images/s/GPU at the fp32 MFMA peak
+    prec = "fp16" if args.fp16 else "fp32"
+    ceiling = (PEAK_F16_MFMA_TFLOPS if args.fp16 else PEAK_FP32_MFMA_TFLOPS) * 1e12 / (flops_step / args.batch)  # images/s/GPU at the MFMA peak
     out = {
-        "metric": "images/sec %s %dx%d fp32 batch=%d per GPU, Engine::Forward()" % (
-            "YOLOv5s" if args.model == "yolov5s" else "ResNet18", shape[1], shape[2], args.batch),
+        "metric": "images/sec %s %dx%d %s batch=%d per GPU, Engine::Forward()" % (
+            "YOLOv5s" if args.model == "yolov5s" else "ResNet18", shape[1], shape[2], prec, args.batch),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s %dx%d fp32 forward, batch %d per GPU (global %d), random-init weights, "
-                               "inputs resident in HBM%s" % (args.model, shape[1], shape[2], args.batch,
+        "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",
+        "config": {"workload": "%s %dx%d %s forward, batch %d per GPU (global %d), random-init weights, "
+                               "inputs resident in HBM%s" % (args.model, shape[1], shape[2], prec, args.batch,
                                                             args.batch * world,
                                                             ", outputs all-gathered over RCCL" if world > 1 else ""),
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,

@@ -45,6 +45,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "alias_cat") opt_alias_cat_ = value != 0;
     else if (key == "graph") opt_graph_ = value != 0;
     else if (key == "outputs_to_host") opt_outputs_to_host_ = value != 0;
+    else if (key == "fp16") opt_fp16_ = value != 0;
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else {
         LOG(ERROR) << "unknown engine option [" << key << "]";
@@ -157,17 +158,20 @@ Status EngineImpl::CreateTensorNodes() {
             shape[rank - 2] = opd->shape[rank - 1];
             shape[rank - 1] = opd->shape[rank - 3];
         }
-        node->tensor = Tensor(PnnxToDataType(opd->type), shape, MemoryType::kDevice, false);
-        tensor_nodes_[opd->name] = node;
-
+        DataType dt = PnnxToDataType(opd->type);
         // graph inputs: produced by an operator with no inputs (pnnx.Input)
-        if (opd->producer && opd->producer->inputs.empty()) input_tensor_nodes_[opd->name] = node;
+        const bool is_input = opd->producer && opd->producer->inputs.empty();
         // graph outputs: consumed by an operator with no outputs (pnnx.Output)
+        bool is_output = false;
         for (pnnx::Operator* c : opd->consumers)
-            if (c && c->outputs.empty()) {
-                output_tensor_nodes_[opd->name] = node;
-                break;
-            }
+            if (c && c->outputs.empty()) is_output = true;
+        // fp16 storage: every internal fp32 activation becomes fp16; the tensors the caller hands over / reads back
+        // (Input / Extract) keep the file's type
+        if (opt_fp16_ && dt == DataType::kFloat32 && !is_input && !is_output) dt = DataType::kFloat16;
+        node->tensor = Tensor(dt, shape, MemoryType::kDevice, false);
+        tensor_nodes_[opd->name] = node;
+        if (is_input) input_tensor_nodes_[opd->name] = node;
+        if (is_output) output_tensor_nodes_[opd->name] = node;
     }
     return Status::kSuccess;
 }
@@ -447,7 +451,8 @@ Status EngineImpl::AliasConcats() {
             bool ok = rs.size() == 4 && !seen.count(r) && !aliases_.count(r->name) &&
                       !input_tensor_nodes_.count(r->name) && !output_tensor_nodes_.count(r->name) && r->producer &&
                       r->producer->type != "torch.cat" && HonoursPixelStride(r->producer->type) &&
-                      (offset % 4 == 0);
+                      tensor_nodes_[r->name]->tensor.GetDataType() == out->tensor.GetDataType() &&
+                      (offset * ElementSize(out->tensor.GetDataType()) % 16 == 0);
             for (const pnnx::Operator* c2 : r->consumers) ok = ok && c2 && HonoursPixelStride(c2->type);
             // flatten writes dense NCHW and Detect writes rank-3 rows: they never feed a rank-4 cat
             if (ok && (r->producer->type == "torch.flatten" || r->producer->type == "models.yolo.Detect")) ok = false;
@@ -488,7 +493,8 @@ Status EngineImpl::AllocateTensorMemory() {
     for (auto& kv : aliases_) {
         Tensor& t = tensor_nodes_[kv.first]->tensor;
         Tensor& parent = kv.second.parent->tensor;
-        t.SetView(parent.Data<float>() + kv.second.channel_offset, MemoryType::kDevice, parent.Shape().back());
+        t.SetView(static_cast<char*>(parent.RawData()) + (size_t)kv.second.channel_offset * ElementSize(parent.GetDataType()),
+                  MemoryType::kDevice, parent.Shape().back());
     }
     // 3. pinned host mirrors for outputs
     if (opt_outputs_to_host_) {

@@ -81,6 +81,15 @@ Status Layer::ValidateFloat32() {
     return Status::kSuccess;
 }
 
+Status Layer::ValidateFloat() {
+    auto ok = [](const Tensor& t) { return t.GetDataType() == DataType::kFloat32 || t.GetDataType() == DataType::kFloat16; };
+    for (auto* n : input_tensor_nodes_)
+        if (!ok(n->tensor)) return Status::kUnsupport;
+    for (auto* n : output_tensor_nodes_)
+        if (!ok(n->tensor)) return Status::kUnsupport;
+    return Status::kSuccess;
+}
+
 si_stream_t Layer::Stream() const { return context_ ? context_->stream() : Context::Default()->stream(); }
 
 Status Layer::CheckHip(int rc, const char* what) const {

@@ -75,6 +75,9 @@ protected:
 
     // all-float check shared by the concrete Validate()s (reference e.g. src/layer/conv_2d.cpp:94-101)
     Status ValidateFloat32();
+    // fp32 or fp16 storage (the fp16 engine path, SetOption("fp16", 1)); inputs / outputs may differ at the graph boundary
+    Status ValidateFloat();
+    static bool IsHalf(const Tensor& t) { return t.GetDataType() == DataType::kFloat16; }
 
     si_stream_t Stream() const;
 

@@ -22,7 +22,7 @@ Status LeakyReLU::Init(const pnnx::Operator* op) {
 Status ActivationLayer::Validate() {
     CHECK_STATUS(Layer::Validate());
     CHECK_STATUS(ValidateShape(1, 1));
-    if (Status::kSuccess != ValidateFloat32()) {
+    if (Status::kSuccess != ValidateFloat()) {
         LOG(ERROR) << label_ << "::Validate fail [unsupport input/output data type]";
         return Status::kUnsupport;
     }
@@ -38,6 +38,11 @@ Status ActivationLayer::Forward(const Tensor& input, Tensor& output) {
         size_t pixels = 0;
         int c = 0;
         if (!GetPixelsChannels(in[0], pixels, c) || in[0].NumElements() != out[0].NumElements()) return Status::kErrorShape;
+        if (IsHalf(in[0]) != IsHalf(out[0])) return Status::kUnsupport;
+        if (IsHalf(in[0]))
+            return CheckHip(si_hip_activation_f16(act_, act_param_, in[0].RawData(), pixels, c, in[0].PixelStride(),
+                                                  out[0].RawData(), out[0].PixelStride(), Stream()),
+                            label_);
         return CheckHip(si_hip_activation_f32(act_, act_param_, in[0].Data<float>(), pixels, c, in[0].PixelStride(),
                                               out[0].Data<float>(), out[0].PixelStride(), Stream()),
                         label_);

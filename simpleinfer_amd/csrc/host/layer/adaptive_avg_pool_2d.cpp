@@ -20,7 +20,7 @@ Status AdaptiveAvgPool2d::Init(const pnnx::Operator* op) {
 Status AdaptiveAvgPool2d::Validate() {
     CHECK_STATUS(Layer::Validate());
     CHECK_STATUS(ValidateShape(1, 1));
-    if (Status::kSuccess != ValidateFloat32()) {
+    if (Status::kSuccess != ValidateFloat()) {
         LOG(ERROR) << "AdaptiveAvgPool2d::Validate fail [unsupport input/output data type]";
         return Status::kUnsupport;
     }
@@ -35,6 +35,11 @@ Status AdaptiveAvgPool2d::Forward(const Tensor& input, Tensor& output) {
             LOG(ERROR) << "AdaptiveAvgPool2d::Forward fail [unsupport input/output shape]";
             return Status::kUnsupport;
         }
+        if (IsHalf(in[0]) != IsHalf(out[0])) return Status::kUnsupport;
+        if (IsHalf(in[0]))
+            return CheckHip(si_hip_adaptive_avgpool2d_f16(in[0].RawData(), id.n, id.h, id.w, id.c, in[0].PixelStride(),
+                                                          out[0].RawData(), od.h, od.w, out[0].PixelStride(), Stream()),
+                            "AdaptiveAvgPool2d");
         return CheckHip(si_hip_adaptive_avgpool2d_f32(in[0].Data<float>(), id.n, id.h, id.w, id.c, in[0].PixelStride(),
                                                       out[0].Data<float>(), od.h, od.w, out[0].PixelStride(), Stream()),
                         "AdaptiveAvgPool2d");

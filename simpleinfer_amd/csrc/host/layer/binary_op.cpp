@@ -37,6 +37,14 @@ Status BinaryOp::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
         const std::vector<int> a = in[0].ShapeAs(4), b = in[1].ShapeAs(4), o = out[0].ShapeAs(4);
         for (int i = 0; i < 4; ++i)
             if (a[i] <= 0 || b[i] <= 0 || o[i] % a[i] != 0 || o[i] % b[i] != 0) return Status::kErrorShape;
+        if (IsHalf(in[0]) || IsHalf(in[1]) || IsHalf(out[0])) {
+            // fp16 path: same-shape add / mul only (what residual blocks need)
+            if (!(IsHalf(in[0]) && IsHalf(in[1]) && IsHalf(out[0])) || a != o || b != o) return Status::kUnsupport;
+            return CheckHip(si_hip_binary_same_f16((int)binary_op_type_, in[0].RawData(), in[0].PixelStride(), in[1].RawData(),
+                                                   in[1].PixelStride(), out[0].RawData(), out[0].PixelStride(),
+                                                   (size_t)o[0] * o[1] * o[2], o[3], Stream()),
+                            "BinaryOp");
+        }
         return CheckHip(si_hip_binary_f32((int)binary_op_type_, in[0].Data<float>(), a.data(), in[0].PixelStride(),
                                           in[1].Data<float>(), b.data(), in[1].PixelStride(), out[0].Data<float>(),
                                           o.data(), out[0].PixelStride(), Stream()),

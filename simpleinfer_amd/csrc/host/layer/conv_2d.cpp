@@ -126,7 +126,7 @@ Status Conv2d::Deinit() {
 Status Conv2d::Validate() {
     CHECK_STATUS(Layer::Validate());
     CHECK_STATUS(ValidateShape(1, 1));
-    if (Status::kSuccess != ValidateFloat32()) {
+    if (Status::kSuccess != ValidateFloat()) {
         LOG(ERROR) << "Conv2d::Validate fail [unsupport input/output data type]";
         return Status::kUnsupport;
     }
@@ -149,8 +149,11 @@ SiConv2dDesc Conv2d::MakeDesc(const Tensor& input, const Tensor& output) const {
     return d;
 }
 
-Status Conv2d::PrepareDevice() {
-    if (device_ready_) return Status::kSuccess;
+// mode 0: fp32 kernels; 1: fp16 implicit GEMM (fp16 weights); 2: stem with fp32 image in / fp16 out (fp32 weights)
+Status Conv2d::PrepareDevice(int mode) {
+    if (device_ready_ && mode == prepared_mode_) return Status::kSuccess;
+    device_ready_ = false;
+    prepared_mode_ = mode;
     CHECK_BOOL(groups_ > 0 && in_channels_ > 0 && out_channels_ > 0 && kernel_h_ > 0 && kernel_w_ > 0);
     CHECK_BOOL(in_channels_ % groups_ == 0 && out_channels_ % groups_ == 0);
     const size_t expect = (size_t)out_channels_ * (in_channels_ / groups_) * kernel_h_ * kernel_w_;
@@ -166,7 +169,8 @@ Status Conv2d::PrepareDevice() {
     memset(&d, 0, sizeof(d));
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
     d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
-    wino_tile_ = WinogradTile(d);
+    if (mode == 1) return PrepareDeviceHalf(d);
+    wino_tile_ = mode == 0 ? WinogradTile(d) : 0;
     use_winograd_ = wino_tile_ != 0;
     if ((algo_ == Algo::kWinograd23 || algo_ == Algo::kWinograd43) && !use_winograd_) {
         LOG(ERROR) << "Conv2d: Winograd requested for a shape it does not support";
@@ -199,15 +203,81 @@ Status Conv2d::PrepareDevice() {
     return Status::kSuccess;
 }
 
+Status Conv2d::PrepareDeviceHalf(const SiConv2dDesc& d) {
+    wino_tile_ = 0;
+    use_winograd_ = false;
+    if (si_hip_conv2d_f16_supported(&d) != 1) {
+        LOG(ERROR) << "Conv2d: no fp16 kernel for " << in_channels_ << " -> " << out_channels_ << " channels, groups " << groups_
+                   << " (needs ic/groups % 32 == 0)";
+        return Status::kUnsupport;
+    }
+    std::vector<uint16_t> packed(si_hip_conv2d_f16_weight_elems(&d));
+    CHECK_STATUS(CheckHip(si_hip_conv2d_f16_pack_weight_host(&d, weight_.data(), packed.data()), "pack fp16 weight"));
+    std::vector<float> bias_all = bias_;
+    if (sibling_) {
+        SiConv2dDesc ds = d;
+        ds.oc = sibling_->out_channels_;
+        CHECK_BOOL(sibling_->weight_.size() == (size_t)ds.oc * in_channels_);
+        std::vector<uint16_t> packed2(si_hip_conv2d_f16_weight_elems(&ds));
+        CHECK_STATUS(CheckHip(si_hip_conv2d_f16_pack_weight_host(&ds, sibling_->weight_.data(), packed2.data()), "pack sibling weight"));
+        packed.insert(packed.end(), packed2.begin(), packed2.end());
+        if (use_bias_) bias_all.insert(bias_all.end(), sibling_->bias_.begin(), sibling_->bias_.end());
+    }
+    CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(uint16_t)), "upload weight"));
+    if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_all.data(), bias_all.size() * sizeof(float)), "upload bias"));
+    device_ready_ = true;
+    return Status::kSuccess;
+}
+
+// which kernel family serves this (input, output) storage pair; a non-stem conv fed an fp32 tensor inside an fp16 graph
+// converts its input first (in_half_)
+int Conv2d::PrecisionMode(const Tensor& input, const Tensor& output) const {
+    if (!IsHalf(input) && !IsHalf(output)) return 0;
+    if (!IsHalf(input)) {
+        SiConv2dDesc d;
+        memset(&d, 0, sizeof(d));
+        d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
+        d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
+        if (si_hip_conv2d_f16_supported(&d) == 2 && !residual_node_ && !sibling_) return 2;
+    }
+    return 1;
+}
+
+Status Conv2d::HalfInput(const Tensor& input, Tensor& half) {
+    if (IsHalf(input)) {
+        half = input;
+        return Status::kSuccess;
+    }
+    size_t pixels = 0;
+    int c = 0;
+    if (!GetPixelsChannels(input, pixels, c)) return Status::kErrorShape;
+    CHECK_STATUS(in_half_.Allocate(DataType::kFloat16, input.Shape()));
+    CHECK_STATUS(CheckHip(si_hip_convert_f32_f16(input.Data<float>(), pixels, c, input.PixelStride(), in_half_.RawData(), c, Stream()),
+                          "conv2d input fp32 -> fp16"));
+    half = in_half_;
+    return Status::kSuccess;
+}
+
 Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
     if (!sibling_ || outputs.size() != 2) return Status::kUnsupport;
     return RunOnDevice({&input}, {&outputs[0], &outputs[1]}, [this](const std::vector<Tensor>& in, std::vector<Tensor>& out) {
-        CHECK_STATUS(PrepareDevice());
+        const int mode = PrecisionMode(in[0], out[0]);
+        if (IsHalf(out[0]) != IsHalf(out[1])) return Status::kUnsupport;
+        CHECK_STATUS(PrepareDevice(mode));
         Dims4 di, d0, d1;
         if (!GetDims4(in[0], di) || !GetDims4(out[0], d0) || !GetDims4(out[1], d1)) return Status::kErrorShape;
         if (di.c != in_channels_ || d0.c != out_channels_ || d1.c != sibling_->out_channels_ || d0.pixels() != d1.pixels()) return Status::kErrorShape;
         SiConv2dDesc d = MakeDesc(in[0], out[0]);
         d.oc = out_channels_ + sibling_->out_channels_;
+        if (mode == 1) {
+            Tensor xin;
+            CHECK_STATUS(HalfInput(in[0], xin));
+            d.in_ld = xin.PixelStride();
+            return CheckHip(si_hip_conv2d_split_f16(&d, xin.RawData(), weight_dev_.As<void>(),
+                                                    use_bias_ ? bias_dev_.As<float>() : nullptr, out[0].RawData(), out_channels_,
+                                                    out[1].RawData(), out[1].PixelStride(), Stream()),
+                            "conv2d fp16 (fused siblings)");
+        }
         return CheckHip(si_hip_conv2d_split_f32(&d, in[0].Data<float>(), weight_dev_.As<float>(),
                                                 use_bias_ ? bias_dev_.As<float>() : nullptr, out[0].Data<float>(), out_channels_,
                                                 out[1].Data<float>(), out[1].PixelStride(), Stream()),
@@ -216,7 +286,8 @@ Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
 }
 
 Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& output) {
-    CHECK_STATUS(PrepareDevice());
+    const int mode = PrecisionMode(input, output);
+    CHECK_STATUS(PrepareDevice(mode));
     Dims4 in, out;
     if (!GetDims4(input, in) || !GetDims4(output, out)) return Status::kErrorShape;
     if (in.c != in_channels_ || out.c != out_channels_ || in.n != out.n) {
@@ -228,6 +299,20 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
         d.has_residual = 1;
         d.res_ld = residual->PixelStride();
     }
+    if (mode == 2)
+        return CheckHip(si_hip_conv2d_stem_f16(&d, input.Data<float>(), weight_dev_.As<float>(),
+                                               use_bias_ ? bias_dev_.As<float>() : nullptr, output.RawData(), Stream()),
+                        "conv2d stem (fp16 out)");
+    if (mode == 1) {
+        if (residual && !IsHalf(*residual)) return Status::kUnsupport;
+        Tensor xin;
+        CHECK_STATUS(HalfInput(input, xin));
+        d.in_ld = xin.PixelStride();
+        return CheckHip(si_hip_conv2d_f16(&d, xin.RawData(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                          residual ? residual->RawData() : nullptr, output.RawData(), IsHalf(output) ? 0 : 1,
+                                          Stream()),
+                        "conv2d fp16");
+    }
     if (use_winograd_) {
         const auto fn = wino_tile_ == 4 ? si_hip_conv2d_wino43_f32 : si_hip_conv2d_wino23_f32;
         const int rc = fn(&d, input.Data<float>(), weight_dev_.As<float>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
@@ -236,7 +321,7 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
         // an unaligned / oversized tensor view: re-pack for the implicit-GEMM kernel once and stay there
         algo_ = Algo::kImplicitGemm;
         device_ready_ = false;
-        CHECK_STATUS(PrepareDevice());
+        CHECK_STATUS(PrepareDevice(0));
     }
     return CheckHip(si_hip_conv2d_f32(&d, input.Data<float>(), weight_dev_.As<float>(),
                                       use_bias_ ? bias_dev_.As<float>() : nullptr,
@@ -247,13 +332,20 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
 // Detect-head variant: device tensors only (called by YoloDetect inside its own RunOnDevice scope)
 Status Conv2d::ForwardYolo(const Tensor& input, const SiYoloLevel& level, const float* grid_dev, const float* anchor_dev,
                            Tensor& detect_out) {
-    CHECK_STATUS(PrepareDevice());
+    const int mode = IsHalf(input) ? 1 : 0;
+    CHECK_STATUS(PrepareDevice(mode));
     Dims4 in;
     if (!GetDims4(input, in) || in.c != in_channels_) return Status::kErrorShape;
     if (input.GetMemoryType() != MemoryType::kDevice || detect_out.GetMemoryType() != MemoryType::kDevice) return Status::kUnsupport;
     Tensor conv_out(DataType::kFloat32, {in.n, in.h, in.w, out_channels_}, MemoryType::kDevice, false);  // shape only
     SiConv2dDesc d = MakeDesc(input, conv_out);
     d.act1 = d.act2 = SI_ACT_NONE;
+    if (mode == 1) {
+        const int rc = si_hip_conv2d_yolo_f16(&d, input.RawData(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                              &level, grid_dev, anchor_dev, detect_out.Data<float>(), Stream());
+        if (rc == SI_E_UNSUPPORTED) return Status::kUnsupport;
+        return CheckHip(rc, "conv2d+yolo fp16");
+    }
     const int rc = si_hip_conv2d_yolo_f32(&d, input.Data<float>(), weight_dev_.As<float>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
                                           &level, grid_dev, anchor_dev, detect_out.Data<float>(), Stream());
     if (rc == SI_E_UNSUPPORTED) return Status::kUnsupport;
@@ -275,6 +367,9 @@ const char* Conv2d::KernelName() const {
     if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
     SiConv2dDesc d = MakeDesc(in, out);
     if (sibling_) d.oc += sibling_->out_channels_;
+    const int mode = PrecisionMode(in, out);
+    if (mode == 1) return "conv_igemm_f16_kernel<64, 64, 2, 2>";
+    if (mode == 2) return "conv_smallc_rows_kernel (fp16 out)";
     const int tile = WinogradTile(d);
     if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
     return si_hip_conv2d_kernel_name(&d, in.Data<float>());

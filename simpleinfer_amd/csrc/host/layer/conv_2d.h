@@ -50,7 +50,10 @@ public:
     void SetSibling(Conv2d* other);
     Conv2d* Sibling() const { return sibling_; }
 
-    Status PrepareDevice();
+    Status PrepareDevice(int mode = 0);
+    Status PrepareDeviceHalf(const SiConv2dDesc& d);
+    int PrecisionMode(const Tensor& input, const Tensor& output) const;
+    Status HalfInput(const Tensor& input, Tensor& half);
 
     // conv + YOLOv5 decode epilogue, writing into the Detect output (kUnsupport: shape not eligible)
     Status ForwardYolo(const Tensor& input, const SiYoloLevel& level, const float* grid_dev, const float* anchor_dev,
@@ -97,6 +100,8 @@ private:
     DeviceBuffer weight_dev_;
     DeviceBuffer bias_dev_;
     bool device_ready_ = false;
+    int prepared_mode_ = 0;      // which weight image weight_dev_ holds (see PrepareDevice)
+    Tensor in_half_;             // fp16 copy of an fp32 input consumed by the fp16 kernel
 };
 
 }  // namespace SimpleInfer

@@ -43,23 +43,35 @@ Status Linear::Deinit() {
 Status Linear::Validate() {
     CHECK_STATUS(Layer::Validate());
     CHECK_STATUS(ValidateShape(1, 1));
-    if (Status::kSuccess != ValidateFloat32()) {
+    if (Status::kSuccess != ValidateFloat()) {
         LOG(ERROR) << "Linear::Validate fail [unsupport input/output data type]";
         return Status::kUnsupport;
     }
     return Status::kSuccess;
 }
 
-Status Linear::PrepareDevice() {
-    if (device_ready_) return Status::kSuccess;
+Status Linear::PrepareDevice(bool half) {
+    if (device_ready_ && half == prepared_half_) return Status::kSuccess;
+    device_ready_ = false;
+    prepared_half_ = half;
     CHECK_BOOL(in_features_ > 0 && out_features_ > 0);
     CHECK_BOOL(weight_.size() == (size_t)in_features_ * out_features_);
     SiConv2dDesc d;
     memset(&d, 0, sizeof(d));
     d.ic = in_features_; d.oc = out_features_; d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1; d.groups = 1;
-    std::vector<float> packed(si_hip_conv2d_weight_elems(&d));
-    CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&d, weight_.data(), packed.data()), "pack weight"));
-    CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(float)), "upload weight"));
+    if (half) {
+        if (si_hip_conv2d_f16_supported(&d) != 1) {
+            LOG(ERROR) << "Linear: no fp16 kernel for in_features " << in_features_ << " (needs a multiple of 32)";
+            return Status::kUnsupport;
+        }
+        std::vector<uint16_t> packed(si_hip_conv2d_f16_weight_elems(&d));
+        CHECK_STATUS(CheckHip(si_hip_conv2d_f16_pack_weight_host(&d, weight_.data(), packed.data()), "pack fp16 weight"));
+        CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(uint16_t)), "upload weight"));
+    } else {
+        std::vector<float> packed(si_hip_conv2d_weight_elems(&d));
+        CHECK_STATUS(CheckHip(si_hip_conv2d_pack_weight_host(&d, weight_.data(), packed.data()), "pack weight"));
+        CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(float)), "upload weight"));
+    }
     if (use_bias_) {
         CHECK_BOOL(bias_.size() == (size_t)out_features_);
         CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_.data(), bias_.size() * sizeof(float)), "upload bias"));
@@ -70,7 +82,8 @@ Status Linear::PrepareDevice() {
 
 Status Linear::Forward(const Tensor& input, Tensor& output) {
     return RunOnDevice({&input}, {&output}, [this](const std::vector<Tensor>& in, std::vector<Tensor>& out) {
-        CHECK_STATUS(PrepareDevice());
+        const bool half = IsHalf(in[0]);
+        CHECK_STATUS(PrepareDevice(half));
         const std::vector<int> is = in[0].ShapeAs(2), os = out[0].ShapeAs(2);
         if (is[1] != in_features_ || os[1] != out_features_ || is[0] != os[0]) return Status::kErrorShape;
         SiConv2dDesc d;
@@ -79,6 +92,11 @@ Status Linear::Forward(const Tensor& input, Tensor& output) {
         d.oh = d.ow = 1; d.oc = out_features_; d.out_ld = out[0].PixelStride();
         d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1; d.groups = 1;
         d.has_bias = use_bias_ ? 1 : 0;
+        if (half)  // fp16 features; the result is stored in the output tensor's own precision (fp32 for a graph output)
+            return CheckHip(si_hip_conv2d_f16(&d, in[0].RawData(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                              nullptr, out[0].RawData(), IsHalf(out[0]) ? 0 : 1, Stream()),
+                            "Linear fp16");
+        if (IsHalf(out[0])) return Status::kUnsupport;
         return CheckHip(si_hip_conv2d_f32(&d, in[0].Data<float>(), weight_dev_.As<float>(),
                                           use_bias_ ? bias_dev_.As<float>() : nullptr, nullptr, out[0].Data<float>(),
                                           Stream()),

@@ -18,7 +18,7 @@ public:
     virtual const char* KernelName() const override { return "conv_igemm_f32"; }
     virtual double Flops() const override;
 
-    Status PrepareDevice();
+    Status PrepareDevice(bool half = false);
 
 public:
     int in_features_  = 0;
@@ -29,6 +29,7 @@ public:
 
 private:
     DeviceBuffer weight_dev_, bias_dev_;
+    bool prepared_half_ = false;
     bool device_ready_ = false;
 };
 

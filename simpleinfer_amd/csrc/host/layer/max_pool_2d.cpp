@@ -36,7 +36,7 @@ Status MaxPool2d::Init(const pnnx::Operator* op) {
 Status MaxPool2d::Validate() {
     CHECK_STATUS(Layer::Validate());
     CHECK_STATUS(ValidateShape(1, 1));
-    if (Status::kSuccess != ValidateFloat32()) {
+    if (Status::kSuccess != ValidateFloat()) {
         LOG(ERROR) << "MaxPool2d::Validate fail [unsupport input/output data type]";
         return Status::kUnsupport;
     }
@@ -53,6 +53,8 @@ Status MaxPool2d::Forward(const Tensor& input, Tensor& output) {
         d.oh = od.h; d.ow = od.w; d.out_ld = out[0].PixelStride();
         d.kh = kernel_h_; d.kw = kernel_w_; d.sh = stride_h_; d.sw = stride_w_;
         d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
+        if (IsHalf(in[0]) != IsHalf(out[0])) return Status::kUnsupport;
+        if (IsHalf(in[0])) return CheckHip(si_hip_maxpool2d_f16(&d, in[0].RawData(), out[0].RawData(), Stream()), "MaxPool2d");
         return CheckHip(si_hip_maxpool2d_f32(&d, in[0].Data<float>(), out[0].Data<float>(), Stream()), "MaxPool2d");
     });
 }

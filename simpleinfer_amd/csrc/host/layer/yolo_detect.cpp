@@ -113,7 +113,7 @@ Status YoloDetect::Deinit() {
 Status YoloDetect::Validate() {
     CHECK_STATUS(Layer::Validate());
     CHECK_STATUS(ValidateShape(3, 1));
-    if (Status::kSuccess != ValidateFloat32()) {
+    if (Status::kSuccess != ValidateFloat()) {
         LOG(ERROR) << "YoloDetect::Validate fail [unsupport input/output data type]";
         return Status::kUnsupport;
     }
@@ -131,6 +131,7 @@ Status YoloDetect::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
             }
             device_ready_ = true;
         }
+        if (IsHalf(out[0])) return Status::kUnsupport;  // detections are always fp32 (features may be fp16)
         const std::vector<int> os = out[0].ShapeAs(3);
         const int rows_total = os[1];
         if (os[2] != num_classes_info_) return Status::kErrorShape;
