@@ -262,7 +262,7 @@ int si_hip_f16_to_f32_host(const void* src, float* dst, size_t n);
  * 2: stem (ic <= 3): fp32 input image and fp32-packed weights (si_hip_conv2d_pack_weight_host), fp16 output */
 int si_hip_conv2d_f16_supported(const SiConv2dDesc* d);
 size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d);
-/* OIHW fp32 -> [oc][K] fp16, K order (c/32, kh, kw, c%32) */
+/* OIHW fp32 -> [oc][K] fp16, K order (c/B, kh, kw, c%B), B = 64 when ic/groups % 64 == 0 else 32 */
 int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
 /* as si_hip_conv2d_f32; in / residual / out fp16 (strides in elements), bias fp32; out_is_f32 != 0 stores fp32 (graph
  * outputs) */

@@ -8,8 +8,9 @@
 // At 2.5 PFLOP/s the matrix cores are 16x faster than in fp32 while HBM is not, so every YOLOv5s layer is now bound by
 // memory or latency.  The kernel is therefore the fp32 fast kernel's structure with the cheapest possible tile
 // (conv_igemm.hip): raw buffer loads of 16-byte (8-channel) vectors with out-of-image taps as out-of-range offsets, a
-// wave-uniform tap walk over the channel-block-major K order (c/32, kh, kw, c%32), ONE LDS stage of [row][32+8] halves
-// (80-byte rows: the 16 lanes of a ds_read_b128 phase land on 16 disjoint 4-bank groups) and many resident workgroups.
+// wave-uniform tap walk over the channel-block-major K order (c/B, kh, kw, c%B) with B = 64 (32 for 32-channel layers),
+// ONE LDS stage of [row][B+8] halves (the 16 lanes of a ds_read_b128 phase land on 16 disjoint 4-bank groups) and many
+// resident workgroups.
 // One ds_read_b128 per operand feeds one 32x32x16 MFMA (lane l holds k = 8*(l>>5) .. +7 of row l&31, A and W alike).
 #include <hip/hip_runtime.h>
 
@@ -142,18 +143,22 @@ __device__ __forceinline__ void epilogue_yolo_h(const ConvArgsH& a, f32x16 (&acc
     }
 }
 
-constexpr int BKH = 32;       // channels per K-tile (one tap of one 32-channel block)
-constexpr int LDH = BKH + 8;  // halves per LDS row
 constexpr unsigned OOB_A = 0xFFFFFF00u;
 constexpr unsigned OOB_B = 0x80000000u;
 
-template <int BM, int BN, int WM, int WN>
+// BKH: channels per K-tile = one tap of one BKH-channel block.  64 whenever the channel count allows: a row of the
+// tile is then a whole 128-byte line per load instruction (32: half lines) and a 1x1 conv over 64 channels needs a
+// single tile with all of its loads in flight at once.
+template <int BM, int BN, int WM, int WN, int BKH>
 __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int LDH = BKH + 8;       // halves per LDS row (80 / 144 bytes: conflict-free ds_read_b128 phases)
+    constexpr int VPR = BKH / 8;       // 16-byte vectors per row
+    constexpr int RPP = 256 / VPR;     // rows per pass of the 256 threads
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
-    constexpr int A_IT = BM / 64;  // 16-byte vectors per thread per K-tile (4 vectors per 64-byte row, 64 rows per pass)
-    constexpr int B_IT = BN / 64;
+    constexpr int A_IT = BM / RPP;     // 16-byte vectors per thread per K-tile
+    constexpr int B_IT = BN / RPP;
     static_assert(TM >= 1 && TN >= 1 && A_IT >= 1 && B_IT >= 1, "tile too small");
 
     __shared__ __attribute__((aligned(16))) half_t lds[(BM + BN) * LDH];
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     const int n0 = n_tile * BN;
 
     const int tid = threadIdx.x;
-    const int kv = tid & 3;
-    const int r0 = tid >> 2;
+    const int kv = tid % VPR;
+    const int r0 = tid / VPR;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<half_t*>(a.in + (size_t)g * a.icg), 0, a.in_bytes - (unsigned)g * a.icg * 2u, 0x00020000);
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     unsigned long long a_mask[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + r0 + 64 * i;
+        const int m = m0 + r0 + RPP * i;
         a_off[i] = 0;
         a_mask[i] = 0ull;
         if (m < a.M) {
@@ -203,23 +208,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     unsigned b_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int o = n0 + r0 + 64 * i;
+        const int o = n0 + r0 + RPP * i;
         b_off[i] = o < a.ocg ? (unsigned)(o * a.Kp * 2 + kv * 16) : OOB_B;
     }
 
-    u32x4 pa[A_IT], pb[B_IT];
-    int cb = 0, ky = 0, kx = 0;  // wave-uniform K walk
-    auto load_tile = [&](int kt) {
-        const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * 32) * 2u;
+    // Register prefetch ring, DEPTH K-tiles deep.  Measured on YOLOv5s batch 32 (MI355X): depth 1 12.2 k img/s, depth 2
+    // 12.1 k, depth 4 10.4 k -- the extra registers cost resident workgroups, and residency (8+ workgroups per CU) is
+    // what hides the memory latency here, as in the fp32 kernel.
+    constexpr int DEPTH = 1;
+    u32x4 pa[DEPTH][A_IT], pb[DEPTH][B_IT];
+    int cb = 0, ky = 0, kx = 0;  // wave-uniform K walk (tiles are requested in ascending order)
+    auto load_tile = [&](u32x4 (&qa)[A_IT], u32x4 (&qb)[B_IT], int kt) {
+        const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * BKH) * 2u;
         const int tapbit = ky * a.kw + kx;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const bool ok = (a_mask[i] >> tapbit) & 1ull;
-            pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
+            qa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
         }
         const unsigned kb = (unsigned)kt * (BKH * 2);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i] + kb, 0, 0);
+        for (int i = 0; i < B_IT; ++i) qb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i] + kb, 0, 0);
         if (++kx == a.kw) {
             kx = 0;
             if (++ky == a.kh) {
@@ -228,13 +237,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const u32x4 (&qa)[A_IT], const u32x4 (&qb)[B_IT]) {
         half_t* As = lds;
         half_t* Bs = lds + BM * LDH;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 64 * i) * LDH + kv * 8) = pa[i];
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * LDH + kv * 8) = qa[i];
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4*>(Bs + (r0 + 64 * i) * LDH + kv * 8) = pb[i];
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4*>(Bs + (r0 + RPP * i) * LDH + kv * 8) = qb[i];
     };
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -250,31 +259,35 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
             for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.0f;
 
     const int nk = a.Kp / BKH;
-    load_tile(0);
-    store_tile();
-    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nk) load_tile(pa[d], pb[d], d);
 
     const half_t* As = lds + (wm * TM * 32 + l31) * LDH + lh * 8;
     const half_t* Bs = lds + BM * LDH + (wn * TN * 32 + l31) * LDH + lh * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tile(kt + 1);
+    for (int kt0 = 0; kt0 < nk; kt0 += DEPTH) {
 #pragma unroll
-        for (int q = 0; q < BKH / 16; ++q) {
-            f16x8 fa[TM], fb[TN];
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kt = kt0 + d;
+            if (kt < nk) {  // wave-uniform
+                if (kt > 0) __syncthreads();  // everyone is done reading the previous tile
+                store_tile(pa[d], pb[d]);
+                __syncthreads();
+                if (kt + DEPTH < nk) load_tile(pa[d], pb[d], kt + DEPTH);  // refill the slot just emptied
 #pragma unroll
-            for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f16x8*>(As + t * 32 * LDH + q * 16);
+                for (int q = 0; q < BKH / 16; ++q) {
+                    f16x8 fa[TM], fb[TN];
 #pragma unroll
-            for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f16x8*>(Bs + u * 32 * LDH + q * 16);
+                    for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f16x8*>(As + t * 32 * LDH + q * 16);
 #pragma unroll
-            for (int t = 0; t < TM; ++t)
+                    for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f16x8*>(Bs + u * 32 * LDH + q * 16);
 #pragma unroll
-                for (int u = 0; u < TN; ++u)
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t], fb[u], acc[t][u], 0, 0, 0);
-        }
-        __syncthreads();  // everyone is done reading tile kt
-        if (kt + 1 < nk) {
-            store_tile();
-            __syncthreads();
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int u = 0; u < TN; ++u)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t], fb[u], acc[t][u], 0, 0, 0);
+                }
+            }
         }
     }
 
@@ -284,14 +297,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     else epilogue_plain<TM, TN, half_t>(a, acc, g, mrow0, ocol0);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BKH>
 int launch_h(const ConvArgsH& a, int groups, hipStream_t s) {
     ConvArgsH b = a;
     b.m_tiles = (a.M + BM - 1) / BM;
     b.n_tiles = (a.ocg + BN - 1) / BN;
     const int chunks = (b.m_tiles + 7) / 8;
     dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
-    hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, b);
+    hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, BKH>), grid, dim3(256), 0, s, b);
     return (int)hipGetLastError();
 }
 
@@ -299,6 +312,9 @@ struct SplitOutH {
     half_t* out2;
     int out2_ld, split;
 };
+
+// channel-block size of the K order (a property of the packed weights, so of the layer's static shape only)
+int f16_block(const SiConv2dDesc* d) { return ((d->ic / d->groups) % 64 == 0) ? 64 : 32; }
 
 bool f16_shape_ok(const SiConv2dDesc* d) {
     if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return false;
@@ -360,10 +376,17 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
         a.ystride = yolo->stride; a.ygrid = ygrid; a.yanchor = yanchor;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (f16_block(d) == 64) {
+        switch (f16_variant(d)) {
+            case 1: return launch_h<128, 64, 2, 2, 64>(a, d->groups, s);
+            case 2: return launch_h<128, 128, 2, 2, 64>(a, d->groups, s);
+            default: return launch_h<64, 64, 2, 2, 64>(a, d->groups, s);
+        }
+    }
     switch (f16_variant(d)) {
-        case 1: return launch_h<128, 64, 2, 2>(a, d->groups, s);
-        case 2: return launch_h<128, 128, 2, 2>(a, d->groups, s);
-        default: return launch_h<64, 64, 2, 2>(a, d->groups, s);
+        case 1: return launch_h<128, 64, 2, 2, 32>(a, d->groups, s);
+        case 2: return launch_h<128, 128, 2, 2, 32>(a, d->groups, s);
+        default: return launch_h<64, 64, 2, 2, 32>(a, d->groups, s);
     }
 }
 
@@ -401,6 +424,7 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
     if (!f16_shape_ok(d)) return SI_E_UNSUPPORTED;
     const int icg = d->ic / d->groups;
     const int ntaps = d->kh * d->kw;
+    const int blk = f16_block(d);
     half_t* w = static_cast<half_t*>(w_packed);
     for (int o = 0; o < d->oc; ++o)
         for (int y = 0; y < d->kh; ++y)
@@ -408,7 +432,7 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
                 const int tap = y * d->kw + x;
                 for (int c = 0; c < icg; ++c) {
                     const float v = w_oihw[(((size_t)o * icg + c) * d->kh + y) * d->kw + x];
-                    const size_t k = ((size_t)(c >> 5) * ntaps + tap) * 32 + (c & 31);  // (c/32, kh, kw, c%32)
+                    const size_t k = ((size_t)(c / blk) * ntaps + tap) * blk + (c % blk);  // (c/blk, kh, kw, c%blk)
                     w[(size_t)o * ntaps * icg + k] = (half_t)v;
                 }
             }
