@@ -46,6 +46,14 @@ const char* si_conv_smallc_name(const SiConv2dDesc* d);
 int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
                           const float* residual, float* out, hipStream_t s);
 
+// conv_depthwise.hip: groups == ic == oc (HBM-bound, no MFMA)
+bool si_conv_depthwise_ok(const SiConv2dDesc* d);
+size_t si_conv_depthwise_weight_elems(const SiConv2dDesc* d);
+void si_conv_depthwise_pack(const SiConv2dDesc* d, const float* w_oihw, float* w_packed);
+const char* si_conv_depthwise_name(const SiConv2dDesc* d);
+int si_conv_depthwise_launch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                             const float* residual, float* out, hipStream_t s);
+
 namespace {
 
 struct ConvArgs {
@@ -594,6 +602,7 @@ static bool conv_vec_a(const SiConv2dDesc* d, const float* in) {
 extern "C" size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d) {
     if (!d || d->groups <= 0) return 0;
     if (si_conv_smallc_ok(d)) return si_conv_smallc_weight_elems(d);  // stem layout, see conv_smallc.hip
+    if (si_conv_depthwise_ok(d)) return si_conv_depthwise_weight_elems(d);
     const int icg = d->ic / d->groups;
     return (size_t)d->oc * d->kh * d->kw * round_up4(icg);
 }
@@ -602,6 +611,10 @@ extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float
     if (!d || !w_oihw || !w_packed || d->groups <= 0) return SI_E_BADARG;
     if (si_conv_smallc_ok(d)) {
         si_conv_smallc_pack(d, w_oihw, w_packed);
+        return 0;
+    }
+    if (si_conv_depthwise_ok(d)) {
+        si_conv_depthwise_pack(d, w_oihw, w_packed);
         return 0;
     }
     const int icg = d->ic / d->groups, icp = round_up4(icg);
@@ -640,6 +653,11 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     if (si_conv_smallc_ok(d)) {
         if (yolo || split) return SI_E_UNSUPPORTED;
         return si_conv_smallc_launch(d, in, w_packed, bias, residual, out, static_cast<hipStream_t>(stream));
+    }
+    // depthwise: one channel per group, HBM-bound (its weight layout is its own as well)
+    if (si_conv_depthwise_ok(d)) {
+        if (yolo || split) return SI_E_UNSUPPORTED;
+        return si_conv_depthwise_launch(d, in, w_packed, bias, residual, out, static_cast<hipStream_t>(stream));
     }
 
     ConvArgs a;
@@ -745,6 +763,7 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>"};
     const int v = conv_variant(d);
     if (si_conv_smallc_ok(d)) return si_conv_smallc_name(d);
+    if (si_conv_depthwise_ok(d)) return si_conv_depthwise_name(d);
     if (conv_fast_ok(d, in)) return fast_names[v];
     static const int generic_of[11] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3};
     return names[generic_of[v]][conv_vec_a(d, in) ? 1 : 0];

@@ -177,6 +177,24 @@ def test_winograd43_fused_epilogue_and_strides(hops, orc):
         w4(rng_uniform(75, (1, 8, 8, 12), -1, 1), rng_uniform(76, (32, 12, 3, 3)), None)  # ic % 16 != 0
 
 
+# depthwise (groups == ic == oc): the dedicated HBM-bound kernel, conv_depthwise.hip.  MobileNet shapes (3x3 s1 / s2,
+# 5x5 s2), dilation, channel counts that are not multiples of 4 (scalar path), batch > 1, odd sizes, fused epilogue.
+@pytest.mark.parametrize("n,h,w,c,k,s,p,d", [
+    (2, 28, 28, 32, 3, 1, 1, 1), (2, 29, 27, 64, 3, 2, 1, 1), (1, 14, 14, 96, 5, 2, 2, 1), (3, 10, 10, 24, 3, 1, 2, 2),
+    (2, 9, 11, 10, 3, 1, 1, 1), (1, 7, 7, 4, 7, 1, 3, 1), (2, 5, 5, 3, 3, 1, 0, 1)])
+def test_conv_depthwise_kernel(hops, orc, n, h, w, c, k, s, p, d):
+    x = rng_uniform(h * 13 + c, (n, h, w, c), -1, 1)
+    wt = rng_uniform(h * 13 + c + 1, (c, 1, k, k), -0.5, 0.5)
+    b = rng_uniform(h * 13 + c + 2, (c,), -0.5, 0.5)
+    ref = orc.conv2d(x, wt, b, (s, s), (p, p), (d, d), c, path="naive")
+    assert_parity(hops.conv2d(x, wt, b, (s, s), (p, p), (d, d), c), ref, what="depthwise")
+    r = rng_uniform(h * 13 + c + 3, ref.shape, -1, 1)
+    got = hops.conv2d(x, wt, b, (s, s), (p, p), (d, d), c, act1="hardswish", residual=r, act2="relu")
+    assert_parity(got, orc.activation("relu", orc.activation("hardswish", ref) + r), what="depthwise fused epilogue")
+    if c % 4 == 0:
+        assert_parity(hops.conv2d(x, wt, b, (s, s), (p, p), (d, d), c, in_ld=c + 8, out_ld=2 * c, out_c_off=c), ref, what="strided")
+
+
 def test_conv_split_siblings(hops, orc):
     """YOLOv5 C3: cv1 and cv2 (both 1x1 + SiLU on the same x) as one launch with a split destination"""
     x = rng_uniform(60, (2, 20, 20, 64), -1, 1)

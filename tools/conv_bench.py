@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--act", default="silu")
     ap.add_argument("--algo", default="direct", choices=["direct", "wino", "wino43"], help="wino: si_hip_conv2d_wino23_f32 on eligible shapes only")
-    ap.add_argument("--shape", action="append", default=[], help="n,h,w,ci,co,k,s,p (repeatable): custom shapes instead of a model")
+    ap.add_argument("--shape", action="append", default=[], help="n,h,w,ci,co,k,s,p[,groups] (repeatable): custom shapes instead of a model")
     args = ap.parse_args()
     H = _native.hip()
     b = mg.build_yolov5s(args.batch, args.size) if args.model == "yolov5s" else mg.build_resnet18(args.batch, 224)
@@ -55,9 +55,11 @@ def main():
     if args.shape:
         shapes = {}
         for sp in args.shape:
-            n, h, w, ci, co, k, st, pd = (int(v) for v in sp.split(","))
+            vals = [int(v) for v in sp.split(",")]
+            n, h, w, ci, co, k, st, pd = vals[:8]
+            grp = vals[8] if len(vals) > 8 else 1
             oh, ow = (h + 2 * pd - k) // st + 1, (w + 2 * pd - k) // st + 1
-            shapes[(n, h, w, ci, oh, ow, co, (k, k), (st, st), (pd, pd), 1)] = 1
+            shapes[(n, h, w, ci, oh, ow, co, (k, k), (st, st), (pd, pd), grp)] = 1
     ev0, ev1 = C.c_void_p(), C.c_void_p()
     H.si_hip_event_create(C.byref(ev0))
     H.si_hip_event_create(C.byref(ev1))
