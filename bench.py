@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (images per Forward)")
     ap.add_argument("--size", type=int, default=640)
-    ap.add_argument("--model", default="yolov5s", choices=["yolov5s", "resnet18"])
+    ap.add_argument("--model", default="yolov5s", choices=["yolov5s", "resnet18", "mobilenetv3"])
     ap.add_argument("--graph", type=int, default=0, help="replay Forward() as a hipGraph")
     ap.add_argument("--winograd", type=int, default=1, help="3x3 s1 convs: 0 implicit GEMM everywhere, 1 fused Winograd F(2,3) where faster (default), 2 fused Winograd F(4,3) on those layers")
     ap.add_argument("--fp16", type=int, default=0, help="1: fp16 storage / fp16 MFMA path (BASELINE.json configs[3]); the headline metric is fp32 (default 0)")
@@ -57,7 +57,10 @@ def parse():
 def build_model(mg, name, batch, size):
     if name == "yolov5s":
         return mg.build_yolov5s(batch, size), (batch, size, size, 3)
-    return mg.build_resnet18(batch, 224 if size == 640 else size), (batch, 224 if size == 640 else size, 224 if size == 640 else size, 3)
+    sz = 224 if size == 640 else size
+    if name == "mobilenetv3":
+        return mg.build_mobilenetv3_small(batch, sz), (batch, sz, sz, 3)
+    return mg.build_resnet18(batch, sz), (batch, sz, sz, 3)
 
 
 def cpu_baseline(args, mg, td):
@@ -309,7 +312,7 @@ def main():
     ceiling = (PEAK_F16_MFMA_TFLOPS if args.fp16 else PEAK_FP32_MFMA_TFLOPS) * 1e12 / (flops_step / args.batch)  # images/s/GPU at the MFMA peak
     out = {
         "metric": "images/sec %s %dx%d %s batch=%d per GPU, Engine::Forward()" % (
-            "YOLOv5s" if args.model == "yolov5s" else "ResNet18", shape[1], shape[2], prec, args.batch),
+            {"yolov5s": "YOLOv5s", "resnet18": "ResNet18", "mobilenetv3": "MobileNetV3-Small"}[args.model], shape[1], shape[2], prec, args.batch),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16" if args.fp16 else "f32", "data": "synthetic",

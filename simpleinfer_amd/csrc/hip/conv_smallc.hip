@@ -267,7 +267,7 @@ bool si_conv_smallc_ok(const SiConv2dDesc* d) {
     if (d->ic < 1 || d->ic > 3) return false;
     if (d->sh < 1 || d->sh > 2 || d->sw < 1 || d->sw > 2 || d->kh > 7 || d->kw > 7) return false;
     const int hp = smallc_hp(d);
-    return hp == 9 || hp == 11;  // 6x6x3 (YOLOv5 stem), 7x7x3 (ResNet stem)
+    return hp == 5 || hp == 9 || hp == 11;  // 3x3x3 (MobileNet stem), 6x6x3 (YOLOv5 stem), 7x7x3 (ResNet stem)
 }
 
 size_t si_conv_smallc_weight_elems(const SiConv2dDesc* d) {
@@ -291,6 +291,7 @@ void si_conv_smallc_pack(const SiConv2dDesc* d, const float* w_oihw, float* w_pa
 
 const char* si_conv_smallc_name(const SiConv2dDesc* d) {
     const int hp = smallc_hp(d);
+    if (hp == 5) return d->oc > 32 ? "conv_smallc_rows_kernel<4, 2, 2, 5, 28>" : "conv_smallc_rows_kernel<4, 1, 2, 5, 28>";
     if (hp == 9)
         return d->oc > 32 ? "conv_smallc_rows_kernel<4, 2, 2, 9, 36>"
                           : ((d->ow % 160 == 0 || d->ow > 128) ? "conv_smallc_rows_kernel<5, 1, 1, 9, 28>" : "conv_smallc_rows_kernel<4, 1, 1, 9, 28>");
@@ -313,6 +314,10 @@ static int smallc_launch_t(const SiConv2dDesc* d, const float* in, const float* 
     a.in_bytes = (unsigned)in_bytes;
     // Variants measured on the YOLOv5s stem at batch 32 (MI355X): 5 waves x 1 output row per item (37 KB LDS, 4 resident
     // workgroups per CU) 0.40 ms; 2 rows per item 0.63 ms; 4 waves 0.45 ms.  Residency beats halo reuse here too.
+    if (smallc_hp(d) == 5) {
+        if (d->oc > 32) return launch_smallc<4, 2, 2, 5, 28, OutT>(a, s);
+        return launch_smallc<4, 1, 2, 5, 28, OutT>(a, s);
+    }
     if (smallc_hp(d) == 9) {
         if (d->oc > 32) return launch_smallc<4, 2, 2, 9, 36, OutT>(a, s);
         if (d->ow % 160 == 0 || d->ow > 128) return launch_smallc<5, 1, 1, 9, 28, OutT>(a, s);

@@ -164,6 +164,31 @@ __global__ void avgpool_kernel(const float* __restrict__ in, int n, int ih, int 
     }
 }
 
+// Global average (output 1x1, the squeeze-excite / classifier-head case): the window is the whole map, so one thread
+// per output would walk thousands of strided elements alone.  Instead a workgroup owns one image and `cw` consecutive
+// channels (cw = power of two <= 64): lane -> channel (coalesced rows), the 256/cw thread groups stride over the pixels,
+// partial sums meet in LDS and are added in a fixed order (results do not depend on the launch shape).
+template <typename T>
+__global__ __launch_bounds__(256) void global_avgpool_kernel(const T* __restrict__ in, int pixels, int c, int in_ld,
+                                                             T* __restrict__ out, int out_ld, int cw) {
+    __shared__ float part[256];
+    const int b = blockIdx.y;
+    const int ch = blockIdx.x * cw + (threadIdx.x % cw);
+    const int pg = threadIdx.x / cw, groups = 256 / cw;
+    float s = 0.0f;
+    if (ch < c) {
+        const T* p = in + (size_t)b * pixels * in_ld + ch;
+        for (int i = pg; i < pixels; i += groups) s += (float)p[(size_t)i * in_ld];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (pg == 0 && ch < c) {
+        float t = 0.0f;
+        for (int g = 0; g < groups; ++g) t += part[g * cw + (threadIdx.x % cw)];
+        out[(size_t)b * out_ld + ch] = (T)(t / (float)pixels);
+    }
+}
+
 // ---- nearest upsample ----------------------------------------------------------------------
 template <bool VEC>
 __global__ void upsample_kernel(const float* __restrict__ in, int n, int ih, int iw, int c, int in_ld,
@@ -364,6 +389,13 @@ int si_hip_adaptive_avgpool2d_f32(const float* in, int n, int ih, int iw, int c,
                                   int out_ld, si_stream_t stream) {
     if (!in || !out || oh <= 0 || ow <= 0) return SI_E_BADARG;
     if (ih % oh != 0 || iw % ow != 0) return SI_E_UNSUPPORTED;  // reference adaptive_avg_pool_2d.cpp:78-84
+    if (oh == 1 && ow == 1 && n > 0 && c > 0) {
+        int cw = 64;
+        while (cw > 1 && cw / 2 >= c) cw /= 2;
+        hipLaunchKernelGGL(global_avgpool_kernel<float>, dim3((c + cw - 1) / cw, n), dim3(256), 0, (hipStream_t)stream, in,
+                           ih * iw, c, in_ld, out, out_ld, cw);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(avgpool_kernel, dim3(si_grid_for((size_t)n * oh * ow * c)), dim3(256), 0, (hipStream_t)stream,
                        in, n, ih, iw, c, in_ld, out, oh, ow, out_ld, ih / oh, iw / ow);
     return (int)hipGetLastError();

@@ -127,6 +127,27 @@ __global__ void avgpool_h_kernel(const half_t* __restrict__ in, int n, int ih, i
     }
 }
 
+// global average (output 1x1): see ops.hip global_avgpool_kernel
+__global__ __launch_bounds__(256) void global_avgpool_h_kernel(const half_t* __restrict__ in, int pixels, int c, int in_ld,
+                                                               half_t* __restrict__ out, int out_ld, int cw) {
+    __shared__ float part[256];
+    const int b = blockIdx.y;
+    const int ch = blockIdx.x * cw + (threadIdx.x % cw);
+    const int pg = threadIdx.x / cw, groups = 256 / cw;
+    float s = 0.0f;
+    if (ch < c) {
+        const half_t* p = in + (size_t)b * pixels * in_ld + ch;
+        for (int i = pg; i < pixels; i += groups) s += (float)p[(size_t)i * in_ld];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (pg == 0 && ch < c) {
+        float t = 0.0f;
+        for (int g = 0; g < groups; ++g) t += part[g * cw + (threadIdx.x % cw)];
+        out[(size_t)b * out_ld + ch] = (half_t)(t / (float)pixels);
+    }
+}
+
 __global__ void cvt_f32_f16_kernel(const float* __restrict__ in, size_t pixels, int c, int in_ld, half_t* __restrict__ out,
                                    int out_ld) {
     const size_t total = pixels * (size_t)c;
@@ -207,6 +228,13 @@ int si_hip_adaptive_avgpool2d_f16(const void* in, int n, int ih, int iw, int c, 
                                   int out_ld, si_stream_t stream) {
     if (!in || !out || n <= 0 || c <= 0 || oh <= 0 || ow <= 0) return SI_E_BADARG;
     if (ih % oh != 0 || iw % ow != 0) return SI_E_UNSUPPORTED;  // uniform windows only, as the fp32 kernel
+    if (oh == 1 && ow == 1) {
+        int cw = 64;
+        while (cw > 1 && cw / 2 >= c) cw /= 2;
+        hipLaunchKernelGGL(global_avgpool_h_kernel, dim3((c + cw - 1) / cw, n), dim3(256), 0, (hipStream_t)stream,
+                           static_cast<const half_t*>(in), ih * iw, c, in_ld, static_cast<half_t*>(out), out_ld, cw);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(avgpool_h_kernel, dim3(si_grid_for((size_t)n * oh * ow * c)), dim3(256), 0, (hipStream_t)stream,
                        static_cast<const half_t*>(in), n, ih, iw, c, in_ld, static_cast<half_t*>(out), oh, ow, out_ld, ih / oh,
                        iw / ow);

@@ -387,6 +387,48 @@ def build_toy_classifier(batch: int = 2, size: int = 32, seed: int = 0) -> PnnxB
     return b
 
 
+def build_mobilenetv3_small(batch: int, size: int = 224, num_classes: int = 1000, seed: int = 0) -> PnnxBuilder:
+    """torchvision MobileNetV3-Small topology with BatchNorm folded into the convolutions (nn.Conv2d bias=True), the
+    model family of the reference's test_classify (test/test_classify/test_classify.cpp:12-15): 3x3 / 5x5 depthwise
+    convs, squeeze-excite (global average pool -> 1x1 -> ReLU -> 1x1 -> Hardsigmoid -> broadcast mul), Hardswish,
+    residual adds."""
+    b = PnnxBuilder(seed)
+
+    def act(x, kind):
+        return b.hardswish(x) if kind == "HS" else b.relu(x)
+
+    def make_div(v, d=8):
+        return max(d, int(v + d / 2) // d * d)
+
+    x = b.input((batch, 3, size, size))
+    x = b.hardswish(b.conv(x, 16, 3, 2, 1))
+    cin = 16
+    # kernel, expanded channels, output channels, squeeze-excite, activation, stride
+    cfg = [(3, 16, 16, True, "RE", 2), (3, 72, 24, False, "RE", 2), (3, 88, 24, False, "RE", 1), (5, 96, 40, True, "HS", 2),
+           (5, 240, 40, True, "HS", 1), (5, 240, 40, True, "HS", 1), (5, 120, 48, True, "HS", 1), (5, 144, 48, True, "HS", 1),
+           (5, 288, 96, True, "HS", 2), (5, 576, 96, True, "HS", 1), (5, 576, 96, True, "HS", 1)]
+    for k, exp, cout, se, nl, s in cfg:
+        y = x
+        if exp != cin:
+            y = act(b.conv(y, exp, 1), nl)
+        y = act(b.conv(y, exp, k, s, k // 2, groups=exp), nl)          # depthwise
+        if se:
+            q = b.adaptive_avgpool(y, (1, 1))
+            q = b.relu(b.conv(q, make_div(exp // 4), 1))
+            q = b.hardsigmoid(b.conv(q, exp, 1))
+            y = b.mul(y, q)                                            # broadcast over H, W
+        y = b.conv(y, cout, 1)
+        x = b.add(x, y) if (s == 1 and cin == cout) else y
+        cin = cout
+    x = b.hardswish(b.conv(x, 576, 1))
+    x = b.adaptive_avgpool(x, (1, 1))
+    x = b.flatten(x)
+    x = b.hardswish(b.linear(x, 1024))
+    x = b.linear(x, num_classes)
+    b.output(x)
+    return b
+
+
 def conv_flops(builder: PnnxBuilder) -> int:
     """Direct-convolution FLOPs (2*MAC) of every nn.Conv2d + Detect 1x1 conv in the graph
     (sum N*OH*OW*KH*KW*(Cin/g)*Cout)."""

@@ -35,6 +35,7 @@ MODELS = {
     "toy_classifier": (lambda mg: mg.build_toy_classifier(2, 32), (2, 32, 32, 3)),
     "resnet18_small": (lambda mg: mg.build_resnet18(2, 64, num_classes=100, base=16), (2, 64, 64, 3)),
     "yolov5s_160": (lambda mg: mg.build_yolov5s(2, 160), (2, 160, 160, 3)),
+    "mobilenetv3_small_96": (lambda mg: mg.build_mobilenetv3_small(2, 96, num_classes=100), (2, 96, 96, 3)),
 }
 
 

@@ -195,6 +195,16 @@ def test_conv_depthwise_kernel(hops, orc, n, h, w, c, k, s, p, d):
         assert_parity(hops.conv2d(x, wt, b, (s, s), (p, p), (d, d), c, in_ld=c + 8, out_ld=2 * c, out_c_off=c), ref, what="strided")
 
 
+@pytest.mark.parametrize("n,size,oc,k,s,p", [(2, 64, 16, 3, 2, 1), (1, 33, 32, 3, 1, 1), (2, 40, 48, 3, 2, 1)])
+def test_stem_3x3_rgb(hops, orc, n, size, oc, k, s, p):
+    # MobileNet-style stems (3x3 over 3 channels) take the persistent row kernel too
+    x = rng_uniform(300 + size, (n, size, size, 3), 0, 1)
+    w = rng_uniform(301 + size, (oc, 3, k, k), -0.5, 0.5)
+    b = rng_uniform(302 + size, (oc,), -0.5, 0.5)
+    ref = orc.activation("hardswish", orc.conv2d(x, w, b, (s, s), (p, p), path="naive"))
+    assert_parity(hops.conv2d(x, w, b, (s, s), (p, p), act1="hardswish"), ref, what="3x3x3 stem")
+
+
 def test_conv_split_siblings(hops, orc):
     """YOLOv5 C3: cv1 and cv2 (both 1x1 + SiLU on the same x) as one launch with a split destination"""
     x = rng_uniform(60, (2, 20, 20, 64), -1, 1)
@@ -252,6 +262,12 @@ def test_avgpool(hops, orc):
     assert_parity(hops.adaptive_avgpool2d(x, (3, 4)), orc.adaptive_avgpool2d(x, (3, 4)), 1e-6)
     with pytest.raises(hops.HipError):
         hops.adaptive_avgpool2d(x, (5, 3))  # not divisible: kUnsupport in the reference (:78-84)
+    # global pooling over large maps (squeeze-excite / classifier heads): the workgroup-reduction kernel, any channel count
+    for shape in [(3, 56, 56, 16), (2, 7, 7, 100), (2, 28, 28, 1), (1, 14, 14, 576)]:
+        x = rng_uniform(40 + shape[3], shape, -1, 1)
+        assert_parity(hops.adaptive_avgpool2d(x, (1, 1)), orc.adaptive_avgpool2d(x, (1, 1)), 1e-5, what="global avgpool %s" % (shape,))
+    x = rng_uniform(45, (2, 28, 28, 64), -1, 1)
+    assert_exact(hops.adaptive_avgpool2d(x[1:2], (1, 1))[0], hops.adaptive_avgpool2d(x, (1, 1))[1], "batch invariance")
 
 
 def test_upsample_exact(hops, orc):

@@ -31,3 +31,14 @@ def test_weights_are_portable_and_seeded():
     # known answer: splitmix64 stream for seed 0 (portable across numpy versions / machines)
     u = mg.splitmix_uniform(0, 3)
     assert np.allclose(u, [0.8833108, 0.43152797, 0.02643377], atol=1e-6), u
+
+
+def test_mobilenetv3_small_topology():
+    b = mg.build_mobilenetv3_small(1, 224)
+    types = [ln.split()[0] for ln in b.lines]
+    # torchvision mobilenet_v3_small: 11 inverted-residual blocks, 9 of them with squeeze-excite, ~56.5 MMAC of conv work
+    assert types.count("nn.AdaptiveAvgPool2d") == 9 + 1 and types.count("nn.Hardsigmoid") == 9
+    depthwise = [ln for ln in b.lines if ln.startswith("nn.Conv2d") and "groups=1 " not in ln + " "]
+    assert len(depthwise) == 11
+    assert 0.10 < mg.conv_flops(b) / 1e9 < 0.13
+    assert b.shapes[str(b._n_operand - 1)] == (1, 1000)
