@@ -61,8 +61,11 @@ public:
     //   "device"          HIP device ordinal (default: current device)
     //   "fuse"            1/0  fold activation / residual add into the conv epilogue (default 1)
     //   "alias_cat"       1/0  producers write straight into torch.cat outputs (default 1)
-    //   "winograd"        1/0  3x3 stride-1 convs run the fused Winograd F(2,3) kernel, as the reference does on the
-    //                          CPU (default 1); 0 = implicit GEMM everywhere
+    //   "winograd"        0/1/2  3x3 stride-1 convs: 1 (default) fused Winograd F(2,3) where it is the faster kernel, as
+    //                          the reference does on the CPU; 0 = implicit GEMM everywhere; 2 = fused Winograd F(4,3)
+    //   "fp16"            1/0  fp16 storage for internal activations and weights, fp16 MFMA with fp32 accumulation;
+    //                          Input / Extract tensors stay fp32 (default 0: the reference's fp32 arithmetic)
+    //   "batch"           N>0  serve batch N whatever batch the .param file was traced with (default 0: as in the file)
     //   "graph"           1/0  replay Forward() as a captured hipGraph (default 0)
     //   "outputs_to_host" 1/0  copy outputs to pinned host memory in Forward() (default 1);
     //                          with 0, Extract() returns device tensors

@@ -46,6 +46,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "graph") opt_graph_ = value != 0;
     else if (key == "outputs_to_host") opt_outputs_to_host_ = value != 0;
     else if (key == "fp16") opt_fp16_ = value != 0;
+    else if (key == "batch") opt_batch_ = value;  // > 0: re-batch the graph at load (the file bakes its batch into every shape)
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else {
         LOG(ERROR) << "unknown engine option [" << key << "]";
@@ -142,6 +143,24 @@ Status EngineImpl::DestroyGraph() {
 }
 
 Status EngineImpl::CreateTensorNodes() {
+    // Re-batch (SetOption("batch", N)): a pnnx file carries the batch it was traced with in every operand shape
+    // (#0=(N,3,640,640)f32).  Every operator here is per-image, so serving another batch is a rewrite of
+    // dim 0 wherever it equals the traced batch of the graph input.
+    int file_batch = 0;
+    if (opt_batch_ > 0) {
+        for (pnnx::Operand* opd : graph_->operands)
+            if (opd->producer && opd->producer->inputs.empty() && !opd->shape.empty()) {
+                if (file_batch != 0 && file_batch != opd->shape[0]) {
+                    LOG(ERROR) << "re-batch: graph inputs disagree on the batch dimension";
+                    return Status::kUnsupport;
+                }
+                file_batch = opd->shape[0];
+            }
+        if (file_batch <= 0) {
+            LOG(ERROR) << "re-batch: no graph input with a static batch dimension";
+            return Status::kUnsupport;
+        }
+    }
     for (pnnx::Operand* opd : graph_->operands) {
         if (tensor_nodes_.count(opd->name) > 0) {
             LOG(ERROR) << "tensor node [" << opd->name << "] already exists";
@@ -152,6 +171,7 @@ Status EngineImpl::CreateTensorNodes() {
 
         // file shapes are NCHW; tensors are NHWC: the last three dims C,H,W -> H,W,C for rank >= 4
         std::vector<int> shape = opd->shape;
+        if (file_batch > 0 && !shape.empty() && shape[0] == file_batch) shape[0] = opt_batch_;
         const int rank = (int)shape.size();
         if (rank > 3) {
             shape[rank - 3] = opd->shape[rank - 2];

@@ -93,6 +93,7 @@ private:
     bool opt_graph_ = false;
     bool opt_outputs_to_host_ = true;
     int opt_winograd_ = 1;
+    int opt_batch_ = 0;          // > 0: serve this batch whatever batch the file was traced with
     bool opt_fp16_ = false;      // fp16 storage for internal activations and weights (BASELINE.json configs[3])
 
     Context* context_ = nullptr;

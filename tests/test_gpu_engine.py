@@ -221,3 +221,25 @@ def test_fp16_unsupported_graph_is_a_status(si, tmp_path):
     with pytest.raises(si.StatusError) as ei:
         e.forward()
     assert ei.value.status == si.Status.kUnsupport
+
+
+def test_rebatch_serves_any_batch_from_one_file(si, tmp_path):
+    """SetOption("batch", N): the file bakes its batch into every operand shape; the engine rewrites it."""
+    mg = si.modelgen
+    p1 = _save(tmp_path, mg.build_yolov5s(1, 160), "b1")
+    p3 = _save(tmp_path, mg.build_yolov5s(3, 160), "b3")
+    x = mg.synth_input((3, 160, 160, 3))
+    _, oname, ref = _run(si, *p3, x)
+    e = si.Engine(batch=3)
+    e.load_model(*p1)
+    assert e.operand_shape("0") == (3, 160, 160, 3) and e.operand_shape(oname)[0] == 3
+    e.input("0", x)
+    e.forward()
+    assert_exact(e.extract(oname), ref, "batch-1 file served at batch 3 == batch-3 file")
+    # and a classifier (rank-2 output, flatten / linear in the path)
+    r1 = _save(tmp_path, mg.build_resnet18(1, 64, num_classes=10, base=16), "r1")
+    r4 = _save(tmp_path, mg.build_resnet18(4, 64, num_classes=10, base=16), "r4")
+    xr = mg.synth_input((4, 64, 64, 3))
+    _, on, refr = _run(si, *r4, xr)
+    _, _, got = _run(si, *r1, xr, batch=4)
+    assert_exact(got, refr, "resnet re-batched")
