@@ -75,7 +75,6 @@ struct ConvArgs {
     int cb_major;               // K order: 0 = (tap, c), 1 = (c/32, tap, c%32)
     int ntaps;                  // kh*kw
     unsigned in_bytes, w_bytes; // buffer-resource extents for the fast path (tensor < 4 GB)
-    int ablate;                 // timing experiments only (SI_CONV_ABLATE): 1 no global loads, 2 no LDS stores, 4 no barrier
     // split output (two sibling convs on one input fused along oc): channels >= split go to out2 (stride out2_ld)
     float* out2;
     int out2_ld, split;
@@ -497,7 +496,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = NBUF == 2 ? (kt & 1) : 0;
-        if (kt + 1 < nk && !(a.ablate & 1)) load_tile(kt + 1);
+        if (kt + 1 < nk) load_tile(kt + 1);
 
         const float* As = lds[cur] + (wm * TM * 32 + l31) * LDS_LD + lh * 4;
         const float* Bs = lds[cur] + BM * LDS_LD + (wn * TN * 32 + l31) * LDS_LD + lh * 4;
@@ -518,8 +517,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         }
 
         if (NBUF == 2) {
-            if (kt + 1 < nk && !(a.ablate & 2)) store_tile(cur ^ 1);
-            if (!(a.ablate & 4)) __syncthreads();
+            if (kt + 1 < nk) store_tile(cur ^ 1);
+            __syncthreads();
         } else {
             __syncthreads();  // everyone is done reading tile kt
             if (kt + 1 < nk) {
@@ -682,11 +681,6 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     a.cb_major = conv_cb_major(d) ? 1 : 0;
     a.ntaps = d->kh * d->kw;
     a.in_bytes = 0; a.w_bytes = 0;
-    static const int ablate = [] {
-        const char* e = getenv("SI_CONV_ABLATE");
-        return e ? atoi(e) : 0;
-    }();
-    a.ablate = ablate;
     a.ymode = 0; a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.f; a.ygrid = a.yanchor = nullptr;
     a.out2 = nullptr; a.out2_ld = 0; a.split = 0;
     if (split) {
