@@ -241,20 +241,21 @@ def main():
         e.input_device(iname, dx.ptr)
         oshape = e.operand_shape(oname)
 
-        gathered = local_view = None
+        og = local_view = None
         if use_dist:
             e.forward()
             optr, _ = e.extract_ptr(oname)
-            local_view = sd.as_torch(optr, oshape, dev)
-            gathered = torch.empty((world * oshape[0],) + tuple(oshape[1:]), dtype=torch.float32, device="cuda:%d" % dev)
+            local_view = sd.as_torch(optr, oshape, dev)   # zero-copy view of the engine-owned output slab
+            og = sd.OverlappedGather(local_view)
 
         def step():
             e.forward()  # synchronous: kernels of this step are done when it returns
             if use_dist:
-                dist.all_gather_into_tensor(gathered, local_view)
+                og.submit(local_view)  # all-gather of THIS step's slab, overlapped with the next step's compute
 
         def fence():
             if use_dist:
+                og.drain()  # every gather issued so far has completed
                 dist.barrier()
                 torch.cuda.synchronize()
             H.si_hip_device_sync()
@@ -272,6 +273,7 @@ def main():
         if use_dist:
             # the gathered buffer must hold this rank's slab at its rank offset, bit for bit
             b0 = rank * oshape[0]
+            gathered = og.latest()
             if not torch.equal(gathered[b0:b0 + oshape[0]], local_view):
                 sys.exit("bench.py: all-gather result does not match the local output slab")
             tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
@@ -319,7 +321,7 @@ def main():
         "config": {"workload": "%s %dx%d %s forward, batch %d per GPU (global %d), random-init weights, "
                                "inputs resident in HBM%s" % (args.model, shape[1], shape[2], prec, args.batch,
                                                             args.batch * world,
-                                                            ", outputs all-gathered over RCCL" if world > 1 else ""),
+                                                            ", every step's output slab all-gathered over RCCL, overlapped with the next step" if world > 1 else ""),
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "hipgraph": bool(args.graph), "winograd_for_3x3s1": {0: "off", 1: "F(2,3)", 2: "F(4,3)"}.get(args.winograd, "F(2,3)")},
         "forward_kernel_ms_per_step": round(fwd_ms / args.steps, 3),

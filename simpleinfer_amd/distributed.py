@@ -53,6 +53,57 @@ def all_gather_slabs(local, gathered=None, group=None):
     return gathered
 
 
+class OverlappedGather:
+    """The step's one exchange, taken off the critical path: the all-gather of step i's output slab runs on the
+    collective's own stream while step i+1 computes (RCCL kernels only need a handful of CUs; the xGMI links are
+    otherwise idle during a forward).
+
+    The engine reuses its output buffer every Forward, so `submit(local)` first copies the slab into one of two staging
+    tensors (a device-to-device copy, ~0.1 ms for the 274 MB YOLOv5s slab, waited for before returning so the next
+    Forward cannot overwrite it) and then issues `all_gather_into_tensor(..., async_op=True)` from the staging tensor
+    into the matching one of two gathered tensors.  `drain()` waits for everything in flight; `latest()` is the last
+    completed [world*b, ...] tensor.  Every step's output is gathered -- nothing is skipped, only overlapped."""
+
+    def __init__(self, local_like, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        shape = (self.world * local_like.shape[0],) + tuple(local_like.shape[1:])
+        self.stage = [torch.empty_like(local_like) for _ in range(2)]
+        self.gathered = [torch.empty(shape, dtype=local_like.dtype, device=local_like.device) for _ in range(2)]
+        self.handles = [None, None]
+        self.i = 0
+        self._cuda = local_like.is_cuda
+        self._torch = torch
+
+    def submit(self, local):
+        k = self.i & 1
+        if self.handles[k] is not None:   # the gather issued two steps ago used these buffers
+            self.handles[k].wait()
+            self.handles[k] = None
+        self.stage[k].copy_(local)
+        if self._cuda:
+            self._torch.cuda.current_stream().synchronize()   # the slab is safe: the next Forward may overwrite `local`
+        if self.world == 1:
+            self.gathered[k].copy_(self.stage[k])
+        else:
+            self.handles[k] = self.dist.all_gather_into_tensor(self.gathered[k], self.stage[k], group=self.group, async_op=True)
+        self.i += 1
+
+    def drain(self):
+        for k in (0, 1):
+            if self.handles[k] is not None:
+                self.handles[k].wait()
+                self.handles[k] = None
+        if self._cuda:
+            self._torch.cuda.synchronize()
+
+    def latest(self):
+        """the gathered tensor of the most recent submit (call drain() first)"""
+        return self.gathered[(self.i - 1) & 1]
+
+
 class DeviceArrayView:
     """Zero-copy handle that lets torch wrap an engine-owned device buffer (`__cuda_array_interface__`)."""
 

@@ -39,9 +39,19 @@ def _worker(rank, world, port, tmpdir, q):
     out = orc.run_graph(pp, bp, {"0": x_full[lo:hi]})
     (name, local), = out.items()
     gathered = sd.all_gather_slabs(torch.from_numpy(local))
+    # the pipelined exchange bench.py uses for N > 1: three "steps" whose outputs differ, every one of them gathered
+    og = sd.OverlappedGather(torch.from_numpy(local))
+    buf = torch.from_numpy(local.copy())
+    seen = []
+    for step in range(3):
+        buf.copy_(torch.from_numpy(local) + float(step))     # the engine overwrites its output buffer every Forward
+        og.submit(buf)
+        buf.fill_(-1.0)                                       # ... and may do so as soon as submit() returns
+        og.drain()
+        seen.append(og.latest().clone())
     dist.barrier()
     if r == 0:
-        q.put((name, gathered.numpy()))
+        q.put((name, gathered.numpy(), [t.numpy() for t in seen]))
     dist.destroy_process_group()
 
 
@@ -55,7 +65,7 @@ def test_two_rank_gloo_sharding_matches_full_batch(tmp_path):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
     for p in procs:
         p.start()
-    name, gathered = q.get(timeout=120)
+    name, gathered, pipelined = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -64,6 +74,8 @@ def test_two_rank_gloo_sharding_matches_full_batch(tmp_path):
     full = orc.run_graph(pp, bp, {"0": mg.synth_input((4, 64, 64, 3))})[name]
     assert gathered.shape == full.shape
     assert np.array_equal(gathered, full)
+    for step, g in enumerate(pipelined):
+        assert np.array_equal(g, full + np.float32(step)), "overlapped gather, step %d" % step
 
 
 def test_shard_range():
