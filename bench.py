@@ -249,9 +249,12 @@ def main():
             og = sd.OverlappedGather(local_view)
 
         def step():
+            if use_dist:
+                # the engine writes this step's [B/G, rows, 85] slab straight into one of two torch tensors (Engine::Output)
+                e.bind_output(oname, og.target().data_ptr())
             e.forward()  # synchronous: kernels of this step are done when it returns
             if use_dist:
-                og.submit(local_view)  # all-gather of THIS step's slab, overlapped with the next step's compute
+                og.submit_inplace()  # all-gather of THIS step's slab, overlapped with the next step's compute
 
         def fence():
             if use_dist:
@@ -274,7 +277,7 @@ def main():
             # the gathered buffer must hold this rank's slab at its rank offset, bit for bit
             b0 = rank * oshape[0]
             gathered = og.latest()
-            if not torch.equal(gathered[b0:b0 + oshape[0]], local_view):
+            if not torch.equal(gathered[b0:b0 + oshape[0]], og.latest_local()):
                 sys.exit("bench.py: all-gather result does not match the local output slab")
             tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -55,6 +55,12 @@ public:
 
     Status Extract(const std::string& name, Tensor& output);
 
+    // Extension: have an output operand written into caller-owned device memory (MemoryType::kDevice, same element
+    // count and type) from the next Forward() on; borrowed until the next Output() / Release().  A tensor without data
+    // restores the engine's own buffer.  Lets a caller alternate output buffers, e.g. to hand one to an asynchronous
+    // collective while the next Forward() fills the other.
+    Status Output(const std::string& name, const Tensor& output);
+
 public:
     // ---- extensions -------------------------------------------------------------------
     // Must be called before LoadModel.  Keys:

@@ -35,6 +35,9 @@ int si_engine_operand_shape(SiEngine* engine, const char* name, int* rank, int* 
 /* Engine::Input: borrows `data` (fp32, NHWC, the operand's element count) until the next Input/Release;
  * it is read at forward time.  on_device != 0: `data` is a device pointer, read in place. */
 int si_engine_input(SiEngine* engine, const char* name, const void* data, int on_device);
+/* Engine::Output (extension): write output operand `name` into caller-owned DEVICE memory of the operand's size from the
+ * next forward on; NULL restores the engine's own buffer */
+int si_engine_bind_output(SiEngine* engine, const char* name, void* device_data);
 /* Engine::Forward: synchronous */
 int si_engine_forward(SiEngine* engine);
 /* Engine::Extract: non-owning view of engine memory (host pinned mirror, or device pointer when the

@@ -157,6 +157,7 @@ def host():
         "si_engine_output_name": (cp, [vp, i]),
         "si_engine_operand_shape": (i, [vp, cp, C.POINTER(i), C.POINTER(i)]),
         "si_engine_input": (i, [vp, cp, vp, i]),
+        "si_engine_bind_output": (i, [vp, cp, vp]),
         "si_engine_forward": (i, [vp]),
         "si_engine_extract": (i, [vp, cp, C.POINTER(vp), C.POINTER(i)]),
         "si_engine_stream": (vp, [vp]),

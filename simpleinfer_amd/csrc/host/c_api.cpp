@@ -104,6 +104,15 @@ int si_engine_input(SiEngine* e, const char* name, const void* data, int on_devi
     return code(e->impl.Input(name, t));
 }
 
+int si_engine_bind_output(SiEngine* e, const char* name, void* device_data) {
+    if (!e || !name) return code(Status::kFail);
+    std::vector<int> shape;
+    if (e->impl.OperandShape(name, shape) != Status::kSuccess) return code(Status::kFail);
+    Tensor t(DataType::kFloat32, shape, false);
+    if (device_data) t.SetData(device_data, MemoryType::kDevice);
+    return code(e->impl.Output(name, t));
+}
+
 int si_engine_forward(SiEngine* e) { return e ? code(e->impl.Forward()) : code(Status::kFail); }
 
 int si_engine_extract(SiEngine* e, const char* name, void** data, int* on_device) {

@@ -20,6 +20,8 @@ const std::vector<std::string> Engine::OutputNames() { return impl_->OutputNames
 Status Engine::Input(const std::string& name, const Tensor& input) { return impl_->Input(name, input); }
 Status Engine::Forward() { return impl_->Forward(); }
 Status Engine::Extract(const std::string& name, Tensor& output) { return impl_->Extract(name, output); }
+
+Status Engine::Output(const std::string& name, const Tensor& output) { return impl_->Output(name, output); }
 Status Engine::SetOption(const std::string& key, int value) { return impl_->SetOption(key, value); }
 Status Engine::OperandShape(const std::string& name, std::vector<int>& shape) { return impl_->OperandShape(name, shape); }
 Status Engine::Profile(std::vector<LayerProfile>& layers) { return impl_->Profile(layers); }

@@ -200,6 +200,7 @@ Status EngineImpl::DestroyTensorNodes() {
     input_tensor_nodes_.clear();
     output_tensor_nodes_.clear();
     user_inputs_.clear();
+    user_outputs_.clear();
     for (auto& kv : tensor_nodes_) delete kv.second;
     tensor_nodes_.clear();
     return Status::kSuccess;
@@ -330,6 +331,7 @@ Status EngineImpl::DestroyPipeline() {
     graph_exec_ = nullptr;
     forward_count_ = 0;
     captured_input_ptrs_.clear();
+    captured_output_ptrs_.clear();
     plan_.clear();
     fused_ops_.clear();
     sibling_ops_.clear();
@@ -507,6 +509,7 @@ Status EngineImpl::AllocateTensorMemory() {
         if (input_tensor_nodes_.count(name)) {
             input_buffers_[name] = p;  // staging for host inputs
         }
+        if (output_tensor_nodes_.count(name)) own_output_ptrs_[name] = p;
         t.SetView(p, MemoryType::kDevice, 0);
     }
     // 2. aliases point into their concat buffer
@@ -531,6 +534,7 @@ Status EngineImpl::DeallocateTensorMemory() {
     for (void* p : device_allocs_) si_hip_free(p);
     device_allocs_.clear();
     input_buffers_.clear();
+    own_output_ptrs_.clear();
     for (auto& kv : host_outputs_) si_hip_host_free(kv.second);
     host_outputs_.clear();
     for (auto& kv : tensor_nodes_) kv.second->tensor.SetView(nullptr, MemoryType::kDevice, 0);
@@ -568,6 +572,40 @@ Status EngineImpl::Input(const std::string& name, const Tensor& input) {
         return Status::kErrorShape;
     }
     user_inputs_[name] = input;  // alias: the caller keeps ownership (reference engine_impl.cpp:528)
+    return Status::kSuccess;
+}
+
+// Output(): the mirror of a device-resident Input() -- the caller provides the HBM buffer an output operand is written
+// to (e.g. one of two tensors that are handed to an asynchronous collective while the next Forward runs).  Borrowed
+// until the next Output() / Release; a null tensor restores the engine's own buffer.
+Status EngineImpl::Output(const std::string& name, const Tensor& output) {
+    auto it = output_tensor_nodes_.find(name);
+    if (it == output_tensor_nodes_.end()) {
+        LOG(ERROR) << "tensor [" << name << "] is not an output tensor";
+        return Status::kFail;
+    }
+    if (nullptr == output.RawData()) {
+        user_outputs_.erase(name);
+        return Status::kSuccess;
+    }
+    if (output.GetMemoryType() != MemoryType::kDevice) {
+        LOG(ERROR) << "Output(" << name << "): a caller-owned output buffer must be device memory";
+        return Status::kUnsupport;
+    }
+    if (output.NumElements() != it->second->tensor.NumElements() || output.GetDataType() != it->second->tensor.GetDataType()) {
+        LOG(ERROR) << "tensor [" << name << "] does not match the model's output shape / type";
+        return Status::kErrorShape;
+    }
+    user_outputs_[name] = output;
+    return Status::kSuccess;
+}
+
+Status EngineImpl::BindOutputs() {
+    for (auto& kv : output_tensor_nodes_) {
+        auto u = user_outputs_.find(kv.first);
+        void* want = u != user_outputs_.end() ? u->second.RawData() : own_output_ptrs_[kv.first];
+        if (want && kv.second->tensor.RawData() != want) kv.second->tensor.SetView(want, MemoryType::kDevice, 0);
+    }
     return Status::kSuccess;
 }
 
@@ -610,15 +648,17 @@ Status EngineImpl::Forward() {
     si_hip_set_device(context_->device());
     si_stream_t stream = context_->stream();
     CHECK_STATUS(UploadInputs());
+    CHECK_STATUS(BindOutputs());
 
-    // a captured graph bakes pointers in: re-capture when a device-resident input moved
+    // a captured graph bakes pointers in: re-capture when a device-resident input or a caller-owned output moved
     if (graph_exec_) {
-        for (auto& kv : input_tensor_nodes_)
-            if (captured_input_ptrs_[kv.first] != kv.second->tensor.RawData()) {
-                si_hip_graph_destroy(graph_exec_);
-                graph_exec_ = nullptr;
-                break;
-            }
+        bool moved = false;
+        for (auto& kv : input_tensor_nodes_) moved = moved || captured_input_ptrs_[kv.first] != kv.second->tensor.RawData();
+        for (auto& kv : output_tensor_nodes_) moved = moved || captured_output_ptrs_[kv.first] != kv.second->tensor.RawData();
+        if (moved) {
+            si_hip_graph_destroy(graph_exec_);
+            graph_exec_ = nullptr;
+        }
     }
 
     SI_TRY_HIP(si_hip_event_record(ev_start_, stream), "event record");
@@ -632,6 +672,7 @@ Status EngineImpl::Forward() {
             SI_TRY_HIP(rc, "end capture");
             graph_exec_ = exec;
             for (auto& kv : input_tensor_nodes_) captured_input_ptrs_[kv.first] = kv.second->tensor.RawData();
+            for (auto& kv : output_tensor_nodes_) captured_output_ptrs_[kv.first] = kv.second->tensor.RawData();
         }
         SI_TRY_HIP(si_hip_graph_launch(graph_exec_, stream), "graph launch");
     } else {
@@ -674,6 +715,7 @@ Status EngineImpl::Profile(std::vector<LayerProfile>& layers) {
     if (nullptr == context_ || plan_.empty()) return Status::kFail;
     si_stream_t stream = context_->stream();
     CHECK_STATUS(UploadInputs());
+    CHECK_STATUS(BindOutputs());
     std::vector<si_event_t> ev(plan_.size() + 1, nullptr);
     for (auto& e : ev) SI_TRY_HIP(si_hip_event_create(&e), "event create");
     Status ret = Status::kSuccess;

@@ -59,6 +59,7 @@ public:
     const std::vector<std::string> OutputNames();
 
     Status Input(const std::string& name, const Tensor& input);
+    Status Output(const std::string& name, const Tensor& output);
     Status Forward();
     Status Extract(const std::string& name, Tensor& output);
 
@@ -83,6 +84,7 @@ private:
     Status FuseSiblingConvs(std::vector<Step>& order);
     Status AliasConcats();
     Status UploadInputs();
+    Status BindOutputs();
     Status LaunchAll();
 
 private:
@@ -116,12 +118,15 @@ private:
 
     std::vector<void*> device_allocs_;
     std::map<std::string, Tensor> user_inputs_;     // what Input() bound (host or device alias)
+    std::map<std::string, Tensor> user_outputs_;    // what Output() bound (caller-owned device buffers)
+    std::map<std::string, void*> own_output_ptrs_;  // the engine's own buffer of every output operand
     std::map<std::string, void*> input_buffers_;    // engine-owned device staging per input
     std::map<std::string, void*> host_outputs_;     // pinned mirrors per output
 
     si_graph_t graph_exec_ = nullptr;
     int forward_count_ = 0;
     std::map<std::string, void*> captured_input_ptrs_;
+    std::map<std::string, void*> captured_output_ptrs_;
 
     si_event_t ev_start_ = nullptr, ev_stop_ = nullptr;
     float last_forward_ms_ = 0.f;

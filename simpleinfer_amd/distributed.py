@@ -91,6 +91,30 @@ class OverlappedGather:
             self.handles[k] = self.dist.all_gather_into_tensor(self.gathered[k], self.stage[k], group=self.group, async_op=True)
         self.i += 1
 
+    # ---- zero-copy variant: the producer writes straight into the staging tensor (Engine::Output binding) --------------
+    def target(self):
+        """The tensor the NEXT step's output must be written into.  Blocks the host until the gather that last read it
+        (two steps ago) has completed."""
+        k = self.i & 1
+        if self.handles[k] is not None:
+            self.handles[k].wait()
+            self.handles[k] = None
+            if self._cuda:
+                self._torch.cuda.current_stream().synchronize()
+        return self.stage[k]
+
+    def submit_inplace(self):
+        """target() has been filled (the producer has finished): issue its all-gather."""
+        k = self.i & 1
+        if self.world == 1:
+            self.gathered[k].copy_(self.stage[k])
+        else:
+            self.handles[k] = self.dist.all_gather_into_tensor(self.gathered[k], self.stage[k], group=self.group, async_op=True)
+        self.i += 1
+
+    def latest_local(self):
+        return self.stage[(self.i - 1) & 1]
+
     def drain(self):
         for k in (0, 1):
             if self.handles[k] is not None:

@@ -97,6 +97,11 @@ class Engine:
         """Device-resident input: the engine reads the buffer in place (no H2D in forward)."""
         self._check("Input(%s)" % name, self._L.si_engine_input(self._h, name.encode(), C.c_void_p(device_ptr), 1))
 
+    def bind_output(self, name: str, device_ptr: Optional[int]):
+        """Engine::Output: write output `name` into caller-owned device memory from the next forward on (None restores
+        the engine's own buffer)."""
+        self._check("Output(%s)" % name, self._L.si_engine_bind_output(self._h, name.encode(), C.c_void_p(device_ptr) if device_ptr else None))
+
     def forward(self):
         self._check("Forward", self._L.si_engine_forward(self._h))
 

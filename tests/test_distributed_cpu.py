@@ -49,6 +49,12 @@ def _worker(rank, world, port, tmpdir, q):
         buf.fill_(-1.0)                                       # ... and may do so as soon as submit() returns
         og.drain()
         seen.append(og.latest().clone())
+    # zero-copy variant: the producer writes straight into the buffer the collective reads (Engine::Output binding)
+    for step in range(3, 6):
+        og.target().copy_(torch.from_numpy(local) + float(step))
+        og.submit_inplace()
+        og.drain()
+        seen.append(og.latest().clone())
     dist.barrier()
     if r == 0:
         q.put((name, gathered.numpy(), [t.numpy() for t in seen]))

@@ -243,3 +243,30 @@ def test_rebatch_serves_any_batch_from_one_file(si, tmp_path):
     _, on, refr = _run(si, *r4, xr)
     _, _, got = _run(si, *r1, xr, batch=4)
     assert_exact(got, refr, "resnet re-batched")
+
+
+def test_output_binding_writes_into_caller_memory(si, tmp_path):
+    """Engine::Output (extension): an output operand is written into caller-owned device memory; alternating two buffers is
+    what the overlapped multi-GPU all-gather does.  Also under hipGraph replay (pointers are baked into the capture)."""
+    from simpleinfer_amd import hipops
+    pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(2, 160), "ob")
+    x = si.modelgen.synth_input((2, 160, 160, 3))
+    _, oname, ref = _run(si, pp, bp, x)
+    for graph in (0, 1):
+        e = si.Engine(outputs_to_host=0, graph=graph)
+        e.load_model(pp, bp)
+        e.input("0", x)
+        bufs = [hipops.DeviceBuffer(ref.nbytes) for _ in range(2)]
+        for step in range(5):
+            b = bufs[step & 1]
+            b.fill(0)
+            e.bind_output(oname, b.ptr)
+            e.forward()
+            assert e.extract_ptr(oname)[0] == b.ptr
+            assert_exact(b.to_numpy(ref.shape), ref, "graph=%d step %d" % (graph, step))
+        e.bind_output(oname, None)                      # back to the engine's own buffer
+        e.forward()
+        assert e.extract_ptr(oname)[0] not in (bufs[0].ptr, bufs[1].ptr)
+        assert_exact(e.extract(oname), ref, "engine-owned buffer again")
+    with pytest.raises(si.StatusError):
+        e.bind_output("no_such_operand", bufs[0].ptr)
