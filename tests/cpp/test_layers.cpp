@@ -26,6 +26,7 @@
 #include "layer/max_pool_2d.h"
 #include "layer/upsample.h"
 #include "layer_registry.h"
+#include "si_hip.h"
 #include "tensor.h"
 
 using namespace SimpleInfer;
@@ -256,6 +257,55 @@ static void TestEngine(const char* param, const char* bin, const char* input_pat
     }
     Tensor bad;
     CHECK_EQ(Status::kFail, engine.Extract("not-an-output", bad));
+
+    // extensions: results left on the device and written into a caller-owned buffer (Engine::Output)
+    {
+        Engine dev;
+        CHECK_EQ(Status::kSuccess, dev.SetOption("outputs_to_host", 0));
+        CHECK_EQ(Status::kUnsupport, dev.SetOption("no-such-option", 1));
+        CHECK_EQ(Status::kSuccess, dev.LoadModel(param, bin));
+        CHECK_EQ(Status::kSuccess, dev.Input(ins[0], input));
+        Tensor mine(DataType::kFloat32, {(int)expect.size()}, MemoryType::kDevice, true);
+        Tensor host_tensor(DataType::kFloat32, {(int)expect.size()}, true);
+        CHECK_EQ(Status::kUnsupport, dev.Output(out_name, host_tensor));   // must be device memory
+        CHECK_EQ(Status::kFail, dev.Output("not-an-output", mine));
+        CHECK_EQ(Status::kSuccess, dev.Output(out_name, mine));
+        CHECK_EQ(Status::kSuccess, dev.Forward());
+        Tensor view;
+        CHECK_EQ(Status::kSuccess, dev.Extract(out_name, view));
+        CHECK(view.GetMemoryType() == MemoryType::kDevice);
+        CHECK(view.RawData() == mine.RawData());
+        std::vector<float> back(expect.size());
+        CHECK_EQ(0, si_hip_memcpy_d2h(back.data(), mine.RawData(), back.size() * sizeof(float), nullptr));
+        CHECK_EQ(0, si_hip_stream_sync(nullptr));
+        double maxref = 0, maxerr = 0;
+        for (size_t i = 0; i < expect.size(); ++i) {
+            maxref = std::max(maxref, (double)std::abs(expect[i]));
+            maxerr = std::max(maxerr, (double)std::abs(expect[i] - back[i]));
+        }
+        CHECK(maxerr <= 1e-4 * maxref);
+    }
+    // extension: one file, any batch (SetOption("batch", N)): the first image of a batch-1 engine equals image 0 above
+    {
+        Engine one;
+        CHECK_EQ(Status::kSuccess, one.SetOption("batch", 1));
+        CHECK_EQ(Status::kSuccess, one.LoadModel(param, bin));
+        std::vector<int> s1;
+        CHECK_EQ(Status::kSuccess, one.OperandShape(ins[0], s1));
+        CHECK_EQ(s1[0], 1);
+        Tensor in1(DataType::kFloat32, s1, false);
+        in1.SetData(x.data());
+        CHECK_EQ(Status::kSuccess, one.Input(ins[0], in1));
+        CHECK_EQ(Status::kSuccess, one.Forward());
+        Tensor o1;
+        CHECK_EQ(Status::kSuccess, one.Extract(out_name, o1));
+        CHECK_EQ(o1.NumElements() * (size_t)ishape[0], expect.size());
+        Tensor full;
+        CHECK_EQ(Status::kSuccess, engine.Extract(out_name, full));
+        bool same = true;
+        for (size_t i = 0; i < o1.NumElements(); ++i) same = same && o1.Data<float>()[i] == full.Data<float>()[i];
+        CHECK(same);  // an image's result does not depend on the batch it travels in
+    }
     CHECK_EQ(Status::kSuccess, engine.Release());
     CHECK_EQ(engine.InputNames().size(), (size_t)0);
     CHECK(nullptr != GetLayerRegistry("nn.Conv2d"));
@@ -267,6 +317,8 @@ int main(int argc, char** argv) {
     TestConv(128, 128, 32, 16, 2, 3, 1, 1);
     TestConv(160, 160, 3, 32, 1, 6, 2, 2);
     TestConv(10, 10, 256, 255, 1, 1, 1, 0);
+    TestConv(28, 28, 48, 48, 48, 3, 1, 1);   // depthwise: the reference's slowest path (conv_2d.cpp:285-380)
+    TestConv(29, 27, 40, 40, 40, 5, 2, 2);
     TestMaxPool(1, 8, 8, 3, 2, 2, 0);
     TestMaxPool(8, 20, 20, 256, 5, 1, 2);
     TestUpsample(1, 16, 16, 3, 2.0f);
