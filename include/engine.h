@@ -11,8 +11,7 @@
 // HIP kernels in topological order on one stream (optionally replayed as a hipGraph).
 //
 // Extensions (no reference counterpart): SetOption(), device-resident Input / Extract, profiling.
-#ifndef SIMPLE_INFER_INCLUDE_ENGINE_H_
-#define SIMPLE_INFER_INCLUDE_ENGINE_H_
+#pragma once
 
 #include <string>
 #include <vector>
@@ -35,25 +34,21 @@ struct LayerProfile {
 
 class Engine {
 public:
-    Engine();
+    // ---- the reference's surface (include/engine.h:12-38), same names, argument meaning and Status codes ------------
+    Engine();   // pimpl, no device work until LoadModel
+    ~Engine();  // Release()s
 
-    ~Engine();
-
-public:
+    // parse .pnnx.param + stored-zip .pnnx.bin, build one Layer per operator through the registry, plan the launch
+    // schedule, allocate HBM; implicitly Release()s a previously loaded model (src/engine_impl.cpp:16-75)
     Status LoadModel(const std::string& parampath, const std::string& binpath);
+    Status Release();  // src/engine_impl.cpp:77-127
 
-    Status Release();
-
-public:
-    const std::vector<std::string> InputNames();
+    const std::vector<std::string> InputNames();   // pnnx operand names, sorted (std::map order, :484-520)
     const std::vector<std::string> OutputNames();
 
-public:
-    Status Input(const std::string& name, const Tensor& input);
-
-    Status Forward();
-
-    Status Extract(const std::string& name, Tensor& output);
+    Status Input(const std::string& name, const Tensor& input);  // borrows; read at Forward() time (:522-531)
+    Status Forward();                                             // synchronous (:533-544)
+    Status Extract(const std::string& name, Tensor& output);     // non-owning view (:546-555)
 
     // Extension: have an output operand written into caller-owned device memory (MemoryType::kDevice, same element
     // count and type) from the next Forward() on; borrowed until the next Output() / Release().  A tensor without data
@@ -96,5 +91,3 @@ private:
 void InitializeContext();
 
 }  // namespace SimpleInfer
-
-#endif  // SIMPLE_INFER_INCLUDE_ENGINE_H_

@@ -9,8 +9,7 @@
 //  * A tensor may live in HBM (MemoryType::kDevice); then Data() is a device pointer.
 //  * A tensor may be a channel slice of a wider buffer: PixelStride() is the distance in
 //    elements between consecutive pixels (== Shape().back() when dense).
-#ifndef SIMPLE_INFER_INCLUDE_TENSOR_H_
-#define SIMPLE_INFER_INCLUDE_TENSOR_H_
+#pragma once
 
 #include <cassert>
 #include <cstddef>
@@ -22,29 +21,20 @@ namespace SimpleInfer {
 
 class Tensor {
 public:
-    Tensor();
-
-    Tensor(const DataType data_type, const std::vector<int>& shape, const bool allocate = false);
-
-    Tensor(const DataType data_type, const std::vector<int>& shape, const MemoryType memory_type,
+    Tensor();                                                                                        // empty, kNone
+    Tensor(const DataType data_type, const std::vector<int>& shape, const bool allocate = false);   // host memory
+    Tensor(const DataType data_type, const std::vector<int>& shape, const MemoryType memory_type,   // host or HBM
            const bool allocate);
-
-    ~Tensor();
-
-    Tensor(const Tensor& tensor);
-
-    Tensor& operator=(const Tensor& tensor);
+    ~Tensor();                                  // frees only what this object allocated itself
+    Tensor(const Tensor& tensor);               // copies ALIAS: non-owning view of the same bytes (reference Q6)
+    Tensor& operator=(const Tensor& tensor);    // same
 
 public:
-    Status Allocate();
-
-    Status Allocate(const DataType data_type, const std::vector<int>& shape);
-
+    Status Allocate();                                                          // malloc / hipMalloc for the current shape
+    Status Allocate(const DataType data_type, const std::vector<int>& shape);  // no-op when nothing changes
     Status Deallocate();
-
     const DataType GetDataType() const;
-
-    const std::vector<int>& Shape() const;
+    const std::vector<int>& Shape() const;      // NHWC for rank 4 (the reference's in-memory layout)
 
 public:
     // borrow caller memory (replaces SetEigenTensor; fails if this tensor owns its buffer)
@@ -90,4 +80,4 @@ protected:
 
 }  // namespace SimpleInfer
 
-#endif  // SIMPLE_INFER_INCLUDE_TENSOR_H_
+

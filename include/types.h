@@ -1,27 +1,27 @@
 // types.h -- public enums and helpers of the SimpleInfer API, kept source compatible with the
 // reference's include/types.h:8-59 (DataType, Status, CHECK_BOOL / CHECK_STATUS, IsSameDataType,
 // PnnxToDataType, ElementSize, IsSameShape).  MemoryType is new: tensors may live in HBM.
-#ifndef SIMPLE_INFER_INCLUDE_TYPES_H_
-#define SIMPLE_INFER_INCLUDE_TYPES_H_
+#pragma once
 
 #include <vector>
 
 namespace SimpleInfer {
 
+// enumerators in the order of pnnx's operand type codes 0..12 (src/pnnx/ir.cpp:24-60), so PnnxToDataType is a cast
 enum class DataType {
-    kNone = 0,
-    kFloat32,
-    kFloat64,
-    kFloat16,
-    kInt32,
-    kInt64,
-    kInt16,
-    kInt8,
-    kUint8,
-    kBool,
-    kComplex64,
-    kComplex128,
-    kComplex32
+    kNone = 0,    // "null"
+    kFloat32,     // 1  f32   the arithmetic of the whole path (and the only type the reference's layers accept)
+    kFloat64,     // 2  f64
+    kFloat16,     // 3  f16   internal storage of the fp16 engine option
+    kInt32,       // 4  i32
+    kInt64,       // 5  i64
+    kInt16,       // 6  i16
+    kInt8,        // 7  i8
+    kUint8,       // 8  u8
+    kBool,        // 9  bool
+    kComplex64,   // 10 cp64
+    kComplex128,  // 11 cp128
+    kComplex32    // 12 cp32
 };
 
 enum class Status { kSuccess = 0, kFail, kEmpty, kErrorShape, kErrorContext, kUnsupport };
@@ -55,5 +55,3 @@ bool IsSameShape(const std::vector<int>& shape0, const std::vector<int>& shape1)
 const char* StatusString(Status s);
 
 }  // namespace SimpleInfer
-
-#endif  // SIMPLE_INFER_INCLUDE_TYPES_H_

@@ -18,43 +18,58 @@
 
 #include "context.h"
 #include "logger.h"
+#include "pnnx/ir.h"
 #include "pnnx/pnnx_helper.h"
 #include "tensor.h"
-#include "tensor_node.h"
 #include "types.h"
 
 namespace SimpleInfer {
 
+// graph operand + the tensor bound to it (the reference keeps this in src/tensor_node.h:9-12)
+struct TensorNode {
+    pnnx::Operand* operand = nullptr;
+    Tensor tensor;
+};
+
+class Layer;
+
+// ---- registry: pnnx type string -> {creator, destroyer}, plain C function pointers (reference
+// src/layer_registry.h:10-18).  RegisterLayer / RegisteredLayerTypes are extensions: the reference's table is closed
+// (src/layer_registry.cpp:33-49).
+using LayerCreatorFunc   = Layer* (*)();
+using LayerDestroyerFunc = void (*)(Layer*);
+
+struct LayerRegistryEntry {
+    LayerCreatorFunc creator     = nullptr;
+    LayerDestroyerFunc destroyer = nullptr;
+};
+
+const LayerRegistryEntry* GetLayerRegistry(std::string type);
+
+// add (or replace) an entry at run time; returns false on null function pointers
+bool RegisterLayer(const std::string& type, LayerCreatorFunc creator, LayerDestroyerFunc destroyer);
+
+std::vector<std::string> RegisteredLayerTypes();
+
 class Layer {
 public:
     Layer();
-
     virtual ~Layer();
 
-public:
-    virtual Status Init(const pnnx::Operator* op);
-
-    virtual Status Init(const std::map<std::string, pnnx::Parameter>& params,
+    // ---- the reference's virtual surface (src/layer.h:15-89), in the order the engine calls it --------------------
+    virtual Status Init(const pnnx::Operator* op);                                   // 1. parse params / attrs of one operator
+    virtual Status Init(const std::map<std::string, pnnx::Parameter>& params,       //    (the form layers usually override)
                         const std::map<std::string, pnnx::Attribute>& attrs);
+    virtual void SetContext(Context* context);                                       // 2. device + stream
+    virtual void SetInputNodes(const std::vector<TensorNode*>& input_tensor_nodes);  // 3.
+    virtual void SetOutputNodes(const std::vector<TensorNode*>& output_tensor_nodes);  // 4.
+    virtual Status Validate();                                                       // 5. arity / dtype / shape checks
+    virtual Status Deinit();                                                         // before the registry destroyer
 
-    virtual void SetContext(Context* context);
-
-    virtual void SetInputNodes(const std::vector<TensorNode*>& input_tensor_nodes);
-
-    virtual void SetOutputNodes(const std::vector<TensorNode*>& output_tensor_nodes);
-
-    virtual Status Deinit();
-
-    virtual Status Validate();
-
-    virtual Status Forward();
-
+    virtual Status Forward();  // arity dispatch on the bound nodes (src/layer.cpp:45-79) into one of:
     virtual Status Forward(const Tensor& input, Tensor& output);
-
     virtual Status Forward(const std::vector<Tensor>& inputs, Tensor& output);
-
     virtual Status Forward(const Tensor& input, std::vector<Tensor>& outputs);
-
     virtual Status Forward(const std::vector<Tensor>& inputs, std::vector<Tensor>& outputs);
 
     const pnnx::Operator* GetOp();

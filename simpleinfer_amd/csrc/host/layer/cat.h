@@ -1,27 +1,3 @@
-// layer/cat.h -- torch.cat over rank-4 tensors; NCHW dim -> NHWC axis map 1->3, 2->1, 3->2
-// (reference src/layer/cat.cpp:59-108).  When the engine aliases the producers into this layer's
-// output buffer (zero-copy cat) the corresponding input is skipped here.
-#ifndef SIMPLE_INFER_SRC_LAYER_CAT_H_
-#define SIMPLE_INFER_SRC_LAYER_CAT_H_
-
-#include "layer.h"
-
-namespace SimpleInfer {
-
-class Cat : public Layer {
-public:
-    virtual Status Init(const pnnx::Operator* op) override;
-    virtual Status Validate() override;
-    virtual Status Forward(const std::vector<Tensor>& inputs, Tensor& output) override;
-    virtual const char* KernelName() const override { return "copy_channels"; }
-
-    // NHWC axis the layer concatenates along
-    int NhwcAxis() const;
-
-public:
-    int dim_ = 0;
-};
-
-}  // namespace SimpleInfer
-
-#endif
+// layer/cat.h -- kept for source compatibility with the reference's include path; the class lives in operators.h
+#pragma once
+#include "operators.h"

@@ -1,25 +1,3 @@
-// layer/flatten.h -- torch.flatten: rank-4 input is re-ordered NHWC -> NCHW then flattened, other ranks
-// are a plain copy; start_dim / end_dim are parsed and ignored (reference src/layer/flatten.cpp:17-21,
-// :55-88).
-#ifndef SIMPLE_INFER_SRC_LAYER_FLATTEN_H_
-#define SIMPLE_INFER_SRC_LAYER_FLATTEN_H_
-
-#include "layer.h"
-
-namespace SimpleInfer {
-
-class Flatten : public Layer {
-public:
-    virtual Status Init(const pnnx::Operator* op) override;
-    virtual Status Validate() override;
-    virtual Status Forward(const Tensor& input, Tensor& output) override;
-    virtual const char* KernelName() const override { return "nhwc_to_nchw"; }
-
-public:
-    int start_dim_ = 0;
-    int end_dim_   = -1;
-};
-
-}  // namespace SimpleInfer
-
-#endif
+// layer/flatten.h -- kept for source compatibility with the reference's include path; the class lives in operators.h
+#pragma once
+#include "operators.h"

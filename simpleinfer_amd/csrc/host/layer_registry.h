@@ -1,31 +1,3 @@
-// layer_registry.h -- pnnx type string -> {creator, destroyer} (reference src/layer_registry.h:10-18:
-// same typedefs, struct and lookup function, plain C function pointers).
-// RegisterLayer() is an extension: the reference's table is closed (src/layer_registry.cpp:33-49).
-#ifndef SIMPLE_INFER_SRC_LAYER_REGISTRY_H_
-#define SIMPLE_INFER_SRC_LAYER_REGISTRY_H_
-
-#include <string>
-#include <vector>
-
-namespace SimpleInfer {
-
-class Layer;
-
-using LayerCreatorFunc   = Layer* (*)();
-using LayerDestroyerFunc = void (*)(Layer*);
-
-struct LayerRegistryEntry {
-    LayerCreatorFunc creator     = nullptr;
-    LayerDestroyerFunc destroyer = nullptr;
-};
-
-const LayerRegistryEntry* GetLayerRegistry(std::string type);
-
-// add (or replace) an entry at run time; returns false on null function pointers
-bool RegisterLayer(const std::string& type, LayerCreatorFunc creator, LayerDestroyerFunc destroyer);
-
-std::vector<std::string> RegisteredLayerTypes();
-
-}  // namespace SimpleInfer
-
-#endif
+// layer_registry.h -- kept for source compatibility with the reference's include path; the registry lives in layer.h
+#pragma once
+#include "layer.h"
