@@ -216,6 +216,11 @@ def main():
 
     dist = None
     torch = None
+    # the contract is ONE JSON line on stdout: RCCL prints a version banner to stdout when its communicator is created,
+    # so everything below runs with fd 1 pointed at stderr and the real stdout is restored for the final line only
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     # SI_BENCH_FORCE_DIST=1 runs the N>1 code path (process group, zero-copy wrap of the engine's output buffer,
     # RCCL all-gather) even at world size 1, so that path can be exercised on a 1-GPU box
     use_dist = world > 1 or os.environ.get("SI_BENCH_FORCE_DIST") == "1"
@@ -337,7 +342,9 @@ def main():
         "cpu_baseline": cpu,
     }
     out.update(aux)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
