@@ -387,3 +387,25 @@ def test_yolo_postprocess_cap_and_empty(hops, orc):
         assert_exact(got[b], ref[b][:5], "first max_det picks")
     got, gcnt = hops.yolo_postprocess(np.zeros((2, 0, 85), np.float32), 0.25, 0.45)
     assert list(gcnt) == [0, 0] and all(len(g) == 0 for g in got)
+
+
+def test_yolo_postprocess_equal_confidences(hops, orc):
+    """Equal confidences: the reference's unstable quicksort leaves their relative order unspecified (test_yolo.cpp:28-66);
+    the device breaks ties by element index.  Same boxes either way when the tied boxes do not suppress each other."""
+    from util import synthetic_predictions
+    pred = synthetic_predictions(21, 2, 600, nc=6, n_gt=3, hot_frac=0.1)
+    pred[:, 100:140, 4] = 0.5            # a run of rows with identical objectness ...
+    pred[:, 100:140, 5:] = 0.1
+    pred[:, 100:140, 5] = 0.9            # ... and identical class score: 40 equal confidences of 0.45
+    pred[:, 100:140, 0] = np.linspace(20, 620, 40)[None]   # far apart: no mutual suppression
+    pred[:, 100:140, 1] = 320
+    pred[:, 100:140, 2:4] = 8
+    got, gcnt = hops.yolo_postprocess(pred, 0.25, 0.45)
+    ref, rcnt = orc.yolo_postprocess(pred, 0.25, 0.45)
+    assert_exact(gcnt, rcnt, "counts")
+    canon = lambda a: a[np.lexsort(a.T[::-1])]  # noqa: E731
+    for b in range(2):
+        assert_exact(canon(got[b]), canon(ref[b]), "same boxes, image %d" % b)
+        assert (np.diff(got[b][:, 4]) <= 0).all()
+        tied = got[b][got[b][:, 4] == np.float32(0.5) * np.float32(0.9)]
+        assert len(tied) == 40 and (np.diff(tied[:, 0]) > 0).all(), "ties come out in element order"
