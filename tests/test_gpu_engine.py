@@ -308,3 +308,41 @@ def test_demo_pipeline_matches_oracle_pipeline(si, orc, tmp_path):
         assert_exact(dets_u[b], rdets[b], "boxes image %d" % b)
         assert (dets_u[b][:, 0] >= 0).all() and (dets_u[b][:, 0] + dets_u[b][:, 2] <= shapes[b][1] - 1 + 1e-3).all()
     assert len(dets) == 2 and all(len(d) <= 300 for d in dets)   # the demo's own capped result
+
+
+def test_full_size_properties_yolov5s_640_batch32(si, orc, tmp_path):
+    """BASELINE.json's metric configuration itself (YOLOv5s 640x640 fp32 batch 32), where the CPU oracle is too slow to
+    run the whole batch: size-independent properties instead.
+      * sharding / batch invariance: image k of the batch-32 forward is bit-identical to the batch-1 engine on image k
+        (the re-batch option makes both engines from ONE file), for images spread over the batch;
+      * one image is checked against the oracle end to end (1e-4);
+      * outputs are finite, confidences and class scores are sigmoid outputs in (0, 1), box sizes positive;
+      * the schedule is the advertised one: 57 launches."""
+    mg = si.modelgen
+    pp, bp = _save(tmp_path, mg.build_yolov5s(1, 640), "y640")
+    x = mg.synth_input((32, 640, 640, 3))
+    e32 = si.Engine(batch=32)
+    e32.load_model(pp, bp)
+    oname = e32.output_names()[0]
+    e32.input("0", x)
+    e32.forward()
+    full = e32.extract(oname)
+    assert full.shape == (32, 25200, 85) and np.isfinite(full).all()
+    assert (full[..., 4:] > 0).all() and (full[..., 4:] < 1).all() and (full[..., 2:4] > 0).all()
+    # 55 launching layers (1 stem + 48 conv + Detect + 3 max pool + 2 upsample; Detect is 3 launches -> 57) + 13 no-op cats
+    run = e32.schedule()["run"]
+    assert len([r for r in run if not r.startswith("cat")]) == 55 and len(run) == 68
+    e1 = si.Engine()
+    e1.load_model(pp, bp)
+    for k in (0, 13, 31):
+        e1.input("0", x[k:k + 1])
+        e1.forward()
+        assert_exact(e1.extract(oname)[0], full[k], "image %d: batch 32 == batch 1" % k)
+    ref = orc.run_graph(pp, bp, {"0": x[13:14]})[oname]
+    assert_parity(full[13:14], ref, what="image 13 of the batch vs the oracle")
+    # same batch through the fp16 storage path: within the fp16 bar of the fp32 result
+    e16 = si.Engine(batch=32, fp16=1)
+    e16.load_model(pp, bp)
+    e16.input("0", x)
+    e16.forward()
+    assert_parity(e16.extract(oname), full, F16_GRAPH_TOL, what="fp16 storage vs fp32 at full size")
