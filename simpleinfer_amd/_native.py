@@ -11,7 +11,8 @@ import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_HIP_PATH = os.path.join(PKG, "libsi_hip.so")
-LIB_HOST_PATH = os.path.join(PKG, "libsimpleinfer_amd.so")
+# SI_HOST_LIB: a differently built host library (tools/asan_host.sh points it at the ASan + UBSan build)
+LIB_HOST_PATH = os.environ.get("SI_HOST_LIB") or os.path.join(PKG, "libsimpleinfer_amd.so")
 
 _hip = None
 _host = None

@@ -1,6 +1,7 @@
 // c_api.cpp -- implementation of include/si_engine.h (extern "C" over SimpleInfer::Engine).
 #include "si_engine.h"
 
+#include <exception>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -166,8 +167,12 @@ int si_registry_types(char* buf, size_t cap) {
 int si_pnnx_dump(const char* param_path, const char* bin_path, int expand, const char* out_path) {
     if (!param_path || !bin_path || !out_path) return -1;
     pnnx::Graph g;
-    if (g.load(param_path, bin_path) != 0) return 1;
-    if (expand) pnnx::expand_expression(g);
+    try {
+        if (g.load(param_path, bin_path) != 0) return 1;
+        if (expand) pnnx::expand_expression(g);
+    } catch (const std::exception&) {
+        return 1;  // malformed file: the parser's std::stoi / map::at threw
+    }
     FILE* f = fopen(out_path, "w");
     if (!f) return 2;
     auto fnv1a = [](const std::vector<char>& d) {

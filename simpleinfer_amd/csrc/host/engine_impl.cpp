@@ -1,5 +1,7 @@
 #include "engine_impl.h"
 
+#include <exception>
+
 #include <algorithm>
 
 #include "layer/activation.h"
@@ -76,7 +78,15 @@ Status EngineImpl::LoadModel(const std::string& parampath, const std::string& bi
         }
     }
     {
-        Status ret = CreateGraph(parampath, binpath);
+        // The reference's loader can throw on malformed files (std::stoi / map::at); nothing may
+        // propagate out of this library (there is a C-ABI on top), so a bad model is a Status.
+        Status ret = Status::kFail;
+        try {
+            ret = CreateGraph(parampath, binpath);
+        } catch (const std::exception& ex) {
+            LOG(ERROR) << "malformed model file: " << ex.what();
+            ret = Status::kFail;
+        }
         if (Status::kSuccess != ret) {
             LOG(ERROR) << "CreateGraph fail";
             Release();
@@ -88,7 +98,13 @@ Status EngineImpl::LoadModel(const std::string& parampath, const std::string& bi
                             {"CreatePipeline", &EngineImpl::CreatePipeline},
                             {"AllocateTensorMemory", &EngineImpl::AllocateTensorMemory}};
     for (const Stage& s : stages) {
-        Status ret = (this->*s.fn)();
+        Status ret = Status::kFail;
+        try {
+            ret = (this->*s.fn)();
+        } catch (const std::exception& ex) {
+            LOG(ERROR) << s.name << ": " << ex.what();
+            ret = Status::kFail;
+        }
         if (Status::kSuccess != ret) {
             LOG(ERROR) << s.name << " fail";
             Release();

@@ -58,9 +58,29 @@ std::string expand_one(Graph& g, const Operator* op, int& counter) {
     const std::vector<std::string> toks = tokenize(op->params.at("expr").s);
     std::vector<std::string> stack;  // printed sub-expressions, top at back
 
-    auto printed = [&](const std::string& t) { return is_argument(t) ? op->inputs[std::stoi(t.substr(1))]->name : t; };
+    // "@k" -> input k.  A malformed file may name an input that does not exist (the reference indexes blindly):
+    // such an expression is left unexpanded, and the engine then reports the operator type as unregistered.
+    auto arg_input = [&](const std::string& t) -> Operand* {
+        if (t.size() < 2 || t.size() > 9) return nullptr;
+        int k = 0;
+        for (size_t i = 1; i < t.size(); ++i) {
+            if (t[i] < '0' || t[i] > '9') return nullptr;
+            k = k * 10 + (t[i] - '0');
+        }
+        return k < (int)op->inputs.size() ? op->inputs[k] : nullptr;
+    };
+    bool bad_argument = false;
+    auto printed = [&](const std::string& t) -> std::string {
+        if (!is_argument(t)) return t;
+        Operand* r = arg_input(t);
+        if (!r) {
+            bad_argument = true;
+            return t;
+        }
+        return r->name;
+    };
     auto operand_of = [&](const std::string& t) -> Operand* {
-        return is_argument(t) ? op->inputs[std::stoi(t.substr(1))] : g.get_operand(op->name + "_" + t);
+        return is_argument(t) ? arg_input(t) : g.get_operand(op->name + "_" + t);
     };
     auto make_out = [&](Operator* nop, const std::string& r, const std::vector<int>& shape, int type) {
         Operand* out = g.new_operand(op->name + "_" + r);
@@ -79,6 +99,7 @@ std::string expand_one(Graph& g, const Operator* op, int& counter) {
             const std::string a = stack.back();
             stack.pop_back();
             const std::string r = t + "(" + printed(a) + ")";
+            if (bad_argument) return std::string();
             stack.push_back(r);
             Operator* nop = g.new_operator_before("UnaryOp", t + "_" + std::to_string(counter++), op);
             nop->params["0"] = unary_codes().at(t);
@@ -94,6 +115,7 @@ std::string expand_one(Graph& g, const Operator* op, int& counter) {
             const std::string b = stack.back();
             stack.pop_back();
             const std::string r = t + "(" + printed(a) + "," + printed(b) + ")";
+            if (bad_argument) return std::string();
             stack.push_back(r);
             Operator* nop = g.new_operator_before("BinaryOp", t + "_" + std::to_string(counter++), op);
             nop->params["0"] = binary_codes().at(t);
@@ -160,6 +182,10 @@ void expand_expression(Graph& graph) {
             }
         if (!target) break;
 
+        if (target->outputs.empty() || !target->params.count("expr")) {  // malformed: leave it alone
+            unsupported.insert(target);
+            continue;
+        }
         const std::string result = expand_one(graph, target, counter);
         Operand* new_out = result.empty() ? nullptr : graph.get_operand(target->name + "_" + result);
         if (!new_out) {

@@ -71,3 +71,11 @@ def test_parameter_value_syntax(native_libs, tmp_path):
                  "param e type=4 s=zeros", "param f type=5 ai=1,2,", "param g type=6 af=2,3.5,", "param h type=7 as=x,y,",
                  "param i type=0", "param j type=4 s=-x", "param k type=3 f=7", "operand 0 type=1 shape=1,-1,4,"):
         assert line in txt, line
+
+
+def test_malformed_files_are_rejected_not_fatal(native_libs):
+    """The reference's loader throws (std::stoi / map::at) or indexes blindly on malformed files; behind a C-ABI that is
+    a crash.  Mutated model files must come back as a return code (tests/fuzz_loader.py; ASan build: tools/asan_host.sh)."""
+    from fuzz_loader import fuzz
+    ok, bad = fuzz(160, seed=3)
+    assert ok + bad == 320 and bad > 0
