@@ -73,6 +73,7 @@ struct ConvArgs {
     int act1, act2;
     float act_param;
     int cb_major;               // K order: 0 = (tap, c), 1 = (c/32, tap, c%32)
+    int pointwise;              // 1x1 stride 1 pad 0: the A matrix is the input tensor itself
     int ntaps;                  // kh*kw
     unsigned in_bytes, w_bytes; // buffer-resource extents for the fast path (tensor < 4 GB)
     // split output (two sibling convs on one input fused along oc): channels >= split go to out2 (stride out2_ld)
@@ -416,7 +417,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         const int m = m0 + r0 + 32 * i;
         a_off[i] = 0;
         a_mask[i] = 0ull;
-        if (m < a.M) {
+        if (m < a.M && a.pointwise) {
+            // 1x1, stride 1, no padding: output pixel m IS input pixel m -- no index decomposition, one always-valid tap
+            a_off[i] = (unsigned)m * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16);
+            a_mask[i] = 1ull;
+        } else if (m < a.M) {
             const int img = m / a.ohow;
             const int rem = m - img * a.ohow;
             const int oy = rem / a.ow;
@@ -680,6 +685,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
     a.cb_major = conv_cb_major(d) ? 1 : 0;
     a.ntaps = d->kh * d->kw;
+    a.pointwise = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow) ? 1 : 0;
     a.in_bytes = 0; a.w_bytes = 0;
     a.ymode = 0; a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.f; a.ygrid = a.yanchor = nullptr;
     a.out2 = nullptr; a.out2_ld = 0; a.split = 0;
