@@ -48,6 +48,7 @@ struct ConvArgsH {
     int act1, act2;
     float act_param;
     unsigned in_bytes;
+    int pointwise;              // 1x1 stride 1 pad 0: the A matrix is the input tensor itself
     int out_f32;                // plain epilogue writing fp32 (graph outputs)
     half_t* out2;               // split output (sibling convs): channels >= split go to out2
     int out2_ld, split;
@@ -189,7 +190,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
         const int m = m0 + r0 + RPP * i;
         a_off[i] = 0;
         a_mask[i] = 0ull;
-        if (m < a.M) {
+        if (m < a.M && a.pointwise) {
+            a_off[i] = (unsigned)m * (unsigned)(a.in_ld * 2) + (unsigned)(kv * 16);
+            a_mask[i] = 1ull;
+        } else if (m < a.M) {
             const int img = m / a.ohow;
             const int rem = m - img * a.ohow;
             const int oy = rem / a.ow;
@@ -362,6 +366,7 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     a.m_tiles = a.n_tiles = 0;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
     a.in_bytes = (unsigned)in_bytes;
+    a.pointwise = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow) ? 1 : 0;
     a.out_f32 = out_f32;
     a.out2 = nullptr; a.out2_ld = 0; a.split = 0;
     a.ymode = 0; a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.f; a.ygrid = a.yanchor = nullptr;

@@ -105,6 +105,10 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
 
+    // the block's first tile row as (image, tile row): one wave-uniform division, reused by the staging slots and the stores
+    const int img0 = row0 / a.th;
+    const int ty0 = row0 - img0 * a.th;
+
     // ---- per-thread staging slots: byte offset of channel block 0 (the LDS destination is recomputed at commit time)
     unsigned g_off[PFV];
 #pragma unroll
@@ -120,8 +124,11 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
             const int tr = slot - j * TBH;
             const int R = row0 + tr;
             if (R < a.rows_total) {
-                const int img = R / a.th;
-                const int ty = R - img * a.th;
+                int img = img0, ty = ty0 + tr;  // tr < TBH <= 16: a couple of subtractions instead of a division
+                while (ty >= a.th) {
+                    ty -= a.th;
+                    ++img;
+                }
                 const int y = 2 * ty - a.pad + j;
                 const int x = 2 * col0 - a.pad + px;
                 if ((unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw)
@@ -279,8 +286,11 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
             const int R = row0 + tr;
             const int txg = col0 + tc;
             if (R < a.rows_total && txg < a.tw && ocok) {
-                const int img = R / a.th;
-                const int ty = R - img * a.th;
+                int img = img0, ty = ty0 + tr;
+                while (ty >= a.th) {
+                    ty -= a.th;
+                    ++img;
+                }
                 const int oy = 2 * ty + i_out, ox = 2 * txg + jc;
                 if (oy < a.oh && ox < a.ow) {
                     const size_t pix = (size_t)(img * a.oh + oy) * a.ow + ox;
