@@ -61,8 +61,8 @@ struct ConvArgsH {
 __device__ __forceinline__ float act_h(int act, float v, float p) {
     switch (act) {
         case SI_ACT_RELU: return fmaxf(v, 0.0f);
-        case SI_ACT_SILU: return __fdividef(v, 1.0f + __expf(-v));
-        case SI_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case SI_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        case SI_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
         case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;
@@ -128,7 +128,7 @@ __device__ __forceinline__ void epilogue_yolo_h(const ConvArgsH& a, f32x16 (&acc
                         pix -= adv * a.ohow;
                         img += adv;
                     }
-                    const float sg = 1.0f / (1.0f + __expf(-(acc[t][u][e] + bv)));
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[t][u][e] + bv)));
                     const size_t row = (size_t)pix * a.yna + anc;
                     float v = sg;
                     if (e_ < 2) {

@@ -47,8 +47,8 @@ struct SmallCArgs {
 __device__ __forceinline__ float act_any(int act, float v, float p) {
     switch (act) {
         case SI_ACT_RELU: return fmaxf(v, 0.0f);
-        case SI_ACT_SILU: return __fdividef(v, 1.0f + __expf(-v));
-        case SI_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case SI_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        case SI_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
         case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
                     for (int e = 0; e < 16; ++e) {
                         const int ox = oxb + (e & 3) + 8 * (e >> 2);
                         const float v = acc[u][e] + bvv;
-                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = (OutT)__fdividef(v, 1.0f + __expf(-v));
+                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = (OutT)v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
                     }
                 } else if (simple && a.act1 == SI_ACT_RELU) {
 #pragma unroll

@@ -54,8 +54,8 @@ struct WinoArgs {
 __device__ __forceinline__ float wino_act(int act, float v, float p) {
     switch (act) {
         case SI_ACT_RELU: return fmaxf(v, 0.0f);
-        case SI_ACT_SILU: return __fdividef(v, 1.0f + __expf(-v));
-        case SI_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case SI_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        case SI_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
         case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;

@@ -20,8 +20,8 @@ namespace {
 __device__ __forceinline__ float act_apply(int act, float v, float p) {
     switch (act) {
         case SI_ACT_RELU: return fmaxf(v, 0.0f);
-        case SI_ACT_SILU: return v / (1.0f + __expf(-v));
-        case SI_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case SI_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        case SI_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
         case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;
@@ -290,7 +290,7 @@ __global__ void yolo_decode_kernel(const float* __restrict__ conv, int n, size_t
         const size_t t = i / ne;
         const size_t r = t % rows;
         const size_t b = t / rows;
-        const float s = 1.0f / (1.0f + __expf(-conv[i]));
+        const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-conv[i]));
         float v = s;
         if (e < 2) {
             v = (s * 2.0f + grid[r * 2 + e]) * stride;
