@@ -35,6 +35,11 @@
 #include "si_hip.h"
 #include "si_hip_internal.h"
 
+// No floating-point contraction in this file: the epilogue exists in several template instantiations (interior / edge
+// tile, with / without residual, activation known or not) and an image's result must not depend on which one a pixel
+// happens to go through (bit-exact batch sharding).  The MFMA builtins are unaffected.
+#pragma clang fp contract(off)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -20,6 +20,12 @@
 #include "si_hip.h"
 #include "si_hip_internal.h"
 
+// No floating-point contraction in this file: the epilogue exists in several template instantiations (interior / edge
+// tile, with / without residual, ...) and an image's result must not depend on which one a pixel happens to go through
+// (bit-exact batch sharding); with contraction the compiler fuses a*b+c differently per instantiation.  The MFMA
+// builtins are unaffected.
+#pragma clang fp contract(off)
+
 typedef _Float16 half_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -94,10 +100,58 @@ __device__ __forceinline__ void epilogue_plain(const ConvArgsH& a, f32x16 (&acc)
                     v = act_h(a.act1, v, a.act_param);
                     if (has_res) v += (float)a.res[(size_t)m * a.res_ld + oc_abs];
                     v = act_h(a.act2, v, a.act_param);
-                    obase[(size_t)m * old] = (OutT)v;
+                    obase[(size_t)m * old] = si_store_cast<OutT>(v);
                 }
             }
         }
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_c(float v, float p) {
+    if (ACT == SI_ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == SI_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    return v;
+}
+
+// straight-line fp16 epilogue for the combinations the graphs produce (see conv_igemm.hip epilogue_lean)
+template <int TM, int TN, int ACT1, int ACT2, bool HAS_RES, bool INTERIOR>
+__device__ __forceinline__ void epilogue_lean_h(const ConvArgsH& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0) {
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = ocol0 + u * 32;
+        if (o >= a.ocg) continue;
+        const int oc_abs = g * a.ocg + o;
+        const float bv = a.bias ? a.bias[oc_abs] : 0.0f;
+        const bool second = a.out2 != nullptr && oc_abs >= a.split;
+        half_t* const obase = second ? a.out2 + (oc_abs - a.split) : static_cast<half_t*>(a.out) + oc_abs;
+        const int old = second ? a.out2_ld : a.out_ld;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int mb = mrow0 + t * 32;
+            half_t* const op = obase + (size_t)mb * old;
+            const half_t* const rp = HAS_RES ? a.res + (size_t)mb * a.res_ld + oc_abs : nullptr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = (e & 3) + 8 * (e >> 2);
+                if (INTERIOR || mb + c < a.M) {
+                    float v = act_c<ACT1>(acc[t][u][e] + bv, a.act_param);
+                    if (HAS_RES) v += (float)rp[c * a.res_ld];
+                    op[c * old] = si_store_cast<half_t>(act_c<ACT2>(v, a.act_param));
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int ACT1, int ACT2>
+__device__ __forceinline__ void epilogue_pick_h(const ConvArgsH& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior) {
+    if (a.res) {
+        if (interior) epilogue_lean_h<TM, TN, ACT1, ACT2, true, true>(a, acc, g, mrow0, ocol0);
+        else epilogue_lean_h<TM, TN, ACT1, ACT2, true, false>(a, acc, g, mrow0, ocol0);
+    } else {
+        if (interior) epilogue_lean_h<TM, TN, ACT1, ACT2, false, true>(a, acc, g, mrow0, ocol0);
+        else epilogue_lean_h<TM, TN, ACT1, ACT2, false, false>(a, acc, g, mrow0, ocol0);
     }
 }
 
@@ -298,7 +352,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     const int mrow0 = m0 + wm * TM * 32 + 4 * lh, ocol0 = n0 + wn * TN * 32 + l31;
     if (a.ymode) epilogue_yolo_h<TM, TN>(a, acc, mrow0, ocol0);
     else if (a.out_f32) epilogue_plain<TM, TN, float>(a, acc, g, mrow0, ocol0);
-    else epilogue_plain<TM, TN, half_t>(a, acc, g, mrow0, ocol0);
+    else {
+        const bool interior = m0 + BM <= a.M;
+        if (a.act1 == SI_ACT_SILU && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_SILU, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior);
+        else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_NONE, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior);
+        else if (a.act1 == SI_ACT_RELU && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_RELU, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior);
+        else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_RELU) epilogue_pick_h<TM, TN, SI_ACT_NONE, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior);
+        else epilogue_plain<TM, TN, half_t>(a, acc, g, mrow0, ocol0);
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int BKH>

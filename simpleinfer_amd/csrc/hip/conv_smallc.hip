@@ -193,13 +193,13 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
                     for (int e = 0; e < 16; ++e) {
                         const int ox = oxb + (e & 3) + 8 * (e >> 2);
                         const float v = acc[u][e] + bvv;
-                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = (OutT)v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = si_store_cast<OutT>(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
                     }
                 } else if (simple && a.act1 == SI_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int ox = oxb + (e & 3) + 8 * (e >> 2);
-                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = (OutT)fmaxf(acc[u][e] + bvv, 0.0f);
+                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = si_store_cast<OutT>(fmaxf(acc[u][e] + bvv, 0.0f));
                     }
                 } else {
 #pragma unroll
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
                             v = act_any(a.act1, v, a.act_param);
                             if (a.res) v += a.res[(mrow + ox) * a.res_ld + o];
                             v = act_any(a.act2, v, a.act_param);
-                            orow[(size_t)ox * a.out_ld] = (OutT)v;
+                            orow[(size_t)ox * a.out_ld] = si_store_cast<OutT>(v);
                         }
                     }
                 }

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "si_hip.h"
 #include "si_hip_internal.h"
@@ -271,37 +272,59 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     const int o = oc0 + l31;
     const bool ocok = o < a.oc;
     const float bv = (a.bias && ocok) ? a.bias[o] : 0.0f;
+    // activation / residual combination resolved once per workgroup: the loop body is straight-line code
+    auto finish = [&](auto act1, auto act2, auto has_res) {
+#pragma clang fp contract(off)  // every instantiation must round alike (bit-exact batch sharding)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 zr[4];
+        for (int g = 0; g < 4; ++g) {
+            f32x4 zr[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zr[r] = *reinterpret_cast<const f32x4*>(xch + (r * 64 + lane) * XLS + jc * 16 + 4 * g);
+            for (int r = 0; r < 4; ++r) zr[r] = *reinterpret_cast<const f32x4*>(xch + (r * 64 + lane) * XLS + jc * 16 + 4 * g);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = 4 * g + k;
-            const float y = (i_out == 0) ? (zr[0][k] + zr[1][k]) + zr[2][k] : (zr[1][k] - zr[2][k]) - zr[3][k];
-            // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh
-            const int m = (e & 3) + 8 * (e >> 2) + 4 * lh;
-            const int tr = m >> LOG_TBW, tc = m & (TBW - 1);
-            const int R = row0 + tr;
-            const int txg = col0 + tc;
-            if (R < a.rows_total && txg < a.tw && ocok) {
-                int img = img0, ty = ty0 + tr;
-                while (ty >= a.th) {
-                    ty -= a.th;
-                    ++img;
-                }
-                const int oy = 2 * ty + i_out, ox = 2 * txg + jc;
-                if (oy < a.oh && ox < a.ow) {
-                    const size_t pix = (size_t)(img * a.oh + oy) * a.ow + ox;
-                    float vv = y + bv;
-                    vv = wino_act(a.act1, vv, a.act_param);
-                    if (a.res) vv += a.res[pix * a.res_ld + o];
-                    vv = wino_act(a.act2, vv, a.act_param);
-                    a.out[pix * a.out_ld + o] = vv;
+            for (int k = 0; k < 4; ++k) {
+                const int e = 4 * g + k;
+                const float y = (i_out == 0) ? (zr[0][k] + zr[1][k]) + zr[2][k] : (zr[1][k] - zr[2][k]) - zr[3][k];
+                // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int tr = m >> LOG_TBW, tc = m & (TBW - 1);
+                const int R = row0 + tr;
+                const int txg = col0 + tc;
+                if (R < a.rows_total && txg < a.tw && ocok) {
+                    int img = img0, ty = ty0 + tr;
+                    while (ty >= a.th) {
+                        ty -= a.th;
+                        ++img;
+                    }
+                    const int oy = 2 * ty + i_out, ox = 2 * txg + jc;
+                    if (oy < a.oh && ox < a.ow) {
+                        const size_t pix = (size_t)(img * a.oh + oy) * a.ow + ox;
+                        float vv = y + bv;
+                        vv = decltype(act1)::value < 0 ? wino_act(a.act1, vv, a.act_param)
+                                                       : (decltype(act1)::value == SI_ACT_SILU ? vv * __builtin_amdgcn_rcpf(1.0f + __expf(-vv))
+                                                          : (decltype(act1)::value == SI_ACT_RELU ? fmaxf(vv, 0.0f) : vv));
+                        if (decltype(has_res)::value) vv += a.res[pix * a.res_ld + o];
+                        vv = decltype(act2)::value < 0 ? wino_act(a.act2, vv, a.act_param)
+                                                       : (decltype(act2)::value == SI_ACT_RELU ? fmaxf(vv, 0.0f) : vv);
+                        a.out[pix * a.out_ld + o] = vv;
+                    }
                 }
             }
         }
+    };
+    using IC = std::integral_constant<int, 0>;
+    (void)sizeof(IC);
+    const bool res = a.res != nullptr;
+    if (a.act1 == SI_ACT_SILU && a.act2 == SI_ACT_NONE) {
+        if (res) finish(std::integral_constant<int, SI_ACT_SILU>{}, std::integral_constant<int, SI_ACT_NONE>{}, std::true_type{});
+        else finish(std::integral_constant<int, SI_ACT_SILU>{}, std::integral_constant<int, SI_ACT_NONE>{}, std::false_type{});
+    } else if (a.act1 == SI_ACT_RELU && a.act2 == SI_ACT_NONE && !res) {
+        finish(std::integral_constant<int, SI_ACT_RELU>{}, std::integral_constant<int, SI_ACT_NONE>{}, std::false_type{});
+    } else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_RELU && res) {
+        finish(std::integral_constant<int, SI_ACT_NONE>{}, std::integral_constant<int, SI_ACT_RELU>{}, std::true_type{});
+    } else if (res) {
+        finish(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{}, std::true_type{});
+    } else {
+        finish(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{}, std::false_type{});
     }
 }
 

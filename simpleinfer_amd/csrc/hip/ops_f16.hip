@@ -42,10 +42,10 @@ __global__ void activation_h_kernel(int act, float ap, const half_t* __restrict_
         if (VEC) {
             f16x8 v = *reinterpret_cast<const f16x8*>(in + p * in_ld + ch * 8);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = (half_t)act_f(act, (float)v[k], ap);
+            for (int k = 0; k < 8; ++k) v[k] = si_store_cast<half_t>(act_f(act, (float)v[k], ap));
             *reinterpret_cast<f16x8*>(out + p * out_ld + ch * 8) = v;
         } else {
-            out[p * out_ld + ch] = (half_t)act_f(act, (float)in[p * in_ld + ch], ap);
+            out[p * out_ld + ch] = si_store_cast<half_t>(act_f(act, (float)in[p * in_ld + ch], ap));
         }
     }
 }
@@ -63,11 +63,11 @@ __global__ void binary_same_h_kernel(int op, const half_t* __restrict__ a, int a
             const f16x8 y = *reinterpret_cast<const f16x8*>(b + p * b_ld + ch * 8);
             f16x8 r;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] = (half_t)((op == 0) ? (float)x[k] + (float)y[k] : (float)x[k] * (float)y[k]);
+            for (int k = 0; k < 8; ++k) r[k] = si_store_cast<half_t>((op == 0) ? (float)x[k] + (float)y[k] : (float)x[k] * (float)y[k]);
             *reinterpret_cast<f16x8*>(out + p * out_ld + ch * 8) = r;
         } else {
             const float x = (float)a[p * a_ld + ch], y = (float)b[p * b_ld + ch];
-            out[p * out_ld + ch] = (half_t)((op == 0) ? x + y : x * y);
+            out[p * out_ld + ch] = si_store_cast<half_t>((op == 0) ? x + y : x * y);
         }
     }
 }

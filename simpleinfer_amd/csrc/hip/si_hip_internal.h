@@ -19,4 +19,13 @@ static inline unsigned si_grid_for(size_t work_items, unsigned block = 256) {
     return (unsigned)blocks;
 }
 
+// fp32 -> storage type. For _Float16 the empty asm keeps the value opaque so the compiler cannot fold the multiply / add
+// that produced it into v_fma_mix{lo,hi}_f16 for some unrolled elements and not others: the fused form rounds once, the
+// separate form twice, and an image's result would then depend on which accumulator slot (= batch position) it used.
+template <typename T>
+__device__ __forceinline__ T si_store_cast(float v) {
+    if constexpr (sizeof(T) == 2) asm("" : "+v"(v));
+    return (T)v;
+}
+
 #endif  // SI_HIP_INTERNAL_H_

@@ -337,6 +337,7 @@ Status EngineImpl::CreatePipeline() {
         CHECK_STATUS(FuseEpilogues(order));
         CHECK_STATUS(FuseSiblingConvs(order));
     }
+    if (opt_fp16_) CHECK_STATUS(InsertOutputCasts(order));
     plan_ = order;
     if (opt_alias_cat_) CHECK_STATUS(AliasConcats());
     return Status::kSuccess;
@@ -472,6 +473,46 @@ Status EngineImpl::FuseSiblingConvs(std::vector<Step>& order) {
     return Status::kSuccess;
 }
 
+// fp16 storage: graph outputs keep the file's fp32 type.  Conv2d / Linear / Detect write fp32 from their own epilogue;
+// any other producer fed by half operands writes a half staging operand instead, and a convert step follows it.
+Status EngineImpl::InsertOutputCasts(std::vector<Step>& order) {
+    for (auto& kv : output_tensor_nodes_) {
+        TensorNode* out = kv.second;
+        if (out->tensor.GetDataType() != DataType::kFloat32) continue;
+        for (size_t i = 0; i < order.size(); ++i) {
+            Layer* layer = order[i].layer;
+            std::vector<TensorNode*> outs = layer->OutputNodes();
+            auto slot = std::find(outs.begin(), outs.end(), out);
+            if (slot == outs.end()) continue;
+            if (dynamic_cast<Conv2d*>(layer) || dynamic_cast<Linear*>(layer) || dynamic_cast<YoloDetect*>(layer)) break;
+            bool half_in = false;
+            for (const TensorNode* in : layer->InputNodes()) half_in = half_in || in->tensor.GetDataType() == DataType::kFloat16;
+            if (!half_in) break;
+
+            const std::string staging_name = kv.first + "#f16";
+            TensorNode* staging = new TensorNode;
+            staging->operand = out->operand;
+            staging->tensor = Tensor(DataType::kFloat16, out->tensor.Shape(), MemoryType::kDevice, false);
+            tensor_nodes_[staging_name] = staging;
+            *slot = staging;
+            layer->SetOutputNodes(outs);
+
+            OutputCast* cast = new OutputCast(order[i].op->name);
+            layers_[cast->GetOp()->name] = cast;
+            cast->SetContext(context_);
+            cast->SetInputNodes({staging});
+            cast->SetOutputNodes({out});
+            CHECK_STATUS(cast->Validate());
+            Step s;
+            s.layer = cast;
+            s.op = cast->GetOp();
+            order.insert(order.begin() + i + 1, s);
+            break;
+        }
+    }
+    return Status::kSuccess;
+}
+
 // torch.cat on the channel axis: every eligible input operand becomes a view into the concat output
 // (same pixel grid, pixel stride = total channels), so its producer writes in place and Cat::Forward
 // finds nothing left to copy.
@@ -479,7 +520,7 @@ Status EngineImpl::AliasConcats() {
     for (const Step& s : plan_) {
         Cat* cat = dynamic_cast<Cat*>(s.layer);
         if (!cat || s.op->type != "torch.cat" || cat->NhwcAxis() != 3 || s.op->outputs.size() != 1) continue;
-        TensorNode* out = tensor_nodes_[s.op->outputs[0]->name];
+        TensorNode* out = cat->OutputNodes()[0];  // the staging operand when an output cast follows
         if (out->tensor.Shape().size() != 4) continue;
         int offset = 0;
         std::set<const pnnx::Operand*> seen;

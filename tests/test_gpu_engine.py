@@ -212,6 +212,41 @@ def test_fp16_graph_vs_fp32_oracle(si, orc, tmp_path, name):
     assert_exact(one[0], got[1], "fp16: an image's result does not depend on the batch")
 
 
+@pytest.mark.parametrize("tail", ["silu_unfused", "maxpool", "cat", "add", "upsample"])
+def test_fp16_graph_output_from_a_non_conv_layer(si, orc, tmp_path, tail):
+    """Extract() stays fp32 when the last layer is not one that converts in its own epilogue: the engine appends a
+    convert step behind a half staging operand (and concat aliasing still applies to that staging operand)."""
+    mg = si.modelgen
+    b = mg.PnnxBuilder(0)
+    x = b.input((2, 3, 66, 66))
+    y = mg._Conv(b, x, 32, 6, 2)
+    opts = dict(fp16=1)
+    if tail == "silu_unfused":
+        opts["fuse"] = 0
+    elif tail == "maxpool":
+        y = b.maxpool(y, 5, 1, 2)
+    elif tail == "cat":
+        y = b.cat([mg._Conv(b, y, 32, 1), b.maxpool(y, 3, 1, 1)], 1)
+    elif tail == "add":
+        y = b.add(y, mg._Conv(b, y, 32, 3))
+        opts["fuse"] = 0
+    else:
+        y = b.upsample(y, 2.0)
+    b.output(y)
+    pp, bp = _save(tmp_path, b, "tail_" + tail)
+    xin = mg.synth_input((2, 66, 66, 3))
+    ref = orc.run_graph(pp, bp, {"0": xin})
+    e, oname, got = _run(si, pp, bp, xin, **opts)
+    assert got.dtype == np.float32
+    (want,) = ref.values()  # one output; expression lowering renames the operand on the engine side
+    assert_parity(got, want, F16_GRAPH_TOL, what="fp16 graph ending in " + tail)
+    sch = e.schedule()
+    assert sch["run"][-1].endswith(".to_f32"), sch["run"]
+    assert "convert_f16_f32" in {L["kernel"] for L in e.profile()}
+    if tail == "cat":
+        assert len(sch["alias"]) == 2, sch
+
+
 def test_fp16_unsupported_graph_is_a_status(si, tmp_path):
     # toy_yolo has channel counts that are not multiples of 32: the fp16 path says so instead of computing something else
     pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(1, 64), "toy16")

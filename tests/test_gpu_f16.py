@@ -67,6 +67,22 @@ def test_conv_f16_fused_epilogue_strides_and_batch_invariance(hops, orc):
         hops.conv2d_f16(h(rng_uniform(5, (1, 8, 8, 24), -1, 1)), h(rng_uniform(6, (32, 24, 3, 3))), None)  # ic % 32 != 0
 
 
+@pytest.mark.parametrize("hw,ic,oc,k,p,res", [(41, 32, 32, 3, 1, False), (41, 64, 64, 1, 0, False), (41, 32, 32, 3, 1, True),
+                                             (5, 128, 96, 1, 0, False), (21, 64, 128, 3, 1, True)])
+def test_conv_f16_batch_invariance_with_odd_pixel_counts(hops, hw, ic, oc, k, p, res):
+    """An odd pixel count per image moves image 1 to other accumulator slots than it has alone.  The fp32 -> fp16 store
+    must round the same way in every slot (a compiler-chosen v_fma_mix for some slots rounds once, the others twice)."""
+    x = h(rng_uniform(1, (3, hw, hw, ic), -1, 1))
+    w = h(rng_uniform(2, (oc, ic, k, k), -0.1, 0.1))
+    b = rng_uniform(3, (oc,), -0.05, 0.05)
+    r = h(rng_uniform(4, (3, hw, hw, oc), -1, 1)) if res else None
+    for act in ("silu", "relu", "none"):
+        full = hops.conv2d_f16(x, w, b, (1, 1), (p, p), act1=act, residual=r)
+        for i in (1, 2):
+            one = hops.conv2d_f16(x[i:i + 1], w, b, (1, 1), (p, p), act1=act, residual=None if r is None else r[i:i + 1])
+            assert_exact(one[0], full[i], "image %d, act %s" % (i, act))
+
+
 @pytest.mark.parametrize("k,s,p,oc,size", [(6, 2, 2, 32, 64), (7, 2, 3, 64, 56)])
 def test_stem_f16_output(hops, orc, k, s, p, oc, size):
     x = rng_uniform(10 + k, (2, size, size, 3), 0, 1)            # the stem reads the fp32 image
