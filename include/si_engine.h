@@ -59,6 +59,14 @@ int si_engine_schedule(SiEngine* engine, char* buf, size_t cap);
  * reference's own loader produces through oracle/_ref/ref_pnnx_dump.  Returns 0 on success. */
 int si_pnnx_dump(const char* param_path, const char* bin_path, int expand, const char* out_path);
 
+/* Model tooling (reference src/pnnx/ir.cpp:817-1008 Graph::save, src/pnnx/storezip.cpp:242-395):
+ * load a model with this library's loader, optionally lower pnnx.Expression (expand != 0) and / or rewrite the traced
+ * batch in every operand shape to `batch` (batch > 0; the same rule SetOption("batch") applies at load), and write it
+ * back as .pnnx.param + stored-zip .pnnx.bin.  Returns 0 on success, 1 for an unreadable / malformed model,
+ * 2 when the output cannot be written, 5 when the graph inputs carry no common static batch. */
+int si_pnnx_save(const char* param_path, const char* bin_path, int expand, int batch, const char* out_param_path,
+                 const char* out_bin_path);
+
 /* registry introspection: newline-separated pnnx type strings */
 int si_registry_types(char* buf, size_t cap);
 

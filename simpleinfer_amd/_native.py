@@ -168,6 +168,7 @@ def host():
                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "si_engine_schedule": (i, [vp, cp, sz]),
         "si_pnnx_dump": (i, [cp, cp, i, cp]),
+        "si_pnnx_save": (i, [cp, cp, i, i, cp, cp]),
         "si_registry_types": (i, [cp, sz]),
     }
     for name, (res, args) in sig.items():

@@ -163,6 +163,30 @@ int si_registry_types(char* buf, size_t cap) {
     return copy_out(s, buf, cap);
 }
 
+int si_pnnx_save(const char* param_path, const char* bin_path, int expand, int batch, const char* out_param_path,
+                 const char* out_bin_path) {
+    if (!param_path || !bin_path || !out_param_path || !out_bin_path) return -1;
+    pnnx::Graph g;
+    try {
+        if (g.load(param_path, bin_path) != 0) return 1;
+        if (expand) pnnx::expand_expression(g);
+        if (batch > 0) {
+            int traced = 0;
+            for (const pnnx::Operand* r : g.operands)
+                if (r->producer && r->producer->inputs.empty() && !r->shape.empty()) {
+                    if (traced != 0 && traced != r->shape[0]) return 5;
+                    traced = r->shape[0];
+                }
+            if (traced <= 0) return 5;
+            for (pnnx::Operand* r : g.operands)
+                if (!r->shape.empty() && r->shape[0] == traced) r->shape[0] = batch;
+        }
+        return g.save(out_param_path, out_bin_path) == 0 ? 0 : 2;
+    } catch (const std::exception&) {
+        return 1;
+    }
+}
+
 // canonical dump; line formats match oracle/ref_pnnx_dump.cpp (the driver around the reference loader)
 int si_pnnx_dump(const char* param_path, const char* bin_path, int expand, const char* out_path) {
     if (!param_path || !bin_path || !out_path) return -1;

@@ -258,4 +258,91 @@ int Graph::load(const std::string& parampath, const std::string& binpath) {
     return 0;
 }
 
+// ---- writer ---------------------------------------------------------------------------------------
+namespace {
+
+const char* type_to_string(int type) {
+    static const char* names[] = {"null", "f32", "f64", "f16", "i32", "i64", "i16", "i8", "u8", "bool", "cp64", "cp128", "cp32"};
+    return type >= 0 && type <= 12 ? names[type] : "null";
+}
+
+// shortest text that parses back to the same float AND is classified as a float by parse_from_string
+std::string float_text(float v) {
+    char buf[48];
+    for (int digits = 6; digits <= 9; ++digits) {
+        snprintf(buf, sizeof(buf), "%.*e", digits, (double)v);
+        if (std::strtof(buf, nullptr) == v) break;
+    }
+    return buf;
+}
+
+std::string shape_text(const std::vector<int>& shape, int type) {
+    std::string t = "(";
+    for (size_t i = 0; i < shape.size(); ++i) {
+        if (i) t += ",";
+        t += shape[i] < 0 ? std::string("?") : std::to_string(shape[i]);
+    }
+    return t + ")" + type_to_string(type);
+}
+
+std::string param_text(const Parameter& p) {
+    std::string t;
+    switch (p.type) {
+        case 1: return p.b ? "True" : "False";
+        case 2: return std::to_string(p.i);
+        case 3: return float_text(p.f);
+        case 4: return p.s;
+        case 5:
+            for (size_t i = 0; i < p.ai.size(); ++i) t += (i ? "," : "") + std::to_string(p.ai[i]);
+            return "(" + t + ")";
+        case 6:
+            for (size_t i = 0; i < p.af.size(); ++i) t += (i ? "," : "") + float_text(p.af[i]);
+            return "(" + t + ")";
+        case 7:
+            for (size_t i = 0; i < p.as.size(); ++i) t += (i ? "," : "") + p.as[i];
+            return "(" + t + ")";
+        default: return "None";
+    }
+}
+
+}  // namespace
+
+int Graph::save(const std::string& parampath, const std::string& binpath) const {
+    FILE* fp = fopen(parampath.c_str(), "wb");
+    if (!fp) {
+        fprintf(stderr, "pnnx: cannot create %s\n", parampath.c_str());
+        return -1;
+    }
+    StoreZipWriter zip;
+    if (zip.open(binpath) != 0) {
+        fclose(fp);
+        return -1;
+    }
+    int rc = 0;
+    fprintf(fp, "7767517\n%d %d\n", (int)ops.size(), (int)operands.size());
+    for (const Operator* op : ops) {
+        fprintf(fp, "%-24s %-24s %d %d", op->type.c_str(), op->name.c_str(), (int)op->inputs.size(), (int)op->outputs.size());
+        for (const Operand* r : op->inputs) fprintf(fp, " %s", r->name.c_str());
+        for (const Operand* r : op->outputs) fprintf(fp, " %s", r->name.c_str());
+        for (const auto& kv : op->params) fprintf(fp, " %s=%s", kv.first.c_str(), param_text(kv.second).c_str());
+        for (const auto& kv : op->attrs) {
+            const Attribute& a = kv.second;
+            fprintf(fp, " @%s=%s", kv.first.c_str(), shape_text(a.shape, a.type).c_str());
+            if (!a.data.empty() && zip.write_file(op->name + "." + kv.first, a.data.data(), a.data.size()) != 0) rc = -1;
+        }
+        for (size_t j = 0; j < op->inputnames.size() && j < op->inputs.size(); ++j)
+            if (!op->inputnames[j].empty()) fprintf(fp, " $%s=%s", op->inputnames[j].c_str(), op->inputs[j]->name.c_str());
+        // operand shapes ride on both the consuming and the producing line, as pnnx writes them
+        for (const Operand* r : op->inputs)
+            if (r->type != 0 || !r->shape.empty()) fprintf(fp, " #%s=%s", r->name.c_str(), shape_text(r->shape, r->type).c_str());
+        for (const Operand* r : op->outputs)
+            if (r->type != 0 || !r->shape.empty()) fprintf(fp, " #%s=%s", r->name.c_str(), shape_text(r->shape, r->type).c_str());
+        fprintf(fp, "\n");
+    }
+    if (ferror(fp)) rc = -1;
+    if (fclose(fp) != 0) rc = -1;
+    if (zip.close() != 0) rc = -1;
+    return rc;
+}
+
 }  // namespace pnnx

@@ -5,7 +5,8 @@
 // plugin surface: Layer::Init receives `const pnnx::Operator*` and
 // `std::map<std::string, pnnx::Parameter>` (reference src/layer.h:22-26).  The implementation
 // (ir.cpp, storezip.cpp, expand_expression.cpp) is written from the file-format description in
-// SURVEY.md 8(b), not from the reference sources; the exporter half (save/python) is out of scope.
+// SURVEY.md 8(b), not from the reference sources.  save() writes the same two files back (SURVEY.md 8(f4):
+// reference src/pnnx/ir.cpp:817-1008 minus its Python / onnx exporters, which stay out of scope).
 #ifndef SIMPLEINFER_AMD_PNNX_IR_H_
 #define SIMPLEINFER_AMD_PNNX_IR_H_
 
@@ -90,6 +91,8 @@ public:
 
     // returns 0 on success
     int load(const std::string& parampath, const std::string& binpath);
+    // writes .pnnx.param / .pnnx.bin that load() (and the reference's loader) read back to the same graph
+    int save(const std::string& parampath, const std::string& binpath) const;
 
     Operator* new_operator(const std::string& type, const std::string& name);
     Operator* new_operator_before(const std::string& type, const std::string& name, const Operator* cur);

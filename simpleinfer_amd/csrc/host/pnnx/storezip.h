@@ -1,7 +1,8 @@
-// pnnx/storezip.h -- reader for the stored-only (method 0) ZIP container of a .pnnx.bin.
-// Behaviour contract: reference src/pnnx/storezip.cpp:117-229 (sequential local-file-header scan,
-// data-descriptor flag and compression rejected).  Own implementation: the archive is read into
-// memory once and entries are slices of that buffer.
+// pnnx/storezip.h -- reader and writer for the stored-only (method 0) ZIP container of a .pnnx.bin.
+// Behaviour contract: reference src/pnnx/storezip.cpp:117-229 (reader: sequential local-file-header scan,
+// data-descriptor flag and compression rejected) and :242-395 (writer: stored entries + central directory,
+// readable by any unzip).  Own implementation: the reader slurps the archive once and entries are slices of that
+// buffer; the writer streams entries out and keeps only the directory records.
 #ifndef SIMPLEINFER_AMD_PNNX_STOREZIP_H_
 #define SIMPLEINFER_AMD_PNNX_STOREZIP_H_
 
@@ -27,6 +28,28 @@ private:
     };
     std::vector<unsigned char> blob_;
     std::map<std::string, Entry> entries_;
+};
+
+class StoreZipWriter {
+public:
+    ~StoreZipWriter();
+    int open(const std::string& path);
+    // one stored entry; sizes are limited to the classic (non-zip64) 4 GiB
+    int write_file(const std::string& name, const char* data, size_t size);
+    // writes the central directory; 0 when every byte reached the file
+    int close();
+
+private:
+    struct Record {
+        std::string name;
+        unsigned int crc = 0;
+        unsigned int size = 0;
+        unsigned int offset = 0;
+    };
+    void* fp_ = nullptr;
+    std::vector<Record> records_;
+    unsigned long long cursor_ = 0;
+    bool failed_ = false;
 };
 
 }  // namespace pnnx

@@ -164,6 +164,14 @@ def pnnx_dump(param_path: str, bin_path: str, expand: bool, out_path: str):
         raise RuntimeError("si_pnnx_dump rc=%d" % rc)
 
 
+def pnnx_save(param_path: str, bin_path: str, out_param_path: str, out_bin_path: str, expand: bool = False, batch: int = 0):
+    """Rewrite a model through the C++ loader + writer (Graph::save): optional pnnx.Expression lowering and re-batching."""
+    rc = _native.host().si_pnnx_save(param_path.encode(), bin_path.encode(), 1 if expand else 0, int(batch),
+                                     out_param_path.encode(), out_bin_path.encode())
+    if rc != 0:
+        raise RuntimeError("si_pnnx_save rc=%d" % rc)
+
+
 def registry_types() -> List[str]:
     L = _native.host()
     n = L.si_registry_types(None, 0)

@@ -278,6 +278,11 @@ def test_rebatch_serves_any_batch_from_one_file(si, tmp_path):
     _, on, refr = _run(si, *r4, xr)
     _, _, got = _run(si, *r1, xr, batch=4)
     assert_exact(got, refr, "resnet re-batched")
+    # the same rewrite as a file-to-file tool (si_pnnx_save: C++ loader -> Graph::save), expressions lowered on the way
+    q3 = (str(tmp_path / "q3.pnnx.param"), str(tmp_path / "q3.pnnx.bin"))
+    si.engine.pnnx_save(*p1, *q3, expand=True, batch=3)
+    _, _, got3 = _run(si, *q3, x)
+    assert_exact(got3, ref, "batch-1 file rewritten to batch 3 by the C++ writer")
 
 
 def test_output_binding_writes_into_caller_memory(si, tmp_path):

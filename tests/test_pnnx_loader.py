@@ -79,3 +79,77 @@ def test_malformed_files_are_rejected_not_fatal(native_libs):
     from fuzz_loader import fuzz
     ok, bad = fuzz(160, seed=3)
     assert ok + bad == 320 and bad > 0
+
+
+# ---- writer: Graph::save + StoreZipWriter through si_pnnx_save ----------------------------------
+WRITER_MODELS = {"yolov5s": lambda: mg.build_yolov5s(2, 64), "resnet18": lambda: mg.build_resnet18(2, 32),
+                 "mobilenetv3": lambda: mg.build_mobilenetv3_small(2, 64, num_classes=10),
+                 "toy_classifier": lambda: mg.build_toy_classifier(2, 16)}
+
+
+def _dump(pp, bp, expand, out):
+    engine.pnnx_dump(pp, bp, expand, out)
+    return open(out).read()
+
+
+@pytest.mark.parametrize("which", sorted(WRITER_MODELS))
+def test_saved_model_loads_back_to_the_same_graph(native_libs, tmp_path, which):
+    import zipfile
+    pp, bp = str(tmp_path / "a.pnnx.param"), str(tmp_path / "a.pnnx.bin")
+    WRITER_MODELS[which]().save(pp, bp)
+    for expand in (False, True):
+        qp, qb = str(tmp_path / ("b%d.pnnx.param" % expand)), str(tmp_path / ("b%d.pnnx.bin" % expand))
+        engine.pnnx_save(pp, bp, qp, qb, expand=expand)
+        want = _dump(pp, bp, expand, str(tmp_path / "d0.txt"))
+        got = _dump(qp, qb, False, str(tmp_path / "d1.txt"))            # params, attrs (hashed bytes), shapes, wiring
+        if expand:  # lowering appends its new operands at the end of the list; a reload lists them in file order
+            key = lambda t: sorted(ln for ln in t.splitlines() if ln.startswith("operand "))
+            rest = lambda t: [ln for ln in t.splitlines() if not ln.startswith("operand ")]
+            assert key(got) == key(want) and rest(got) == rest(want)
+        else:
+            assert got == want
+        # any unzip reads the container: CRCs check out and the entries are the original bytes
+        with zipfile.ZipFile(bp) as za, zipfile.ZipFile(qb) as zb:
+            assert zb.testzip() is None
+            assert all(i.compress_type == zipfile.ZIP_STORED for i in zb.infolist())
+            if not expand:
+                assert sorted(za.namelist()) == sorted(zb.namelist())
+            for n in zb.namelist():
+                if n in za.namelist():
+                    assert za.read(n) == zb.read(n), n
+        if os.path.exists(REF_BIN):  # and the reference's own loader reads what we wrote
+            ref = subprocess.run([REF_BIN, qp, qb], check=True, capture_output=True, text=True).stdout
+            assert ref == got
+
+
+def test_save_rebatches_every_operand(native_libs, tmp_path):
+    pp, bp = str(tmp_path / "a.pnnx.param"), str(tmp_path / "a.pnnx.bin")
+    mg.build_yolov5s(2, 64).save(pp, bp)
+    qp, qb = str(tmp_path / "b.pnnx.param"), str(tmp_path / "b.pnnx.bin")
+    engine.pnnx_save(pp, bp, qp, qb, batch=7)
+    before = _dump(pp, bp, False, str(tmp_path / "d0.txt")).splitlines()
+    after = _dump(qp, qb, False, str(tmp_path / "d1.txt")).splitlines()
+    assert len(before) == len(after)
+    n_shapes = 0
+    for a, b in zip(before, after):
+        if a.startswith("operand "):
+            n_shapes += 1
+            assert a.replace("shape=2,", "shape=7,") == b
+        else:
+            assert a == b
+    assert n_shapes > 100
+    with pytest.raises(RuntimeError):
+        engine.pnnx_save(pp + ".missing", bp, qp, qb)
+
+
+def test_saved_float_parameters_keep_their_bits(native_libs, tmp_path):
+    import zipfile
+    pp, bp = tmp_path / "m.pnnx.param", tmp_path / "m.pnnx.bin"
+    zipfile.ZipFile(bp, "w").close()
+    pp.write_text("7767517\n2 1\npnnx.Input in0 0 1 0 #0=(1,?,4)f32\n"
+                  "nn.ReLU r0 1 0 0 a=None b=True c=-3 d=1.5e-1 e=zeros f=(1,2) g=(2.0,3.5,1e-05,0.1) h=(x,y) k=7. "
+                  "eps=1.0000000e-05 third=0.333333343 big=3.4e38 $input=0 #0=(1,?,4)f32\n")
+    qp, qb = str(tmp_path / "q.pnnx.param"), str(tmp_path / "q.pnnx.bin")
+    engine.pnnx_save(str(pp), str(bp), qp, qb)
+    assert _dump(qp, qb, False, str(tmp_path / "d1.txt")) == _dump(str(pp), str(bp), False, str(tmp_path / "d0.txt"))
+    assert "$input=0" in open(qp).read()
