@@ -259,7 +259,8 @@ int si_hip_yolo_postprocess_f32(const float* pred, int n, int rows, int ne, floa
 int si_hip_f32_to_f16_host(const float* src, void* dst, size_t n);
 int si_hip_f16_to_f32_host(const void* src, float* dst, size_t n);
 /* 0: no fp16 kernel for this shape; 1: implicit GEMM on v_mfma_f32_32x32x16_f16 (needs ic/groups % 32 == 0);
- * 2: stem (ic <= 3): fp32 input image and fp32-packed weights (si_hip_conv2d_pack_weight_host), fp16 output */
+ * 2: stem (ic <= 3; 6x6, 7x7 or 3x3 RGB kernels): fp32 input image, fp16 output, weights packed by
+ *    si_hip_conv2d_stem_f16_pack_weight_host (csrc/hip/conv_stem_f16.hip) */
 int si_hip_conv2d_f16_supported(const SiConv2dDesc* d);
 size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d);
 /* OIHW fp32 -> [oc][K] fp16, K order (c/B, kh, kw, c%B), B = 64 when ic/groups % 64 == 0 else 32 */
@@ -268,7 +269,12 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
  * outputs) */
 int si_hip_conv2d_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
                       void* out, int out_is_f32, si_stream_t stream);
-int si_hip_conv2d_stem_f16(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias, void* out,
+/* stem of the fp16 path: the reference's first Conv2d (src/layer/conv_2d.cpp:207-283 on a 3-channel image) with the
+ * image read as fp32, rounded to fp16 on the way into LDS, contracted on v_mfma_f32_32x32x16_f16, bias / activation in
+ * fp32, fp16 activations out.  Weights: OIHW fp32 -> [step][lane half][oc padded][8] fp16 B fragments. */
+size_t si_hip_conv2d_stem_f16_weight_elems(const SiConv2dDesc* d);
+int si_hip_conv2d_stem_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
+int si_hip_conv2d_stem_f16(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, void* out,
                            si_stream_t stream);
 int si_hip_conv2d_split_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, void* out,
                             int split_oc, void* out2, int out2_ld, si_stream_t stream);

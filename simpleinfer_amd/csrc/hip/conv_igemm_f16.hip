@@ -31,10 +31,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// conv_smallc.hip: stem kernel (fp32 input, fp16 or fp32 output)
-bool si_conv_smallc_ok(const SiConv2dDesc* d);
-int si_conv_smallc_launch_f16out(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
-                                 void* out, hipStream_t s);
+// conv_stem_f16.hip: stem kernel of this path (fp32 image in, fp16 out)
+bool si_conv_stem_f16_ok(const SiConv2dDesc* d);
 
 namespace {
 
@@ -476,7 +474,7 @@ int si_hip_f16_to_f32_host(const void* src, float* dst, size_t n) {
 
 int si_hip_conv2d_f16_supported(const SiConv2dDesc* d) {
     if (!d) return 0;
-    if (si_conv_smallc_ok(d)) return 2;  // stem: fp32 input, fp32 weights (si_hip_conv2d_pack_weight_host), fp16 output
+    if (si_conv_stem_f16_ok(d)) return 2;  // stem: fp32 image in, fp16 out, weights from si_hip_conv2d_stem_f16_pack_weight_host
     return f16_shape_ok(d) ? 1 : 0;
 }
 
@@ -508,13 +506,6 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
 int si_hip_conv2d_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
                       void* out, int out_is_f32, si_stream_t stream) {
     return dispatch_h(d, in, w_packed, bias, residual, out, out_is_f32 ? 1 : 0, stream, nullptr, nullptr, nullptr, nullptr);
-}
-
-int si_hip_conv2d_stem_f16(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias, void* out,
-                           si_stream_t stream) {
-    if (!d || !in || !w_packed || !out) return SI_E_BADARG;
-    if (!si_conv_smallc_ok(d) || d->has_residual) return SI_E_UNSUPPORTED;
-    return si_conv_smallc_launch_f16out(d, in, w_packed, d->has_bias ? bias : nullptr, out, static_cast<hipStream_t>(stream));
 }
 
 int si_hip_conv2d_split_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, void* out,

@@ -332,8 +332,3 @@ int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w
     return smallc_launch_t<float>(d, in, w_packed, bias, residual, out, s);
 }
 
-// fp16 engine path: same kernel (fp32 input image, fp32 MFMA), activations leave as fp16
-int si_conv_smallc_launch_f16out(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
-                                 void* out, hipStream_t s) {
-    return smallc_launch_t<_Float16>(d, in, w_packed, bias, nullptr, out, s);
-}

@@ -28,4 +28,18 @@ __device__ __forceinline__ T si_store_cast(float v) {
     return (T)v;
 }
 
+// Lanes 2k and 2k+1 of a 32x32 MFMA C/D tile hold neighbouring channels of the same pixels.  The pair trades one value
+// each (DPP quad_perm [1,0,3,2]) so that every lane stores ONE dword -- two channels of one pixel -- instead of two 2-byte
+// values: half the store instructions for fp16 activations.  v0 / v1: this lane's channel at two pixels; afterwards the
+// even lane owns the first pixel and the odd lane the second.  Returns {channel 2k, channel 2k+1} as packed halves.
+__device__ __forceinline__ unsigned si_pair_halves(float v0, float v1, bool odd) {
+    typedef _Float16 si_h2 __attribute__((ext_vector_type(2)));
+    const float send = odd ? v0 : v1;
+    const float recv = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+    si_h2 p;
+    p[0] = si_store_cast<_Float16>(odd ? recv : v0);
+    p[1] = si_store_cast<_Float16>(odd ? v1 : recv);
+    return __builtin_bit_cast(unsigned, p);
+}
+
 #endif  // SI_HIP_INTERNAL_H_

@@ -149,7 +149,7 @@ SiConv2dDesc Conv2d::MakeDesc(const Tensor& input, const Tensor& output) const {
     return d;
 }
 
-// mode 0: fp32 kernels; 1: fp16 implicit GEMM (fp16 weights); 2: stem with fp32 image in / fp16 out (fp32 weights)
+// mode 0: fp32 kernels; 1: fp16 implicit GEMM (fp16 weights); 2: fp16 stem kernel, fp32 image in / fp16 out (fp16 B fragments)
 Status Conv2d::PrepareDevice(int mode) {
     if (device_ready_ && mode == prepared_mode_) return Status::kSuccess;
     device_ready_ = false;
@@ -170,7 +170,18 @@ Status Conv2d::PrepareDevice(int mode) {
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
     d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
     if (mode == 1) return PrepareDeviceHalf(d);
-    wino_tile_ = mode == 0 ? WinogradTile(d) : 0;
+    if (mode == 2) {
+        wino_tile_ = 0;
+        use_winograd_ = false;
+        std::vector<uint16_t> packed(si_hip_conv2d_stem_f16_weight_elems(&d));
+        CHECK_BOOL(!packed.empty());
+        CHECK_STATUS(CheckHip(si_hip_conv2d_stem_f16_pack_weight_host(&d, weight_.data(), packed.data()), "pack stem weight"));
+        CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(uint16_t)), "upload weight"));
+        if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_.data(), bias_.size() * sizeof(float)), "upload bias"));
+        device_ready_ = true;
+        return Status::kSuccess;
+    }
+    wino_tile_ = WinogradTile(d);
     use_winograd_ = wino_tile_ != 0;
     if ((algo_ == Algo::kWinograd23 || algo_ == Algo::kWinograd43) && !use_winograd_) {
         LOG(ERROR) << "Conv2d: Winograd requested for a shape it does not support";
@@ -300,7 +311,7 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
         d.res_ld = residual->PixelStride();
     }
     if (mode == 2)
-        return CheckHip(si_hip_conv2d_stem_f16(&d, input.Data<float>(), weight_dev_.As<float>(),
+        return CheckHip(si_hip_conv2d_stem_f16(&d, input.Data<float>(), weight_dev_.As<void>(),
                                                use_bias_ ? bias_dev_.As<float>() : nullptr, output.RawData(), Stream()),
                         "conv2d stem (fp16 out)");
     if (mode == 1) {
@@ -369,7 +380,7 @@ const char* Conv2d::KernelName() const {
     if (sibling_) d.oc += sibling_->out_channels_;
     const int mode = PrecisionMode(in, out);
     if (mode == 1) return "conv_igemm_f16_kernel<64, 64, 2, 2>";
-    if (mode == 2) return "conv_smallc_rows_kernel (fp16 out)";
+    if (mode == 2) return "conv_stem_f16_kernel";
     const int tile = WinogradTile(d);
     if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
     return si_hip_conv2d_kernel_name(&d, in.Data<float>());

@@ -415,9 +415,14 @@ def conv2d_f16(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1,
     dy = DeviceBuffer(n * oh * ow * out_ld * osz)
     dy.fill(0)
     if kind == 2:
-        packed = np.zeros(H.si_hip_conv2d_weight_elems(C.byref(d)), np.float32)
-        _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack")
-        dx, dw = DeviceBuffer.from_numpy(_f32(x)), DeviceBuffer.from_numpy(packed)
+        packed = np.zeros(H.si_hip_conv2d_stem_f16_weight_elems(C.byref(d)), np.float16)
+        _chk(H.si_hip_conv2d_stem_f16_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p),
+                                                       packed.ctypes.data_as(C.c_void_p)), "pack stem f16")
+        xs = _f32(x)
+        if in_ld != ic:
+            xs = np.zeros((n, ih, iw, in_ld), np.float32)
+            xs[..., :ic] = x
+        dx, dw = DeviceBuffer.from_numpy(xs), DeviceBuffer.from_numpy(packed)
         _chk(H.si_hip_conv2d_stem_f16(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dy.ptr + 2 * out_c_off, None),
              "si_hip_conv2d_stem_f16")
         y = dy.to_numpy((n, oh, ow, out_ld), np.float16)

@@ -83,15 +83,50 @@ def test_conv_f16_batch_invariance_with_odd_pixel_counts(hops, hw, ic, oc, k, p,
             assert_exact(one[0], full[i], "image %d, act %s" % (i, act))
 
 
-@pytest.mark.parametrize("k,s,p,oc,size", [(6, 2, 2, 32, 64), (7, 2, 3, 64, 56)])
-def test_stem_f16_output(hops, orc, k, s, p, oc, size):
-    x = rng_uniform(10 + k, (2, size, size, 3), 0, 1)            # the stem reads the fp32 image
+STEM_CASES = [
+    # k, s, p, oc, n, h, w, act          (6x6 = YOLOv5, 7x7 = ResNet, 3x3 = MobileNet stems)
+    (6, 2, 2, 32, 2, 64, 64, "silu"),
+    (6, 2, 2, 32, 3, 40, 328, "silu"),      # two 160-pixel column tiles + a ragged one, odd row-block count
+    (6, 2, 2, 64, 2, 32, 48, "relu"),       # 64 channels: two channel waves per workgroup
+    (6, 2, 1, 32, 2, 30, 36, "none"),       # pad 1: fragments start on odd half indices (funnel-shift path)
+    (7, 2, 3, 64, 2, 56, 56, "relu"),
+    (7, 2, 3, 32, 1, 33, 47, "silu"),       # odd width: element-wise row loads
+    (3, 2, 1, 16, 2, 48, 48, "hardswish"),
+    (3, 2, 1, 96, 1, 24, 40, "silu"),       # > 64 channels: channel tiles as items
+    (3, 1, 1, 32, 1, 20, 24, "relu"),       # stride 1
+]
+
+
+@pytest.mark.parametrize("k,s,p,oc,n,ih,iw,act", STEM_CASES)
+def test_stem_f16_output(hops, orc, k, s, p, oc, n, ih, iw, act):
+    """The stem of the fp16 path reads the fp32 image, rounds it to fp16 on the way into LDS and contracts on the fp16
+    matrix cores: the yardstick is the oracle on fp16-rounded image and weights (same contract as every other fp16 conv)."""
+    x = rng_uniform(10 + k, (n, ih, iw, 3), 0, 1)
     w = rng_uniform(11 + k, (oc, 3, k, k), -0.3, 0.3)
     b = rng_uniform(12 + k, (oc,), -0.5, 0.5)
-    ref = orc.activation("silu", orc.conv2d(x, w, b, (s, s), (p, p), path="naive"))
-    got = hops.conv2d_f16(x, w, b, (s, s), (p, p), act1="silu")
-    assert got.dtype == np.float16
-    assert_parity(got.astype(np.float32), ref, F16_TOL, what="stem")
+    fact = (lambda t: t) if act == "none" else (lambda t: orc.activation(act, t))
+    ref = fact(orc.conv2d(h(x), h(w), b, (s, s), (p, p), path="naive"))
+    got = hops.conv2d_f16(x, w, b, (s, s), (p, p), act1=act)
+    assert got.dtype == np.float16 and got.shape == ref.shape
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="stem %dx%d" % (k, k))
+    # against the unrounded operands the error is the fp16 rounding of the image and the weights
+    full = fact(orc.conv2d(x, w, b, (s, s), (p, p), path="naive"))
+    assert_parity(got.astype(np.float32), full, 4 * F16_TOL, what="stem vs fp32 operands")
+    if n > 1:
+        one = hops.conv2d_f16(x[n - 1:n], w, b, (s, s), (p, p), act1=act)
+        assert_exact(one[0], got[n - 1], "an image's result does not depend on the batch")
+
+
+def test_stem_f16_strided_output_and_two_channel_image(hops, orc):
+    x = rng_uniform(31, (2, 32, 32, 2), 0, 1)
+    w = rng_uniform(32, (32, 2, 3, 3), -0.3, 0.3)   # kw*c = 6 does not form a supported kernel row: no stem kernel
+    with pytest.raises(hops.HipError):
+        hops.conv2d_f16(x, w, None, (2, 2), (1, 1))
+    x = rng_uniform(33, (2, 32, 32, 3), 0, 1)
+    w = rng_uniform(34, (32, 3, 6, 6), -0.3, 0.3)
+    ref = orc.conv2d(h(x), h(w), None, (2, 2), (2, 2), path="naive")
+    got = hops.conv2d_f16(x, w, None, (2, 2), (2, 2), in_ld=4, out_ld=96, out_c_off=32)   # strided image: element-wise loads
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="strided stem")
 
 
 def test_conv_split_f16(hops, orc):
