@@ -17,12 +17,14 @@
 // One wave owns 32 consecutive output pixels of one output row and NT*32 output channels.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdlib>
 
 #include "si_hip.h"
 #include "si_hip_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -38,7 +40,7 @@ struct SmallCArgs {
     int row_len;        // floats staged per input row
     int n_in_rows;
     int w_tiles, oc_tiles, row_blocks;
-    int items;          // n * row_blocks * w_tiles * oc_tiles
+    int items;          // n * row_blocks * w_tiles (per channel tile)
     unsigned in_bytes;  // extent of the input tensor for the buffer resource (< 4 GB)
     int act1, act2;
     float act_param;
@@ -59,7 +61,7 @@ __device__ __forceinline__ float act_any(int act, float v, float p) {
 // NW waves per workgroup (32*NW output pixels along W), NT 32-wide output-channel tiles per wave, RB output rows per
 // item, HP = (kw*c rounded up to even)/2 MFMA steps per kernel row (compile time: 9 for 6x6x3, 11 for 7x7x3),
 // PF = prefetch registers per thread (>= n_in_rows*row_len / (64*NW)).
-template <int NW, int NT, int RB, int HP, int PF, typename OutT = float>
+template <int NW, int NT, int RB, int HP, int PF, typename OutT, bool VEC>
 __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NTHR = NW * 64;
@@ -69,60 +71,58 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
 
-    float pre[PF];
+    f32x4 pre[PF / 4];
 
-    // item -> coordinates (oc tile fastest, then column tile, row block, image)
-    auto decode = [&](int item, int& img, int& oy0, int& ox0, int& oc0) {
+    // item -> coordinates (column tile fastest, then row block, image); the channel tile is blockIdx.y, so bias and
+    // everything else that is loaded from global memory besides the row prefetch is read once, before the item loop
+    const int oc0 = blockIdx.y * 32 * NT;
+    auto decode = [&](int item, int& img, int& oy0, int& ox0) {
         int t = item;
-        const int ot = t % a.oc_tiles; t /= a.oc_tiles;
         const int wt = t % a.w_tiles; t /= a.w_tiles;
         const int rbk = t % a.row_blocks; t /= a.row_blocks;
-        img = t; oy0 = rbk * RB; ox0 = wt * TOW; oc0 = ot * 32 * NT;
+        img = t; oy0 = rbk * RB; ox0 = wt * TOW;
     };
 
-    // issue the global loads of one item's input rows into registers (zero outside the image)
-    // register q holds element e = tid + (q % PER_ROW) * NTHR of staged row r = q / PER_ROW (no divisions at run time)
-    constexpr int PER_ROW = 4;   // ceil(row_len / NTHR) <= 4 for every instantiated shape (checked at launch)
-    constexpr int MAX_ROWS = PF / PER_ROW;
-    // Raw buffer loads: an element outside the image gets an out-of-range offset and the hardware returns 0, so the
-    // loaded value is not touched (no select, hence no wait) until it is committed to LDS after the MFMAs.
+    // Issue the global loads of one item's input rows into registers (zero outside the image).  The staged window starts
+    // at a multiple of 4 floats of the image row; thread t holds floats [4t, 4t+4) of every staged row.  VEC (dense image,
+    // width*channels a multiple of 4, 16-byte aligned base): one 16-byte load per row -- a vector lies inside its row or
+    // entirely outside, and then an offset outside the buffer makes the hardware return zeros.  Otherwise element-wise
+    // loads with per-element bounds.  The values are not touched until they are committed to LDS after the MFMAs.
+    constexpr int MAX_ROWS = PF / 4;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+    const int row_floats = a.iw * a.c;
+    const bool mine = 4 * tid < a.row_len;
     auto prefetch = [&](int item) {
-        int img, oy0, ox0, oc0;
-        decode(item, img, oy0, ox0, oc0);
-        const int ix0 = ox0 * a.sw - a.pl, iy0 = oy0 * a.sh - a.pt;
-        const int lo = ix0 < 0 ? -ix0 * a.c : 0;
-        const int hi = min(a.row_len, (a.iw - ix0) * a.c);
-        const bool dense = a.in_ld == a.c;
+        int img, oy0, ox0;
+        decode(item, img, oy0, ox0);
+        const int x0 = (ox0 * a.sw - a.pl) * a.c, iy0 = oy0 * a.sh - a.pt;
+        const int e = (x0 & ~3) + 4 * tid;
 #pragma unroll
         for (int r = 0; r < MAX_ROWS; ++r) {
             const int y = iy0 + r;
-            const bool yok = r < a.n_in_rows && (unsigned)y < (unsigned)a.ih;
-            // byte offset of staged element 0 of this row, modulo 2^32 (ix0 may be negative; valid elements land in range)
-            const unsigned row_off = ((unsigned)((img * a.ih + (yok ? y : 0)) * a.iw + ix0)) * (unsigned)(a.in_ld * 4);
+            const bool yok = mine && r < a.n_in_rows && (unsigned)y < (unsigned)a.ih;
+            if (VEC) {
+                unsigned off = ((unsigned)((img * a.ih + y) * row_floats + e)) * 4u;  // modulo 2^32
+                if (!(yok && e >= 0 && e + 3 < row_floats)) off = 0xFFFFFF00u;
+                pre[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+            } else {
 #pragma unroll
-            for (int p = 0; p < PER_ROW; ++p) {
-                const int e = tid + p * NTHR;
-                unsigned off;
-                if (dense) {
-                    off = row_off + (unsigned)e * 4u;
-                } else {
-                    const int px = e / a.c, ch = e - px * a.c;
-                    off = row_off + (unsigned)(px * a.in_ld + ch) * 4u;
+                for (int t = 0; t < 4; ++t) {
+                    const int ee = e + t;
+                    const int px = ee / a.c, ch = ee - px * a.c;
+                    unsigned off = ((unsigned)(((img * a.ih + y) * a.iw + px) * a.in_ld + ch)) * 4u;
+                    if (!(yok && ee >= 0 && ee < row_floats)) off = 0xFFFFFF00u;
+                    pre[r][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0));
                 }
-                if (!(yok && e >= lo && e < hi)) off = 0xFFFFFF00u;
-                pre[r * PER_ROW + p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0));
             }
         }
     };
     auto commit = [&](float* buf) {
+        if (mine) {
 #pragma unroll
-        for (int r = 0; r < MAX_ROWS; ++r)
-#pragma unroll
-            for (int p = 0; p < PER_ROW; ++p) {
-                const int e = tid + p * NTHR;
-                if (r < a.n_in_rows && e < a.row_len) buf[r * a.row_len + e] = pre[r * PER_ROW + p];
-            }
+            for (int r = 0; r < MAX_ROWS; ++r)
+                if (r < a.n_in_rows) *reinterpret_cast<f32x4*>(buf + r * a.row_len + 4 * tid) = pre[r];
+        }
     };
 
     int item = blockIdx.x;
@@ -137,6 +137,15 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
         float4* dst = reinterpret_cast<float4*>(wl);
         for (int i = tid; i < nvec; i += NTHR) dst[i] = src[i];
     }
+    float bvv[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const int o = oc0 + u * 32 + l31;
+        bvv[u] = (a.bias && o < a.oc) ? a.bias[o] : 0.0f;
+    }
+    // nothing but the next item's rows is pending inside the loop (a load still in flight at the loop head makes the
+    // compiler wait for ALL outstanding loads -- the prefetch included -- at its first use)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
 
     const int px_off = (wave * 32 + l31) * a.sw * a.c + lh;  // lane half h reads element 2*jj + h of a kernel row
@@ -144,9 +153,9 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
         const int next = item + gridDim.x;
         if (next < a.items) prefetch(next);
 
-        int img, oy0, ox0, oc0;
-        decode(item, img, oy0, ox0, oc0);
-        const float* rows = smem;
+        int img, oy0, ox0;
+        decode(item, img, oy0, ox0);
+        const float* rows = smem + (((ox0 * a.sw - a.pl) * a.c) & 3);  // the item's first pixel within the staged window
 
 #pragma unroll 1
         for (int rb = 0; rb < RB; ++rb) {
@@ -186,27 +195,27 @@ __global__ __launch_bounds__(NW * 64) void conv_smallc_rows_kernel(const SmallCA
             for (int u = 0; u < NT; ++u) {
                 const int o = oc0 + u * 32 + l31;
                 if (o >= a.oc) continue;
-                const float bvv = a.bias ? a.bias[o] : 0.0f;
+                const float bvu = bvv[u];
                 OutT* orow = static_cast<OutT*>(a.out) + mrow * a.out_ld + o;
                 if (simple && a.act1 == SI_ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int ox = oxb + (e & 3) + 8 * (e >> 2);
-                        const float v = acc[u][e] + bvv;
+                        const float v = acc[u][e] + bvu;
                         if (ox < a.ow) orow[(size_t)ox * a.out_ld] = si_store_cast<OutT>(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)));
                     }
                 } else if (simple && a.act1 == SI_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int ox = oxb + (e & 3) + 8 * (e >> 2);
-                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = si_store_cast<OutT>(fmaxf(acc[u][e] + bvv, 0.0f));
+                        if (ox < a.ow) orow[(size_t)ox * a.out_ld] = si_store_cast<OutT>(fmaxf(acc[u][e] + bvu, 0.0f));
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int ox = oxb + (e & 3) + 8 * (e >> 2);
                         if (ox < a.ow) {
-                            float v = acc[u][e] + bvv;
+                            float v = acc[u][e] + bvu;
                             v = act_any(a.act1, v, a.act_param);
                             if (a.res) v += a.res[(mrow + ox) * a.res_ld + o];
                             v = act_any(a.act2, v, a.act_param);
@@ -231,28 +240,41 @@ int launch_smallc(SmallCArgs a, hipStream_t s) {
     a.w_tiles = (a.ow + TOW - 1) / TOW;
     a.oc_tiles = (a.oc + 32 * NT - 1) / (32 * NT);
     a.row_blocks = (a.oh + RB - 1) / RB;
-    a.row_len = ((TOW - 1) * a.sw + a.kw) * a.c + 2;  // +2: the even-padded kernel row may read one element past
+    // window shift (<= 3) + taps of the last pixel + 2 (the even-padded kernel row may read one element past), rounded to
+    // whole 16-byte vectors
+    a.row_len = (3 + ((TOW - 1) * a.sw + a.kw) * a.c + 2 + 3) / 4 * 4;
     a.n_in_rows = (RB - 1) * a.sh + a.kh;
     if (a.n_in_rows > PF / 4 || a.row_len > 4 * NW * 64) return SI_E_UNSUPPORTED;
-    const long long items = (long long)a.n * a.row_blocks * a.w_tiles * a.oc_tiles;
+    const long long items = (long long)a.n * a.row_blocks * a.w_tiles;
     if (items > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     a.items = (int)items;
     // one row buffer (padded so the weight image behind it is 16-byte aligned) + the weight image
-    while ((a.n_in_rows * a.row_len) % 4 != 0) a.row_len += 1;
     const size_t lds = ((size_t)a.n_in_rows * a.row_len + (size_t)a.kh * 2 * HP * a.ocp) * sizeof(float);
     if (lds > 160 * 1024) return SI_E_UNSUPPORTED;
-    auto kern = conv_smallc_rows_kernel<NW, NT, RB, HP, PF, OutT>;
-    static bool attr_set = false;
+    const bool vec = a.in_ld == a.c && (a.iw * a.c) % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
+    auto kern = vec ? conv_smallc_rows_kernel<NW, NT, RB, HP, PF, OutT, true> : conv_smallc_rows_kernel<NW, NT, RB, HP, PF, OutT, false>;
+    static bool attr_set_v[2] = {false, false};
+    bool& attr_set = attr_set_v[vec ? 1 : 0];
     if (lds > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    // persistent grid: as many workgroups as stay resident (LDS-limited), never more than there are items
-    const int per_cu = (int)((160 * 1024) / lds);
-    int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    // persistent grid: exactly the workgroups that are resident at once (registers or LDS, whichever binds)
+    static int per_cu_v[2] = {0, 0};
+    static size_t per_cu_lds_v[2] = {0, 0};
+    int& per_cu = per_cu_v[vec ? 1 : 0];
+    size_t& per_cu_lds = per_cu_lds_v[vec ? 1 : 0];
+    if (per_cu == 0 || per_cu_lds != lds) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, lds) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb;
+        per_cu_lds = lds;
+    }
+    int grid = 256 * per_cu / a.oc_tiles;
+    if (grid < 1) grid = 1;
     if ((long long)grid > items) grid = (int)items;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid, a.oc_tiles), dim3(NW * 64), lds, s, a);
     return (int)hipGetLastError();
 }
 
