@@ -242,10 +242,13 @@ __device__ __forceinline__ void epilogue_yolo(const ConvArgs& a, f32x16 (&acc)[T
 }
 
 // `interior`: every row of the workgroup's tile is below M (workgroup-uniform)
+// `yolo_img` >= 0: the tile also lies inside that one image (Detect decode takes its straight-line form)
 template <int TM, int TN>
-__device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior = false) {
+__device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior = false,
+                                         int yolo_img = -1) {
     if (a.ymode) {
-        epilogue_yolo<TM, TN>(a, acc, mrow0, ocol0);
+        if (yolo_img >= 0) si_yolo_tile_one_image<TM, TN>(a, a.out, acc, mrow0, ocol0, yolo_img);
+        else epilogue_yolo<TM, TN>(a, acc, mrow0, ocol0);
         return;
     }
     // the shapes the YOLOv5 / ResNet graphs produce get straight-line code; the rest is generic
@@ -584,7 +587,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         }
     }
 
-    epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31, m0 + BM <= a.M);
+    int yolo_img = -1;
+    if (a.ymode && m0 + BM <= a.M) {
+        const int img = m0 / a.ohow;
+        if (m0 - img * a.ohow + BM <= a.ohow) yolo_img = img;
+    }
+    epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31, m0 + BM <= a.M, yolo_img);
 }
 
 template <int BM, int BN, int WM, int WN, int NBUF>

@@ -348,8 +348,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     }
 
     const int mrow0 = m0 + wm * TM * 32 + 4 * lh, ocol0 = n0 + wn * TN * 32 + l31;
-    if (a.ymode) epilogue_yolo_h<TM, TN>(a, acc, mrow0, ocol0);
-    else if (a.out_f32) epilogue_plain<TM, TN, float>(a, acc, g, mrow0, ocol0);
+    if (a.ymode) {
+        const int img = m0 / a.ohow;
+        if (m0 + BM <= a.M && m0 - img * a.ohow + BM <= a.ohow)  // the tile lies inside one image: straight-line decode
+            si_yolo_tile_one_image<TM, TN>(a, static_cast<float*>(a.out), acc, mrow0, ocol0, img);
+        else
+            epilogue_yolo_h<TM, TN>(a, acc, mrow0, ocol0);
+    } else if (a.out_f32) epilogue_plain<TM, TN, float>(a, acc, g, mrow0, ocol0);
     else {
         const bool interior = m0 + BM <= a.M;
         if (a.act1 == SI_ACT_SILU && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_SILU, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior);

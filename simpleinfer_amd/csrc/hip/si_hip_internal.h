@@ -42,4 +42,47 @@ __device__ __forceinline__ unsigned si_pair_halves(float v0, float v1, bool odd)
     return __builtin_bit_cast(unsigned, p);
 }
 
+// YOLOv5 Detect decode of one workgroup's conv tile, straight-line form for a tile that lies inside ONE image and below M
+// (reference src/layer/yolo_detect.cpp:223-266: sigmoid, xy = (2s + grid) * stride, wh = (2s)^2 * anchor, rows
+// [img][row_off + pix*na + anchor][ne]).  Per lane (= output channel) the element kind, the grid / anchor pointer and
+// the output pointer are fixed before the 16-element loop; per element: sigmoid, one masked 4-byte load for the four
+// box channels, two selects, one store.  Args: the conv kernels' argument structs (ocg, bias, yna, yne, ohow, ygrid,
+// yanchor, ystride, yrows_total, yrow_off).  C/D map of the 32x32 MFMA tile as everywhere: col = lane&31 (channel),
+// row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel).
+typedef float si_f32x16 __attribute__((ext_vector_type(16)));
+template <int TM, int TN, typename Args>
+__device__ __forceinline__ void si_yolo_tile_one_image(const Args& a, float* out, si_f32x16 (&acc)[TM][TN], int mrow0, int ocol0, int img) {
+#pragma clang fp contract(off)
+    const int per_pix = a.yna * a.yne;
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = ocol0 + u * 32;
+        const bool live = o < a.ocg;
+        const int oo = live ? o : 0;
+        const float bv = a.bias ? a.bias[oo] : 0.0f;
+        const int anc = oo / a.yne;
+        const int e_ = oo - anc * a.yne;
+        const bool is_xy = e_ < 2, is_box = e_ < 4;
+        const float* const auxp = (is_xy ? a.ygrid + e_ : a.yanchor + (is_box ? e_ - 2 : 0)) + anc * 2;
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int pix0 = mrow0 + t * 32 - img * a.ohow;
+            float* const op = out + ((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix0 * per_pix + oo;
+            const float* const ap = auxp + (size_t)pix0 * a.yna * 2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dm = (e & 3) + 8 * (e >> 2);
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[t][u][e] + bv)));
+                float aux = 0.0f;
+                if (is_box) aux = ap[dm * a.yna * 2];
+                const float t2 = sg * 2.0f;
+                const float xy = (t2 + aux) * a.ystride;
+                const float wh = t2 * t2 * aux;
+                const float v = is_xy ? xy : (is_box ? wh : sg);
+                if (live) op[dm * per_pix] = v;
+            }
+        }
+    }
+}
+
 #endif  // SI_HIP_INTERNAL_H_
