@@ -125,13 +125,14 @@ __device__ __forceinline__ float act_fn(float v, float p) {
 // M" (all tiles but the last) resolved once per workgroup, row offsets c*ld computed once -- per element this leaves
 // bias add, activation, (residual load + add), one store.
 template <int TM, int TN, int ACT1, int ACT2, bool HAS_RES, bool INTERIOR>
-__device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0) {
+__device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0,
+                                              const float* bias_pre) {
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
         const int o = ocol0 + u * 32;  // channel inside the group
         if (o >= a.ocg) continue;
         const int oc_abs = g * a.ocg + o;
-        const float bv = a.bias ? a.bias[oc_abs] : 0.0f;
+        const float bv = bias_pre ? bias_pre[u] : (a.bias ? a.bias[oc_abs] : 0.0f);
         const bool second = a.out2 != nullptr && oc_abs >= a.split;
         float* const obase = second ? a.out2 + (oc_abs - a.split) : a.out + oc_abs;
         const int old = second ? a.out2_ld : a.out_ld;
@@ -154,13 +155,14 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[T
 }
 
 template <int TM, int TN, int ACT1, int ACT2 = SI_ACT_NONE>
-__device__ __forceinline__ void epilogue_pick(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior) {
+__device__ __forceinline__ void epilogue_pick(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior,
+                                              const float* bias_pre) {
     if (a.res) {
-        if (interior) epilogue_lean<TM, TN, ACT1, ACT2, true, true>(a, acc, g, mrow0, ocol0);
-        else epilogue_lean<TM, TN, ACT1, ACT2, true, false>(a, acc, g, mrow0, ocol0);
+        if (interior) epilogue_lean<TM, TN, ACT1, ACT2, true, true>(a, acc, g, mrow0, ocol0, bias_pre);
+        else epilogue_lean<TM, TN, ACT1, ACT2, true, false>(a, acc, g, mrow0, ocol0, bias_pre);
     } else {
-        if (interior) epilogue_lean<TM, TN, ACT1, ACT2, false, true>(a, acc, g, mrow0, ocol0);
-        else epilogue_lean<TM, TN, ACT1, ACT2, false, false>(a, acc, g, mrow0, ocol0);
+        if (interior) epilogue_lean<TM, TN, ACT1, ACT2, false, true>(a, acc, g, mrow0, ocol0, bias_pre);
+        else epilogue_lean<TM, TN, ACT1, ACT2, false, false>(a, acc, g, mrow0, ocol0, bias_pre);
     }
 }
 
@@ -243,9 +245,11 @@ __device__ __forceinline__ void epilogue_yolo(const ConvArgs& a, f32x16 (&acc)[T
 
 // `interior`: every row of the workgroup's tile is below M (workgroup-uniform)
 // `yolo_img` >= 0: the tile also lies inside that one image (Detect decode takes its straight-line form)
+// `bias_pre`: this lane's TN bias values, loaded before the K loop (their latency is otherwise paid at the head of the
+// epilogue, by every workgroup of a round at the same time)
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior = false,
-                                         int yolo_img = -1) {
+                                         int yolo_img = -1, const float* bias_pre = nullptr) {
     if (a.ymode) {
         if (yolo_img >= 0) si_yolo_tile_one_image<TM, TN>(a, a.out, acc, mrow0, ocol0, yolo_img);
         else epilogue_yolo<TM, TN>(a, acc, mrow0, ocol0);
@@ -253,13 +257,13 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN
     }
     // the shapes the YOLOv5 / ResNet graphs produce get straight-line code; the rest is generic
     if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_SILU) {
-        epilogue_pick<TM, TN, SI_ACT_SILU>(a, acc, g, mrow0, ocol0, interior);
+        epilogue_pick<TM, TN, SI_ACT_SILU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
     } else if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_NONE) {
-        epilogue_pick<TM, TN, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior);
+        epilogue_pick<TM, TN, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior, bias_pre);
     } else if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_RELU) {
-        epilogue_pick<TM, TN, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior);
+        epilogue_pick<TM, TN, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
     } else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_RELU) {  // ResNet: conv -> add -> ReLU
-        epilogue_pick<TM, TN, SI_ACT_NONE, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior);
+        epilogue_pick<TM, TN, SI_ACT_NONE, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
     } else {
         epilogue_generic<TM, TN>(a, acc, g, mrow0, ocol0);
     }
@@ -550,6 +554,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     const int nk = a.Kp / BK;  // icg_pad % 32 == 0
 
     load_tile(0);
+    // this lane's bias values ride along with the first tile's loads
+    float bias_pre[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = n0 + wn * TN * 32 + l31 + u * 32;
+        bias_pre[u] = (a.bias && o < a.ocg) ? a.bias[g * a.ocg + o] : 0.0f;
+    }
     store_tile(0);
     __syncthreads();
 
@@ -592,7 +603,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         const int img = m0 / a.ohow;
         if (m0 - img * a.ohow + BM <= a.ohow) yolo_img = img;
     }
-    epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31, m0 + BM <= a.M, yolo_img);
+    epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31, m0 + BM <= a.M, yolo_img, bias_pre);
 }
 
 template <int BM, int BN, int WM, int WN, int NBUF>

@@ -114,13 +114,14 @@ __device__ __forceinline__ float act_c(float v, float p) {
 
 // straight-line fp16 epilogue for the combinations the graphs produce (see conv_igemm.hip epilogue_lean)
 template <int TM, int TN, int ACT1, int ACT2, bool HAS_RES, bool INTERIOR>
-__device__ __forceinline__ void epilogue_lean_h(const ConvArgsH& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0) {
+__device__ __forceinline__ void epilogue_lean_h(const ConvArgsH& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0,
+                                                const float* bias_pre) {
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
         const int o = ocol0 + u * 32;
         if (o >= a.ocg) continue;
         const int oc_abs = g * a.ocg + o;
-        const float bv = a.bias ? a.bias[oc_abs] : 0.0f;
+        const float bv = bias_pre[u];  // loaded before the K loop
         const bool second = a.out2 != nullptr && oc_abs >= a.split;
         half_t* const obase = second ? a.out2 + (oc_abs - a.split) : static_cast<half_t*>(a.out) + oc_abs;
         const int old = second ? a.out2_ld : a.out_ld;
@@ -143,13 +144,14 @@ __device__ __forceinline__ void epilogue_lean_h(const ConvArgsH& a, f32x16 (&acc
 }
 
 template <int TM, int TN, int ACT1, int ACT2>
-__device__ __forceinline__ void epilogue_pick_h(const ConvArgsH& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior) {
+__device__ __forceinline__ void epilogue_pick_h(const ConvArgsH& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior,
+                                                const float* bias_pre) {
     if (a.res) {
-        if (interior) epilogue_lean_h<TM, TN, ACT1, ACT2, true, true>(a, acc, g, mrow0, ocol0);
-        else epilogue_lean_h<TM, TN, ACT1, ACT2, true, false>(a, acc, g, mrow0, ocol0);
+        if (interior) epilogue_lean_h<TM, TN, ACT1, ACT2, true, true>(a, acc, g, mrow0, ocol0, bias_pre);
+        else epilogue_lean_h<TM, TN, ACT1, ACT2, true, false>(a, acc, g, mrow0, ocol0, bias_pre);
     } else {
-        if (interior) epilogue_lean_h<TM, TN, ACT1, ACT2, false, true>(a, acc, g, mrow0, ocol0);
-        else epilogue_lean_h<TM, TN, ACT1, ACT2, false, false>(a, acc, g, mrow0, ocol0);
+        if (interior) epilogue_lean_h<TM, TN, ACT1, ACT2, false, true>(a, acc, g, mrow0, ocol0, bias_pre);
+        else epilogue_lean_h<TM, TN, ACT1, ACT2, false, false>(a, acc, g, mrow0, ocol0, bias_pre);
     }
 }
 
@@ -318,6 +320,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (d < nk) load_tile(pa[d], pb[d], d);
+    // this lane's bias values ride along with the first tile's loads (in the epilogue their latency would be paid by every
+    // workgroup of a round at the same time)
+    float bias_pre[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = n0 + wn * TN * 32 + l31 + u * 32;
+        bias_pre[u] = (a.bias && o < a.ocg) ? a.bias[g * a.ocg + o] : 0.0f;
+    }
 
     const half_t* As = lds + (wm * TM * 32 + l31) * LDH + lh * 8;
     const half_t* Bs = lds + BM * LDH + (wn * TN * 32 + l31) * LDH + lh * 8;
@@ -357,10 +367,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     } else if (a.out_f32) epilogue_plain<TM, TN, float>(a, acc, g, mrow0, ocol0);
     else {
         const bool interior = m0 + BM <= a.M;
-        if (a.act1 == SI_ACT_SILU && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_SILU, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior);
-        else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_NONE, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior);
-        else if (a.act1 == SI_ACT_RELU && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_RELU, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior);
-        else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_RELU) epilogue_pick_h<TM, TN, SI_ACT_NONE, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior);
+        if (a.act1 == SI_ACT_SILU && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_SILU, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_NONE, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        else if (a.act1 == SI_ACT_RELU && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_RELU, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_RELU) epilogue_pick_h<TM, TN, SI_ACT_NONE, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
         else epilogue_plain<TM, TN, half_t>(a, acc, g, mrow0, ocol0);
     }
 }

@@ -253,24 +253,9 @@ int launch_smallc(SmallCArgs a, hipStream_t s) {
     if (lds > 160 * 1024) return SI_E_UNSUPPORTED;
     const bool vec = a.in_ld == a.c && (a.iw * a.c) % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
     auto kern = vec ? conv_smallc_rows_kernel<NW, NT, RB, HP, PF, OutT, true> : conv_smallc_rows_kernel<NW, NT, RB, HP, PF, OutT, false>;
-    static bool attr_set_v[2] = {false, false};
-    bool& attr_set = attr_set_v[vec ? 1 : 0];
-    if (lds > 64 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (hipError_t e = si_allow_dynamic_lds(kern, lds); e != hipSuccess) return (int)e;
     // persistent grid: exactly the workgroups that are resident at once (registers or LDS, whichever binds)
-    static int per_cu_v[2] = {0, 0};
-    static size_t per_cu_lds_v[2] = {0, 0};
-    int& per_cu = per_cu_v[vec ? 1 : 0];
-    size_t& per_cu_lds = per_cu_lds_v[vec ? 1 : 0];
-    if (per_cu == 0 || per_cu_lds != lds) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NW * 64, lds) != hipSuccess || nb < 1) nb = 1;
-        per_cu = nb;
-        per_cu_lds = lds;
-    }
+    const int per_cu = si_resident_blocks(kern, NW * 64, lds);
     int grid = 256 * per_cu / a.oc_tiles;
     if (grid < 1) grid = 1;
     if ((long long)grid > items) grid = (int)items;

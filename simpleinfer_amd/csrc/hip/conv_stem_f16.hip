@@ -261,14 +261,7 @@ int launch_stem(StemArgs a, hipStream_t s) {
     // persistent grid: exactly the workgroups that are resident at once (a workgroup that has to wait for a slot would
     // start its share of the items when the others are finishing theirs)
     auto launch = [&](auto kern) {
-        static int per_cu = 0;  // per instantiation
-        static size_t per_cu_lds = 0;
-        if (per_cu == 0 || per_cu_lds != lds) {
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NTHR, lds) != hipSuccess || nb < 1) nb = 1;
-            per_cu = nb;
-            per_cu_lds = lds;
-        }
+        const int per_cu = si_resident_blocks(kern, NTHR, lds);
         int grid = 256 * per_cu / a.oc_tiles;
         if (grid < 1) grid = 1;
         if ((long long)grid > items) grid = (int)items;

@@ -103,6 +103,10 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     const int row0 = by * TBH;               // first flattened tile row of the block
     const int col0 = bc * TBW;               // first tile column
     const int oc0 = ocb * 32;
+    // this lane's output channel and its bias, loaded up front (not at the head of the epilogue)
+    const int o = oc0 + ((int)threadIdx.x & 31);
+    const bool ocok = o < a.oc;
+    const float bv = (a.bias && ocok) ? a.bias[o] : 0.0f;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
 
@@ -269,9 +273,6 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     }
     __syncthreads();
     const int i_out = wave & 1, jc = wave >> 1;
-    const int o = oc0 + l31;
-    const bool ocok = o < a.oc;
-    const float bv = (a.bias && ocok) ? a.bias[o] : 0.0f;
     // activation / residual combination resolved once per workgroup: the loop body is straight-line code
     auto finish = [&](auto act1, auto act2, auto has_res) {
 #pragma clang fp contract(off)  // every instantiation must round alike (bit-exact batch sharding)

@@ -4,6 +4,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #define SI_HIP_TRY(expr)                      \
     do {                                      \
         hipError_t _e = (expr);               \
@@ -17,6 +21,37 @@ static inline unsigned si_grid_for(size_t work_items, unsigned block = 256) {
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     return (unsigned)blocks;
+}
+
+// Workgroups of `kern` that are resident per CU at this block size and dynamic-LDS size: the grid of a persistent kernel
+// (a workgroup that has to wait for a slot starts its share of the work when the others are finishing theirs).  Cached
+// per (kernel, LDS size); engines may launch from several host threads, hence the lock.
+template <typename Kern>
+static inline int si_resident_blocks(Kern kern, int threads, size_t lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int> cache;
+    const std::pair<const void*, size_t> key(reinterpret_cast<const void*>(kern), lds);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, threads, lds) != hipSuccess || nb < 1) nb = 1;
+    cache[key] = nb;
+    return nb;
+}
+
+// Dynamic LDS above the 64 KB default needs the per-function opt-in once (not again during a stream capture).
+template <typename Kern>
+static inline hipError_t si_allow_dynamic_lds(Kern kern, size_t lds) {
+    if (lds <= 64 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::map<const void*, size_t> allowed;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = allowed[reinterpret_cast<const void*>(kern)];
+    if (have >= lds) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) have = lds;
+    return e;
 }
 
 // fp32 -> storage type. For _Float16 the empty asm keeps the value opaque so the compiler cannot fold the multiply / add
