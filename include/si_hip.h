@@ -288,6 +288,14 @@ int si_hip_activation_f16(int act, float act_param, const void* in, size_t pixel
 int si_hip_binary_same_f16(int op, const void* a, int a_ld, const void* b, int b_ld, void* out, int out_ld, size_t pixels,
                            int c, si_stream_t stream);
 int si_hip_maxpool2d_f16(const SiPool2dDesc* d, const void* in, void* out, si_stream_t stream);
+/* SPPF pool chain: out1 = maxpool5(in), out2 = maxpool5(out1), out3 = maxpool5(out2), all 5x5 stride 1 pad 2 on [n,h,w,c]
+ * maps -- three consecutive MaxPool2d::Forward calls of the reference (src/layer/max_pool_2d.cpp:77-121) in one launch
+ * that reads `in` once (csrc/hip/pool_chain.hip).  Strides in elements; every tensor 16-byte aligned with c and the
+ * strides multiples of 4 (f32) / 8 (f16), else SI_E_UNSUPPORTED (also for maps too large for LDS): run three pools. */
+int si_hip_maxpool5_chain3_f32(const float* in, int n, int h, int w, int c, int in_ld, float* out1, int out1_ld, float* out2,
+                               int out2_ld, float* out3, int out3_ld, si_stream_t stream);
+int si_hip_maxpool5_chain3_f16(const void* in, int n, int h, int w, int c, int in_ld, void* out1, int out1_ld, void* out2,
+                               int out2_ld, void* out3, int out3_ld, si_stream_t stream);
 int si_hip_adaptive_avgpool2d_f16(const void* in, int n, int ih, int iw, int c, int in_ld, void* out, int oh, int ow,
                                   int out_ld, si_stream_t stream);
 int si_hip_convert_f32_f16(const float* in, size_t pixels, int c, int in_ld, void* out, int out_ld, si_stream_t stream);

@@ -122,6 +122,8 @@ def hip():
         "si_hip_activation_f16": (i, [i, f, vp, sz, i, i, vp, i, vp]),
         "si_hip_binary_same_f16": (i, [i, vp, i, vp, i, vp, i, sz, i, vp]),
         "si_hip_maxpool2d_f16": (i, [C.POINTER(SiPool2dDesc), vp, vp, vp]),
+        "si_hip_maxpool5_chain3_f32": (i, [vp, i, i, i, i, i, vp, i, vp, i, vp, i, vp]),
+        "si_hip_maxpool5_chain3_f16": (i, [vp, i, i, i, i, i, vp, i, vp, i, vp, i, vp]),
         "si_hip_adaptive_avgpool2d_f16": (i, [vp, i, i, i, i, i, vp, i, i, i, vp]),
         "si_hip_convert_f32_f16": (i, [vp, sz, i, i, vp, i, vp]),
         "si_hip_convert_f16_f32": (i, [vp, sz, i, i, vp, i, vp]),

@@ -8,6 +8,7 @@
 #include "layer/binary_op.h"
 #include "layer/cat.h"
 #include "layer/conv_2d.h"
+#include "layer/max_pool_2d.h"
 #include "layer/yolo_detect.h"
 #include "layer_registry.h"
 #include "logger.h"
@@ -336,6 +337,7 @@ Status EngineImpl::CreatePipeline() {
     if (opt_fuse_) {
         CHECK_STATUS(FuseEpilogues(order));
         CHECK_STATUS(FuseSiblingConvs(order));
+        CHECK_STATUS(FusePoolChains(order));
     }
     if (opt_fp16_) CHECK_STATUS(InsertOutputCasts(order));
     plan_ = order;
@@ -465,6 +467,46 @@ Status EngineImpl::FuseSiblingConvs(std::vector<Step>& order) {
             sibling_ops_.insert(order[j].op->name);
             break;
         }
+    }
+    std::vector<Step> out;
+    for (size_t i = 0; i < order.size(); ++i)
+        if (!removed[i]) out.push_back(order[i]);
+    order.swap(out);
+    return Status::kSuccess;
+}
+
+// SPPF: maxpool5 -> maxpool5 -> maxpool5 (each fed by the previous one, every intermediate also read by the concat)
+// ==> one launch at the first pool's slot that reads the input once and writes all three operands.
+Status EngineImpl::FusePoolChains(std::vector<Step>& order) {
+    std::vector<bool> removed(order.size(), false);
+    auto pool_at = [&](size_t i) -> MaxPool2d* {
+        if (removed[i]) return nullptr;
+        MaxPool2d* p = dynamic_cast<MaxPool2d*>(order[i].layer);
+        return (p && p->InputNodes().size() == 1 && p->OutputNodes().size() == 1 && p->chain_.empty()) ? p : nullptr;
+    };
+    auto follower = [&](size_t from, MaxPool2d* head) -> size_t {
+        for (size_t j = from + 1; j < order.size(); ++j) {
+            MaxPool2d* p = pool_at(j);
+            if (p && p->InputNodes()[0] == head->OutputNodes()[0] && head->ChainHead(*p) &&
+                IsSameShape(p->OutputNodes()[0]->tensor.Shape(), head->OutputNodes()[0]->tensor.Shape()))
+                return j;
+        }
+        return 0;
+    };
+    for (size_t i = 0; i < order.size(); ++i) {
+        MaxPool2d* a = pool_at(i);
+        if (!a || !IsSameShape(a->InputNodes()[0]->tensor.Shape(), a->OutputNodes()[0]->tensor.Shape())) continue;
+        const size_t j = follower(i, a);
+        if (j == 0) continue;
+        MaxPool2d* b = pool_at(j);
+        const size_t k = follower(j, b);
+        if (k == 0) continue;
+        MaxPool2d* c = pool_at(k);
+        a->SetChain(b, c);
+        a->SetOutputNodes({a->OutputNodes()[0], b->OutputNodes()[0], c->OutputNodes()[0]});
+        removed[j] = removed[k] = true;
+        fused_ops_.insert(order[j].op->name);
+        fused_ops_.insert(order[k].op->name);
     }
     std::vector<Step> out;
     for (size_t i = 0; i < order.size(); ++i)

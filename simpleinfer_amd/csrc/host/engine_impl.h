@@ -82,6 +82,7 @@ private:
 
     Status FuseEpilogues(std::vector<Step>& order);
     Status FuseSiblingConvs(std::vector<Step>& order);
+    Status FusePoolChains(std::vector<Step>& order);
     Status InsertOutputCasts(std::vector<Step>& order);
     Status AliasConcats();
     Status UploadInputs();

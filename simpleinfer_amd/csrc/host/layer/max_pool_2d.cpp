@@ -59,4 +59,39 @@ Status MaxPool2d::Forward(const Tensor& input, Tensor& output) {
     });
 }
 
+bool MaxPool2d::ChainHead(const MaxPool2d& next) const {
+    auto sppf = [](const MaxPool2d& p) {
+        return p.kernel_h_ == 5 && p.kernel_w_ == 5 && p.stride_h_ == 1 && p.stride_w_ == 1 && p.dilation_h_ == 1 &&
+               p.dilation_w_ == 1 && p.padding_t_ == 2 && p.padding_l_ == 2 && !p.return_indices_;
+    };
+    return sppf(*this) && sppf(next);
+}
+
+Status MaxPool2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
+    if (chain_.size() != 2 || outputs.size() != 3) return Status::kUnsupport;
+    Status st = RunOnDevice({&input}, {&outputs[0], &outputs[1], &outputs[2]},
+                            [this](const std::vector<Tensor>& in, std::vector<Tensor>& out) {
+        Dims4 id;
+        if (!GetDims4(in[0], id)) return Status::kErrorShape;
+        for (const Tensor& o : out) {
+            Dims4 od;
+            if (!GetDims4(o, od) || od.n != id.n || od.h != id.h || od.w != id.w || od.c != id.c) return Status::kErrorShape;
+            if (IsHalf(o) != IsHalf(in[0])) return Status::kUnsupport;
+        }
+        const int rc = IsHalf(in[0])
+                           ? si_hip_maxpool5_chain3_f16(in[0].RawData(), id.n, id.h, id.w, id.c, in[0].PixelStride(), out[0].RawData(),
+                                                        out[0].PixelStride(), out[1].RawData(), out[1].PixelStride(), out[2].RawData(),
+                                                        out[2].PixelStride(), Stream())
+                           : si_hip_maxpool5_chain3_f32(in[0].Data<float>(), id.n, id.h, id.w, id.c, in[0].PixelStride(),
+                                                        out[0].Data<float>(), out[0].PixelStride(), out[1].Data<float>(),
+                                                        out[1].PixelStride(), out[2].Data<float>(), out[2].PixelStride(), Stream());
+        if (rc == SI_E_UNSUPPORTED) return Status::kEmpty;  // not an error: the caller runs the three pools one by one
+        return CheckHip(rc, "MaxPool2d chain");
+    });
+    if (st != Status::kEmpty) return st;
+    CHECK_STATUS(Forward(input, outputs[0]));
+    CHECK_STATUS(chain_[0]->Forward(outputs[0], outputs[1]));
+    return chain_[1]->Forward(outputs[1], outputs[2]);
+}
+
 }  // namespace SimpleInfer

@@ -137,9 +137,15 @@ public:
     virtual Status Init(const pnnx::Operator* op) override;
     virtual Status Validate() override;
     virtual Status Forward(const Tensor& input, Tensor& output) override;
-    virtual const char* KernelName() const override { return "maxpool"; }
+    // SPPF: this pool and the two that follow it (same 5x5 s1 p2 window, each fed by the previous one) as one launch;
+    // outputs[k] is the k-th pool's operand.  Falls back to three launches where the fused kernel does not apply.
+    virtual Status Forward(const Tensor& input, std::vector<Tensor>& outputs) override;
+    virtual const char* KernelName() const override { return chain_.empty() ? "maxpool" : "maxpool5_chain3"; }
+    bool ChainHead(const MaxPool2d& next) const;  // `next` may follow this pool in a fused chain
+    void SetChain(MaxPool2d* second, MaxPool2d* third) { chain_ = {second, third}; }
 
 public:
+    std::vector<MaxPool2d*> chain_;
     bool ceil_mode_      = false;
     bool return_indices_ = false;
     int padding_t_ = 0, padding_b_ = 0, padding_l_ = 0, padding_r_ = 0;

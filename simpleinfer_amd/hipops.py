@@ -207,6 +207,25 @@ def maxpool2d(x, k, s, p, d=(1, 1)):
     return dy.to_numpy((n, oh, ow, c))
 
 
+def maxpool5_chain3(x, half=False, out_ld=None, out_c_off=(0, 0, 0)):
+    """si_hip_maxpool5_chain3_{f32,f16}: the three chained 5x5 s1 p2 pools of SPPF; the outputs may be channel slices of
+    wider rows (out_ld elements per pixel, starting at out_c_off[k]), as the concat aliasing hands them over."""
+    H = _native.hip()
+    x = _f16(x) if half else _f32(x)
+    n, h, w, c = x.shape
+    esz = 2 if half else 4
+    ld = out_ld or c
+    dx = DeviceBuffer.from_numpy(x)
+    outs = [DeviceBuffer(n * h * w * ld * esz) for _ in range(3)]
+    for o in outs:
+        o.fill(0)
+    fn = H.si_hip_maxpool5_chain3_f16 if half else H.si_hip_maxpool5_chain3_f32
+    _chk(fn(dx.ptr, n, h, w, c, c, outs[0].ptr + esz * out_c_off[0], ld, outs[1].ptr + esz * out_c_off[1], ld,
+            outs[2].ptr + esz * out_c_off[2], ld, None), "si_hip_maxpool5_chain3")
+    dt = np.float16 if half else np.float32
+    return [o.to_numpy((n, h, w, ld), dt)[..., off:off + c].copy() for o, off in zip(outs, out_c_off)]
+
+
 def adaptive_avgpool2d(x, out_hw):
     H = _native.hip()
     x = _f32(x)

@@ -84,6 +84,12 @@ def test_yolov5s_640_batch1_parity(si, orc, tmp_path):
     assert_parity(e.extract(oname), orc.run_graph(pp, bp, {"0": xc})[oname], what="constant input")
 
 
+def _profile_after_forward(si, e, shape):
+    e.input(e.input_names()[0], si.modelgen.synth_input(shape))
+    e.forward()
+    return e.profile()
+
+
 def test_schedule_fusion_and_aliasing(si, tmp_path):
     pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(1, 64), "sched")  # full-width YOLOv5s at 64x64
     e = si.Engine()
@@ -97,10 +103,13 @@ def test_schedule_fusion_and_aliasing(si, tmp_path):
     # the 8 C3 blocks: cv2 is computed by cv1's launch (same input, same 1x1 geometry)
     siblings = [n for n in s["fused"] if n.startswith("conv_")]
     assert len(siblings) == 8
+    # SPPF: the second and third 5x5 pool are produced by the first one's launch
+    assert sorted(n for n in s["fused"] if n.startswith("maxpool")) == ["maxpool_1", "maxpool_2"] and "maxpool_0" in s["run"]
+    assert "maxpool5_chain3" in {L["kernel"] for L in _profile_after_forward(si, e, (1, 64, 64, 3))}
     e2 = si.Engine(fuse=0, alias_cat=0)
     e2.load_model(pp, bp)
     s2 = e2.schedule()
-    assert not s2["fused"] and not s2["alias"] and len(s2["run"]) == len(s["run"]) + 64 + 8
+    assert not s2["fused"] and not s2["alias"] and len(s2["run"]) == len(s["run"]) + 64 + 8 + 2
 
 
 def test_forward_is_repeatable_and_input_is_read_at_forward_time(si, tmp_path):
@@ -247,6 +256,24 @@ def test_fp16_graph_output_from_a_non_conv_layer(si, orc, tmp_path, tail):
         assert len(sch["alias"]) == 2, sch
 
 
+@pytest.mark.parametrize("hw,c", [(72, 32), (12, 6)])
+def test_pool_chain_falls_back_to_three_pools(si, orc, tmp_path, hw, c):
+    """SPPF-shaped pool chains the fused kernel does not take (a map too large for LDS; a channel count that is not a
+    multiple of 4) still run, as three launches, and stay exact."""
+    mg = si.modelgen
+    b = mg.PnnxBuilder(0)
+    x = b.input((2, c, hw, hw))
+    y1 = b.maxpool(x, 5, 1, 2)
+    y2 = b.maxpool(y1, 5, 1, 2)
+    y3 = b.maxpool(y2, 5, 1, 2)
+    b.output(b.cat([x, y1, y2, y3], 1))
+    pp, bp = _save(tmp_path, b, "chain_%d_%d" % (hw, c))
+    xin = mg.synth_input((2, hw, hw, c))
+    e, oname, got = _run(si, pp, bp, xin)
+    assert_exact(got, orc.run_graph(pp, bp, {"0": xin})[oname], "pool chain fallback")
+    assert e.schedule()["run"].count("maxpool_0") == 1 and "maxpool_1" in e.schedule()["fused"]
+
+
 def test_fp16_unsupported_graph_is_a_status(si, tmp_path):
     # toy_yolo has channel counts that are not multiples of 32: the fp16 path says so instead of computing something else
     pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(1, 64), "toy16")
@@ -369,9 +396,9 @@ def test_full_size_properties_yolov5s_640_batch32(si, orc, tmp_path):
     full = e32.extract(oname)
     assert full.shape == (32, 25200, 85) and np.isfinite(full).all()
     assert (full[..., 4:] > 0).all() and (full[..., 4:] < 1).all() and (full[..., 2:4] > 0).all()
-    # 55 launching layers (1 stem + 48 conv + Detect + 3 max pool + 2 upsample; Detect is 3 launches -> 57) + 13 no-op cats
+    # 53 launching layers (1 stem + 48 conv + Detect + 1 fused pool chain + 2 upsample; Detect is 3 launches -> 55) + 13 no-op cats
     run = e32.schedule()["run"]
-    assert len([r for r in run if not r.startswith("cat")]) == 55 and len(run) == 68
+    assert len([r for r in run if not r.startswith("cat")]) == 53 and len(run) == 66
     e1 = si.Engine()
     e1.load_model(pp, bp)
     for k in (0, 13, 31):

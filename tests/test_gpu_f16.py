@@ -129,6 +129,15 @@ def test_stem_f16_strided_output_and_two_channel_image(hops, orc):
     assert_parity(got.astype(np.float32), ref, F16_TOL, what="strided stem")
 
 
+def test_maxpool5_chain3_f16_exact(hops, orc):
+    x = h(rng_uniform(71, (2, 20, 20, 64), -3, 3))
+    cur = x
+    got = hops.maxpool5_chain3(x, half=True, out_ld=256, out_c_off=(64, 128, 192))
+    for k in range(3):
+        cur = orc.maxpool2d(cur, (5, 5), (1, 1), (2, 2))
+        assert_exact(got[k].astype(np.float32), cur, "fp16 stage %d" % k)
+
+
 def test_conv_split_f16(hops, orc):
     x = h(rng_uniform(20, (2, 12, 12, 64), -1, 1))
     wa, wb = h(rng_uniform(21, (32, 64, 1, 1), -0.3, 0.3)), h(rng_uniform(22, (64, 64, 1, 1), -0.3, 0.3))

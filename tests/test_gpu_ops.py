@@ -243,6 +243,27 @@ def test_linear(hops, orc):
     assert_parity(hops.linear(x, w, None), orc.linear(x, w, None))
 
 
+@pytest.mark.parametrize("n,h,w,c", [(2, 20, 20, 64), (3, 13, 7, 24), (1, 5, 5, 8), (2, 40, 40, 4)])
+def test_maxpool5_chain3_exact(hops, orc, n, h, w, c):
+    """SPPF's three chained 5x5 s1 p2 pools in one launch == the reference's MaxPool2d applied three times."""
+    x = rng_uniform(70 + h, (n, h, w, c), -3, 3)
+    want, cur = [], x
+    for _ in range(3):
+        cur = orc.maxpool2d(cur, (5, 5), (1, 1), (2, 2))
+        want.append(cur)
+    got = hops.maxpool5_chain3(x)
+    for k in range(3):
+        assert_exact(got[k], want[k], "stage %d" % k)
+    # outputs as channel slices of a wider concat row (what the engine's aliasing hands over)
+    got = hops.maxpool5_chain3(x, out_ld=4 * c, out_c_off=(c, 2 * c, 3 * c))
+    for k in range(3):
+        assert_exact(got[k], want[k], "strided stage %d" % k)
+    with pytest.raises(hops.HipError):
+        hops.maxpool5_chain3(rng_uniform(1, (1, 80, 80, 8), -1, 1))      # two map planes do not fit 64 KB of LDS
+    with pytest.raises(hops.HipError):
+        hops.maxpool5_chain3(rng_uniform(1, (1, 8, 8, 6), -1, 1))        # channels not a multiple of 4
+
+
 def test_maxpool_exact(hops, orc):
     assert_exact(hops.maxpool2d(GOLD["maxpool_k5s1p2/x"], (5, 5), (1, 1), (2, 2)), GOLD["maxpool_k5s1p2/y"])
     assert_exact(hops.maxpool2d(GOLD["maxpool_k3s2p1/x"], (3, 3), (2, 2), (1, 1)), GOLD["maxpool_k3s2p1/y"])
