@@ -577,6 +577,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
             for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f32x4*>(As + t * 32 * LDS_LD + q * 8);
 #pragma unroll
             for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f32x4*>(Bs + u * 32 * LDS_LD + q * 8);
+            // raised priority around the MFMA cluster: +0.5-1.2 % on YOLOv5s (same-box A/B; per cdna_hip_programming.md T5 the
+            // effect is on how hipcc places the cluster relative to the LDS reads and barriers, not the s_setprio itself)
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -584,6 +587,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 #pragma unroll
                     for (int u = 0; u < TN; ++u)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[u][j], acc[t][u], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
 
         if (NBUF == 2) {
