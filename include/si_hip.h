@@ -132,7 +132,7 @@ const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);
  * si_hip_conv2d_wino23_pack_weight_host into U = G g G^T laid out [16][ic][oc] (replaces
  * Conv3x3s1Winograd23TransformKernelPack4, winograd_helper.cpp:40-143). */
 int si_hip_conv2d_wino23_eligible(const SiConv2dDesc* d);
-/* eligible AND measured faster than si_hip_conv2d_f32 on MI355X (currently: ic >= 64) */
+/* eligible AND measured faster than si_hip_conv2d_f32 on MI355X (currently: ic >= 32) */
 int si_hip_conv2d_wino23_preferred(const SiConv2dDesc* d);
 size_t si_hip_conv2d_wino23_weight_elems(const SiConv2dDesc* d);
 int si_hip_conv2d_wino23_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* u);

@@ -381,7 +381,7 @@ extern "C" int si_hip_conv2d_wino23_eligible(const SiConv2dDesc* d) {
 // channels there are only 2 channel blocks per workgroup, its prologue / exchange epilogue dominate and direct wins
 // (0.184 vs 0.174 ms at 160x160x32).
 extern "C" int si_hip_conv2d_wino23_preferred(const SiConv2dDesc* d) {
-    static const int min_ic = [] { const char* e = getenv("SI_WINO_MIN_IC"); return e ? atoi(e) : 64; }();  // dev override
+    static const int min_ic = [] { const char* e = getenv("SI_WINO_MIN_IC"); return e ? atoi(e) : 32; }();  // dev override
     return si_hip_conv2d_wino23_eligible(d) && d->ic >= min_ic;
 }
 
