@@ -118,10 +118,19 @@ def roofline_from_profile(passes, fp16=False):
     flops_per_launch = a["flops"] / a["launches"]
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "traffic_fp16.json" if fp16 else "traffic.json")
     if os.path.exists(tpath):
         try:
-            rec = json.load(open(tpath)).get(name)
+            table = json.load(open(tpath))
+            rec = table.get(name)
+            if rec is None:
+                # the profile's kernel name drops trailing template arguments the profiler prints (e.g. the K-block width
+                # of conv_igemm_f16_kernel): launch-weighted mean over the instantiations that share the prefix
+                stem = name.rstrip(">")
+                hits = [v for k, v in table.items() if k.startswith(stem) and isinstance(v, dict)]
+                n = sum(v.get("launches", 0) for v in hits)
+                if n:
+                    rec = {"hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] * v.get("launches", 0) for v in hits) / n)}
             traffic = rec.get("hbm_bytes_per_launch") if isinstance(rec, dict) else rec
         except Exception:
             traffic = None

@@ -1,17 +1,18 @@
 #!/bin/bash
-# tools/run_traffic.sh <tag> -- HBM traffic of the bench kernels from the TCC PMC counters, as MI355X_MICROARCH.md
+# tools/run_traffic.sh <tag> [extra bench.py args, e.g. --fp16 1] -- HBM traffic of the bench kernels from the TCC PMC counters, as MI355X_MICROARCH.md
 # prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one pass), kernel-trace only.
 # Writes gpurun_out/<tag>/traffic.json: per kernel name, average bytes per launch, with the gfx950 correction
 # (FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads -> doubled; WRITE_SIZE is exact), units KiB.
 set -e
 TAG=${1:-traffic}
+shift || true
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
 for C in FETCH_SIZE WRITE_SIZE; do
   cd /tmp
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/raw_$C" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --profile-passes 1 > "$OUT/bench_$C.json" 2> "$OUT/stderr_$C.txt" || true
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/raw_$C" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-aux --profile-passes 1 "$@" > "$OUT/bench_$C.json" 2> "$OUT/stderr_$C.txt" || true
   cd "$REPO"
   find "$OUT/raw_$C" -name "*counter_collection.csv" -exec cp {} "$OUT/counters_$C.csv" \;
   rm -rf "$OUT/raw_$C"
