@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int y = a_ih0[i] + dy, x = a_iw0[i] + dx;
-            const bool ok = kvalid && (unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw;
+            const bool ok = kvalid && c < a.icg && (unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
                 const float* p = in_g + (size_t)(a_pix[i] + y * a.iw + x) * a.in_ld + c;
@@ -435,7 +435,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB_A = 0xFFFFFF00u;  // >= any legal num_records
 constexpr unsigned OOB_B = 0x80000000u;  // weights are < 2 GB; + kt*128 cannot wrap
 
-template <int BM, int BN, int WM, int WN, int NBUF>
+// PADK: the K axis of a 1x1 conv is zero-padded to whole 32-channel blocks (conv_icg_pad); a separate instantiation so the
+// channel check costs the ordinary layers nothing (it was worth 0.5 % of the YOLOv5s step inside the shared loop)
+template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
@@ -511,9 +513,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     auto load_tile = [&](int kt) {
         const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * 32) * 4u;
         const int tapbit = ky * a.kw + kx;
+        const bool cok = !PADK || cb * 32 + kv * 4 < a.icg;  // false only in the zero-padded tail block of a 1x1 conv
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const bool ok = (a_mask[i] >> tapbit) & 1ull;
+            const bool ok = ((a_mask[i] >> tapbit) & 1ull) && cok;
             const unsigned off = ok ? a_off[i] + delta : OOB_A;
             pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
         }
@@ -617,7 +620,15 @@ int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
     b.n_tiles = (a.ocg + BN - 1) / BN;
     const int chunks = (b.m_tiles + 7) / 8;
     dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
-    hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), 0, s, b);
+    if (a.icg % 32 != 0) {
+        // zero-padded K (1x1 convs with a channel count that is not a multiple of 32): the two default tiles carry the check
+        if constexpr (NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32)))
+            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, true>), grid, dim3(256), 0, s, b);
+        else
+            return SI_E_UNSUPPORTED;
+    } else {
+        hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), 0, s, b);
+    }
     return (int)hipGetLastError();
 }
 
@@ -663,12 +674,22 @@ static bool conv_cb_major(const SiConv2dDesc* d) {
     return (icg % 32 == 0) && (d->kh * d->kw > 1);
 }
 
+// Channels per tap in the packed weights (shape-only, it fixes the weight layout).  A 1x1 ungrouped conv whose channel
+// count is a multiple of 4 but not of 32 (MobileNet's 16 / 24 / 40 / 72 / 96 ... pointwise and squeeze-excite convs) pads
+// its K axis with zero weights to whole 32-channel blocks, so the fast kernel serves it: the thread whose 4-channel vector
+// lies behind the last channel gets an out-of-range buffer offset (zeros) instead of the neighbouring pixel.
+static int conv_icg_pad(const SiConv2dDesc* d) {
+    const int icg = d->ic / d->groups;
+    if (d->kh * d->kw == 1 && d->groups == 1 && icg % 4 == 0 && icg % 32 != 0 && icg >= 8) return (icg + 31) / 32 * 32;
+    return round_up4(icg);
+}
+
 static bool conv_fast_ok(const SiConv2dDesc* d, const float* in) {
     const int icg = d->ic / d->groups;
-    if (icg % 32 != 0 || d->in_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
+    if (conv_icg_pad(d) % 32 != 0 || d->in_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return false;
     if (d->kh * d->kw > 64) return false;
     const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull;
-    const unsigned long long w_bytes = (unsigned long long)d->oc * d->kh * d->kw * icg * 4ull;
+    const unsigned long long w_bytes = (unsigned long long)d->oc * d->kh * d->kw * conv_icg_pad(d) * 4ull;
     return in_bytes < 0xFFFFFF00ull && w_bytes < 0x40000000ull;
 }
 
@@ -681,8 +702,7 @@ extern "C" size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d) {
     if (!d || d->groups <= 0) return 0;
     if (si_conv_smallc_ok(d)) return si_conv_smallc_weight_elems(d);  // stem layout, see conv_smallc.hip
     if (si_conv_depthwise_ok(d)) return si_conv_depthwise_weight_elems(d);
-    const int icg = d->ic / d->groups;
-    return (size_t)d->oc * d->kh * d->kw * round_up4(icg);
+    return (size_t)d->oc * d->kh * d->kw * conv_icg_pad(d);
 }
 
 extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* w_packed) {
@@ -695,7 +715,7 @@ extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float
         si_conv_depthwise_pack(d, w_oihw, w_packed);
         return 0;
     }
-    const int icg = d->ic / d->groups, icp = round_up4(icg);
+    const int icg = d->ic / d->groups, icp = conv_icg_pad(d);
     const int ntaps = d->kh * d->kw;
     const bool cbm = conv_cb_major(d);
     for (int o = 0; o < d->oc; ++o)
@@ -749,7 +769,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     a.kh = d->kh; a.kw = d->kw; a.sh = d->sh; a.sw = d->sw; a.dh = d->dh; a.dw = d->dw;
     a.pt = d->pt; a.pl = d->pl;
     a.icg = d->ic / d->groups;
-    a.icg_pad = round_up4(a.icg);
+    a.icg_pad = conv_icg_pad(d);
     a.ocg = d->oc / d->groups;
     a.oc = d->oc;
     a.Kp = d->kh * d->kw * a.icg_pad;
@@ -777,7 +797,9 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     if (conv_fast_ok(d, in)) {
         a.in_bytes = (unsigned)((unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull);
         hipStream_t fs = static_cast<hipStream_t>(stream);
-        switch (conv_variant(d)) {
+        // a zero-padded K axis only exists in the two default tiles (SI_CONV_VARIANT is ignored for those layers)
+        const int variant = (a.icg % 32 != 0) ? ((d->oc / d->groups) <= 32 ? 10 : 4) : conv_variant(d);
+        switch (variant) {
             case 0: return launch_fast<128, 128, 2, 2, 2>(a, d->groups, fs);
             case 1: return launch_fast<128, 64, 2, 2, 2>(a, d->groups, fs);
             case 2: return launch_fast<64, 64, 2, 2, 2>(a, d->groups, fs);

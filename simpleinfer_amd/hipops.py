@@ -93,7 +93,7 @@ def conv_out_hw(ih, iw, k, s, p, d):
 
 def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, act1="none",
            residual=None, act2="none", act_param=0.0, in_ld: Optional[int] = None, out_ld: Optional[int] = None,
-           out_c_off: int = 0):
+           out_c_off: int = 0, in_fill: float = 0.0):
     """si_hip_conv2d_f32.  in_ld/out_ld > C exercise the strided (concat-slice) addressing: the input is
     embedded in / the output is written into a wider zero-filled buffer and sliced back."""
     H = _native.hip()
@@ -110,7 +110,7 @@ def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
     _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)),
          "pack weight")
     if in_ld != ic:
-        xw = np.zeros((n, ih, iw, in_ld), np.float32)
+        xw = np.full((n, ih, iw, in_ld), in_fill, np.float32)  # in_fill: what lies between the pixels' channels
         xw[..., :ic] = x
         x = xw
     dx, dw = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(packed)
@@ -122,6 +122,17 @@ def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
                              dy.ptr + 4 * out_c_off, None), "si_hip_conv2d_f32")
     y = dy.to_numpy((n, oh, ow, out_ld))
     return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
+
+
+def conv2d_kernel_name(x_shape, w_shape, stride=(1, 1), padding=(0, 0), groups=1) -> str:
+    """The kernel instantiation si_hip_conv2d_f32 picks for this shape with dense, 16-byte aligned tensors."""
+    H = _native.hip()
+    n, ih, iw, ic = x_shape
+    oc, _, kh, kw = w_shape
+    oh, ow = conv_out_hw(ih, iw, (kh, kw), stride, padding, (1, 1))
+    d = SiConv2dDesc(n, ih, iw, ic, ic, oh, ow, oc, oc, kh, kw, stride[0], stride[1], 1, 1, padding[0], padding[1], groups, 1,
+                     ACT["none"], 0, oc, ACT["none"], 0.0)
+    return H.si_hip_conv2d_kernel_name(C.byref(d), C.c_void_p(4096)).decode()
 
 
 def conv2d_winograd(x, w_oihw, bias=None, padding=(1, 1), act1="none", residual=None, act2="none", in_ld=None,

@@ -100,6 +100,22 @@ def test_conv_fused_residual_orders(hops, orc):
     assert_parity(hops.conv2d(x, w, b, (1, 1), (1, 1), residual=r, act2="relu"), orc.activation("relu", y + r))
 
 
+@pytest.mark.parametrize("ic,oc", [(24, 72), (40, 24), (72, 16), (8, 40), (144, 48), (36, 64)])
+def test_conv_pointwise_padded_k(hops, orc, ic, oc):
+    """1x1 convs whose channel count is a multiple of 4 but not of 32 (MobileNet's pointwise / squeeze-excite convs): the
+    weights are zero-padded to whole 32-channel blocks and the fast kernel masks the tail vectors.  The input is a NaN-filled
+    wider row here, so a vector read past the last channel would poison the result."""
+    x = rng_uniform(40 + ic, (2, 9, 7, ic), -1, 1)
+    w = rng_uniform(41 + ic, (oc, ic, 1, 1), -0.5, 0.5)
+    b = rng_uniform(42 + ic, (oc,), -0.5, 0.5)
+    ref = orc.conv2d(x, w, b, (1, 1), (0, 0), path="naive")
+    assert_parity(hops.conv2d(x, w, b), ref, what="dense")
+    assert_parity(hops.conv2d(x, w, b, act1="hardswish"), orc.activation("hardswish", ref), what="hardswish")
+    assert_parity(hops.conv2d(x, w, b, in_ld=ic + 12, out_ld=oc + 8, out_c_off=4, in_fill=np.nan), ref, what="strided, NaN beyond the channels")
+    name = hops.conv2d_kernel_name(x.shape, w.shape)
+    assert "fast" in name, name
+
+
 def test_conv_strided_tensors(hops, orc):
     """input read from / output written into a wider concat buffer (pixel stride > channels)"""
     x = rng_uniform(11, (2, 9, 9, 16), -1, 1)
