@@ -274,6 +274,22 @@ def test_pool_chain_falls_back_to_three_pools(si, orc, tmp_path, hw, c):
     assert e.schedule()["run"].count("maxpool_0") == 1 and "maxpool_1" in e.schedule()["fused"]
 
 
+def test_yolov5s_at_another_input_size(si, orc, tmp_path):
+    """416x416: 208-pixel stem rows (ragged 160-pixel column tiles), 13x13 / 26x26 / 52x52 maps (odd pixel counts per image,
+    SPPF on a 13x13 map) -- fp32 against the oracle, the fp16 path against fp32."""
+    mg = si.modelgen
+    pp, bp = _save(tmp_path, mg.build_yolov5s(2, 416), "y416")
+    x = mg.synth_input((2, 416, 416, 3))
+    ref = orc.run_graph(pp, bp, {"0": x})
+    e, oname, got = _run(si, pp, bp, x)
+    assert got.shape == (2, 3 * (52 * 52 + 26 * 26 + 13 * 13), 85)
+    assert_parity(got, ref[oname], what="416x416 fp32")
+    _, _, half = _run(si, pp, bp, x, fp16=1)
+    assert_parity(half, ref[oname], F16_GRAPH_TOL, what="416x416 fp16")
+    _, _, one = _run(si, *_save(tmp_path, mg.build_yolov5s(1, 416), "y416b1"), x[1:2])
+    assert_exact(one[0], got[1], "416x416: an image's result does not depend on the batch")
+
+
 def test_fp16_unsupported_graph_is_a_status(si, tmp_path):
     # toy_yolo has channel counts that are not multiples of 32: the fp16 path says so instead of computing something else
     pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(1, 64), "toy16")
