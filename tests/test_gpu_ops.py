@@ -348,6 +348,12 @@ def test_binary(hops, orc):
     assert_exact(hops.binary_op(2, GOLD["binary/a"], GOLD["binary/b"]), GOLD["binary/mul"])
     a, b = rng_uniform(42, (2, 6, 6, 16)), rng_uniform(43, (2, 1, 1, 16))          # SE-style broadcast
     assert_exact(hops.binary_op(2, a, b), orc.binary_op(2, a, b))
+    assert_exact(hops.binary_op(2, b, a), orc.binary_op(2, b, a))                   # channel vector on the left
+    assert_exact(hops.binary_op(0, a, b), orc.binary_op(0, a, b))
+    g = rng_uniform(46, (1, 1, 1, 16))                                             # one vector for every image
+    assert_exact(hops.binary_op(2, a, g), orc.binary_op(2, a, g))
+    a6, b6 = rng_uniform(47, (3, 5, 7, 6)), rng_uniform(48, (3, 1, 1, 6))          # c % 4 != 0: the general kernel
+    assert_exact(hops.binary_op(2, a6, b6), orc.binary_op(2, a6, b6))
     a, b = rng_uniform(44, (1, 3, 1, 4)), rng_uniform(45, (2, 3, 5, 1))            # both sides broadcast
     assert_exact(hops.binary_op(0, a, b), orc.binary_op(0, a, b))
     with pytest.raises(hops.HipError):
