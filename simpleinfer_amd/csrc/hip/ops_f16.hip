@@ -229,7 +229,7 @@ int si_hip_adaptive_avgpool2d_f16(const void* in, int n, int ih, int iw, int c, 
     if (!in || !out || n <= 0 || c <= 0 || oh <= 0 || ow <= 0) return SI_E_BADARG;
     if (ih % oh != 0 || iw % ow != 0) return SI_E_UNSUPPORTED;  // uniform windows only, as the fp32 kernel
     if (oh == 1 && ow == 1) {
-        int cw = 64;
+        int cw = 8;  // as the fp32 kernel: 8 channels x 32 pixel groups (latency, not bandwidth)
         while (cw > 1 && cw / 2 >= c) cw /= 2;
         hipLaunchKernelGGL(global_avgpool_h_kernel, dim3((c + cw - 1) / cw, n), dim3(256), 0, (hipStream_t)stream,
                            static_cast<const half_t*>(in), ih * iw, c, in_ld, static_cast<half_t*>(out), out_ld, cw);
