@@ -5,7 +5,7 @@ and conversions are exact."""
 import numpy as np
 import pytest
 
-from util import assert_exact, assert_parity, rng_uniform
+from util import assert_detect_parity, assert_exact, assert_parity, rng_uniform
 
 pytestmark = pytest.mark.gpu
 
@@ -162,7 +162,7 @@ def test_yolo_detect_head_f16(hops, orc, n, levels):
     ref = orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na)
     got = hops.yolo_detect_f16(feats, ws, bs, grids, anchors, strides, na)
     assert got.dtype == np.float32
-    assert_parity(got, ref, 1e-4, what="fp16 features, fp32 decode")   # output is fp32: the fp32 bar applies
+    assert_detect_parity(got, ref, 1e-4, 1e-4, what="fp16 features, fp32 decode")   # output is fp32: the fp32 bar applies, per column group
 
 
 def test_pool_activation_binary_convert_f16(hops, orc):

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from util import assert_exact, assert_parity, rng_uniform
+from util import assert_detect_parity, assert_exact, assert_parity, rng_uniform
 
 pytestmark = pytest.mark.gpu
 
@@ -382,8 +382,9 @@ def test_yolo_detect_head(hops, orc, n, levels):
         anchors.append(np.broadcast_to(rng_uniform(80 + i, (1, na, 1, 1, 2), 5, 300), (1, na, h, h, 2)).copy())
     strides = [8.0, 16.0, 32.0]
     ref = orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na)
-    assert_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na), ref, what="conv + decode kernels")
-    assert_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na, fused=True), ref, what="decode fused in conv epilogue")
+    # per column group: a whole-tensor scale (box sizes ~1e3) would leave the sigmoid scores unconstrained
+    assert_detect_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na), ref, what="conv + decode kernels")
+    assert_detect_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na, fused=True), ref, what="decode fused in conv epilogue")
 
 
 # ---- letterbox + detection post-processing (test/test_yolo/test_yolo.cpp:194-259, 337-428) ----

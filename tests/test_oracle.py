@@ -181,16 +181,22 @@ def test_yolo_detect_row_order_and_decode(orc):
     assert mg is not None
 
 
-def test_graph_oracle_matches_torch_composition(orc, tmp_path):
+@pytest.mark.parametrize("model", ["toy_classifier", "resnet18_224", "resnet18_224_const2"])
+def test_graph_oracle_matches_torch_composition(orc, tmp_path, model):
     """Whole-graph oracle (oracle/orc.py run_graph) vs an independent torch-CPU float64 evaluation of the
-    same synthesized toy classifier -- pins graph wiring, NCHW->NHWC handling and expression lowering."""
+    same synthesized graph -- pins graph wiring, NCHW->NHWC handling and expression lowering.  `resnet18_224` is
+    BASELINE.json configs[0] (ResNet18 1x3x224x224 on the CPU path: plumbing, no GPU), once on a synthetic image and once
+    on the constant 2.0 image the reference's classifier demo feeds (test_classify.cpp:25)."""
     import torch
     import torch.nn.functional as F
     from simpleinfer_amd import modelgen as mg
-    b = mg.build_toy_classifier(2, 32)
+    if model == "toy_classifier":
+        b, shape = mg.build_toy_classifier(2, 32), (2, 32, 32, 3)
+    else:
+        b, shape = mg.build_resnet18(1, 224), (1, 224, 224, 3)
     pp, bp = str(tmp_path / "m.param"), str(tmp_path / "m.bin")
     b.save(pp, bp)
-    x = mg.synth_input((2, 32, 32, 3))
+    x = np.full(shape, 2.0, np.float32) if model.endswith("const2") else mg.synth_input(shape)
     got = orc.run_graph(pp, bp, {"0": x})
     (name, y), = got.items()
     ops, shapes = orc.load_pnnx(pp, bp)
@@ -210,12 +216,14 @@ def test_graph_oracle_matches_torch_composition(orc, tmp_path):
         elif t == "nn.Hardsigmoid": o = F.hardsigmoid(i[0])
         elif t == "nn.ReLU": o = F.relu(i[0])
         elif t == "nn.Sigmoid": o = torch.sigmoid(i[0])
+        elif t == "nn.MaxPool2d": o = F.max_pool2d(i[0], P["kernel_size"], P["stride"], P["padding"], P["dilation"])
         elif t == "nn.AdaptiveAvgPool2d": o = F.adaptive_avg_pool2d(i[0], P["output_size"])
         elif t == "pnnx.Expression": o = i[0] + i[1] if P["expr"].startswith("add") else i[0] * i[1]
         elif t == "torch.flatten": o = torch.flatten(i[0], 1)
         elif t == "nn.Linear": o = F.linear(i[0], T(A["weight"]), T(A["bias"]))
         else: raise AssertionError(t)
         vals[op.outputs[0]] = o
+    assert model == "toy_classifier" or y.shape == (1, 1000)
     assert_parity(y, vals[name].float().numpy(), 1e-5)
 
 

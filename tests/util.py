@@ -24,6 +24,28 @@ def assert_parity(got, ref, rel=REL_TOL, what=""):
     return e
 
 
+def detect_group_errors(got, ref):
+    """Errors of a Detect output [..., 5+nc] per column group: box centres and box sizes each against their own scale
+    (pixels, up to ~1e3), objectness + class scores ABSOLUTE (they are sigmoid outputs in (0, 1): a whole-tensor scale
+    set by the box columns would leave them unconstrained)."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape and got.shape[-1] > 5, (got.shape, ref.shape)
+    return {"xy": rel_err(got[..., 0:2], ref[..., 0:2]), "wh": rel_err(got[..., 2:4], ref[..., 2:4]),
+            "score_abs": float(np.abs(got[..., 4:] - ref[..., 4:]).max())}
+
+
+def assert_detect_parity(got, ref, rel=REL_TOL, score_abs=REL_TOL, what=""):
+    """The parity bar for `models.yolo.Detect` outputs (yolo_detect.cpp:204-272): xy and wh within `rel` of their own
+    column group's scale, every objectness / class score within `score_abs` ABSOLUTE of the reference's."""
+    assert np.isfinite(np.asarray(got)).all(), "%s: non-finite values" % what
+    e = detect_group_errors(got, ref)
+    assert e["xy"] <= rel, "%s: xy max|diff|/max|ref| = %.3e > %.1e" % (what, e["xy"], rel)
+    assert e["wh"] <= rel, "%s: wh max|diff|/max|ref| = %.3e > %.1e" % (what, e["wh"], rel)
+    assert e["score_abs"] <= score_abs, "%s: scores max|diff| = %.3e > %.1e" % (what, e["score_abs"], score_abs)
+    return e
+
+
 def assert_exact(got, ref, what=""):
     got, ref = np.asarray(got), np.asarray(ref)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
