@@ -70,6 +70,15 @@ int si_hip_event_destroy(si_event_t ev);
 int si_hip_event_record(si_event_t ev, si_stream_t stream);
 int si_hip_event_sync(si_event_t ev);
 int si_hip_event_elapsed_ms(si_event_t start, si_event_t stop, float* ms);
+int si_hip_stream_wait_event(si_stream_t stream, si_event_t ev); /* later work on `stream` waits for `ev` */
+/* Device memory shared between the per-GPU processes of one node -- the transport of the direct (non-ring) output
+ * all-gather of include/si_shard.h (no reference counterpart: SimpleInfer is single-process).
+ * `handle` is SI_IPC_HANDLE_BYTES opaque bytes to be carried to the peer process by any host transport. */
+#define SI_IPC_HANDLE_BYTES 64
+int si_hip_ipc_get_mem_handle(void* dptr, void* handle);
+int si_hip_ipc_open_mem_handle(const void* handle, void** dptr);
+int si_hip_ipc_close_mem_handle(void* dptr);
+int si_hip_enable_peer_access(int peer_device); /* current device -> peer_device; 0 when already enabled or same device */
 /* stream capture -> executable graph (replaces the CGraph pipeline of
  * src/engine_impl.cpp:336-437 for launch-bound small batches) */
 int si_hip_graph_begin_capture(si_stream_t stream);

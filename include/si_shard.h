@@ -1,0 +1,78 @@
+/*
+ * si_shard.h -- C-ABI of the multi-GPU part of the path: one process per GPU of ONE node, the batch sharded by
+ * contiguous slabs, and ONE exchange per step -- the all-gather of the output slabs [B/G, rows, 85] into
+ * [B, rows, 85] (BASELINE.json north_star).  The reference has no counterpart
+ * (SimpleInfer is single-process): these entry points are what a C++ / cgo / JNI host of
+ * include/engine.h binds to shard a batch without torch.
+ *
+ * Two pieces:
+ *   SiNodeGroup    host-only rendezvous of the node's ranks through POSIX shared memory: barrier and small
+ *                  all-gather of host bytes (handles, checksums, timings).  No GPU, no sockets.
+ *   SiDirectGather the direct (non-ring) all-gather: every rank owns `slots` gathered buffers
+ *                  [world][slab_bytes] in its HBM, exports them with hipIpcGetMemHandle, opens every peer's, and
+ *                  after each step PUSHES its slab into the same slot of every peer with one device-to-device
+ *                  copy per peer on that peer's own stream (xGMI is point to point: 7 concurrent copies use 7
+ *                  links; a ring would move 7 slabs over one link per GPU).  The producer writes its slab in
+ *                  place (si_gather_slab is where Engine::Output binds), so the local copy costs nothing.
+ *
+ * Step protocol (slot = step % slots, slots >= 3 for the overlapped form):
+ *     bind the engine's output to si_gather_slab(g, slot); Forward()
+ *     si_gather_push(g, slot, engine_stream)        asynchronous fan-out behind the producer's work
+ *     si_gather_complete(g, previous slot)          waits for MY pushes of the previous step, then the node
+ *                                                    barrier: every rank's slab of that step is now in
+ *                                                    si_gather_buffer(g, previous slot)
+ * A consumer must be done with a completed slot before it calls si_gather_complete two more times (the slot
+ * is then pushed into again).  With slots == 1 call push and complete back to back (no overlap).
+ *
+ * Return value: 0 on success; positive hipError_t / negative SI_E_* from the HIP layer (include/si_hip.h); or
+ * SI_SHARD_E_* below.
+ */
+#ifndef SI_SHARD_H_
+#define SI_SHARD_H_
+
+#include <stddef.h>
+
+#include "si_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SI_SHARD_E_BADARG (-101)
+#define SI_SHARD_E_SYS (-102)      /* shm_open / mmap / ftruncate failed */
+#define SI_SHARD_E_TIMEOUT (-103)  /* a peer did not arrive within the group's timeout */
+#define SI_SHARD_E_TOOBIG (-104)   /* more than SI_GROUP_MAX_BYTES per rank in si_group_allgather */
+#define SI_SHARD_E_PEER (-105)     /* another rank reported a failure in a collective setup step */
+
+#define SI_GROUP_MAX_BYTES 4096
+#define SI_GROUP_MAX_WORLD 64
+
+typedef struct SiNodeGroup SiNodeGroup;
+typedef struct SiDirectGather SiDirectGather;
+
+/* Every rank of the node calls this with the same `name` (a POSIX shm name: "/something", unique per job -- e.g.
+ * derived from the launcher's pid and port) and `world`; rank 0 creates the segment, the others attach, and the
+ * name is unlinked as soon as all have (nothing stale survives a crash).  `timeout_s` bounds every wait. */
+int si_group_create(const char* name, int rank, int world, double timeout_s, SiNodeGroup** group);
+int si_group_destroy(SiNodeGroup* group);
+int si_group_rank(const SiNodeGroup* group);
+int si_group_world(const SiNodeGroup* group);
+int si_group_barrier(SiNodeGroup* group);
+/* all[r * bytes .. ] = rank r's `mine`; bytes <= SI_GROUP_MAX_BYTES, the same on every rank */
+int si_group_allgather(SiNodeGroup* group, const void* mine, size_t bytes, void* all);
+
+/* Collective over the group.  `device`: this rank's HIP device.  Allocates slots x world x slab_bytes of HBM. */
+int si_gather_create(SiNodeGroup* group, int device, size_t slab_bytes, int slots, SiDirectGather** gather);
+int si_gather_destroy(SiDirectGather* gather); /* collective */
+int si_gather_slots(const SiDirectGather* gather);
+size_t si_gather_slab_bytes(const SiDirectGather* gather);
+void* si_gather_buffer(SiDirectGather* gather, int slot); /* device pointer, world x slab_bytes */
+void* si_gather_slab(SiDirectGather* gather, int slot);   /* = buffer + rank x slab_bytes: the producer writes here */
+int si_gather_push(SiDirectGather* gather, int slot, si_stream_t producer_stream);
+int si_gather_complete(SiDirectGather* gather, int slot); /* collective */
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SI_SHARD_H_ */

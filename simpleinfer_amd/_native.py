@@ -77,6 +77,11 @@ def hip():
         "si_hip_event_record": (i, [vp, vp]),
         "si_hip_event_sync": (i, [vp]),
         "si_hip_event_elapsed_ms": (i, [vp, vp, C.POINTER(f)]),
+        "si_hip_stream_wait_event": (i, [vp, vp]),
+        "si_hip_ipc_get_mem_handle": (i, [vp, vp]),
+        "si_hip_ipc_open_mem_handle": (i, [vp, C.POINTER(vp)]),
+        "si_hip_ipc_close_mem_handle": (i, [vp]),
+        "si_hip_enable_peer_access": (i, [i]),
         "si_hip_graph_begin_capture": (i, [vp]),
         "si_hip_graph_end_capture": (i, [vp, C.POINTER(vp)]),
         "si_hip_graph_launch": (i, [vp, vp]),
@@ -175,10 +180,28 @@ def host():
         "si_pnnx_save": (i, [cp, cp, i, i, cp, cp]),
         "si_registry_types": (i, [cp, sz]),
     }
-    for name, (res, args) in sig.items():
+    # include/si_shard.h: node-local rank group + direct output all-gather
+    shard = {
+        "si_group_create": (i, [cp, i, i, C.c_double, C.POINTER(vp)]),
+        "si_group_destroy": (i, [vp]),
+        "si_group_rank": (i, [vp]),
+        "si_group_world": (i, [vp]),
+        "si_group_barrier": (i, [vp]),
+        "si_group_allgather": (i, [vp, vp, sz, vp]),
+        "si_gather_create": (i, [vp, i, sz, i, C.POINTER(vp)]),
+        "si_gather_destroy": (i, [vp]),
+        "si_gather_slots": (i, [vp]),
+        "si_gather_slab_bytes": (sz, [vp]),
+        "si_gather_buffer": (vp, [vp, i]),
+        "si_gather_slab": (vp, [vp, i]),
+        "si_gather_push": (i, [vp, i, vp]),
+        "si_gather_complete": (i, [vp, i]),
+    }
+    for name, (res, args) in list(sig.items()) + list(shard.items()):
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
     L._si_signatures = sig
+    L._si_shard_signatures = shard
     _host = L
     return L

@@ -108,6 +108,42 @@ int si_hip_event_elapsed_ms(si_event_t a, si_event_t b, float* ms) {
     return 0;
 }
 
+int si_hip_stream_wait_event(si_stream_t s, si_event_t ev) {
+    SI_HIP_TRY(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)ev, 0));
+    return 0;
+}
+
+// ---- device memory shared between the per-GPU processes of one node (direct output all-gather) ----
+static_assert(sizeof(hipIpcMemHandle_t) == SI_IPC_HANDLE_BYTES, "SI_IPC_HANDLE_BYTES must match hipIpcMemHandle_t");
+
+int si_hip_ipc_get_mem_handle(void* dptr, void* handle) {
+    if (!dptr || !handle) return SI_E_BADARG;
+    hipIpcMemHandle_t h;
+    SI_HIP_TRY(hipIpcGetMemHandle(&h, dptr));
+    memcpy(handle, &h, sizeof(h));
+    return 0;
+}
+int si_hip_ipc_open_mem_handle(const void* handle, void** dptr) {
+    if (!dptr || !handle) return SI_E_BADARG;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    *dptr = nullptr;
+    SI_HIP_TRY(hipIpcOpenMemHandle(dptr, h, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+int si_hip_ipc_close_mem_handle(void* dptr) { if (dptr) SI_HIP_TRY(hipIpcCloseMemHandle(dptr)); return 0; }
+int si_hip_enable_peer_access(int peer_device) {
+    int cur = -1;
+    SI_HIP_TRY(hipGetDevice(&cur));
+    if (cur == peer_device) return 0;
+    int can = 0;
+    SI_HIP_TRY(hipDeviceCanAccessPeer(&can, cur, peer_device));
+    if (!can) return SI_E_UNSUPPORTED;
+    hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return 0; }
+    return (int)e;
+}
+
 int si_hip_graph_begin_capture(si_stream_t s) {
     SI_HIP_TRY(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
     return 0;

@@ -346,11 +346,9 @@ Status EngineImpl::CreatePipeline() {
 }
 
 Status EngineImpl::DestroyPipeline() {
-    if (graph_exec_) si_hip_graph_destroy(graph_exec_);
-    graph_exec_ = nullptr;
+    for (auto& g : graph_cache_) si_hip_graph_destroy(g.second);
+    graph_cache_.clear();
     forward_count_ = 0;
-    captured_input_ptrs_.clear();
-    captured_output_ptrs_.clear();
     plan_.clear();
     fused_ops_.clear();
     sibling_ops_.clear();
@@ -749,31 +747,34 @@ Status EngineImpl::Forward() {
     CHECK_STATUS(UploadInputs());
     CHECK_STATUS(BindOutputs());
 
-    // a captured graph bakes pointers in: re-capture when a device-resident input or a caller-owned output moved
-    if (graph_exec_) {
-        bool moved = false;
-        for (auto& kv : input_tensor_nodes_) moved = moved || captured_input_ptrs_[kv.first] != kv.second->tensor.RawData();
-        for (auto& kv : output_tensor_nodes_) moved = moved || captured_output_ptrs_[kv.first] != kv.second->tensor.RawData();
-        if (moved) {
-            si_hip_graph_destroy(graph_exec_);
-            graph_exec_ = nullptr;
-        }
-    }
-
     SI_TRY_HIP(si_hip_event_record(ev_start_, stream), "event record");
     if (opt_graph_ && forward_count_ > 0) {
-        if (!graph_exec_) {
+        // a captured graph bakes pointers in: key the cache on where the device-resident inputs and the outputs are now
+        std::vector<void*> key;
+        for (auto& kv : input_tensor_nodes_) key.push_back(kv.second->tensor.RawData());
+        for (auto& kv : output_tensor_nodes_) key.push_back(kv.second->tensor.RawData());
+        si_graph_t exec = nullptr;
+        for (size_t i = 0; i < graph_cache_.size(); ++i) {
+            if (graph_cache_[i].first == key) {
+                exec = graph_cache_[i].second;
+                if (i != 0) std::rotate(graph_cache_.begin(), graph_cache_.begin() + i, graph_cache_.begin() + i + 1);  // most recent first
+                break;
+            }
+        }
+        if (!exec) {
             SI_TRY_HIP(si_hip_graph_begin_capture(stream), "begin capture");
             Status ret = LaunchAll();
-            si_graph_t exec = nullptr;
             const int rc = si_hip_graph_end_capture(stream, &exec);
             CHECK_STATUS(ret);
             SI_TRY_HIP(rc, "end capture");
-            graph_exec_ = exec;
-            for (auto& kv : input_tensor_nodes_) captured_input_ptrs_[kv.first] = kv.second->tensor.RawData();
-            for (auto& kv : output_tensor_nodes_) captured_output_ptrs_[kv.first] = kv.second->tensor.RawData();
+            constexpr size_t kMaxGraphs = 8;
+            if (graph_cache_.size() >= kMaxGraphs) {
+                si_hip_graph_destroy(graph_cache_.back().second);
+                graph_cache_.pop_back();
+            }
+            graph_cache_.insert(graph_cache_.begin(), std::make_pair(key, exec));
         }
-        SI_TRY_HIP(si_hip_graph_launch(graph_exec_, stream), "graph launch");
+        SI_TRY_HIP(si_hip_graph_launch(exec, stream), "graph launch");
     } else {
         // first call is always eager: it uploads weights and sizes scratch buffers
         CHECK_STATUS(LaunchAll());

@@ -125,10 +125,10 @@ private:
     std::map<std::string, void*> input_buffers_;    // engine-owned device staging per input
     std::map<std::string, void*> host_outputs_;     // pinned mirrors per output
 
-    si_graph_t graph_exec_ = nullptr;
+    // one captured graph per distinct set of I/O pointers (a capture bakes them in): alternating caller-owned output
+    // buffers (ShardedEngine, OverlappedGather) replay instead of re-capturing every Forward.  Small LRU.
+    std::vector<std::pair<std::vector<void*>, si_graph_t>> graph_cache_;
     int forward_count_ = 0;
-    std::map<std::string, void*> captured_input_ptrs_;
-    std::map<std::string, void*> captured_output_ptrs_;
 
     si_event_t ev_start_ = nullptr, ev_stop_ = nullptr;
     float last_forward_ms_ = 0.f;

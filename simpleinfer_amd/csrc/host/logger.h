@@ -14,27 +14,34 @@ enum LogSeverity { INFO = 0, WARNING = 1, ERROR = 2 };
 int LogThreshold();
 void InitializeLogger();
 
+// only ever constructed for an enabled severity (see LOG below)
 class LogLine {
 public:
-    LogLine(LogSeverity sev, const char* file, int line) : on_(sev >= LogThreshold()) {
-        if (on_) os_ << "[simpleinfer " << (sev == INFO ? "I" : sev == WARNING ? "W" : "E") << " " << file << ":" << line << "] ";
+    LogLine(LogSeverity sev, const char* file, int line) {
+        os_ << "[simpleinfer " << (sev == INFO ? "I" : sev == WARNING ? "W" : "E") << " " << file << ":" << line << "] ";
     }
-    ~LogLine() {
-        if (on_) std::cerr << os_.str() << std::endl;
-    }
+    ~LogLine() { std::cerr << os_.str() << std::endl; }
     template<typename T>
     LogLine& operator<<(const T& v) {
-        if (on_) os_ << v;
+        os_ << v;
         return *this;
     }
 
 private:
-    bool on_;
     std::ostringstream os_;
+};
+
+// swallows the stream expression of a disabled LOG so that both arms of the conditional have type void
+struct LogVoidify {
+    void operator&(const LogLine&) const {}
 };
 
 }  // namespace SimpleInfer
 
-#define LOG(sev) ::SimpleInfer::LogLine(::SimpleInfer::sev, __FILE__, __LINE__)
+// Short circuit: with the severity below the threshold neither the stream nor any operand of << is evaluated (the
+// reference logs one line per layer per Forward, src/layer.cpp:46 -- that sits on the launch path).
+#define LOG(sev)                                                       \
+    (::SimpleInfer::sev < ::SimpleInfer::LogThreshold()) ? (void)0     \
+        : ::SimpleInfer::LogVoidify() & ::SimpleInfer::LogLine(::SimpleInfer::sev, __FILE__, __LINE__)
 
 #endif

@@ -1,0 +1,322 @@
+// shard.cpp -- implementation of include/si_shard.h: the node-local rank group (POSIX shared memory) and the
+// direct output all-gather over IPC-shared HBM buffers.  Host code only; the GPU is reached through si_hip.h.
+// No reference counterpart (SimpleInfer is single-process); the partitioning it serves is SURVEY.md 8(e).
+#include "si_shard.h"
+
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "logger.h"
+
+namespace {
+
+constexpr uint32_t kMagic = 0x53494752u;  // "SIGR"
+
+struct alignas(64) ShmHeader {
+    std::atomic<uint32_t> magic;
+    uint32_t world;
+    std::atomic<uint32_t> attached;
+    std::atomic<uint32_t> count;
+    std::atomic<uint32_t> gen;
+    std::atomic<uint32_t> failed;
+};
+static_assert(std::atomic<uint32_t>::is_always_lock_free, "cross-process atomics must be lock free");
+
+double now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// bounded wait: spin, then yield, then sleep 20 us at a time
+template <typename Pred>
+bool wait_until(Pred done, double timeout_s) {
+    for (int i = 0; i < 4000; ++i) {
+        if (done()) return true;
+        if (i > 1000) sched_yield();
+    }
+    const double t0 = now_s();
+    const timespec nap = {0, 20000};
+    while (!done()) {
+        if (now_s() - t0 > timeout_s) return false;
+        nanosleep(&nap, nullptr);
+    }
+    return true;
+}
+
+size_t segment_bytes(int world) { return sizeof(ShmHeader) + (size_t)world * SI_GROUP_MAX_BYTES; }
+
+}  // namespace
+
+struct SiNodeGroup {
+    int rank = 0, world = 1;
+    double timeout_s = 60.0;
+    ShmHeader* hdr = nullptr;
+    unsigned char* slots = nullptr;
+    size_t bytes = 0;
+    std::string name;
+};
+
+extern "C" {
+
+int si_group_create(const char* name, int rank, int world, double timeout_s, SiNodeGroup** group) {
+    if (!group) return SI_SHARD_E_BADARG;
+    *group = nullptr;
+    if (!name || name[0] != '/' || world < 1 || world > SI_GROUP_MAX_WORLD || rank < 0 || rank >= world) return SI_SHARD_E_BADARG;
+    if (timeout_s <= 0) timeout_s = 60.0;
+    const size_t bytes = segment_bytes(world);
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(name);  // a leftover of a crashed job with the same name
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) { LOG(ERROR) << "si_group_create: shm_open(" << name << "): " << strerror(errno); return SI_SHARD_E_SYS; }
+        if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); return SI_SHARD_E_SYS; }
+    } else {
+        // the segment appears (full size) once rank 0 has created it
+        const bool ok = wait_until([&] {
+            fd = shm_open(name, O_RDWR, 0600);
+            if (fd < 0) return false;
+            struct stat st;
+            if (fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) return true;
+            close(fd);
+            fd = -1;
+            return false;
+        }, timeout_s);
+        if (!ok) { LOG(ERROR) << "si_group_create: rank " << rank << " timed out waiting for " << name; return SI_SHARD_E_TIMEOUT; }
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { if (rank == 0) shm_unlink(name); return SI_SHARD_E_SYS; }
+    ShmHeader* h = static_cast<ShmHeader*>(p);
+    if (rank == 0) {
+        // a fresh segment is zero filled; publish it with the magic word last
+        h->world = (uint32_t)world;
+        h->attached.store(0, std::memory_order_relaxed);
+        h->count.store(0, std::memory_order_relaxed);
+        h->gen.store(0, std::memory_order_relaxed);
+        h->failed.store(0, std::memory_order_relaxed);
+        h->magic.store(kMagic, std::memory_order_release);
+    } else {
+        const bool ok = wait_until([&] { return h->magic.load(std::memory_order_acquire) == kMagic; }, timeout_s);
+        if (!ok || h->world != (uint32_t)world) { munmap(p, bytes); return ok ? SI_SHARD_E_BADARG : SI_SHARD_E_TIMEOUT; }
+    }
+    h->attached.fetch_add(1, std::memory_order_acq_rel);
+    const bool all = wait_until([&] { return h->attached.load(std::memory_order_acquire) >= (uint32_t)world; }, timeout_s);
+    if (rank == 0) shm_unlink(name);  // mapped segments live on; the name cannot go stale
+    if (!all) {
+        LOG(ERROR) << "si_group_create: only " << h->attached.load() << " of " << world << " ranks attached";
+        munmap(p, bytes);
+        return SI_SHARD_E_TIMEOUT;
+    }
+    SiNodeGroup* g = new (std::nothrow) SiNodeGroup;
+    if (!g) { munmap(p, bytes); return SI_SHARD_E_SYS; }
+    g->rank = rank; g->world = world; g->timeout_s = timeout_s; g->hdr = h;
+    g->slots = reinterpret_cast<unsigned char*>(h + 1); g->bytes = bytes; g->name = name;
+    *group = g;
+    return 0;
+}
+
+int si_group_destroy(SiNodeGroup* g) {
+    if (!g) return 0;
+    if (g->hdr) munmap(g->hdr, g->bytes);
+    delete g;
+    return 0;
+}
+
+int si_group_rank(const SiNodeGroup* g) { return g ? g->rank : -1; }
+int si_group_world(const SiNodeGroup* g) { return g ? g->world : -1; }
+
+int si_group_barrier(SiNodeGroup* g) {
+    if (!g) return SI_SHARD_E_BADARG;
+    if (g->world == 1) return 0;
+    ShmHeader* h = g->hdr;
+    const uint32_t gen = h->gen.load(std::memory_order_acquire);
+    if (h->count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)g->world) {
+        h->count.store(0, std::memory_order_relaxed);
+        h->gen.fetch_add(1, std::memory_order_acq_rel);
+        return 0;
+    }
+    const bool ok = wait_until([&] { return h->gen.load(std::memory_order_acquire) != gen; }, g->timeout_s);
+    if (!ok) {
+        h->failed.store(1, std::memory_order_release);
+        LOG(ERROR) << "si_group_barrier: rank " << g->rank << " timed out after " << g->timeout_s << " s";
+        return SI_SHARD_E_TIMEOUT;
+    }
+    return 0;
+}
+
+int si_group_allgather(SiNodeGroup* g, const void* mine, size_t bytes, void* all) {
+    if (!g || (!mine && bytes) || !all) return SI_SHARD_E_BADARG;
+    if (bytes > SI_GROUP_MAX_BYTES) return SI_SHARD_E_TOOBIG;
+    memcpy(g->slots + (size_t)g->rank * SI_GROUP_MAX_BYTES, mine, bytes);
+    int rc = si_group_barrier(g);
+    if (rc != 0) return rc;
+    for (int r = 0; r < g->world; ++r) memcpy(static_cast<unsigned char*>(all) + (size_t)r * bytes, g->slots + (size_t)r * SI_GROUP_MAX_BYTES, bytes);
+    return si_group_barrier(g);  // nobody overwrites a slot before everybody has read it
+}
+
+}  // extern "C"
+
+// ---- direct all-gather -----------------------------------------------------------------------------------------------
+struct SiDirectGather {
+    SiNodeGroup* group = nullptr;
+    int device = 0, slots = 0;
+    size_t slab = 0;
+    std::vector<void*> mine;                 // [slot] my gathered buffer, world x slab
+    std::vector<std::vector<void*>> peer;    // [rank][slot] that rank's gathered buffer as mapped here (nullptr for me)
+    std::vector<si_stream_t> stream;         // [rank] copy stream towards that peer
+    std::vector<si_event_t> ready;           // [slot] producer finished writing the slab
+    std::vector<std::vector<si_event_t>> sent;  // [slot][rank] my slab of that slot has landed in that peer
+    std::vector<char> pushed;                // [slot] a push is outstanding
+};
+
+namespace {
+
+struct Advert {  // what a rank tells the others about itself
+    int32_t device;
+    int32_t ok;
+    unsigned char handle[8][SI_IPC_HANDLE_BYTES];
+};
+static_assert(sizeof(Advert) <= SI_GROUP_MAX_BYTES, "advert must fit one group slot");
+
+// every rank reports rc; all return the first non-zero one (so a setup failure on one rank fails every rank the same way)
+int agree(SiNodeGroup* g, int rc) {
+    std::vector<int32_t> all((size_t)g->world);
+    const int32_t mine = rc;
+    const int e = si_group_allgather(g, &mine, sizeof(mine), all.data());
+    if (e != 0) return e;
+    if (rc != 0) return rc;
+    for (int32_t v : all) if (v != 0) return SI_SHARD_E_PEER;
+    return 0;
+}
+
+void release(SiDirectGather* d) {
+    for (auto& slots : d->peer) for (void* p : slots) if (p) si_hip_ipc_close_mem_handle(p);
+    for (si_stream_t s : d->stream) if (s) si_hip_stream_destroy(s);
+    for (si_event_t e : d->ready) if (e) si_hip_event_destroy(e);
+    for (auto& evs : d->sent) for (si_event_t e : evs) if (e) si_hip_event_destroy(e);
+    for (void* p : d->mine) if (p) si_hip_free(p);
+    delete d;
+}
+
+}  // namespace
+
+extern "C" {
+
+int si_gather_create(SiNodeGroup* g, int device, size_t slab_bytes, int slots, SiDirectGather** out) {
+    if (!out) return SI_SHARD_E_BADARG;
+    *out = nullptr;
+    if (!g || slab_bytes == 0 || slots < 1 || slots > 8) return SI_SHARD_E_BADARG;
+    SiDirectGather* d = new (std::nothrow) SiDirectGather;
+    if (!d) return SI_SHARD_E_SYS;
+    d->group = g; d->device = device; d->slots = slots; d->slab = slab_bytes;
+    const int world = g->world, rank = g->rank;
+    d->mine.assign((size_t)slots, nullptr);
+    d->peer.assign((size_t)world, std::vector<void*>((size_t)slots, nullptr));
+    d->stream.assign((size_t)world, nullptr);
+    d->ready.assign((size_t)slots, nullptr);
+    d->sent.assign((size_t)slots, std::vector<si_event_t>((size_t)world, nullptr));
+    d->pushed.assign((size_t)slots, 0);
+
+    Advert me;
+    memset(&me, 0, sizeof(me));
+    me.device = device;
+    int rc = si_hip_set_device(device);
+    for (int s = 0; rc == 0 && s < slots; ++s) {
+        rc = si_hip_malloc(&d->mine[(size_t)s], slab_bytes * (size_t)world);
+        if (rc == 0) rc = si_hip_memset_async(d->mine[(size_t)s], 0, slab_bytes * (size_t)world, nullptr);
+        if (rc == 0 && world > 1) rc = si_hip_ipc_get_mem_handle(d->mine[(size_t)s], me.handle[s]);
+        if (rc == 0) rc = si_hip_event_create(&d->ready[(size_t)s]);
+    }
+    if (rc == 0) rc = si_hip_device_sync();
+    me.ok = rc == 0;
+    std::vector<Advert> all((size_t)world);
+    int e = si_group_allgather(g, &me, sizeof(me), all.data());
+    if (e == 0) for (const Advert& a : all) if (!a.ok && rc == 0) rc = SI_SHARD_E_PEER;
+    if (e != 0) rc = e;
+    if (rc != 0) { LOG(ERROR) << "si_gather_create: rank " << rank << " setup failed (" << rc << ")"; release(d); return rc; }
+
+    for (int p = 0; rc == 0 && p < world; ++p) {
+        if (p == rank) continue;
+        if (all[(size_t)p].device != device) {
+            const int pe = si_hip_enable_peer_access(all[(size_t)p].device);
+            if (pe != 0) LOG(INFO) << "si_gather_create: peer access " << device << " -> " << all[(size_t)p].device << " not enabled (" << pe << "); relying on the IPC mapping";
+        }
+        for (int s = 0; rc == 0 && s < slots; ++s) rc = si_hip_ipc_open_mem_handle(all[(size_t)p].handle[s], &d->peer[(size_t)p][(size_t)s]);
+        if (rc == 0) rc = si_hip_stream_create(&d->stream[(size_t)p]);
+        for (int s = 0; rc == 0 && s < slots; ++s) rc = si_hip_event_create(&d->sent[(size_t)s][(size_t)p]);
+    }
+    rc = agree(g, rc);
+    if (rc != 0) { LOG(ERROR) << "si_gather_create: opening the peers' buffers failed (" << rc << ")"; release(d); return rc; }
+    *out = d;
+    return 0;
+}
+
+int si_gather_destroy(SiDirectGather* d) {
+    if (!d) return 0;
+    si_hip_set_device(d->device);
+    for (si_stream_t s : d->stream) if (s) si_hip_stream_sync(s);
+    // nobody frees a buffer a peer may still be copying into
+    const int rc = si_group_barrier(d->group);
+    SiNodeGroup* g = d->group;
+    for (auto& slots : d->peer) for (void*& p : slots) if (p) { si_hip_ipc_close_mem_handle(p); p = nullptr; }
+    const int rc2 = si_group_barrier(g);  // every mapping is closed before the owner frees
+    release(d);
+    return rc != 0 ? rc : rc2;
+}
+
+int si_gather_slots(const SiDirectGather* d) { return d ? d->slots : -1; }
+size_t si_gather_slab_bytes(const SiDirectGather* d) { return d ? d->slab : 0; }
+void* si_gather_buffer(SiDirectGather* d, int slot) { return (d && slot >= 0 && slot < d->slots) ? d->mine[(size_t)slot] : nullptr; }
+void* si_gather_slab(SiDirectGather* d, int slot) {
+    void* b = si_gather_buffer(d, slot);
+    return b ? static_cast<unsigned char*>(b) + (size_t)d->group->rank * d->slab : nullptr;
+}
+
+int si_gather_push(SiDirectGather* d, int slot, si_stream_t producer) {
+    if (!d || slot < 0 || slot >= d->slots) return SI_SHARD_E_BADARG;
+    const int world = d->group->world, rank = d->group->rank;
+    if (world == 1) return 0;
+    int rc = si_hip_event_record(d->ready[(size_t)slot], producer);
+    const size_t off = (size_t)rank * d->slab;
+    const unsigned char* src = static_cast<const unsigned char*>(d->mine[(size_t)slot]) + off;
+    // one copy per peer, each on its own stream: point-to-point links, no ring; start at rank + 1 so that at any moment the
+    // ranks are not all writing into the same destination
+    for (int i = 1; rc == 0 && i < world; ++i) {
+        const int p = (rank + i) % world;
+        rc = si_hip_stream_wait_event(d->stream[(size_t)p], d->ready[(size_t)slot]);
+        if (rc == 0) rc = si_hip_memcpy_d2d(static_cast<unsigned char*>(d->peer[(size_t)p][(size_t)slot]) + off, src, d->slab, d->stream[(size_t)p]);
+        if (rc == 0) rc = si_hip_event_record(d->sent[(size_t)slot][(size_t)p], d->stream[(size_t)p]);
+    }
+    d->pushed[(size_t)slot] = 1;
+    return rc;
+}
+
+int si_gather_complete(SiDirectGather* d, int slot) {
+    if (!d || slot < 0 || slot >= d->slots) return SI_SHARD_E_BADARG;
+    int rc = 0;
+    // a copy command completes with its bytes visible at system scope; the barrier then tells every rank that all peers'
+    // pushes into ITS buffer are done; kernels launched afterwards see them
+    // (only THIS slot's copies are waited for: a later slot's fan-out keeps running behind the next step's compute)
+    if (d->pushed[(size_t)slot]) {
+        for (si_event_t e : d->sent[(size_t)slot]) if (e && rc == 0) rc = si_hip_event_sync(e);
+        d->pushed[(size_t)slot] = 0;
+    }
+    const int b = si_group_barrier(d->group);
+    return rc != 0 ? rc : b;
+}
+
+}  // extern "C"

@@ -43,6 +43,13 @@ class DeviceBuffer:
         _chk(_native.hip().si_hip_stream_sync(stream), "sync")
         return b
 
+    @classmethod
+    def view(cls, ptr: int, nbytes: int) -> "DeviceBuffer":
+        """Non-owning handle on device memory somebody else allocated (an engine output, a gathered buffer)."""
+        b = cls.__new__(cls)
+        b.nbytes, b.ptr, b._borrowed = int(nbytes), int(ptr), True
+        return b
+
     def to_numpy(self, shape, dtype=np.float32, stream=None) -> np.ndarray:
         out = np.empty(shape, dtype)
         assert out.nbytes <= max(self.nbytes, 16)
@@ -56,7 +63,8 @@ class DeviceBuffer:
 
     def free(self):
         if getattr(self, "ptr", None):
-            _native.hip().si_hip_free(self.ptr)
+            if not getattr(self, "_borrowed", False):
+                _native.hip().si_hip_free(self.ptr)
             self.ptr = None
 
     def __del__(self):

@@ -34,6 +34,15 @@ def test_engine_abi_exports_every_declared_symbol(native_libs):
     assert sorted(host._si_signatures) == names
 
 
+def test_shard_abi_exports_every_declared_symbol(native_libs):
+    _, host = native_libs
+    names = declared("si_shard.h")
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(host, n), "libsimpleinfer_amd.so does not export " + n
+    assert sorted(host._si_shard_signatures) == names
+
+
 def test_host_library_exports_cpp_drop_in_api(native_libs):
     """Engine / Tensor / registry C++ symbols of the reference API (include/engine.h, tensor.h) are exported."""
     import subprocess
@@ -43,7 +52,8 @@ def test_host_library_exports_cpp_drop_in_api(native_libs):
                 "SimpleInfer::Engine::Input(", "SimpleInfer::Engine::InputNames", "SimpleInfer::Engine::Release()",
                 "SimpleInfer::InitializeContext()", "SimpleInfer::Tensor::Allocate()", "SimpleInfer::GetLayerRegistry(",
                 "SimpleInfer::Conv2d_LayerCreator()", "SimpleInfer::YoloDetect_LayerDestroyer(", "pnnx::Graph::load(",
-                "pnnx::expand_expression("):
+                "pnnx::expand_expression(", "SimpleInfer::ShardedEngine::Init(", "SimpleInfer::ShardedEngine::Forward()",
+                "SimpleInfer::ShardedEngine::Gathered("):
         assert sym in out, sym
 
 

@@ -464,7 +464,8 @@ def test_full_size_properties_resnet18_224_batch64(si, orc, tmp_path):
     kernels = [L["kernel"] for L in prof]
     assert sum("conv_wino23" in k for k in kernels) == 13, kernels          # every 3x3 s1 conv
     assert sum("conv_smallc_rows" in k for k in kernels) == 1, kernels       # the 7x7 s2 stem
-    assert sum("conv_igemm_f32_fast" in k for k in kernels) == 7, kernels    # 3 3x3 s2 + 3 1x1 s2 + the Linear head
+    assert sum("conv_igemm_f32_fast" in k for k in kernels) == 6, kernels    # 3 3x3 s2 + 3 1x1 s2 downsample convs
+    assert prof[-1]["type"] == "nn.Linear" and prof[-1]["kernel"].startswith("conv_igemm"), prof[-1]   # the head runs as a 1x1 conv
     s = e64.schedule()
     assert sum(n.startswith("relu_") for n in s["fused"]) == 17 and sum(n.startswith("add_") for n in s["fused"]) == 8
     e1 = si.Engine()

@@ -1,0 +1,72 @@
+"""GPU: the multi-rank path on ONE device.  hipIpc handles work between processes that share a device, so the direct
+output all-gather of include/si_shard.h (IPC-shared gathered buffers, one device-to-device copy per peer, node barrier)
+and bench.py's self-launched `--gpus 2` run are exercised end to end on the 1-GPU box; only the xGMI links are missing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = os.path.join(ROOT, "tests", "_rank_child.py")
+
+
+@pytest.mark.parametrize("world,slots,graph", [(2, 3, 0), (3, 3, 1), (2, 1, 0)])
+def test_direct_gather_between_processes_is_bit_exact(gpu, tmp_path, world, slots, graph):
+    """Every rank ends up with every rank's slab, bit for bit, for five consecutive steps with different inputs: overlapped
+    (3 slots: step s computes while step s-1's slabs travel), with hipGraph replay (one captured graph per output slot), and
+    unoverlapped (1 slot)."""
+    from simpleinfer_amd import launch
+    code, out = launch.spawn_ranks([sys.executable, CHILD, "gather", str(tmp_path), str(slots), str(graph)], world, timeout=300)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert code == 0 and lines, out
+    res = json.loads(lines[-1])
+    assert res["ok"] == [1] * world
+    assert res["shape"][0] == 2 * world
+
+
+def _bench(*args, env_extra=None, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + [str(a) for a in args], env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_line_single_gpu(gpu):
+    p, r = _bench("--steps", 3, "--warmup", 1, "--size", 160, "--batch", 4, "--min-time", 0.2, "--cpu-images", 1, "--cpu-batch", 2)
+    assert p.returncode == 0 and r is not None, p.stderr[-3000:]
+    assert len([ln for ln in p.stdout.splitlines() if ln.strip()]) == 1          # ONE line on stdout
+    assert r["n_gpus"] == 1 and r["steps"] == 3 and r["scaling"] == "weak" and r["dtype"] == "f32" and r["unit"] == "images/sec"
+    assert r["value"] > 0 and abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-3
+    w = r["windows"]
+    assert w["count"] >= 1 and w["ms_per_step_min"] <= w["ms_per_step_median"] <= w["ms_per_step_max"] and w["timed_s_total"] >= 0.2
+    roof = r["roofline"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1.2 and roof["peak"] == 157.3 and "traffic_source" in roof
+    for k in ("cpu_baseline", "cpu_baseline_batched"):
+        assert r[k]["kind"] == "port" and r[k]["value"] > 0 and r[k]["cores"] >= 1
+    assert r["config"]["gather"] is None
+
+
+def test_bench_self_launches_two_ranks_sharing_the_device(gpu):
+    """`python bench.py --gpus 2` (no launcher): the parent spawns two ranks; with SI_BENCH_SHARE_DEVICE=1 both use device 0
+    and the IPC all-gather runs for real (RCCL refuses two ranks on one device).  Strong scaling flag: 8 images over 2."""
+    p, r = _bench("--gpus", 2, "--steps", 3, "--warmup", 1, "--size", 160, "--global-batch", 8, "--min-time", 0.2, "--gather", "p2p",
+                  env_extra={"SI_BENCH_SHARE_DEVICE": "1"})
+    assert p.returncode == 0 and r is not None, p.stderr[-3000:]
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["per_gpu_batch"] == 4 and r["config"]["global_batch"] == 8
+    assert r["config"]["gather"] == "p2p" and r["value"] > 0
+    assert r["cpu_baseline"] is None      # rank 0 at N = 1 only
+
+
+def test_bench_needs_as_many_devices_as_ranks(gpu):
+    from simpleinfer_amd import device_count
+    if device_count() >= 2:
+        pytest.skip("two devices present")
+    p, r = _bench("--gpus", 2, "--steps", 1, "--warmup", 0, "--size", 64, "--batch", 1)
+    assert p.returncode != 0 and r is None
+    assert "need 2 HIP devices" in p.stderr
