@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_HIP_PATH = os.path.join(PKG, "libsi_hip.so")
+# SI_HIP_LIB: a differently built kernel library (development: diagnostic / variant builds under build_variants/)
+LIB_HIP_PATH = os.environ.get("SI_HIP_LIB") or os.path.join(PKG, "libsi_hip.so")
 # SI_HOST_LIB: a differently built host library (tools/asan_host.sh points it at the ASan + UBSan build)
 LIB_HOST_PATH = os.environ.get("SI_HOST_LIB") or os.path.join(PKG, "libsimpleinfer_amd.so")
 

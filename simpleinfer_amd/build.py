@@ -51,16 +51,37 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
-def build_hip(force=False, verbose_resources=False):
+def build_hip(force=False, verbose_resources=False, defines=(), out=None, objdir=None):
+    """One object per .hip file (compiled in parallel, rebuilt only when stale), then one link.  `defines` / `out` /
+    `objdir` build a variant (diagnostic stamps, experiment switches) next to the product library without touching it."""
     srcs = hip_sources()
-    if not force and not _stale(LIB_HIP, srcs + _headers()):
-        return LIB_HIP
+    out = out or LIB_HIP
+    objdir = objdir or os.path.join(PKG, "build", "hip")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INC, "-I" + HIP_DIR]
+    hdr_time = _newest(_headers())
+    base = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INC, "-I" + HIP_DIR] + ["-D" + d for d in defines]
     if verbose_resources:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    _run(cmd + srcs + ["-o", LIB_HIP])
-    return LIB_HIP
+        base.append("-Rpass-analysis=kernel-resource-usage")
+    objs, procs = [], []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            cmd = base + ["-c", s, "-o", o]
+            print("+ " + " ".join(cmd), flush=True)
+            procs.append(subprocess.Popen(cmd))
+            if len(procs) >= 6:
+                for p in procs:
+                    if p.wait() != 0:
+                        raise subprocess.CalledProcessError(p.returncode, p.args)
+                procs = []
+    for p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, p.args)
+    if force or _stale(out, objs):
+        _run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", out])
+    return out
 
 
 def build_host(force=False):

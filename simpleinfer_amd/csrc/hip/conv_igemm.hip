@@ -272,6 +272,30 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
+// Diagnostic build only (-DSI_DIAG_STAMPS, tools/conv_diag.py): per-workgroup s_memtime / s_memrealtime stamps at the phase
+// boundaries of the fast kernel, written to a buffer of their own that nothing else reads.  In the product build no stamp
+// executes and the macros expand to nothing.
+
+#ifdef SI_DIAG_STAMPS
+__device__ unsigned long long si_diag_stamps[65536 * 8];
+#define SI_STAMP_DECL unsigned long long st_[8]
+#define SI_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#define SI_STAMP_RT(i) st_[i] = __builtin_amdgcn_s_memrealtime()
+#define SI_STAMP_FLUSH()                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 65536) {                                            \
+        unsigned hw_, xcc_;                                                                                     \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                       \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                     \
+        st_[7] = ((unsigned long long)xcc_ << 32) | hw_;                                                        \
+        for (int i_ = 0; i_ < 8; ++i_) si_diag_stamps[(size_t)blockIdx.x * 8 + i_] = st_[i_];                   \
+    }
+#else
+#define SI_STAMP_DECL
+#define SI_STAMP(i)
+#define SI_STAMP_RT(i)
+#define SI_STAMP_FLUSH()
+#endif
+
 template <int BM, int BN, int WM, int WN, bool VEC_A>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -449,6 +473,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     // NBUF = 2: one barrier per K-tile.  NBUF = 1: half the LDS (more workgroups per CU), two barriers
     // per K-tile; the other resident workgroups cover them.
     __shared__ __attribute__((aligned(16))) float lds[NBUF][(BM + BN) * LDS_LD];
+    SI_STAMP_DECL;
+    SI_STAMP_RT(0);
+    SI_STAMP(1);
 
     const int g = blockIdx.y;
     const int per_chunk = 8 * a.n_tiles;
@@ -491,6 +518,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
             // every VALID tap back into [0, in_bytes))
             a_off[i] = (unsigned)((img * a.ih + y0) * a.iw + x0) * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16);
             unsigned long long mk = 0ull;
+            if (a.kh == 3 && a.kw == 3) {
+                // the 3x3 case straight-line: three row bits, three column bits (the generic loop below is ~15 instructions per
+                // tap with 64-bit shifts; tools/conv_diag.py: prologue 55 k -> 30 k cycles for a workgroup that starts beside
+                // seven others in their K loops -- a shorter launch ramp, no measurable change in steady state)
+                unsigned rowbits = 0, colbits = 0;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    rowbits |= ((unsigned)(y0 + t * a.dh) < (unsigned)a.ih ? 1u : 0u) << t;
+                    colbits |= ((unsigned)(x0 + t * a.dw) < (unsigned)a.iw ? 1u : 0u) << t;
+                }
+                unsigned m9 = 0;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) m9 |= ((rowbits >> t) & 1u) ? (colbits << (3 * t)) : 0u;
+                mk = m9;
+            } else
             for (int ky = 0; ky < a.kh; ++ky)
                 for (int kx = 0; kx < a.kw; ++kx) {
                     const int y = y0 + ky * a.dh, x = x0 + kx * a.dw;
@@ -564,8 +606,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         const int o = n0 + wn * TN * 32 + l31 + u * 32;
         bias_pre[u] = (a.bias && o < a.ocg) ? a.bias[g * a.ocg + o] : 0.0f;
     }
+    SI_STAMP(2);
     store_tile(0);
     __syncthreads();
+    SI_STAMP(3);
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = NBUF == 2 ? (kt & 1) : 0;
@@ -605,13 +649,32 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         }
     }
 
+    SI_STAMP(4);
+
     int yolo_img = -1;
     if (a.ymode && m0 + BM <= a.M) {
         const int img = m0 / a.ohow;
         if (m0 - img * a.ohow + BM <= a.ohow) yolo_img = img;
     }
     epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31, m0 + BM <= a.M, yolo_img, bias_pre);
+    SI_STAMP(5);
+    SI_STAMP_RT(6);
+    SI_STAMP_FLUSH();
 }
+
+#ifdef SI_DIAG_STAMPS
+}  // namespace
+extern "C" int si_hip_diag_stamps_read(unsigned long long* host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(si_diag_stamps), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int si_hip_diag_stamps_clear(void) {
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(si_diag_stamps));
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 65536 * 8);
+}
+namespace {
+#endif
 
 template <int BM, int BN, int WM, int WN, int NBUF>
 int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {

@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--min-ms", type=float, default=0.0, help="sustained timing: repeat until this many ms of launches were timed (DVFS: a "
+                    "few-ms burst after idle runs at 1.7-2.0 GHz, a sustained run at ~2.35 GHz), after an equally long warm-up")
     ap.add_argument("--model", default="yolov5s")
     ap.add_argument("--only", default="")
     ap.add_argument("--act", default="silu")
@@ -86,14 +88,19 @@ def main():
             rc = fn(C.byref(d), dx.ptr, dw.ptr, db.ptr, None, dy.ptr, None)
             assert rc == 0, rc
         H.si_hip_device_sync()
-        H.si_hip_event_record(ev0, None)
-        for _ in range(args.reps):
-            fn(C.byref(d), dx.ptr, dw.ptr, db.ptr, None, dy.ptr, None)
-        H.si_hip_event_record(ev1, None)
-        H.si_hip_event_sync(ev1)
+        reps = args.reps
         ms = C.c_float()
-        H.si_hip_event_elapsed_ms(ev0, ev1, C.byref(ms))
-        ms = ms.value / args.reps
+        while True:
+            H.si_hip_event_record(ev0, None)
+            for _ in range(reps):
+                fn(C.byref(d), dx.ptr, dw.ptr, db.ptr, None, dy.ptr, None)
+            H.si_hip_event_record(ev1, None)
+            H.si_hip_event_sync(ev1)
+            H.si_hip_event_elapsed_ms(ev0, ev1, C.byref(ms))
+            if ms.value >= args.min_ms:
+                break
+            reps = int(reps * max(2.0, 1.2 * args.min_ms / max(ms.value, 1e-3)))   # the short passes double as warm-up
+        ms = ms.value / reps
         flops = 2.0 * n * oh * ow * co * k[0] * k[1] * (ci // g)
         byts = 4.0 * (n * ih * iw * ci + n * oh * ow * co + wn)
         name = fam if wino else H.si_hip_conv2d_kernel_name(C.byref(d), dx.ptr).decode().replace("conv_igemm_f32_kernel", "")
