@@ -217,11 +217,25 @@ int si_hip_nhwc_to_nchw_f32(const float* in, int n, int h, int w, int c, int in_
 /* y = act(x) over [pixels, c] with pixel strides */
 int si_hip_activation_f32(int act, float act_param, const float* in, size_t pixels, int c, int in_ld, float* out,
                           int out_ld, si_stream_t stream);
-/* op 0 = add, 2 = mul (src/layer/binary_op.cpp:17-31) with Eigen-style tiling broadcast by integer
- * factors out/in per dim (:60-75).  Shapes are rank-4 NHWC; *_ld pixel strides. */
+/* out = a (op) b with Eigen-style tiling broadcast by integer factors out/in per dim (src/layer/binary_op.cpp:60-75).
+ * op: the codes pnnx's expression lowering writes into BinaryOp's param "0" (src/pnnx/expand_expression.cpp:198-216):
+ * 0 add, 1 sub, 2 mul, 3 div, 6 pow, 10 atan2, and operand-reversed 7 (b - a), 8 (b / a), 9 (pow(b, a)), 11.  The reference
+ * layer implements 0 and 2 only (binary_op.cpp:17-31) and fails LoadModel on the rest; here they all run.
+ * Shapes are rank-4 NHWC; *_ld pixel strides. */
 int si_hip_binary_f32(int op, const float* a, const int a_shape[4], int a_ld, const float* b,
                       const int b_shape[4], int b_ld, float* out, const int out_shape[4], int out_ld,
                       si_stream_t stream);
+/* out = in (op) scalar over [pixels, c]: BinaryOp's `with_scalar` form (params "1" = 1, "2" = the literal;
+ * src/pnnx/expand_expression.cpp:206-236), same op codes; 7 / 8 / 9 / 11 put the scalar on the left.  The reference's
+ * BinaryOp::Init does not read those params. */
+int si_hip_binary_scalar_f32(int op, const float* in, size_t pixels, int c, int in_ld, float scalar, float* out,
+                             int out_ld, si_stream_t stream);
+/* out = f(in) over [pixels, c]: the UnaryOp operator pnnx's expression lowering emits (src/pnnx/expand_expression.cpp:
+ * 123-165) and the reference never registered (LoadModel returns kEmpty, src/engine_impl.cpp:247-250).  op: 0 abs, 1 neg,
+ * 2 floor, 3 ceil, 4 square, 5 sqrt, 6 rsqrt, 7 exp, 8 log, 9 sin, 10 cos, 11 tan, 12 asin, 13 acos, 14 atan, 15 reciprocal,
+ * 16 tanh, 17 log10. */
+int si_hip_unary_f32(int op, const float* in, size_t pixels, int c, int in_ld, float* out, int out_ld,
+                     si_stream_t stream);
 /* (x-mean)*rsqrt(var+eps)*gamma+beta   (src/layer/batch_norm_2d.cpp:84-137) */
 int si_hip_batchnorm2d_f32(const float* in, size_t pixels, int c, int in_ld, const float* mean, const float* var,
                            const float* gamma, const float* beta, float eps, float* out, int out_ld,

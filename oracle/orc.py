@@ -325,19 +325,60 @@ def nhwc_shape(shape_nchw: Sequence[int]) -> List[int]:
     return s
 
 
+UNARY_CODES = {"abs": 0, "neg": 1, "floor": 2, "ceil": 3, "square": 4, "sqrt": 5, "rsqrt": 6, "exp": 7, "log": 8, "sin": 9,
+               "cos": 10, "tan": 11, "asin": 12, "acos": 13, "atan": 14, "reciprocal": 15, "tanh": 16, "log10": 17}
+BINARY_CODES = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 6, "atan2": 10}
+BINARY_REVERSED = {"sub": 7, "div": 8, "pow": 9, "atan2": 11}
+
+
+def unary_op(op: int, x: np.ndarray) -> np.ndarray:
+    x = _f32(x)
+    out = np.empty_like(x)
+    rc = lib().orc_unary_op(op, _p(x), _p(out), C.c_size_t(x.size))
+    if rc != 0:
+        raise RuntimeError("unary_op rc=%d" % rc)
+    return out
+
+
+def binary_scalar(op: int, x: np.ndarray, scalar: float) -> np.ndarray:
+    x = _f32(x)
+    out = np.empty_like(x)
+    rc = lib().orc_binary_scalar(op, _p(x), C.c_float(scalar), _p(out), C.c_size_t(x.size))
+    if rc != 0:
+        raise RuntimeError("binary_scalar rc=%d" % rc)
+    return out
+
+
 def _eval_expr(expr: str, args: List[np.ndarray], out_shape):
-    """add/mul-only prefix expressions, as BinaryOp supports (reference src/layer/binary_op.cpp:17-31)."""
+    """A pnnx.Expression evaluated as the reference's loader lowers it (src/pnnx/expand_expression.cpp:65-307): prefix
+    expression scanned right to left; unary functions -> UnaryOp, binary ones -> BinaryOp, a literal operand -> the scalar
+    form (the literal first: the operand-reversed code), pow(x, 2) -> square.  (The reference's BinaryOp layer then only runs
+    add and mul of two tensors, src/layer/binary_op.cpp:17-31; the rest has float libm semantics here.)"""
     toks = expr.replace("(", " ").replace(")", " ").replace(",", " ").split()
-    stack: List[np.ndarray] = []
+    stack: list = []
+    is_lit = lambda v: isinstance(v, float)
     for t in reversed(toks):
-        if t in ("add", "mul"):
+        if t in UNARY_CODES:
+            a = stack.pop()
+            stack.append(unary_op(UNARY_CODES[t], a))
+        elif t in BINARY_CODES:
             a, b = stack.pop(), stack.pop()
-            o4 = [max(x, y) for x, y in zip(pad4(a.shape), pad4(b.shape))]
-            stack.append(binary_op(0 if t == "add" else 2, a, b, o4))
+            if is_lit(a) and is_lit(b):
+                raise NotImplementedError("constant folding is pnnx's job, not the loader's")
+            if is_lit(a):
+                stack.append(binary_scalar(BINARY_REVERSED.get(t, BINARY_CODES[t]), b, a))
+            elif is_lit(b):
+                stack.append(unary_op(4, a) if (t == "pow" and b == 2.0) else binary_scalar(BINARY_CODES[t], a, b))
+            else:
+                o4 = [max(x, y) for x, y in zip(pad4(a.shape), pad4(b.shape))]
+                stack.append(binary_op(BINARY_CODES[t], a, b, o4))
         elif t[0] == "@":
             stack.append(args[int(t[1:])])
         else:
-            raise NotImplementedError("expression token %r (the reference BinaryOp layer rejects it too)" % t)
+            try:
+                stack.append(float(t))
+            except ValueError:
+                raise NotImplementedError("expression token %r (the reference's lowering gives up on it too)" % t)
     return stack.pop().reshape(out_shape)
 
 

@@ -540,9 +540,30 @@ void orc_cat_axis(const float* in, const int s[4], float* out, const int o[4],
 
 /* src/layer/binary_op.cpp:52-94: Eigen broadcast(factor) tiles the input, so
  * element i of the output reads input index i % in_dim on each axis. */
+/* The reference layer has add (0) and mul (2) only (binary_op.cpp:17-31).  The other codes are what pnnx's expression lowering
+ * writes into BinaryOp's param "0" (src/pnnx/expand_expression.cpp:198-216: 1 sub, 3 div, 6 pow, 10 atan2; with a literal first
+ * operand the reversed forms 7 rsub, 8 rdiv, 9 rpow, 11 ratan2).  No reference arithmetic exists for them: the restatement is
+ * the C operator / libm function the code names, in float. */
+static inline float orc_binary_apply(int op, float x, float y) {
+    switch (op) {
+        case 0: return x + y;
+        case 1: return x - y;
+        case 2: return x * y;
+        case 3: return x / y;
+        case 6: return powf(x, y);
+        case 7: return y - x;
+        case 8: return y / x;
+        case 9: return powf(y, x);
+        case 10: return atan2f(x, y);
+        case 11: return atan2f(y, x);
+        default: return x;
+    }
+}
+static int orc_binary_known(int op) { return (op >= 0 && op <= 3) || (op >= 6 && op <= 11); }
+
 int orc_binary_op(int op, const float* a, const int as[4], const float* b,
                   const int bs[4], float* out, const int os[4]) {
-    if (op != 0 && op != 2) return -1;
+    if (!orc_binary_known(op)) return -1;
     for (int d = 0; d < 4; ++d)
         if (as[d] <= 0 || bs[d] <= 0 || os[d] % as[d] != 0 || os[d] % bs[d] != 0) return -2;
 #pragma omp parallel for schedule(static)
@@ -552,8 +573,49 @@ int orc_binary_op(int op, const float* a, const int as[4], const float* b,
                 for (int i3 = 0; i3 < os[3]; ++i3) {
                     const float x = a[(((size_t)(i0 % as[0]) * as[1] + (i1 % as[1])) * as[2] + (i2 % as[2])) * as[3] + (i3 % as[3])];
                     const float y = b[(((size_t)(i0 % bs[0]) * bs[1] + (i1 % bs[1])) * bs[2] + (i2 % bs[2])) * bs[3] + (i3 % bs[3])];
-                    out[(((size_t)i0 * os[1] + i1) * os[2] + i2) * os[3] + i3] = (op == 0) ? x + y : x * y;
+                    out[(((size_t)i0 * os[1] + i1) * os[2] + i2) * os[3] + i3] = orc_binary_apply(op, x, y);
                 }
+    return 0;
+}
+
+/* BinaryOp's `with_scalar` form (expand_expression.cpp:206-236: params "1" = 1, "2" = the literal): out = in (op) scalar */
+int orc_binary_scalar(int op, const float* in, float scalar, float* out, size_t count) {
+    if (!orc_binary_known(op)) return -1;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)count; ++i) out[i] = orc_binary_apply(op, in[i], scalar);
+    return 0;
+}
+
+/* UnaryOp as emitted by expand_expression.cpp:123-165 (ncnn's operator numbering).  The reference registers no such layer
+ * (LoadModel returns kEmpty): the restatement is the libm function each name stands for, in float. */
+int orc_unary_op(int op, const float* in, float* out, size_t count) {
+    if (op < 0 || op > 17) return -1;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)count; ++i) {
+        const float x = in[i];
+        float y;
+        switch (op) {
+            case 0: y = fabsf(x); break;
+            case 1: y = -x; break;
+            case 2: y = floorf(x); break;
+            case 3: y = ceilf(x); break;
+            case 4: y = x * x; break;
+            case 5: y = sqrtf(x); break;
+            case 6: y = 1.0f / sqrtf(x); break;
+            case 7: y = expf(x); break;
+            case 8: y = logf(x); break;
+            case 9: y = sinf(x); break;
+            case 10: y = cosf(x); break;
+            case 11: y = tanf(x); break;
+            case 12: y = asinf(x); break;
+            case 13: y = acosf(x); break;
+            case 14: y = atanf(x); break;
+            case 15: y = 1.0f / x; break;
+            case 16: y = tanhf(x); break;
+            default: y = log10f(x); break;
+        }
+        out[i] = y;
+    }
     return 0;
 }
 

@@ -124,6 +124,10 @@ void orc_cat_axis(const float* in, const int in_shape[4], float* out,
  * factors out/in per dim (:60-75) */
 int orc_binary_op(int op, const float* a, const int a_shape[4], const float* b,
                   const int b_shape[4], float* out, const int out_shape[4]);
+/* BinaryOp `with_scalar` form and UnaryOp, as pnnx's expression lowering emits them (src/pnnx/expand_expression.cpp:123-165,
+ * 198-244); no reference layer exists for either -- float libm semantics. */
+int orc_binary_scalar(int op, const float* in, float scalar, float* out, size_t count);
+int orc_unary_op(int op, const float* in, float* out, size_t count);
 
 /* act: 1 relu (relu.cpp:55-67), 2 silu (silu.cpp:49-62), 3 sigmoid
  * (sigmoid.cpp:55-67), 4 hardsigmoid (hard_sigmoid.cpp:62-78), 5 hardswish

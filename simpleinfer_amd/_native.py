@@ -112,6 +112,8 @@ def hip():
         "si_hip_nhwc_to_nchw_f32": (i, [vp, i, i, i, i, i, vp, vp]),
         "si_hip_activation_f32": (i, [i, f, vp, sz, i, i, vp, i, vp]),
         "si_hip_binary_f32": (i, [i, vp, ip, i, vp, ip, i, vp, ip, i, vp]),
+        "si_hip_binary_scalar_f32": (i, [i, vp, sz, i, i, f, vp, i, vp]),
+        "si_hip_unary_f32": (i, [i, vp, sz, i, i, vp, i, vp]),
         "si_hip_batchnorm2d_f32": (i, [vp, sz, i, i, vp, vp, vp, vp, f, vp, i, vp]),
         "si_hip_yolo_decode_f32": (i, [vp, i, i, i, i, i, vp, vp, f, vp, i, i, vp]),
         "si_hip_f32_to_f16_host": (i, [vp, vp, sz]),

@@ -53,10 +53,49 @@ __global__ void activation_kernel(int act, float ap, const float* __restrict__ i
     }
 }
 
-// ---- binary add / mul with tiling broadcast ------------------------------------------------
+// ---- binary ops with tiling broadcast ------------------------------------------------------
 struct Shape4 {
     int d[4];
 };
+
+// operator codes of the BinaryOp layers pnnx's expression lowering emits (reference src/pnnx/expand_expression.cpp:198-244):
+// 0 add, 1 sub, 2 mul, 3 div, 6 pow, 10 atan2 and their operand-reversed forms 7 (y - x), 8 (y / x), 9 (pow(y, x)), 11.
+// Division is IEEE (correctly rounded): no reciprocal approximation in a standalone arithmetic operator.
+__device__ __forceinline__ float binary_apply(int op, float x, float y) {
+    switch (op) {
+        case 0: return x + y;
+        case 1: return x - y;
+        case 2: return x * y;
+        case 3: return x / y;
+        case 6: return powf(x, y);
+        case 7: return y - x;
+        case 8: return y / x;
+        case 9: return powf(y, x);
+        case 10: return atan2f(x, y);
+        case 11: return atan2f(y, x);
+        default: return x;
+    }
+}
+__device__ __forceinline__ f32x4 binary_apply4(int op, f32x4 x, f32x4 y) {
+    if (op == 0) return x + y;
+    if (op == 2) return x * y;
+    if (op == 1) return x - y;
+    if (op == 7) return y - x;
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = binary_apply(op, x[i], y[i]);
+    return r;
+}
+__host__ __device__ inline bool binary_op_known(int op) { return (op >= 0 && op <= 3) || (op >= 6 && op <= 11); }
+__host__ __device__ inline int binary_op_reversed(int op) {
+    switch (op) {
+        case 1: return 7; case 7: return 1;
+        case 3: return 8; case 8: return 3;
+        case 6: return 9; case 9: return 6;
+        case 10: return 11; case 11: return 10;
+        default: return op;  // add, mul commute exactly
+    }
+}
 
 template <bool VEC>
 __global__ void binary_same_kernel(int op, const float* __restrict__ a, int a_ld, const float* __restrict__ b,
@@ -69,10 +108,10 @@ __global__ void binary_same_kernel(int op, const float* __restrict__ a, int a_ld
         if (VEC) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(a + p * a_ld + ch * 4);
             const f32x4 y = *reinterpret_cast<const f32x4*>(b + p * b_ld + ch * 4);
-            *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = (op == 0) ? x + y : x * y;
+            *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = binary_apply4(op, x, y);
         } else {
             const float x = a[p * a_ld + ch], y = b[p * b_ld + ch];
-            out[p * out_ld + ch] = (op == 0) ? x + y : x * y;
+            out[p * out_ld + ch] = binary_apply(op, x, y);
         }
     }
 }
@@ -89,7 +128,7 @@ __global__ void binary_chan_kernel(int op, const float* __restrict__ full, int f
         const size_t img = p / hw;
         const f32x4 x = *reinterpret_cast<const f32x4*>(full + p * full_ld + ch * 4);
         const f32x4 y = *reinterpret_cast<const f32x4*>(vec + img * vec_img_stride + ch * 4);
-        *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = (op == 0) ? x + y : x * y;
+        *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = binary_apply4(op, x, y);
     }
 }
 
@@ -108,7 +147,71 @@ __global__ void binary_bcast_kernel(int op, const float* __restrict__ a, Shape4 
         const size_t op_ = ((size_t)i0 * os.d[1] + i1) * os.d[2] + i2;
         const float x = a[ap * a_ld + (i3 % as.d[3])];
         const float y = b[bp * b_ld + (i3 % bs.d[3])];
-        out[op_ * out_ld + i3] = (op == 0) ? x + y : x * y;
+        out[op_ * out_ld + i3] = binary_apply(op, x, y);
+    }
+}
+
+// tensor (op) scalar: the `with_scalar` BinaryOp form (params "1" = 1, "2" = value; expand_expression.cpp:206-236)
+template <bool VEC>
+__global__ void binary_scalar_kernel(int op, const float* __restrict__ in, int in_ld, float scalar, float* __restrict__ out, int out_ld,
+                                     size_t pixels, int c) {
+    const int cv = VEC ? c / 4 : c;
+    const size_t total = pixels * (size_t)cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cv;
+        const int ch = (int)(i - p * cv);
+        if (VEC) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(in + p * in_ld + ch * 4);
+            const f32x4 y = {scalar, scalar, scalar, scalar};
+            *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = binary_apply4(op, x, y);
+        } else {
+            out[p * out_ld + ch] = binary_apply(op, in[p * in_ld + ch], scalar);
+        }
+    }
+}
+
+// UnaryOp codes of expand_expression.cpp:146-165 (ncnn's numbering): 0 abs 1 neg 2 floor 3 ceil 4 square 5 sqrt 6 rsqrt 7 exp
+// 8 log 9 sin 10 cos 11 tan 12 asin 13 acos 14 atan 15 reciprocal 16 tanh 17 log10.  Library-accurate functions, IEEE sqrt and
+// division: this is a standalone arithmetic operator, not a fused epilogue.
+__device__ __forceinline__ float unary_apply(int op, float x) {
+    switch (op) {
+        case 0: return fabsf(x);
+        case 1: return -x;
+        case 2: return floorf(x);
+        case 3: return ceilf(x);
+        case 4: return x * x;
+        case 5: return sqrtf(x);
+        case 6: return 1.0f / sqrtf(x);
+        case 7: return expf(x);
+        case 8: return logf(x);
+        case 9: return sinf(x);
+        case 10: return cosf(x);
+        case 11: return tanf(x);
+        case 12: return asinf(x);
+        case 13: return acosf(x);
+        case 14: return atanf(x);
+        case 15: return 1.0f / x;
+        case 16: return tanhf(x);
+        case 17: return log10f(x);
+        default: return x;
+    }
+}
+template <bool VEC>
+__global__ void unary_kernel(int op, const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, size_t pixels, int c) {
+    const int cv = VEC ? c / 4 : c;
+    const size_t total = pixels * (size_t)cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cv;
+        const int ch = (int)(i - p * cv);
+        if (VEC) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(in + p * in_ld + ch * 4);
+            f32x4 r;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = unary_apply(op, x[k]);
+            *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = r;
+        } else {
+            out[p * out_ld + ch] = unary_apply(op, in[p * in_ld + ch]);
+        }
     }
 }
 
@@ -350,7 +453,7 @@ int si_hip_activation_f32(int act, float act_param, const float* in, size_t pixe
 int si_hip_binary_f32(int op, const float* a, const int a_shape[4], int a_ld, const float* b, const int b_shape[4],
                       int b_ld, float* out, const int out_shape[4], int out_ld, si_stream_t stream) {
     if (!a || !b || !out || !a_shape || !b_shape || !out_shape) return SI_E_BADARG;
-    if (op != 0 && op != 2) return SI_E_UNSUPPORTED;  // reference binary_op.cpp:27-30
+    if (!binary_op_known(op)) return SI_E_UNSUPPORTED;  // the reference layer itself only has add / mul (binary_op.cpp:27-30)
     bool same = true;
     Shape4 as, bs, os;
     for (int i = 0; i < 4; ++i) {
@@ -372,8 +475,8 @@ int si_hip_binary_f32(int op, const float* a, const int a_shape[4], int a_ld, co
             hipLaunchKernelGGL(binary_same_kernel<false>, dim3(si_grid_for(pixels * c)), dim3(256), 0, s, op, a, a_ld,
                                b, b_ld, out, out_ld, pixels, c);
     } else {
-        // one operand is the whole tensor, the other a per-image (or global) channel vector: add and mul commute exactly,
-        // so which of a / b is which does not matter for the result
+        // one operand is the whole tensor, the other a per-image (or global) channel vector; when the vector is `a` the
+        // operator is applied operand-reversed (add and mul commute exactly)
         auto full_shape = [&](const Shape4& t) { return t.d[0] == os.d[0] && t.d[1] == os.d[1] && t.d[2] == os.d[2] && t.d[3] == os.d[3]; };
         auto chan_shape = [&](const Shape4& t) { return (t.d[0] == os.d[0] || t.d[0] == 1) && t.d[1] == 1 && t.d[2] == 1 && t.d[3] == os.d[3]; };
         const bool ab = full_shape(as) && chan_shape(bs), ba = full_shape(bs) && chan_shape(as);
@@ -383,13 +486,42 @@ int si_hip_binary_f32(int op, const float* a, const int a_shape[4], int a_ld, co
             const float* vec = ab ? b : a;
             const int full_ld = ab ? a_ld : b_ld, vec_ld = ab ? b_ld : a_ld;
             const Shape4& vs = ab ? bs : as;
-            hipLaunchKernelGGL(binary_chan_kernel, dim3(si_grid_for(pixels * (c / 4))), dim3(256), 0, s, op, full, full_ld, vec,
-                               vs.d[0] == 1 ? 0 : vec_ld, out, out_ld, pixels, os.d[1] * os.d[2], c);
+            hipLaunchKernelGGL(binary_chan_kernel, dim3(si_grid_for(pixels * (c / 4))), dim3(256), 0, s, ab ? op : binary_op_reversed(op),
+                               full, full_ld, vec, vs.d[0] == 1 ? 0 : vec_ld, out, out_ld, pixels, os.d[1] * os.d[2], c);
         } else {
             hipLaunchKernelGGL(binary_bcast_kernel, dim3(si_grid_for(pixels * c)), dim3(256), 0, s, op, a, as, a_ld, b, bs,
                                b_ld, out, os, out_ld);
         }
     }
+    return (int)hipGetLastError();
+}
+
+int si_hip_binary_scalar_f32(int op, const float* in, size_t pixels, int c, int in_ld, float scalar, float* out, int out_ld,
+                             si_stream_t stream) {
+    if (!in || !out || c <= 0) return SI_E_BADARG;
+    if (!binary_op_known(op)) return SI_E_UNSUPPORTED;
+    if (pixels == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && (in_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(in) && aligned16(out);
+    if (vec)
+        hipLaunchKernelGGL(binary_scalar_kernel<true>, dim3(si_grid_for(pixels * (c / 4))), dim3(256), 0, s, op, in, in_ld, scalar, out,
+                           out_ld, pixels, c);
+    else
+        hipLaunchKernelGGL(binary_scalar_kernel<false>, dim3(si_grid_for(pixels * c)), dim3(256), 0, s, op, in, in_ld, scalar, out, out_ld,
+                           pixels, c);
+    return (int)hipGetLastError();
+}
+
+int si_hip_unary_f32(int op, const float* in, size_t pixels, int c, int in_ld, float* out, int out_ld, si_stream_t stream) {
+    if (!in || !out || c <= 0) return SI_E_BADARG;
+    if (op < 0 || op > 17) return SI_E_UNSUPPORTED;
+    if (pixels == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (c % 4 == 0) && (in_ld % 4 == 0) && (out_ld % 4 == 0) && aligned16(in) && aligned16(out);
+    if (vec)
+        hipLaunchKernelGGL(unary_kernel<true>, dim3(si_grid_for(pixels * (c / 4))), dim3(256), 0, s, op, in, in_ld, out, out_ld, pixels, c);
+    else
+        hipLaunchKernelGGL(unary_kernel<false>, dim3(si_grid_for(pixels * c)), dim3(256), 0, s, op, in, in_ld, out, out_ld, pixels, c);
     return (int)hipGetLastError();
 }
 

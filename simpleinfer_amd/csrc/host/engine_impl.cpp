@@ -8,7 +8,9 @@
 #include "layer/binary_op.h"
 #include "layer/cat.h"
 #include "layer/conv_2d.h"
+#include "layer/linear.h"
 #include "layer/max_pool_2d.h"
+#include "layer/output_cast.h"
 #include "layer/yolo_detect.h"
 #include "layer_registry.h"
 #include "logger.h"
@@ -22,7 +24,7 @@ namespace {
 bool HonoursPixelStride(const std::string& type) {
     static const std::set<std::string> ok = {
         "nn.Conv2d", "nn.SiLU", "nn.ReLU", "nn.Sigmoid", "nn.Hardsigmoid", "nn.Hardswish", "nn.LeakyReLU",
-        "nn.MaxPool2d", "nn.AdaptiveAvgPool2d", "nn.Upsample", "torch.cat", "BinaryOp", "nn.BatchNorm2d",
+        "nn.MaxPool2d", "nn.AdaptiveAvgPool2d", "nn.Upsample", "torch.cat", "BinaryOp", "UnaryOp", "nn.BatchNorm2d",
         "torch.flatten", "models.yolo.Detect", "pnnx.Output"};
     return ok.count(type) > 0;
 }

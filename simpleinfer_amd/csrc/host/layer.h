@@ -17,39 +17,15 @@
 #include <vector>
 
 #include "context.h"
+#include "layer_registry.h"
 #include "logger.h"
 #include "pnnx/ir.h"
 #include "pnnx/pnnx_helper.h"
 #include "tensor.h"
+#include "tensor_node.h"
 #include "types.h"
 
 namespace SimpleInfer {
-
-// graph operand + the tensor bound to it (the reference keeps this in src/tensor_node.h:9-12)
-struct TensorNode {
-    pnnx::Operand* operand = nullptr;
-    Tensor tensor;
-};
-
-class Layer;
-
-// ---- registry: pnnx type string -> {creator, destroyer}, plain C function pointers (reference
-// src/layer_registry.h:10-18).  RegisterLayer / RegisteredLayerTypes are extensions: the reference's table is closed
-// (src/layer_registry.cpp:33-49).
-using LayerCreatorFunc   = Layer* (*)();
-using LayerDestroyerFunc = void (*)(Layer*);
-
-struct LayerRegistryEntry {
-    LayerCreatorFunc creator     = nullptr;
-    LayerDestroyerFunc destroyer = nullptr;
-};
-
-const LayerRegistryEntry* GetLayerRegistry(std::string type);
-
-// add (or replace) an entry at run time; returns false on null function pointers
-bool RegisterLayer(const std::string& type, LayerCreatorFunc creator, LayerDestroyerFunc destroyer);
-
-std::vector<std::string> RegisteredLayerTypes();
 
 class Layer {
 public:

@@ -1,5 +1,7 @@
 #include "binary_op.h"
 
+#include "layer_util.h"
+
 #include "si_hip.h"
 
 namespace SimpleInfer {
@@ -10,25 +12,40 @@ Status BinaryOp::Init(const pnnx::Operator* op) {
     CHECK_STATUS(Layer::Init(op));
     CHECK_BOOL(CheckParam(op, "0", 2));
     const int code = op->params.at("0").i;
-    if (code == 0) {
-        binary_op_type_ = BinaryOpType::kAdd;
-    } else if (code == 2) {
-        binary_op_type_ = BinaryOpType::kMul;
-    } else {
-        LOG(ERROR) << "unsupport BinaryOp type [" << code << "]";
-        return Status::kUnsupport;
+    switch (code) {
+        case 0: case 1: case 2: case 3: case 6: case 7: case 8: case 9: case 10: case 11:
+            binary_op_type_ = static_cast<BinaryOpType>(code);
+            break;
+        default:  // 4 / 5 (max / min) are never emitted by expand_expression
+            LOG(ERROR) << "unsupport BinaryOp type [" << code << "]";
+            return Status::kUnsupport;
     }
+    with_scalar_ = false;
     if (CheckParam(op, "1", 2) && op->params.at("1").i != 0) {
-        // scalar operand form ("1"=with_scalar, "2"=value): the reference layer has no handling for it
-        LOG(ERROR) << "unsupport BinaryOp with scalar operand";
-        return Status::kUnsupport;
+        // scalar operand form (expand_expression.cpp:206-236): "1" = with_scalar, "2" = the literal as a float
+        CHECK_BOOL(CheckParam(op, "2", 3));
+        with_scalar_ = true;
+        scalar_ = op->params.at("2").f;
     }
     return Status::kSuccess;
 }
 
 Status BinaryOp::Validate() {
     CHECK_STATUS(Layer::Validate());
-    return ValidateShape(2, 1);
+    return ValidateShape(with_scalar_ ? 1 : 2, 1);
+}
+
+Status BinaryOp::Forward(const Tensor& input, Tensor& output) {
+    if (!with_scalar_) return Status::kErrorShape;
+    return RunOnDevice({&input}, {&output}, [this](const std::vector<Tensor>& in, std::vector<Tensor>& out) {
+        if (IsHalf(in[0]) || IsHalf(out[0])) return Status::kUnsupport;  // fp16 storage: not built for this operator
+        size_t pixels = 0, opix = 0;
+        int c = 0, oc = 0;
+        if (!GetPixelsChannels(in[0], pixels, c) || !GetPixelsChannels(out[0], opix, oc) || pixels != opix || c != oc) return Status::kErrorShape;
+        return CheckHip(si_hip_binary_scalar_f32((int)binary_op_type_, in[0].Data<float>(), pixels, c, in[0].PixelStride(), scalar_,
+                                                 out[0].Data<float>(), out[0].PixelStride(), Stream()),
+                        "BinaryOp (scalar)");
+    });
 }
 
 Status BinaryOp::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
@@ -40,6 +57,7 @@ Status BinaryOp::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
         if (IsHalf(in[0]) || IsHalf(in[1]) || IsHalf(out[0])) {
             // fp16 path: same-shape add / mul only (what residual blocks need)
             if (!(IsHalf(in[0]) && IsHalf(in[1]) && IsHalf(out[0])) || a != o || b != o) return Status::kUnsupport;
+            if (binary_op_type_ != BinaryOpType::kAdd && binary_op_type_ != BinaryOpType::kMul) return Status::kUnsupport;
             return CheckHip(si_hip_binary_same_f16((int)binary_op_type_, in[0].RawData(), in[0].PixelStride(), in[1].RawData(),
                                                    in[1].PixelStride(), out[0].RawData(), out[0].PixelStride(),
                                                    (size_t)o[0] * o[1] * o[2], o[3], Stream()),

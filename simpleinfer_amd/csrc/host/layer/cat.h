@@ -1,3 +1,25 @@
-// layer/cat.h -- kept for source compatibility with the reference's include path; the class lives in operators.h
+// layer/cat.h -- torch.cat over rank-4 tensors; NCHW dim -> NHWC axis map 1->3, 2->1, 3->2
+// (reference src/layer/cat.cpp:59-108).  When the engine aliases the producers into this layer's
+// output buffer (zero-copy cat) the corresponding input is skipped here.
 #pragma once
-#include "operators.h"
+
+#include "layer.h"
+#include "layer_util.h"
+
+namespace SimpleInfer {
+
+class Cat : public Layer {
+public:
+    virtual Status Init(const pnnx::Operator* op) override;
+    virtual Status Validate() override;
+    virtual Status Forward(const std::vector<Tensor>& inputs, Tensor& output) override;
+    virtual const char* KernelName() const override { return "copy_channels"; }
+
+    // NHWC axis the layer concatenates along
+    int NhwcAxis() const;
+
+public:
+    int dim_ = 0;
+};
+
+}  // namespace SimpleInfer

@@ -22,6 +22,7 @@ SI_DECLARE_LAYER(MaxPool2d)
 SI_DECLARE_LAYER(ReLU)
 SI_DECLARE_LAYER(Sigmoid)
 SI_DECLARE_LAYER(SiLU)
+SI_DECLARE_LAYER(UnaryOp)
 SI_DECLARE_LAYER(Upsample)
 SI_DECLARE_LAYER(YoloDetect)
 
@@ -46,6 +47,7 @@ static std::map<std::string, LayerRegistryEntry>& Table() {
         SI_ENTRY("nn.ReLU", ReLU),
         SI_ENTRY("nn.Sigmoid", Sigmoid),
         SI_ENTRY("nn.SiLU", SiLU),
+        SI_ENTRY("UnaryOp", UnaryOp),   // emitted by expand_expression, never registered by the reference
         SI_ENTRY("nn.Upsample", Upsample),
         SI_ENTRY("models.yolo.Detect", YoloDetect),
     };

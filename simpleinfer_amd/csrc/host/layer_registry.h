@@ -1,3 +1,28 @@
-// layer_registry.h -- kept for source compatibility with the reference's include path; the registry lives in layer.h
+// layer_registry.h -- pnnx type string -> {creator, destroyer}, plain C function pointers (reference
+// src/layer_registry.h:10-18).  RegisterLayer / RegisteredLayerTypes are extensions: the reference's table is closed
+// (src/layer_registry.cpp:33-49).
 #pragma once
-#include "layer.h"
+
+#include <string>
+#include <vector>
+
+namespace SimpleInfer {
+
+class Layer;
+
+using LayerCreatorFunc   = Layer* (*)();
+using LayerDestroyerFunc = void (*)(Layer*);
+
+struct LayerRegistryEntry {
+    LayerCreatorFunc creator     = nullptr;
+    LayerDestroyerFunc destroyer = nullptr;
+};
+
+const LayerRegistryEntry* GetLayerRegistry(std::string type);
+
+// add (or replace) an entry at run time; returns false on null function pointers
+bool RegisterLayer(const std::string& type, LayerCreatorFunc creator, LayerDestroyerFunc destroyer);
+
+std::vector<std::string> RegisteredLayerTypes();
+
+}  // namespace SimpleInfer

@@ -1,3 +1,14 @@
-// tensor_node.h -- kept for source compatibility with the reference's include path; TensorNode lives in layer.h
+// tensor_node.h -- graph operand + the tensor bound to it (reference src/tensor_node.h:9-12)
 #pragma once
-#include "layer.h"
+
+#include "pnnx/ir.h"
+#include "tensor.h"
+
+namespace SimpleInfer {
+
+struct TensorNode {
+    pnnx::Operand* operand = nullptr;
+    Tensor tensor;
+};
+
+}  // namespace SimpleInfer

@@ -296,6 +296,31 @@ def binary_op(op, a, b, out_shape=None):
     return dy.to_numpy(o4).reshape(out_shape if out_shape is not None else o4)
 
 
+def binary_scalar(op, x, scalar):
+    """out = x (op) scalar -- BinaryOp's with_scalar form (op codes of include/si_hip.h; 7 / 8 / 9 / 11 put the scalar first)."""
+    H = _native.hip()
+    x = _f32(x)
+    c = x.shape[-1]
+    dx, dy = DeviceBuffer.from_numpy(x), DeviceBuffer(x.nbytes)
+    _chk(H.si_hip_binary_scalar_f32(op, dx.ptr, x.size // c, c, c, float(scalar), dy.ptr, c, None), "si_hip_binary_scalar_f32")
+    return dy.to_numpy(x.shape)
+
+
+def unary_op(op, x, in_ld=None, out_ld=None):
+    """out = f(x) -- UnaryOp codes 0..17 (include/si_hip.h); optional pixel strides exercise the strided form."""
+    H = _native.hip()
+    x = _f32(x)
+    c = x.shape[-1]
+    pixels = x.size // c
+    ild, old = in_ld or c, out_ld or c
+    xin = np.full((pixels, ild), np.nan, np.float32)
+    xin[:, :c] = x.reshape(pixels, c)
+    dx, dy = DeviceBuffer.from_numpy(xin), DeviceBuffer(pixels * old * 4)
+    dy.fill(0)
+    _chk(H.si_hip_unary_f32(op, dx.ptr, pixels, c, ild, dy.ptr, old, None), "si_hip_unary_f32")
+    return dy.to_numpy((pixels, old))[:, :c].reshape(x.shape)
+
+
 def activation(kind, x, param=0.0):
     H = _native.hip()
     x = _f32(x)

@@ -172,6 +172,33 @@ def test_batch_sharding_is_bit_exact(si, tmp_path):
         assert_exact(part, full[2 * r:2 * r + 2])
 
 
+def test_expression_graph_with_unary_and_scalar_ops(si, orc, tmp_path):
+    """expressions that lower to UnaryOp and to BinaryOp's scalar / sub / div / pow forms
+    (expand_expression.cpp:123-244).  The reference registers no UnaryOp layer and its BinaryOp::Init reads neither the scalar
+    params nor any code but add / mul, so it fails LoadModel on such a file; here it loads, runs and matches the oracle."""
+    mg = si.modelgen
+    b = mg.PnnxBuilder(3)
+    x = b.input((2, 3, 32, 32))
+    c1 = mg._Conv(b, x, 16, 3, 1)
+    c2 = mg._Conv(b, x, 16, 3, 1)
+    y = b.expression("add(@0,mul(@1,2.0))", [c1, c2])                 # scalar mul feeding a tensor add
+    y = b.expression("sqrt(add(pow(@0,2),1.0))", [y])                  # pow(x, 2) -> square; add scalar; UnaryOp sqrt
+    z = b.expression("div(1.0,add(exp(neg(@0)),1.0))", [c1])           # a hand-written sigmoid: neg, exp, +1, reversed div
+    y = b.expression("sub(@0,mul(@1,@2))", [y, z, c2])                  # three-operand expression, tensor sub
+    y = mg._Conv(b, y, 8, 1, 1)
+    b.output(b.expression("tanh(div(@0,4.0))", [y]))
+    pp, bp = _save(tmp_path, b, "expr")
+    xin = mg.synth_input((2, 32, 32, 3))
+    ref = orc.run_graph(pp, bp, {"0": xin})
+    e, oname, got = _run(si, pp, bp, xin)
+    (want,) = ref.values()   # expression lowering renames the output operand on the engine side (SURVEY.md Q8)
+    assert_parity(got, want, what="expression graph")
+    kernels = [L["kernel"] for L in e.profile()]
+    assert kernels.count("unary") >= 4 and "binary_scalar" in kernels and "binary" in kernels, kernels
+    _, _, plain = _run(si, pp, bp, xin, fuse=0, alias_cat=0)
+    assert_parity(plain, want, what="expression graph, plain schedule")
+
+
 def test_errors_are_statuses(si, tmp_path):
     e = si.Engine()
     with pytest.raises(si.StatusError):
@@ -486,3 +513,46 @@ def test_full_size_properties_resnet18_224_batch64(si, orc, tmp_path):
     e16.input("0", x)
     e16.forward()
     assert_parity(e16.extract(oname), full, F16_GRAPH_TOL, what="fp16 storage vs fp32 at full size")
+
+
+def test_reference_python_module_call_sequence(si, orc, tmp_path):
+    """the reference's Python surface (python/pybind11_main.cpp:13-68), name for name, in `python/simpleinfer.py`.
+    The call sequence of the reference's binding smoke test (InitializeContext, Engine, LoadModel, InputNames / OutputNames,
+    Tensor(DataType.Float32, shape), SetTensorDim4(constant 42.0 image), Input, Forward, Extract into an empty Tensor,
+    GetTensorDim4) on a synthesized narrow YOLOv5 -- checked against the oracle, which the reference's own test never does."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "python"))
+    import simpleinfer as infer
+    pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(4, 96), "py")
+    infer.InitializeContext()
+    engine = infer.Engine()
+    assert engine.LoadModel(str(tmp_path / "missing.param"), str(tmp_path / "missing.bin")) != infer.Status.Success
+    assert engine.LoadModel(pp, bp) == infer.Status.Success
+    input_names, output_names = engine.InputNames(), engine.OutputNames()
+    assert input_names == ["0"] and len(output_names) == 1
+    input_shape = [4, 96, 96, 3]                                     # NHWC
+    input_np = np.ones(input_shape, dtype=np.float32) * 42.0
+    input_tensor = infer.Tensor(infer.DataType.Float32, input_shape)
+    assert input_tensor.GetDataType() == infer.DataType.Float32 and input_tensor.Shape() == input_shape
+    assert input_tensor.SetTensorDim4(input_np) == infer.Status.Success
+    assert engine.Input(input_names[0], input_tensor) == infer.Status.Success
+    assert engine.Input("nope", input_tensor) == infer.Status.Fail
+    assert engine.Forward() == infer.Status.Success
+    output_tensor = infer.Tensor()
+    assert output_tensor.GetDataType() == infer.DataType["None"]
+    assert engine.Extract(output_names[0], output_tensor) == infer.Status.Success
+    output_np = output_tensor.GetTensorDim4()
+    rows = 3 * (12 * 12 + 6 * 6 + 3 * 3)
+    assert output_np.dtype == np.float32 and output_np.shape == (1, 4, rows, 8) and output_tensor.Shape() == [4, rows, 8]
+    ref = orc.run_graph(pp, bp, {"0": input_np})[output_names[0]]
+    assert_detect_parity(output_np[0], ref, what="constant-42 image through the reference-shaped module")
+    # borrow semantics: the array is read when Forward() runs, not when Input() was called (bench_yolo.cpp:22-27)
+    input_np[...] = si.modelgen.synth_input(tuple(input_shape), seed=5)
+    assert engine.Forward() == infer.Status.Success
+    assert engine.Extract(output_names[0], output_tensor) == infer.Status.Success
+    assert_detect_parity(output_tensor.GetTensorDim4()[0], orc.run_graph(pp, bp, {"0": input_np})[output_names[0]], what="second forward")
+    wrong = infer.Tensor(infer.DataType.Float32, [1, 8, 8, 3])
+    wrong.SetTensorDim4(np.zeros([1, 8, 8, 3], np.float32))
+    assert engine.Input(input_names[0], wrong) == infer.Status.ErrorShape
+    assert engine.Release() == infer.Status.Success and engine.InputNames() == []

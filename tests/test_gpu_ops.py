@@ -360,6 +360,39 @@ def test_binary(hops, orc):
         hops.binary_op(1, a, a)  # sub: unsupported by the reference layer too (binary_op.cpp:27-30)
 
 
+@pytest.mark.parametrize("op", range(18))
+def test_unary_ops(hops, orc, op):
+    """UnaryOp (expand_expression.cpp:123-165; no reference layer): the arithmetic codes bit-exact against the oracle (IEEE sqrt
+    and division on both sides), the library functions within 4 ulp element by element; also through pixel strides."""
+    from test_oracle import assert_ulp, unary_input
+    x = unary_input(op, (3, 9, 11, 20))
+    ref = orc.unary_op(op, x)
+    for kw in ({}, {"in_ld": 28, "out_ld": 24}, {"in_ld": 21, "out_ld": 23}):
+        got = hops.unary_op(op, x, **kw)
+        if op in (0, 1, 2, 3, 4, 5, 6, 15):
+            assert_exact(got, ref, "unary %d %s" % (op, kw))
+        else:
+            assert_ulp(got, ref, 4, "unary %d %s" % (op, kw))
+
+
+def test_binary_all_codes_and_scalar_forms(hops, orc):
+    """BinaryOp codes the loader can emit beyond the reference layer's add / mul (expand_expression.cpp:198-244): two tensors,
+    tensor (op) literal, literal (op) tensor, and the squeeze-excite style broadcast with a non-commutative operator."""
+    from test_oracle import assert_ulp
+    a, b = rng_uniform(1, (2, 6, 5, 16), 0.5, 3.0), rng_uniform(2, (2, 6, 5, 16), 0.5, 3.0)
+    for op in (0, 1, 2, 3, 7, 8):
+        assert_exact(hops.binary_op(op, a, b), orc.binary_op(op, a, b), "binary %d" % op)
+        assert_exact(hops.binary_scalar(op, a, 1.75), orc.binary_scalar(op, a, 1.75), "scalar %d" % op)
+    for op in (6, 9, 10, 11):
+        assert_ulp(hops.binary_op(op, a, b - 1.2), orc.binary_op(op, a, b - np.float32(1.2)), 4, "binary %d" % op)
+        assert_ulp(hops.binary_scalar(op, a, 2.5), orc.binary_scalar(op, a, 2.5), 4, "scalar %d" % op)
+    v = rng_uniform(3, (2, 1, 1, 16), 0.5, 2.0)
+    assert_exact(hops.binary_op(3, a, v), orc.binary_op(3, a, v), "x / se")
+    assert_exact(hops.binary_op(1, v, a, a.shape), orc.binary_op(1, v, a, a.shape), "se - x (the vector is the first operand)")
+    odd = rng_uniform(4, (1, 3, 5, 7), 0.5, 2.0)     # channel count without a 16-byte vector path
+    assert_exact(hops.binary_scalar(8, odd, 3.0), orc.binary_scalar(8, odd, 3.0), "3.0 / x, 7 channels")
+
+
 def test_batchnorm_flatten(hops, orc):
     g = GOLD
     assert_parity(hops.batchnorm2d(g["bn/x"], g["bn/mean"], g["bn/var"], g["bn/gamma"], g["bn/beta"], 1e-5), g["bn/y"], 1e-5)

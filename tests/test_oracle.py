@@ -181,6 +181,76 @@ def test_yolo_detect_row_order_and_decode(orc):
     assert mg is not None
 
 
+UNARY_NUMPY = {0: np.abs, 1: np.negative, 2: np.floor, 3: np.ceil, 4: np.square, 5: np.sqrt, 6: lambda x: np.float32(1) / np.sqrt(x),
+               7: np.exp, 8: np.log, 9: np.sin, 10: np.cos, 11: np.tan, 12: np.arcsin, 13: np.arccos, 14: np.arctan,
+               15: lambda x: np.float32(1) / x, 16: np.tanh, 17: np.log10}
+
+
+def unary_input(op, shape=(2, 5, 7, 12), seed=90):
+    """inputs inside each function's domain (and away from tan's poles)"""
+    lo, hi = {5: (0.05, 9), 6: (0.05, 9), 8: (0.05, 9), 17: (0.05, 9), 12: (-0.99, 0.99), 13: (-0.99, 0.99), 11: (-1.3, 1.3),
+              7: (-6, 6), 15: (0.2, 5)}.get(op, (-4, 4))
+    return rng_uniform(seed + op, shape, lo, hi)
+
+
+def assert_ulp(got, ref, ulps, what=""):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    bound = ulps * np.finfo(np.float32).eps * np.abs(ref) + 1e-37
+    bad = np.abs(got - ref) > bound
+    assert not bad.any(), "%s: %d elements beyond %g ulp (worst %.3g)" % (what, int(bad.sum()), ulps, float((np.abs(got - ref) / np.maximum(np.abs(ref), 1e-37)).max()))
+
+
+@pytest.mark.parametrize("op", range(18))
+def test_unary_op_restates_libm(orc, op):
+    """UnaryOp has no reference layer: the oracle's restatement is float libm; cross-checked against numpy's float32
+    functions (exact for the arithmetic ones, a couple of ulp for the transcendental ones)."""
+    x = unary_input(op)
+    got = orc.unary_op(op, x)
+    ref = UNARY_NUMPY[op](x).astype(np.float32)
+    if op in (0, 1, 2, 3, 4, 5, 6, 15):
+        assert_exact(got, ref, "unary %d" % op)
+    else:
+        assert_ulp(got, ref, 2, "unary %d" % op)
+
+
+def test_binary_ops_and_scalar_forms(orc):
+    a, b = rng_uniform(1, (2, 3, 4, 8), 0.5, 3.0), rng_uniform(2, (2, 3, 4, 8), 0.5, 3.0)
+    f = np.float32
+    for op, fn in {0: np.add, 1: np.subtract, 2: np.multiply, 3: np.divide}.items():
+        assert_exact(orc.binary_op(op, a, b), fn(a, b), "binary %d" % op)
+        assert_exact(orc.binary_scalar(op, a, 1.75), fn(a, f(1.75)), "binary scalar %d" % op)
+    assert_exact(orc.binary_op(7, a, b), b - a)
+    assert_exact(orc.binary_op(8, a, b), b / a)
+    assert_exact(orc.binary_scalar(7, a, 2.0), f(2.0) - a, "2.0 - x")
+    assert_exact(orc.binary_scalar(8, a, 2.0), f(2.0) / a, "2.0 / x")
+    assert_ulp(orc.binary_op(6, a, b), np.power(a, b), 2, "pow")
+    assert_ulp(orc.binary_scalar(9, a, 2.5), np.power(f(2.5), a), 2, "2.5 ** x")
+    assert_ulp(orc.binary_op(10, a, b - 1.5), np.arctan2(a, b - f(1.5)), 2, "atan2")
+    # broadcast of a non-commutative op: [N,H,W,C] / [N,1,1,C] and the operand-reversed code
+    v = rng_uniform(3, (2, 1, 1, 8), 0.5, 2.0)
+    assert_exact(orc.binary_op(3, a, v), a / v)
+    assert_exact(orc.binary_op(8, v, a, a.shape), a / v)
+    with pytest.raises(RuntimeError):
+        orc.binary_op(4, a, b)     # max / min are never emitted by the loader
+
+
+def test_expression_lowering_semantics(orc):
+    """orc._eval_expr follows the reference loader's lowering (expand_expression.cpp:65-307): literal first -> reversed code,
+    pow(x, 2) -> square, nesting."""
+    f = np.float32
+    x, y = rng_uniform(5, (1, 4, 4, 8), 0.5, 2.0), rng_uniform(6, (1, 4, 4, 8), 0.5, 2.0)
+    ev = lambda e, *a: orc._eval_expr(e, list(a), list(x.shape))
+    assert_exact(ev("add(@0,mul(@1,2.0))", x, y), x + y * f(2.0))
+    assert_exact(ev("sub(1.5,@0)", x), f(1.5) - x)
+    assert_exact(ev("div(@0,4.0)", x), x / f(4.0))
+    assert_exact(ev("div(1.0,sqrt(@0))", x), f(1.0) / np.sqrt(x))
+    assert_exact(ev("pow(@0,2)", x), x * x)
+    assert_exact(ev("neg(sub(@0,@1))", x, y), -(x - y))
+    assert_ulp(ev("mul(tanh(@0),exp(neg(@1)))", x, y), np.tanh(x) * np.exp(-y), 4)
+    with pytest.raises(NotImplementedError):
+        ev("size(@0,1)", x)
+
+
 @pytest.mark.parametrize("model", ["toy_classifier", "resnet18_224", "resnet18_224_const2"])
 def test_graph_oracle_matches_torch_composition(orc, tmp_path, model):
     """Whole-graph oracle (oracle/orc.py run_graph) vs an independent torch-CPU float64 evaluation of the
