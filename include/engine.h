@@ -72,6 +72,11 @@ public:
     //                          with 0, Extract() returns device tensors
     Status SetOption(const std::string& key, int value);
 
+    // Forward() in two halves: ForwardAsync() enqueues the launches on the engine's stream and returns, Sync() waits for them
+    // (and for the output copies).  One host thread can keep several engines busy this way.
+    Status ForwardAsync();
+    Status Sync();
+
     // shape (NHWC / as stored) of any input or output operand
     Status OperandShape(const std::string& name, std::vector<int>& shape);
 

@@ -40,6 +40,9 @@ int si_engine_input(SiEngine* engine, const char* name, const void* data, int on
 int si_engine_bind_output(SiEngine* engine, const char* name, void* device_data);
 /* Engine::Forward: synchronous */
 int si_engine_forward(SiEngine* engine);
+/* Engine::ForwardAsync / Sync (extension): the two halves of forward */
+int si_engine_forward_async(SiEngine* engine);
+int si_engine_sync(SiEngine* engine);
 /* Engine::Extract: non-owning view of engine memory (host pinned mirror, or device pointer when the
  * engine was created with outputs_to_host = 0) */
 int si_engine_extract(SiEngine* engine, const char* name, void** data, int* on_device);

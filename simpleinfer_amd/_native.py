@@ -172,6 +172,8 @@ def host():
         "si_engine_input": (i, [vp, cp, vp, i]),
         "si_engine_bind_output": (i, [vp, cp, vp]),
         "si_engine_forward": (i, [vp]),
+        "si_engine_forward_async": (i, [vp]),
+        "si_engine_sync": (i, [vp]),
         "si_engine_extract": (i, [vp, cp, C.POINTER(vp), C.POINTER(i)]),
         "si_engine_stream": (vp, [vp]),
         "si_engine_last_forward_ms": (C.c_float, [vp]),

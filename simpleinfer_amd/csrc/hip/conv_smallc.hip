@@ -26,6 +26,25 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// conv_stem_roll.hip: the rolling-window kernel that serves the RGB stride-2 stems (6x6, 7x7, 3x3; <= 64 output channels);
+// this file's kernel remains for every other 1..3-channel shape (other strides / kernel sizes, wider outputs)
+bool si_conv_stemroll_ok(const SiConv2dDesc* d);
+size_t si_conv_stemroll_weight_elems(const SiConv2dDesc* d);
+void si_conv_stemroll_pack(const SiConv2dDesc* d, const float* w_oihw, float* w_packed);
+const char* si_conv_stemroll_name(const SiConv2dDesc* d);
+int si_conv_stemroll_launch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
+                            const float* residual, float* out, hipStream_t s);
+
+// which of the two a shape goes to is a function of the shape alone (it fixes the weight layout); SI_STEM_ROLL=0 is a
+// development switch that sends everything to the old kernel (read once per process)
+static bool stem_roll(const SiConv2dDesc* d) {
+    static const bool enabled = [] {
+        const char* e = getenv("SI_STEM_ROLL");
+        return !(e && e[0] == '0');
+    }();
+    return enabled && si_conv_stemroll_ok(d);
+}
+
 namespace {
 
 struct SmallCArgs {
@@ -278,12 +297,14 @@ bool si_conv_smallc_ok(const SiConv2dDesc* d) {
 }
 
 size_t si_conv_smallc_weight_elems(const SiConv2dDesc* d) {
+    if (stem_roll(d)) return si_conv_stemroll_weight_elems(d);
     const int ocp = (d->oc + 31) / 32 * 32;
     return (size_t)d->kh * 2 * smallc_hp(d) * ocp;
 }
 
 // OIHW -> [ky][j = kx*c + ch, padded to 2*HP][ocp], zero filled
 void si_conv_smallc_pack(const SiConv2dDesc* d, const float* w_oihw, float* w_packed) {
+    if (stem_roll(d)) return si_conv_stemroll_pack(d, w_oihw, w_packed);
     const int hp2 = 2 * smallc_hp(d);
     const int ocp = (d->oc + 31) / 32 * 32;
     const size_t total = si_conv_smallc_weight_elems(d);
@@ -297,6 +318,7 @@ void si_conv_smallc_pack(const SiConv2dDesc* d, const float* w_oihw, float* w_pa
 }
 
 const char* si_conv_smallc_name(const SiConv2dDesc* d) {
+    if (stem_roll(d)) return si_conv_stemroll_name(d);
     const int hp = smallc_hp(d);
     if (hp == 5) return d->oc > 32 ? "conv_smallc_rows_kernel<4, 2, 2, 5, 28>" : "conv_smallc_rows_kernel<4, 1, 2, 5, 28>";
     if (hp == 9)
@@ -336,6 +358,7 @@ static int smallc_launch_t(const SiConv2dDesc* d, const float* in, const float* 
 
 int si_conv_smallc_launch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
                           const float* residual, float* out, hipStream_t s) {
+    if (stem_roll(d)) return si_conv_stemroll_launch(d, in, w_packed, bias, residual, out, s);
     return smallc_launch_t<float>(d, in, w_packed, bias, residual, out, s);
 }
 

@@ -115,6 +115,8 @@ int si_engine_bind_output(SiEngine* e, const char* name, void* device_data) {
 }
 
 int si_engine_forward(SiEngine* e) { return e ? code(e->impl.Forward()) : code(Status::kFail); }
+int si_engine_forward_async(SiEngine* e) { return e ? code(e->impl.ForwardAsync()) : code(Status::kFail); }
+int si_engine_sync(SiEngine* e) { return e ? code(e->impl.Sync()) : code(Status::kFail); }
 
 int si_engine_extract(SiEngine* e, const char* name, void** data, int* on_device) {
     if (!e || !name || !data) return code(Status::kFail);

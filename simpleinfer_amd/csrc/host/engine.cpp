@@ -19,6 +19,8 @@ const std::vector<std::string> Engine::InputNames() { return impl_->InputNames()
 const std::vector<std::string> Engine::OutputNames() { return impl_->OutputNames(); }
 Status Engine::Input(const std::string& name, const Tensor& input) { return impl_->Input(name, input); }
 Status Engine::Forward() { return impl_->Forward(); }
+Status Engine::ForwardAsync() { return impl_->ForwardAsync(); }
+Status Engine::Sync() { return impl_->Sync(); }
 Status Engine::Extract(const std::string& name, Tensor& output) { return impl_->Extract(name, output); }
 
 Status Engine::Output(const std::string& name, const Tensor& output) { return impl_->Output(name, output); }

@@ -740,6 +740,22 @@ Status EngineImpl::LaunchAll() {
 }
 
 Status EngineImpl::Forward() {
+    CHECK_STATUS(ForwardAsync());
+    return Sync();
+}
+
+// Forward() is synchronous by contract (reference engine_impl.cpp:533-544)
+Status EngineImpl::Sync() {
+    if (nullptr == context_) return Status::kFail;
+    SI_TRY_HIP(si_hip_stream_sync(context_->stream()), "stream sync");
+    if (forward_pending_) {
+        si_hip_event_elapsed_ms(ev_start_, ev_stop_, &last_forward_ms_);
+        forward_pending_ = false;
+    }
+    return Status::kSuccess;
+}
+
+Status EngineImpl::ForwardAsync() {
     if (nullptr == context_ || plan_.empty()) {
         LOG(ERROR) << "Forward before a successful LoadModel";
         return Status::kFail;
@@ -789,9 +805,7 @@ Status EngineImpl::Forward() {
             SI_TRY_HIP(si_hip_memcpy_d2h(host_outputs_[kv.first], t.RawData(), t.ByteSize(), stream), "output d2h");
         }
     }
-    // Forward() is synchronous by contract (reference engine_impl.cpp:533-544)
-    SI_TRY_HIP(si_hip_stream_sync(stream), "stream sync");
-    si_hip_event_elapsed_ms(ev_start_, ev_stop_, &last_forward_ms_);
+    forward_pending_ = true;
     ++forward_count_;
     return Status::kSuccess;
 }

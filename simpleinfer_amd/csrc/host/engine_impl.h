@@ -61,6 +61,10 @@ public:
     Status Input(const std::string& name, const Tensor& input);
     Status Output(const std::string& name, const Tensor& output);
     Status Forward();
+    // extension: enqueue the forward on the engine's stream and return; Sync() waits for it (Forward() = both).  Lets a
+    // caller keep several engines (e.g. half-batches, or ranks of a node) busy from one host thread.
+    Status ForwardAsync();
+    Status Sync();
     Status Extract(const std::string& name, Tensor& output);
 
     Status SetOption(const std::string& key, int value);
@@ -129,6 +133,7 @@ private:
     // buffers (ShardedEngine, OverlappedGather) replay instead of re-capturing every Forward.  Small LRU.
     std::vector<std::pair<std::vector<void*>, si_graph_t>> graph_cache_;
     int forward_count_ = 0;
+    bool forward_pending_ = false;
 
     si_event_t ev_start_ = nullptr, ev_stop_ = nullptr;
     float last_forward_ms_ = 0.f;

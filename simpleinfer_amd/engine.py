@@ -105,6 +105,13 @@ class Engine:
     def forward(self):
         self._check("Forward", self._L.si_engine_forward(self._h))
 
+    def forward_async(self):
+        """Engine::ForwardAsync: enqueue the launches and return; sync() waits (forward() = both)."""
+        self._check("ForwardAsync", self._L.si_engine_forward_async(self._h))
+
+    def sync(self):
+        self._check("Sync", self._L.si_engine_sync(self._h))
+
     def extract_ptr(self, name: str) -> Tuple[int, bool]:
         p = C.c_void_p()
         on_dev = C.c_int()

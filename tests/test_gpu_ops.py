@@ -486,3 +486,28 @@ def test_yolo_postprocess_equal_confidences(hops, orc):
         assert (np.diff(got[b][:, 4]) <= 0).all()
         tied = got[b][got[b][:, 4] == np.float32(0.5) * np.float32(0.9)]
         assert len(tied) == 40 and (np.diff(tied[:, 0]) > 0).all(), "ties come out in element order"
+
+
+@pytest.mark.parametrize("n,ih,iw,oc,k,p,act,strided", [
+    (2, 96, 640, 32, 6, 2, "silu", False),    # two 160-pixel column tiles (5-wave workgroup), runs of several rows
+    (1, 50, 66, 32, 6, 2, "silu", False),     # odd sizes: ragged column tile, row width not a multiple of 4 floats (scalar loads)
+    (3, 37, 224, 64, 7, 3, "relu", False),    # ResNet stem: 7x7, two channel tiles, K = 147 padded to 148, odd height
+    (2, 64, 64, 16, 3, 1, "hardswish", True), # MobileNet stem: 3x3, 16 of 32 channel lanes live, strided output slice
+    (1, 18, 20, 32, 6, 2, "none", False),     # smaller than one run / one column tile
+])
+def test_stem_rolling_window_kernel(hops, orc, n, ih, iw, oc, k, p, act, strided):
+    """conv_stem_roll.hip: persistent workgroups walking down runs of output rows over an LDS ring of input rows, 16x16x4 MFMAs.
+    Against the reference path's restatement and fp64; the kernel name is the rolling one; an image's result does not depend on
+    its batch position (bit exact)."""
+    x = rng_uniform(300 + k, (n, ih, iw, 3))
+    w = rng_uniform(301 + k, (oc, 3, k, k), -0.3, 0.3)
+    b = rng_uniform(302 + k, (oc,), -0.5, 0.5)
+    kw = dict(out_ld=oc + 8, out_c_off=4) if strided else {}
+    got = hops.conv2d(x, w, b, (2, 2), (p, p), act1=act, **kw)
+    ref = orc.conv2d(x, w, b, (2, 2), (p, p), path="naive")
+    ref = orc.activation(act, ref) if act != "none" else ref
+    assert_parity(got, ref, 2e-5, what="rolling stem vs fp64")
+    assert "conv_stem_roll" in hops.conv2d_kernel_name(x.shape, w.shape, (2, 2), (p, p))
+    if n > 1:
+        one = hops.conv2d(x[n - 1:n], w, b, (2, 2), (p, p), act1=act, **kw)
+        assert_exact(one[0], got[n - 1], "stem: batch position")

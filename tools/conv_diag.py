@@ -30,7 +30,7 @@ def build():
     extra = [d for d in os.environ.get("SI_DIAG_DEFINES", "").split() if d]
     tag = os.environ.get("SI_DIAG_TAG", "diag")
     out = os.path.join(os.path.dirname(DIAG), "libsi_hip_%s.so" % tag)
-    b.build_hip(defines=["SI_DIAG_STAMPS"] + extra, out=out, objdir=os.path.join(b.PKG, "build", "hip_" + tag))
+    b.build_hip(defines=([] if os.environ.get("SI_DIAG_NOSTAMPS") else ["SI_DIAG_STAMPS"]) + extra, out=out, objdir=os.path.join(b.PKG, "build", "hip_" + tag))
     print("built", out)
 
 
