@@ -323,7 +323,11 @@ def main():
         flops_step = mg.conv_flops(builder)
 
         e = si.Engine(device=dev, outputs_to_host=0, graph=args.graph, winograd=args.winograd, fp16=args.fp16)
-        e.load_model(pp, bp)
+        try:
+            e.load_model(pp, bp)
+        except si.StatusError as ex:
+            sys.exit("bench.py: %s cannot be loaded with these options (%s)%s" % (
+                args.model, ex, "; the fp16 storage path has no kernels for some of its layers -- see the engine's log line above" if args.fp16 else ""))
         iname, oname = e.input_names()[0], e.output_names()[0]
         # global batch = per-GPU batch * world; this rank's slab gets its own seed (distinct images)
         x = mg.synth_input(shape, seed=1 + rank)

@@ -62,6 +62,8 @@ public:
     //   "device"          HIP device ordinal (default: current device)
     //   "fuse"            1/0  fold activation / residual add into the conv epilogue (default 1)
     //   "alias_cat"       1/0  producers write straight into torch.cat outputs (default 1)
+    //   "fuse_upsample"   1/0  a 1x1 conv that consumes cat(upsample(x), skip) reads x at the source pixel; the upsample launch
+    //                          and its output disappear (default 1; needs "fuse" and "alias_cat")
     //   "winograd"        0/1/2  3x3 stride-1 convs: 1 (default) fused Winograd F(2,3) where it is the faster kernel, as
     //                          the reference does on the CPU; 0 = implicit GEMM everywhere; 2 = fused Winograd F(4,3)
     //   "fp16"            1/0  fp16 storage for internal activations and weights, fp16 MFMA with fp32 accumulation;

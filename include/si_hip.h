@@ -125,6 +125,21 @@ size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d);
 int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* w_packed);
 int si_hip_conv2d_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
                       const float* residual, float* out, si_stream_t stream);
+/* A 1x1 stride-1 conv whose input is torch.cat(..., nn.Upsample(x, nearest), ...) reads the upsampled channels straight
+ * from the LOW-RESOLUTION tensor (dual-source A rows): channels [c0, c0 + c) of the conv's K axis come from `src`
+ * [n, ih, iw, c] (pixel stride ld) at src = clamp(int(float(dst) * inv_scale)) -- the reference's index rule,
+ * src/layer/upsample.cpp:85-92 -- the remaining channels from `in` (the concat buffer) as usual.  Replaces Upsample::Forward +
+ * the Cat copy (src/layer/upsample.cpp:101-170, cat.cpp:59-108) in front of such a conv: the upsampled tensor is never
+ * written.  c0 and c multiples of 32.  split_oc > 0: sibling-fused form (as si_hip_conv2d_split_f32). */
+typedef struct SiConv2dUpsampledSource {
+    const float* src;
+    int ih, iw, c, ld;
+    int c0;
+    float inv_scale_h, inv_scale_w;
+} SiConv2dUpsampledSource;
+int si_hip_conv2d_upcat_f32(const SiConv2dDesc* d, const float* in, const SiConv2dUpsampledSource* up,
+                            const float* w_packed, const float* bias, float* out, int split_oc, float* out2,
+                            int out2_ld, si_stream_t stream);
 /* name of the kernel instantiation si_hip_conv2d_f32 would launch for this problem (as rocprofv3 prints
  * it, minus the namespace), so profiles can be joined with per-layer timings */
 const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);

@@ -37,6 +37,11 @@ class SiConv2dDesc(C.Structure):
                  "pt", "pl", "groups", "has_bias", "act1", "has_residual", "res_ld", "act2")] + [("act_param", C.c_float)]
 
 
+class SiConv2dUpsampledSource(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("ih", C.c_int), ("iw", C.c_int), ("c", C.c_int), ("ld", C.c_int), ("c0", C.c_int),
+                ("inv_scale_h", C.c_float), ("inv_scale_w", C.c_float)]
+
+
 class SiYoloLevel(C.Structure):
     _fields_ = [("na", C.c_int), ("ne", C.c_int), ("rows_total", C.c_int), ("row_off", C.c_int), ("stride", C.c_float)]
 
@@ -101,6 +106,7 @@ def hip():
         "si_hip_conv2d_wino43_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_wino43_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_split_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, i, vp, i, vp]),
+        "si_hip_conv2d_upcat_f32": (i, [C.POINTER(SiConv2dDesc), vp, C.POINTER(SiConv2dUpsampledSource), vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_yolo_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),
         "si_hip_conv2d_kernel_name": (C.c_char_p, [C.POINTER(SiConv2dDesc), vp]),
         "si_hip_linear_f32": (i, [vp, i, i, vp, vp, i, vp, vp]),

@@ -89,6 +89,13 @@ struct ConvArgs {
     float ystride;
     const float* ygrid;         // [oh*ow*na][2]
     const float* yanchor;       // [oh*ow*na][2]
+    // dual-source input of a 1x1 conv that consumes cat(..., nn.Upsample(x), ...): 32-channel blocks [up_cb0, up_cb1) of the K
+    // axis are read from the LOW-RESOLUTION tensor `up` at the nearest-neighbour source pixel (reference index rule,
+    // src/layer/upsample.cpp:85-92) instead of from `in`; the upsampled tensor is never written
+    const float* up;
+    int up_ih, up_iw, up_ld, up_cb0, up_cb1;
+    float up_inv_h, up_inv_w;
+    unsigned up_bytes;
 };
 
 __device__ __forceinline__ float apply_act(int act, float v, float p) {
@@ -461,7 +468,9 @@ constexpr unsigned OOB_B = 0x80000000u;  // weights are < 2 GB; + kt*128 cannot 
 
 // PADK: the K axis of a 1x1 conv is zero-padded to whole 32-channel blocks (conv_icg_pad); a separate instantiation so the
 // channel check costs the ordinary layers nothing (it was worth 0.5 % of the YOLOv5s step inside the shared loop)
-template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false>
+// UPS: the dual-source pointwise form (ConvArgs::up); its own instantiation, so the ordinary layers carry neither the extra row
+// offsets nor the per-K-tile source select
+template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false, bool UPS = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
@@ -496,14 +505,31 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.w + (size_t)g * a.ocg * a.Kp), 0, (unsigned)a.ocg * a.Kp * 4u, 0x00020000);
 
+    const __amdgpu_buffer_rsrc_t rs_up = UPS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.up), 0, a.up_bytes, 0x00020000) : rs_in;
+
     // per-thread A rows: byte offset of (tap 0, channel kv*4) and the tap validity mask
     unsigned a_off[A_IT];
+    unsigned u_off[UPS ? A_IT : 1];   // UPS: byte offset of the row's source pixel in the low-resolution tensor
     unsigned long long a_mask[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + r0 + 32 * i;
         a_off[i] = 0;
         a_mask[i] = 0ull;
+        if (UPS) {
+            u_off[i] = OOB_A;
+            if (m < a.M) {
+                const int img = m / a.ohow;
+                const int rem = m - img * a.ohow;
+                const int oy = rem / a.ow;
+                const int ox = rem - oy * a.ow;
+                // upsample.cpp:85-92: src = clamp(int(float(dst) * (1 / scale)), 0, in - 1)
+                int sy = (int)((float)oy * a.up_inv_h), sx = (int)((float)ox * a.up_inv_w);
+                sy = max(0, min(a.up_ih - 1, sy));
+                sx = max(0, min(a.up_iw - 1, sx));
+                u_off[i] = (unsigned)((img * a.up_ih + sy) * a.up_iw + sx) * (unsigned)(a.up_ld * 4) + (unsigned)(kv * 16);
+            }
+        }
         if (m < a.M && a.pointwise) {
             // 1x1, stride 1, no padding: output pixel m IS input pixel m -- no index decomposition, one always-valid tap
             a_off[i] = (unsigned)m * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16);
@@ -556,11 +582,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * 32) * 4u;
         const int tapbit = ky * a.kw + kx;
         const bool cok = !PADK || cb * 32 + kv * 4 < a.icg;  // false only in the zero-padded tail block of a 1x1 conv
+        const bool from_up = UPS && cb >= a.up_cb0 && cb < a.up_cb1;   // wave-uniform: this K-tile's channels are upsampled ones
+        if (from_up) {
+            const unsigned du = (unsigned)(cb - a.up_cb0) * 128u;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const bool ok = ((a_mask[i] >> tapbit) & 1ull) && cok;
-            const unsigned off = ok ? a_off[i] + delta : OOB_A;
-            pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+            for (int i = 0; i < A_IT; ++i) pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_up, u_off[i] == OOB_A ? OOB_A : u_off[i] + du, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const bool ok = ((a_mask[i] >> tapbit) & 1ull) && cok;
+                const unsigned off = ok ? a_off[i] + delta : OOB_A;
+                pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+            }
         }
         const unsigned kb = (unsigned)kt * (BK * 4);
 #pragma unroll
@@ -683,7 +716,15 @@ int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
     b.n_tiles = (a.ocg + BN - 1) / BN;
     const int chunks = (b.m_tiles + 7) / 8;
     dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
-    if (a.icg % 32 != 0) {
+    if (a.up) {
+        // dual-source pointwise conv (consumer of cat(upsample(x), skip)): the two default tiles only
+        if constexpr (NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32))) {
+            if (a.icg % 32 != 0 || !a.pointwise) return SI_E_UNSUPPORTED;
+            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, true>), grid, dim3(256), 0, s, b);
+        } else {
+            return SI_E_UNSUPPORTED;
+        }
+    } else if (a.icg % 32 != 0) {
         // zero-padded K (1x1 convs with a channel count that is not a multiple of 32): the two default tiles carry the check
         if constexpr (NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32)))
             hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, true>), grid, dim3(256), 0, s, b);
@@ -801,7 +842,8 @@ struct SplitOut {
 
 static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
                            const float* residual, float* out, si_stream_t stream, const SiYoloLevel* yolo,
-                           const float* ygrid, const float* yanchor, const SplitOut* split = nullptr) {
+                           const float* ygrid, const float* yanchor, const SplitOut* split = nullptr,
+                           const SiConv2dUpsampledSource* up = nullptr) {
     if (!d || !in || !w_packed || !out) return SI_E_BADARG;
     if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return SI_E_BADARG;
     if (d->n <= 0 || d->oh <= 0 || d->ow <= 0) return SI_E_BADARG;
@@ -846,6 +888,17 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     a.in_bytes = 0; a.w_bytes = 0;
     a.ymode = 0; a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.f; a.ygrid = a.yanchor = nullptr;
     a.out2 = nullptr; a.out2_ld = 0; a.split = 0;
+    a.up = nullptr; a.up_ih = a.up_iw = a.up_ld = a.up_cb0 = a.up_cb1 = 0; a.up_inv_h = a.up_inv_w = 0.f; a.up_bytes = 0;
+    if (up) {
+        // channels [c0, c0 + c) of this 1x1 conv's input are nn.Upsample(nearest) of up->src: read them at the source
+        if (!up->src || !a.pointwise || d->groups != 1 || yolo || up->c <= 0 || up->c % 32 != 0 || up->c0 % 32 != 0 || up->c0 + up->c > d->ic ||
+            up->ld % 4 != 0 || (reinterpret_cast<uintptr_t>(up->src) & 15) != 0 || up->ih <= 0 || up->iw <= 0 || !conv_fast_ok(d, in))
+            return SI_E_UNSUPPORTED;
+        const unsigned long long ub = (unsigned long long)d->n * up->ih * up->iw * up->ld * 4ull;
+        if (ub >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+        a.up = up->src; a.up_ih = up->ih; a.up_iw = up->iw; a.up_ld = up->ld; a.up_cb0 = up->c0 / 32; a.up_cb1 = (up->c0 + up->c) / 32;
+        a.up_inv_h = up->inv_scale_h; a.up_inv_w = up->inv_scale_w; a.up_bytes = (unsigned)ub;
+    }
     if (split) {
         if (d->groups != 1 || split->split <= 0 || split->split >= d->oc || split->split % 32 != 0 || !split->out2) return SI_E_BADARG;
         a.out2 = split->out2; a.out2_ld = split->out2_ld; a.split = split->split;
@@ -861,7 +914,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
         a.in_bytes = (unsigned)((unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull);
         hipStream_t fs = static_cast<hipStream_t>(stream);
         // a zero-padded K axis only exists in the two default tiles (SI_CONV_VARIANT is ignored for those layers)
-        const int variant = (a.icg % 32 != 0) ? ((d->oc / d->groups) <= 32 ? 10 : 4) : conv_variant(d);
+        const int variant = (a.icg % 32 != 0 || a.up) ? ((d->oc / d->groups) <= 32 ? 10 : 4) : conv_variant(d);
         switch (variant) {
             case 0: return launch_fast<128, 128, 2, 2, 2>(a, d->groups, fs);
             case 1: return launch_fast<128, 64, 2, 2, 2>(a, d->groups, fs);
@@ -897,6 +950,16 @@ extern "C" int si_hip_conv2d_split_f32(const SiConv2dDesc* d, const float* in, c
     if (!d || d->has_residual) return SI_E_BADARG;
     SplitOut sp{out2, out2_ld, split_oc};
     return conv2d_dispatch(d, in, w_packed, bias, nullptr, out, stream, nullptr, nullptr, nullptr, &sp);
+}
+
+extern "C" int si_hip_conv2d_upcat_f32(const SiConv2dDesc* d, const float* in, const SiConv2dUpsampledSource* up, const float* w_packed,
+                                       const float* bias, float* out, int split_oc, float* out2, int out2_ld, si_stream_t stream) {
+    if (!d || !up || d->has_residual) return SI_E_BADARG;
+    if (split_oc > 0) {
+        SplitOut sp{out2, out2_ld, split_oc};
+        return conv2d_dispatch(d, in, w_packed, bias, nullptr, out, stream, nullptr, nullptr, nullptr, &sp, up);
+    }
+    return conv2d_dispatch(d, in, w_packed, bias, nullptr, out, stream, nullptr, nullptr, nullptr, nullptr, up);
 }
 
 extern "C" int si_hip_conv2d_yolo_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,

@@ -377,9 +377,10 @@ extern "C" int si_hip_conv2d_wino23_eligible(const SiConv2dDesc* d) {
 }
 
 // Measured on MI355X (YOLOv5s batch 32, in-network): the fused kernel beats the implicit-GEMM kernel from 64 input
-// channels up (0.125 vs 0.144 ms at 80x80x64, 0.114 vs 0.150 ms at 40x40x128, 0.105 vs 0.157 ms at 20x20x256); at 32
-// channels there are only 2 channel blocks per workgroup, its prologue / exchange epilogue dominate and direct wins
-// (0.184 vs 0.174 ms at 160x160x32).
+// channels up (0.125 vs 0.144 ms at 80x80x64, 0.114 vs 0.150 ms at 40x40x128, 0.105 vs 0.157 ms at 20x20x256).  At 32
+// channels there are only 2 channel blocks per workgroup; the first version of this kernel lost there (0.184 vs 0.174 ms at
+// 160x160x32), the current one (double-buffered staging, vectorised exchange) wins by +0.8-1.1 % of the YOLOv5s step
+// (6690-6705 vs 6634-6639 img/s, same-box A/B) -- hence the threshold of 32.
 extern "C" int si_hip_conv2d_wino23_preferred(const SiConv2dDesc* d) {
     static const int min_ic = [] { const char* e = getenv("SI_WINO_MIN_IC"); return e ? atoi(e) : 32; }();  // dev override
     return si_hip_conv2d_wino23_eligible(d) && d->ic >= min_ic;

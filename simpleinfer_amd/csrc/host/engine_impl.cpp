@@ -11,6 +11,7 @@
 #include "layer/linear.h"
 #include "layer/max_pool_2d.h"
 #include "layer/output_cast.h"
+#include "layer/upsample.h"
 #include "layer/yolo_detect.h"
 #include "layer_registry.h"
 #include "logger.h"
@@ -52,6 +53,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "outputs_to_host") opt_outputs_to_host_ = value != 0;
     else if (key == "fp16") opt_fp16_ = value != 0;
     else if (key == "batch") opt_batch_ = value;  // > 0: re-batch the graph at load (the file bakes its batch into every shape)
+    else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else {
         LOG(ERROR) << "unknown engine option [" << key << "]";
@@ -340,8 +342,21 @@ Status EngineImpl::CreatePipeline() {
         CHECK_STATUS(FuseEpilogues(order));
         CHECK_STATUS(FuseSiblingConvs(order));
         CHECK_STATUS(FusePoolChains(order));
+        if (opt_fuse_upsample_ && opt_alias_cat_ && !opt_fp16_) CHECK_STATUS(FuseUpsampleIntoConvs(order));
     }
-    if (opt_fp16_) CHECK_STATUS(InsertOutputCasts(order));
+    if (opt_fp16_) {
+        CHECK_STATUS(InsertOutputCasts(order));
+        // every layer is asked NOW whether it has a kernel for the storage types it ended up with: an fp16 engine that cannot run
+        // a graph says so at LoadModel, with the layer and the reason (not at the first Forward)
+        for (const Step& st : order) {
+            std::string why;
+            if (!st.layer->HalfStorageOk(why)) {
+                LOG(ERROR) << "fp16 storage: layer [" << st.op->name << "] (" << st.op->type << ") cannot run: " << why
+                           << "; load the model without the fp16 option";
+                return Status::kUnsupport;
+            }
+        }
+    }
     plan_ = order;
     if (opt_alias_cat_) CHECK_STATUS(AliasConcats());
     return Status::kSuccess;
@@ -507,6 +522,69 @@ Status EngineImpl::FusePoolChains(std::vector<Step>& order) {
         removed[j] = removed[k] = true;
         fused_ops_.insert(order[j].op->name);
         fused_ops_.insert(order[k].op->name);
+    }
+    std::vector<Step> out;
+    for (size_t i = 0; i < order.size(); ++i)
+        if (!removed[i]) out.push_back(order[i]);
+    order.swap(out);
+    return Status::kSuccess;
+}
+
+// nn.Upsample(nearest) -> torch.cat(dim = channels) -> 1x1 convs only  ==>  the upsample launch disappears: every consumer conv
+// reads the upsampled channel range from the LOW-RESOLUTION tensor at the nearest-neighbour source pixel (dual-source A rows,
+// si_hip_conv2d_upcat_f32), with the reference's index rule (src/layer/upsample.cpp:85-92), so the results are bit-identical to
+// the unfused schedule.  YOLOv5s: both upsamples of the PAN top-down path (20x20x256 -> 40x40, 40x40x128 -> 80x80): 131 MB per
+// batch-32 forward that are neither written nor read back.  Requires concat aliasing (the cat then has nothing to copy for that
+// input) and fp32 storage.
+Status EngineImpl::FuseUpsampleIntoConvs(std::vector<Step>& order) {
+    std::map<const pnnx::Operator*, size_t> index;
+    for (size_t i = 0; i < order.size(); ++i) index[order[i].op] = i;
+    std::vector<bool> removed(order.size(), false);
+    for (size_t i = 0; i < order.size(); ++i) {
+        Upsample* up = dynamic_cast<Upsample*>(order[i].layer);
+        if (!up || order[i].op->type != "nn.Upsample" || up->InputNodes().size() != 1 || up->OutputNodes().size() != 1) continue;
+        const pnnx::Operand* u = up->OutputNodes()[0]->operand;
+        if (!u || u->consumers.size() != 1 || output_tensor_nodes_.count(u->name)) continue;
+        const pnnx::Operator* cat = u->consumers[0];
+        if (!cat || cat->type != "torch.cat" || cat->outputs.size() != 1 || !index.count(cat)) continue;
+        Cat* cat_layer = dynamic_cast<Cat*>(order[index[cat]].layer);
+        if (!cat_layer || cat_layer->NhwcAxis() != 3) continue;
+        const std::vector<int>& us = up->OutputNodes()[0]->tensor.Shape();
+        if (us.size() != 4) continue;
+        // channel offset of the upsampled tensor inside the concat
+        int c0 = 0;
+        bool found = false;
+        for (const pnnx::Operand* r : cat->inputs) {
+            if (r == u) { found = true; break; }
+            const std::vector<int>& rs = tensor_nodes_[r->name]->tensor.Shape();
+            if (rs.size() != 4) { found = false; break; }
+            c0 += rs[3];
+        }
+        if (!found) continue;
+        const pnnx::Operand* co = cat->outputs[0];
+        if (output_tensor_nodes_.count(co->name) || co->consumers.empty()) continue;
+        // every reader of the concat must be a pointwise conv that can take the dual-source form (a sibling-fused secondary has
+        // left the order: its primary reads the same operand)
+        std::vector<Conv2d*> readers;
+        bool ok = true;
+        for (const pnnx::Operator* c : co->consumers) {
+            if (!c || c->type != "nn.Conv2d") { ok = false; break; }
+            if (sibling_ops_.count(c->name)) continue;
+            Conv2d* conv = index.count(c) ? dynamic_cast<Conv2d*>(order[index[c]].layer) : nullptr;
+            if (!conv || !conv->CanReadUpsampled(c0, us[3]) || conv->UpsampledSource()) { ok = false; break; }
+            readers.push_back(conv);
+        }
+        // ... and every sibling-fused secondary must have its primary among them
+        for (const pnnx::Operator* c : co->consumers) {
+            if (!ok || !c || !sibling_ops_.count(c->name)) continue;
+            bool has_primary = false;
+            for (Conv2d* r : readers) has_primary = has_primary || (r->Sibling() && r->Sibling()->GetOp() == c);
+            ok = has_primary;
+        }
+        if (!ok || readers.empty()) continue;
+        for (Conv2d* r : readers) r->SetUpsampledSource(up->InputNodes()[0], c0, up->scale_factor_h_, up->scale_factor_w_);
+        removed[i] = true;
+        fused_ops_.insert(order[i].op->name);
     }
     std::vector<Step> out;
     for (size_t i = 0; i < order.size(); ++i)

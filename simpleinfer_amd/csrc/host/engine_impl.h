@@ -87,6 +87,7 @@ private:
     Status FuseEpilogues(std::vector<Step>& order);
     Status FuseSiblingConvs(std::vector<Step>& order);
     Status FusePoolChains(std::vector<Step>& order);
+    Status FuseUpsampleIntoConvs(std::vector<Step>& order);
     Status InsertOutputCasts(std::vector<Step>& order);
     Status AliasConcats();
     Status UploadInputs();
@@ -98,6 +99,7 @@ private:
     int opt_device_ = -1;
     bool opt_fuse_ = true;
     bool opt_alias_cat_ = true;
+    bool opt_fuse_upsample_ = true;
     bool opt_graph_ = false;
     bool opt_outputs_to_host_ = true;
     int opt_winograd_ = 1;

@@ -54,6 +54,15 @@ Status Layer::Forward(const std::vector<Tensor>&, std::vector<Tensor>&) { return
 
 const pnnx::Operator* Layer::GetOp() { return op_; }
 
+bool Layer::HalfStorageOk(std::string& why) const {
+    int half = 0, total = 0;
+    for (auto* n : input_tensor_nodes_) { half += IsHalf(n->tensor); ++total; }
+    for (auto* n : output_tensor_nodes_) { half += IsHalf(n->tensor); ++total; }
+    if (half == 0 || half == total) return true;
+    why = "mixed fp16 / fp32 operands";
+    return false;
+}
+
 double Layer::Bytes() const {
     double b = 0.0;
     for (auto* n : input_tensor_nodes_) b += (double)n->tensor.ByteSize();

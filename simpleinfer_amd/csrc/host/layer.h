@@ -56,6 +56,10 @@ public:
     virtual const char* KernelName() const { return "none"; }
     // algorithmic cost of one Forward with the currently bound nodes
     virtual double Flops() const { return 0.0; }
+    // fp16 storage (Engine option "fp16"): can this layer run with the storage types its bound nodes now have?  Asked once, at
+    // LoadModel, so that an unsupported combination is a load-time Status with a reason instead of a failing first Forward().
+    // Default: fine when no bound tensor is fp16, or when inputs and outputs are all fp16.
+    virtual bool HalfStorageOk(std::string& why) const;
     virtual double Bytes() const;
 
     const std::vector<TensorNode*>& InputNodes() const { return input_tensor_nodes_; }

@@ -81,4 +81,10 @@ Status BatchNorm2d::Forward(const Tensor& input, Tensor& output) {
     });
 }
 
+bool BatchNorm2d::HalfStorageOk(std::string& why) const {
+    for (auto* n : input_tensor_nodes_) if (IsHalf(n->tensor)) { why = "BatchNorm2d has no fp16 kernel"; return false; }
+    for (auto* n : output_tensor_nodes_) if (IsHalf(n->tensor)) { why = "BatchNorm2d has no fp16 kernel"; return false; }
+    return true;
+}
+
 }  // namespace SimpleInfer

@@ -13,6 +13,7 @@ public:
     virtual Status Deinit() override;
     virtual Status Validate() override;
     virtual Status Forward(const Tensor& input, Tensor& output) override;
+    virtual bool HalfStorageOk(std::string& why) const override;
     virtual const char* KernelName() const override { return "batchnorm"; }
 
     Status PrepareDevice();

@@ -90,4 +90,20 @@ Status BroadcastShape(const std::vector<int>& s0, const std::vector<int>& s1, st
     return Status::kSuccess;
 }
 
+bool BinaryOp::HalfStorageOk(std::string& why) const {
+    bool any = false, all = true;
+    for (auto* n : input_tensor_nodes_) { any = any || IsHalf(n->tensor); all = all && IsHalf(n->tensor); }
+    for (auto* n : output_tensor_nodes_) { any = any || IsHalf(n->tensor); all = all && IsHalf(n->tensor); }
+    if (!any) return true;
+    const bool addmul = binary_op_type_ == BinaryOpType::kAdd || binary_op_type_ == BinaryOpType::kMul;
+    bool same = !with_scalar_ && input_tensor_nodes_.size() == 2 && output_tensor_nodes_.size() == 1;
+    if (same) {
+        const std::vector<int>& o = output_tensor_nodes_[0]->tensor.Shape();
+        same = input_tensor_nodes_[0]->tensor.Shape() == o && input_tensor_nodes_[1]->tensor.Shape() == o;
+    }
+    if (all && addmul && same) return true;
+    why = "BinaryOp has an fp16 kernel for same-shape add / mul only (no broadcast, no scalar form, no sub / div / pow)";
+    return false;
+}
+
 }  // namespace SimpleInfer

@@ -14,6 +14,7 @@ public:
     virtual Status Validate() override;
     virtual Status Forward(const std::vector<Tensor>& inputs, Tensor& output) override;
     virtual Status Forward(const Tensor& input, Tensor& output) override;  // the `with_scalar` form: one tensor operand
+    virtual bool HalfStorageOk(std::string& why) const override;
     virtual const char* KernelName() const override { return with_scalar_ ? "binary_scalar" : "binary"; }
 
 public:

@@ -289,6 +289,14 @@ Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
                                                     out[1].RawData(), out[1].PixelStride(), Stream()),
                             "conv2d fp16 (fused siblings)");
         }
+        if (up_node_) {
+            if (mode != 0) return Status::kUnsupport;
+            SiConv2dUpsampledSource up;
+            CHECK_STATUS(MakeUpsampledSource(up));
+            return CheckHip(si_hip_conv2d_upcat_f32(&d, in[0].Data<float>(), &up, weight_dev_.As<float>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                    out[0].Data<float>(), out_channels_, out[1].Data<float>(), out[1].PixelStride(), Stream()),
+                            "conv2d (fused siblings, upsampled source)");
+        }
         return CheckHip(si_hip_conv2d_split_f32(&d, in[0].Data<float>(), weight_dev_.As<float>(),
                                                 use_bias_ ? bias_dev_.As<float>() : nullptr, out[0].Data<float>(), out_channels_,
                                                 out[1].Data<float>(), out[1].PixelStride(), Stream()),
@@ -334,10 +342,42 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
         device_ready_ = false;
         CHECK_STATUS(PrepareDevice(0));
     }
+    if (up_node_) {
+        if (residual) return Status::kUnsupport;
+        SiConv2dUpsampledSource up;
+        CHECK_STATUS(MakeUpsampledSource(up));
+        return CheckHip(si_hip_conv2d_upcat_f32(&d, input.Data<float>(), &up, weight_dev_.As<float>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                output.Data<float>(), 0, nullptr, 0, Stream()),
+                        "conv2d (upsampled source)");
+    }
     return CheckHip(si_hip_conv2d_f32(&d, input.Data<float>(), weight_dev_.As<float>(),
                                       use_bias_ ? bias_dev_.As<float>() : nullptr,
                                       residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream()),
                     "conv2d");
+}
+
+bool Conv2d::CanReadUpsampled(int c0, int c) const {
+    return kernel_h_ == 1 && kernel_w_ == 1 && stride_h_ == 1 && stride_w_ == 1 && padding_t_ == 0 && padding_b_ == 0 && padding_l_ == 0 &&
+           padding_r_ == 0 && groups_ == 1 && in_channels_ % 32 == 0 && c0 % 32 == 0 && c % 32 == 0 && c0 + c <= in_channels_ &&
+           residual_node_ == nullptr && algo_ != Algo::kWinograd23 && algo_ != Algo::kWinograd43;
+}
+
+void Conv2d::SetUpsampledSource(TensorNode* low, int c0, float scale_h, float scale_w) {
+    up_node_ = low;
+    up_c0_ = c0;
+    up_scale_h_ = scale_h;
+    up_scale_w_ = scale_w;
+}
+
+Status Conv2d::MakeUpsampledSource(SiConv2dUpsampledSource& up) const {
+    Dims4 lo;
+    if (!up_node_ || !GetDims4(up_node_->tensor, lo) || IsHalf(up_node_->tensor)) return Status::kUnsupport;
+    up.src = up_node_->tensor.Data<float>();
+    up.ih = lo.h; up.iw = lo.w; up.c = lo.c; up.ld = up_node_->tensor.PixelStride();
+    up.c0 = up_c0_;
+    up.inv_scale_h = 1.0f / up_scale_h_;   // as si_hip_upsample_nearest_f32 forms it (reference upsample.cpp:85-92)
+    up.inv_scale_w = 1.0f / up_scale_w_;
+    return Status::kSuccess;
 }
 
 // Detect-head variant: device tensors only (called by YoloDetect inside its own RunOnDevice scope)
@@ -383,6 +423,7 @@ const char* Conv2d::KernelName() const {
     if (mode == 2) return "conv_stem_f16_kernel";
     const int tile = WinogradTile(d);
     if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
+    if (up_node_) return d.oc <= 32 ? "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, true>" : "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, true>";
     return si_hip_conv2d_kernel_name(&d, in.Data<float>());
 }
 
@@ -412,6 +453,21 @@ double Conv2d::Bytes() const {
     if (sibling_) b += (double)sibling_->weight_.size() * sizeof(float);
     if (residual_node_) b += (double)residual_node_->tensor.ByteSize();
     return b;
+}
+
+bool Conv2d::HalfStorageOk(std::string& why) const {
+    if (input_tensor_nodes_.empty() || output_tensor_nodes_.empty()) return true;
+    const Tensor& in = input_tensor_nodes_[0]->tensor;
+    const Tensor& out = output_tensor_nodes_[0]->tensor;
+    if (!IsHalf(in) && !IsHalf(out)) return true;
+    SiConv2dDesc d;
+    memset(&d, 0, sizeof(d));
+    d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
+    d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
+    if (si_hip_conv2d_f16_supported(&d) != 0) return true;
+    why = "no fp16 conv kernel for " + std::to_string(in_channels_) + " -> " + std::to_string(out_channels_) + " channels, groups " +
+          std::to_string(groups_) + " (needs ic / groups % 32 == 0, or an RGB stem)";
+    return false;
 }
 
 }  // namespace SimpleInfer

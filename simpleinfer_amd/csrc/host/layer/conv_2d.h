@@ -32,6 +32,7 @@ public:
     virtual Status Forward(const Tensor& input, std::vector<Tensor>& outputs) override;
 
     virtual const char* KernelName() const override;
+    virtual bool HalfStorageOk(std::string& why) const override;
     int WinogradTile(const SiConv2dDesc& d) const;
     virtual double Flops() const override;
     virtual double Bytes() const override;
@@ -49,6 +50,12 @@ public:
     bool CanFuseSibling(const Conv2d& other) const;
     void SetSibling(Conv2d* other);
     Conv2d* Sibling() const { return sibling_; }
+
+    // engine fusion hook: channels [c0, c0 + low->C) of this 1x1 conv's input (a torch.cat output) are nn.Upsample(nearest) of
+    // `low`; the conv reads them from `low` at the source pixel and the upsample / concat copy never run
+    bool CanReadUpsampled(int c0, int c) const;
+    void SetUpsampledSource(TensorNode* low, int c0, float scale_h, float scale_w);
+    TensorNode* UpsampledSource() const { return up_node_; }
 
     Status PrepareDevice(int mode = 0);
     Status PrepareDeviceHalf(const SiConv2dDesc& d);
@@ -92,10 +99,14 @@ public:
     float act_param_ = 0.0f;
     TensorNode* residual_node_ = nullptr;
     Conv2d* sibling_ = nullptr;
+    TensorNode* up_node_ = nullptr;   // see SetUpsampledSource
+    int up_c0_ = 0;
+    float up_scale_h_ = 1.0f, up_scale_w_ = 1.0f;
 
 private:
     Status Launch(const Tensor& input, const Tensor* residual, Tensor& output);
     SiConv2dDesc MakeDesc(const Tensor& input, const Tensor& output) const;
+    Status MakeUpsampledSource(SiConv2dUpsampledSource& up) const;
 
     DeviceBuffer weight_dev_;
     DeviceBuffer bias_dev_;

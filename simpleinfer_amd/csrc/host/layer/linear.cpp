@@ -109,4 +109,13 @@ double Linear::Flops() const {
     return 2.0 * (double)output_tensor_nodes_[0]->tensor.NumElements() * in_features_;
 }
 
+bool Linear::HalfStorageOk(std::string& why) const {
+    if (!output_tensor_nodes_.empty() && IsHalf(output_tensor_nodes_[0]->tensor)) { why = "Linear writes fp32 only"; return false; }
+    if (!input_tensor_nodes_.empty() && IsHalf(input_tensor_nodes_[0]->tensor) && in_features_ % 32 != 0) {
+        why = "Linear's fp16 kernel needs in_features % 32 == 0";
+        return false;
+    }
+    return true;
+}
+
 }  // namespace SimpleInfer

@@ -14,6 +14,7 @@ public:
     virtual Status Deinit() override;
     virtual Status Validate() override;
     virtual Status Forward(const Tensor& input, Tensor& output) override;
+    virtual bool HalfStorageOk(std::string& why) const override;
     virtual const char* KernelName() const override { return "conv_igemm_f32"; }
     virtual double Flops() const override;
 

@@ -13,6 +13,7 @@ public:
     virtual Status Validate() override;
     virtual Status Forward(const Tensor& input, Tensor& output) override;
     virtual const char* KernelName() const override { return "convert_f16_f32"; }
+    virtual bool HalfStorageOk(std::string&) const override { return true; }   // fp16 in, fp32 out is what it is for
 
 private:
     pnnx::Operator op_storage_;  // the schedule / profile name of this step

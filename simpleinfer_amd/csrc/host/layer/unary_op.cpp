@@ -37,4 +37,10 @@ Status UnaryOp::Forward(const Tensor& input, Tensor& output) {
     });
 }
 
+bool UnaryOp::HalfStorageOk(std::string& why) const {
+    for (auto* n : input_tensor_nodes_) if (IsHalf(n->tensor)) { why = "UnaryOp has no fp16 kernel"; return false; }
+    for (auto* n : output_tensor_nodes_) if (IsHalf(n->tensor)) { why = "UnaryOp has no fp16 kernel"; return false; }
+    return true;
+}
+
 }  // namespace SimpleInfer

@@ -135,6 +135,20 @@ Status YoloDetect::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
         const std::vector<int> os = out[0].ShapeAs(3);
         const int rows_total = os[1];
         if (os[2] != num_classes_info_) return Status::kErrorShape;
+        // the output's row count comes from the model file: check it against what the levels will write BEFORE any launch (a
+        // file whose Detect operand is too small would otherwise get out-of-bounds device writes, then an error)
+        {
+            long long expect = 0;
+            for (int i = 0; i < num_spatial_sizes; ++i) {
+                Dims4 d;
+                if (!GetDims4(in[i], d) || d.h != level_h_[i] || d.w != level_w_[i] || d.n != os[0]) return Status::kErrorShape;
+                expect += (long long)d.h * d.w * num_anchor_grid_levels_;
+            }
+            if (expect != rows_total) {
+                LOG(ERROR) << "YoloDetect: output has " << rows_total << " rows per image, the levels produce " << expect;
+                return Status::kErrorShape;
+            }
+        }
         int row_off = 0;
         for (int i = 0; i < num_spatial_sizes; ++i) {
             Dims4 d;
@@ -169,6 +183,15 @@ double YoloDetect::Flops() const {
     for (int i = 0; i < num_spatial_sizes && i < (int)input_tensor_nodes_.size(); ++i)
         f += 2.0 * (double)input_tensor_nodes_[i]->tensor.NumElements() * num_elements_;
     return f;
+}
+
+bool YoloDetect::HalfStorageOk(std::string& why) const {
+    if (!output_tensor_nodes_.empty() && IsHalf(output_tensor_nodes_[0]->tensor)) { why = "Detect writes fp32 only"; return false; }
+    for (int i = 0; i < num_spatial_sizes && i < (int)input_tensor_nodes_.size(); ++i) {
+        const Tensor& t = input_tensor_nodes_[i]->tensor;
+        if (IsHalf(t) && !t.Shape().empty() && t.Shape().back() % 32 != 0) { why = "Detect's fp16 1x1 convs need channel counts that are multiples of 32"; return false; }
+    }
+    return true;
 }
 
 }  // namespace SimpleInfer

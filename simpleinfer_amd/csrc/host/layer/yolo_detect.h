@@ -19,6 +19,7 @@ public:
     virtual Status Deinit() override;
     virtual Status Validate() override;
     virtual Status Forward(const std::vector<Tensor>& inputs, Tensor& output) override;
+    virtual bool HalfStorageOk(std::string& why) const override;
     virtual const char* KernelName() const override {
         const bool half = !input_tensor_nodes_.empty() && IsHalf(input_tensor_nodes_[0]->tensor);
         if (half) return fuse_decode_ ? "conv_igemm_f16(yolo epilogue)" : "conv_igemm_f16+yolo_decode";

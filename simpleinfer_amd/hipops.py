@@ -132,6 +132,38 @@ def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
     return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
 
 
+def conv2d_upcat(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1="none", split_oc=0):
+    """si_hip_conv2d_upcat_f32: a 1x1 conv over cat([upsample(low), skip]) (or [skip, upsample(low)]) that reads `low` at the
+    source pixel.  Returns y, or (y, y2) for the sibling-split form."""
+    H = _native.hip()
+    low, skip, w_oihw = _f32(low), _f32(skip), _f32(w_oihw)
+    n, oh, ow, cs = skip.shape
+    _, lh, lw, cl = low.shape
+    ic, oc = cl + cs, w_oihw.shape[0]
+    assert w_oihw.shape[1] == ic and w_oihw.shape[2:] == (1, 1)
+    d = SiConv2dDesc(n, oh, ow, ic, ic, oh, ow, oc, oc, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1 if bias is not None else 0, ACT[act1], 0, oc, 0, 0.0)
+    wn = H.si_hip_conv2d_weight_elems(C.byref(d))
+    wp = np.empty(wn, np.float32)
+    _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p)), "pack")
+    # the concat buffer: only the skip channels are ever written; the upsampled range is poisoned to prove nobody reads it
+    cat = np.full((n, oh, ow, ic), np.nan, np.float32)
+    c0 = 0 if up_first else cs
+    cat[..., (cl if up_first else 0):(cl if up_first else 0) + cs] = skip
+    dcat, dlow, dw = DeviceBuffer.from_numpy(cat), DeviceBuffer.from_numpy(low), DeviceBuffer.from_numpy(wp)
+    db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
+    up = _native.SiConv2dUpsampledSource(dlow.ptr, lh, lw, cl, cl, c0, np.float32(1.0) / np.float32(scale[0]), np.float32(1.0) / np.float32(scale[1]))
+    if split_oc:
+        d.out_ld = split_oc
+        dy, dy2 = DeviceBuffer(n * oh * ow * split_oc * 4), DeviceBuffer(n * oh * ow * (oc - split_oc) * 4)
+        _chk(H.si_hip_conv2d_upcat_f32(C.byref(d), dcat.ptr, C.byref(up), dw.ptr, db.ptr if db else None, dy.ptr, split_oc, dy2.ptr,
+                                       oc - split_oc, None), "si_hip_conv2d_upcat_f32")
+        return dy.to_numpy((n, oh, ow, split_oc)), dy2.to_numpy((n, oh, ow, oc - split_oc))
+    dy = DeviceBuffer(n * oh * ow * oc * 4)
+    _chk(H.si_hip_conv2d_upcat_f32(C.byref(d), dcat.ptr, C.byref(up), dw.ptr, db.ptr if db else None, dy.ptr, 0, None, 0, None),
+         "si_hip_conv2d_upcat_f32")
+    return dy.to_numpy((n, oh, ow, oc))
+
+
 def conv2d_kernel_name(x_shape, w_shape, stride=(1, 1), padding=(0, 0), groups=1) -> str:
     """The kernel instantiation si_hip_conv2d_f32 picks for this shape with dense, 16-byte aligned tensors."""
     H = _native.hip()

@@ -114,7 +114,25 @@ def test_schedule_fusion_and_aliasing(si, tmp_path):
     e2 = si.Engine(fuse=0, alias_cat=0)
     e2.load_model(pp, bp)
     s2 = e2.schedule()
-    assert not s2["fused"] and not s2["alias"] and len(s2["run"]) == len(s["run"]) + 64 + 8 + 2
+    # 57 SiLU + 7 add, 8 sibling convs, 2 pools of the SPPF chain, 2 upsamples read at the source
+    assert sorted(n for n in s["fused"] if n.startswith("upsample")) == ["upsample_0", "upsample_1"]
+    assert not s2["fused"] and not s2["alias"] and len(s2["run"]) == len(s["run"]) + 64 + 8 + 2 + 2
+
+
+def test_upsample_read_at_the_source_is_bit_identical(si, tmp_path):
+    """FuseUpsampleIntoConvs: the PAN top-down path's two upsamples disappear from the schedule (the convs behind the concat read
+    the low-resolution tensor with the reference's index rule, upsample.cpp:85-92) and the network output does not change by a
+    bit against the schedule that materialises them."""
+    pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(2, 160), "ups")
+    x = si.modelgen.synth_input((2, 160, 160, 3))
+    e1, oname, fused = _run(si, pp, bp, x)
+    e0, _, plain = _run(si, pp, bp, x, fuse_upsample=0)
+    assert_exact(fused, plain, "upsample read at the source vs materialised")
+    s1, s0 = e1.schedule(), e0.schedule()
+    assert len(s0["run"]) == len(s1["run"]) + 2 and not any(n.startswith("upsample") for n in s1["run"])
+    k1 = [L["kernel"] for L in e1.profile()]
+    assert sum(k.endswith("false, true>") for k in k1) == 2 and "upsample_nearest" not in k1, k1
+    assert [L["kernel"] for L in e0.profile()].count("upsample_nearest") == 2
 
 
 def test_forward_is_repeatable_and_input_is_read_at_forward_time(si, tmp_path):
@@ -329,15 +347,19 @@ def test_yolov5s_at_another_input_size(si, orc, tmp_path):
     assert_exact(one[0], got[1], "416x416: an image's result does not depend on the batch")
 
 
-def test_fp16_unsupported_graph_is_a_status(si, tmp_path):
-    # toy_yolo has channel counts that are not multiples of 32: the fp16 path says so instead of computing something else
-    pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(1, 64), "toy16")
-    e = si.Engine(fp16=1)
-    e.load_model(pp, bp)
-    e.input("0", si.modelgen.synth_input((1, 64, 64, 3)))
-    with pytest.raises(si.StatusError) as ei:
-        e.forward()
-    assert ei.value.status == si.Status.kUnsupport
+def test_fp16_unsupported_graph_is_a_load_time_status(si, tmp_path):
+    """An fp16 engine that has no kernel for some layer of a graph says so at LoadModel (kUnsupport, with the layer and the
+    reason in the log) -- not at the first Forward, and never by computing something else.  toy_yolo: channel counts that are
+    not multiples of 32; MobileNetV3: depthwise convs and the squeeze-excite broadcast multiply."""
+    for name, builder in (("toy16", si.modelgen.build_toy_yolo(1, 64)), ("mnv3", si.modelgen.build_mobilenetv3_small(1, 96, num_classes=10))):
+        pp, bp = _save(tmp_path, builder, name)
+        e = si.Engine(fp16=1)
+        with pytest.raises(si.StatusError) as ei:
+            e.load_model(pp, bp)
+        assert ei.value.status == si.Status.kUnsupport, name
+        assert e.input_names() == []          # nothing half-loaded is left behind
+        e32 = si.Engine()
+        e32.load_model(pp, bp)                # the same file loads without the option
 
 
 def test_rebatch_serves_any_batch_from_one_file(si, tmp_path):
@@ -451,9 +473,11 @@ def test_full_size_properties_yolov5s_640_batch32(si, orc, tmp_path):
     full = e32.extract(oname)
     assert full.shape == (32, 25200, 85) and np.isfinite(full).all()
     assert (full[..., 4:] > 0).all() and (full[..., 4:] < 1).all() and (full[..., 2:4] > 0).all()
-    # 53 launching layers (1 stem + 48 conv + Detect + 1 fused pool chain + 2 upsample; Detect is 3 launches -> 55) + 13 no-op cats
+    # 51 launching layers (1 stem + 48 conv + Detect + 1 fused pool chain; Detect is 3 launches -> 53 launches; the two upsamples
+    # are read at the source by the convs behind the concat) + 13 no-op cats
     run = e32.schedule()["run"]
-    assert len([r for r in run if not r.startswith("cat")]) == 53 and len(run) == 66
+    assert len([r for r in run if not r.startswith("cat")]) == 51 and len(run) == 64
+    assert sorted(n for n in e32.schedule()["fused"] if n.startswith("upsample")) == ["upsample_0", "upsample_1"]
     e1 = si.Engine()
     e1.load_model(pp, bp)
     for k in (0, 13, 31):

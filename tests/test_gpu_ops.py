@@ -511,3 +511,24 @@ def test_stem_rolling_window_kernel(hops, orc, n, ih, iw, oc, k, p, act, strided
     if n > 1:
         one = hops.conv2d(x[n - 1:n], w, b, (2, 2), (p, p), act1=act, **kw)
         assert_exact(one[0], got[n - 1], "stem: batch position")
+
+
+@pytest.mark.parametrize("n,lh,lw,cl,cs,oc,scale,up_first", [
+    (2, 10, 10, 64, 32, 64, (2.0, 2.0), True),      # the YOLOv5 PAN form: cat([upsample(x), skip])
+    (3, 5, 7, 32, 96, 32, (2.0, 2.0), False),       # upsampled tensor second; <= 32 output channels (the 128x32 tile)
+    (1, 4, 6, 32, 32, 96, (3.0, 2.0), True),        # non-square scale: the index rule with inv = 1/3
+])
+def test_conv_reads_upsampled_source(hops, orc, n, lh, lw, cl, cs, oc, scale, up_first):
+    """si_hip_conv2d_upcat_f32 against the reference's three passes restated (Upsample::Forward, Cat::Forward, the 1x1 conv): BIT
+    exact versus this library's own unfused kernels on the materialised concat, within the bar of the oracle."""
+    oh, ow = int(lh * scale[0]), int(lw * scale[1])
+    low, skip = rng_uniform(400, (n, lh, lw, cl), -1, 1), rng_uniform(401, (n, oh, ow, cs), -1, 1)
+    w, b = rng_uniform(402, (oc, cl + cs, 1, 1), -0.3, 0.3), rng_uniform(403, (oc,), -0.5, 0.5)
+    upo = orc.upsample_nearest(low, scale[0], scale[1], (oh, ow))
+    cat = np.concatenate([upo, skip] if up_first else [skip, upo], axis=-1)
+    got = hops.conv2d_upcat(low, skip, w, b, scale, up_first, act1="silu")
+    assert_exact(got, hops.conv2d(cat, w, b, act1="silu"), "dual-source conv == conv over the materialised concat")
+    assert_parity(got, orc.activation("silu", orc.conv2d(cat, w, b)), what="vs the oracle's upsample + cat + conv")
+    if oc >= 64:
+        ya, yb = hops.conv2d_upcat(low, skip, w, b, scale, up_first, act1="silu", split_oc=32)
+        assert_exact(np.concatenate([ya, yb], -1), got, "sibling-split form")
