@@ -772,6 +772,28 @@ static int conv_variant(const SiConv2dDesc* d) {
     return ocg <= 32 ? 10 : 4;
 }
 
+// General grouped convolution with few channels per group (ForwardIm2ColWithGroup, reference src/layer/conv_2d.cpp:285-380: one
+// Eigen expression per group): 4, 8 or 16 input channels per group.  G = 32 / (ic / groups) neighbouring groups are contiguous
+// 32-channel blocks of the input and contiguous blocks of the output, so they run as ONE dense group on the fast MFMA kernel
+// with a block-diagonal weight image (zeros where an output channel does not see an input channel of its super-group): G x the
+// necessary multiplies, but on full-width 32x32x2 MFMAs with 16-byte loads -- these layers are memory-bound either way, and the
+// alternative was the generic kernel's per-element bounds checks.  Shape-only (it fixes the weight layout).
+static int conv_group_merge(const SiConv2dDesc* d) {
+    static const bool enabled = [] { const char* e = getenv("SI_GROUP_MERGE"); return !(e && e[0] == '0'); }();  // development A/B switch
+    if (!enabled) return 1;
+    if (d->groups <= 1 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return 1;
+    const int icg = d->ic / d->groups;
+    if (icg != 4 && icg != 8 && icg != 16) return 1;
+    const int G = 32 / icg;
+    return d->groups % G == 0 ? G : 1;
+}
+// the descriptor the kernels see: the same tensors with groups / G dense super-groups of 32 input channels
+static SiConv2dDesc conv_effective(const SiConv2dDesc* d) {
+    SiConv2dDesc e = *d;
+    e.groups = d->groups / conv_group_merge(d);
+    return e;
+}
+
 // K order is a property of the weight buffer, so it depends on the layer shape only
 static bool conv_cb_major(const SiConv2dDesc* d) {
     const int icg = d->ic / d->groups;
@@ -806,7 +828,8 @@ extern "C" size_t si_hip_conv2d_weight_elems(const SiConv2dDesc* d) {
     if (!d || d->groups <= 0) return 0;
     if (si_conv_smallc_ok(d)) return si_conv_smallc_weight_elems(d);  // stem layout, see conv_smallc.hip
     if (si_conv_depthwise_ok(d)) return si_conv_depthwise_weight_elems(d);
-    return (size_t)d->oc * d->kh * d->kw * conv_icg_pad(d);
+    const SiConv2dDesc e = conv_effective(d);
+    return (size_t)e.oc * e.kh * e.kw * conv_icg_pad(&e);
 }
 
 extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* w_packed) {
@@ -819,8 +842,25 @@ extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float
         si_conv_depthwise_pack(d, w_oihw, w_packed);
         return 0;
     }
-    const int icg = d->ic / d->groups, icp = conv_icg_pad(d);
     const int ntaps = d->kh * d->kw;
+    if (const int G = conv_group_merge(d); G > 1) {
+        // block-diagonal image of G merged groups: output channel o (group g, position g % G inside its super-group) sees the
+        // icg channels [ (g % G) * icg, +icg ) of the super-group's 32, zeros elsewhere; K order of the dense 32-channel case
+        const SiConv2dDesc e = conv_effective(d);
+        const int icg = d->ic / d->groups, ocg = d->oc / d->groups;
+        (void)e;   // one 32-channel block per tap: channel-block-major and tap-major K orders coincide (k = tap * 32 + c)
+        for (int o = 0; o < d->oc; ++o) {
+            const int gi = (o / ocg) % G;
+            for (int tap = 0; tap < ntaps; ++tap)
+                for (int c = 0; c < 32; ++c) {
+                    const int cl = c - gi * icg;
+                    const float v = (cl >= 0 && cl < icg) ? w_oihw[((size_t)o * icg + cl) * ntaps + tap] : 0.0f;
+                    w_packed[((size_t)o * ntaps + tap) * 32 + c] = v;
+                }
+        }
+        return 0;
+    }
+    const int icg = d->ic / d->groups, icp = conv_icg_pad(d);
     const bool cbm = conv_cb_major(d);
     for (int o = 0; o < d->oc; ++o)
         for (int y = 0; y < d->kh; ++y)
@@ -846,6 +886,11 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
                            const SiConv2dUpsampledSource* up = nullptr) {
     if (!d || !in || !w_packed || !out) return SI_E_BADARG;
     if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return SI_E_BADARG;
+    SiConv2dDesc eff;
+    if (!si_conv_smallc_ok(d) && !si_conv_depthwise_ok(d) && conv_group_merge(d) > 1) {
+        eff = conv_effective(d);   // merged groups: from here on a dense-per-super-group conv (the weights were packed for it)
+        d = &eff;
+    }
     if (d->n <= 0 || d->oh <= 0 || d->ow <= 0) return SI_E_BADARG;
     if (d->has_bias && !bias) return SI_E_BADARG;
     if (d->has_residual && !residual) return SI_E_BADARG;
@@ -983,9 +1028,11 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 1>",  "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 1>",
         "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 2>",  "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>",
         "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>"};
-    const int v = conv_variant(d);
     if (si_conv_smallc_ok(d)) return si_conv_smallc_name(d);
     if (si_conv_depthwise_ok(d)) return si_conv_depthwise_name(d);
+    SiConv2dDesc eff = conv_effective(d);
+    d = &eff;
+    const int v = conv_variant(d);
     if (conv_fast_ok(d, in)) return fast_names[v];
     static const int generic_of[11] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3};
     return names[generic_of[v]][conv_vec_a(d, in) ? 1 : 0];

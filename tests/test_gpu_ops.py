@@ -532,3 +532,24 @@ def test_conv_reads_upsampled_source(hops, orc, n, lh, lw, cl, cs, oc, scale, up
     if oc >= 64:
         ya, yb = hops.conv2d_upcat(low, skip, w, b, scale, up_first, act1="silu", split_oc=32)
         assert_exact(np.concatenate([ya, yb], -1), got, "sibling-split form")
+
+
+@pytest.mark.parametrize("n,hw,ic,oc,k,s,p,g", [
+    (2, 20, 32, 16, 3, 1, 1, 2),      # the reference's grouped test shape (test_conv_2d.cpp:134-274): 16 -> 8 per group
+    (1, 14, 128, 128, 3, 1, 1, 32),   # ResNeXt-style: 4 channels per group, 8 groups per MFMA block
+    (2, 9, 64, 96, 3, 2, 1, 8),       # 8 -> 12 per group, stride 2, odd size
+    (1, 12, 48, 48, 1, 1, 0, 6),      # 8 per group but 6 groups: not a multiple of 4 groups per block -> the generic kernel
+    (3, 7, 64, 32, 5, 1, 2, 4),       # 16 -> 8 per group, 5x5
+])
+def test_conv_general_groups(hops, orc, n, hw, ic, oc, k, s, p, g):
+    """ForwardIm2ColWithGroup (conv_2d.cpp:285-380) for 1 < channels/group < 32: neighbouring groups merged into dense 32-channel
+    blocks with a block-diagonal weight image, on the fast MFMA kernel."""
+    x = rng_uniform(500 + g, (n, hw, hw, ic), -1, 1)
+    w = rng_uniform(501 + g, (oc, ic // g, k, k), -0.3, 0.3)
+    b = rng_uniform(502 + g, (oc,), -0.5, 0.5)
+    ref = orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, path="naive")
+    got = hops.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, act1="relu")
+    assert_parity(got, orc.activation("relu", ref), 2e-5, what="grouped conv vs fp64")
+    assert_parity(hops.conv2d(x, w, b, (s, s), (p, p), (1, 1), g), orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, path="auto"), what="vs the reference path")
+    name = hops.conv2d_kernel_name(x.shape, w.shape, (s, s), (p, p), g)
+    assert ("fast" in name) == (g != 6), name
