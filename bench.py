@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (reference uses 16 intra-op)")
     ap.add_argument("--profile-passes", type=int, default=3)
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra Engine::SetOption for A/B runs (e.g. arena=0, fuse_upsample=0); recorded in config.engine_options")
     return ap.parse_args()
 
 
@@ -322,7 +324,8 @@ def main():
         builder.save(pp, bp)
         flops_step = mg.conv_flops(builder)
 
-        e = si.Engine(device=dev, outputs_to_host=0, graph=args.graph, winograd=args.winograd, fp16=args.fp16)
+        extra_opts = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.engine_opt}
+        e = si.Engine(device=dev, outputs_to_host=0, graph=args.graph, winograd=args.winograd, fp16=args.fp16, **extra_opts)
         try:
             e.load_model(pp, bp)
         except si.StatusError as ex:
@@ -484,7 +487,7 @@ def main():
                                                             args.batch * world,
                                                             (", every step's output slab all-gathered (%s), overlapped with the next step" % gather_text) if use_dist else ""),
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "gather": gather_mode, "gather_note": gather_note,
+                   "gather": gather_mode, "gather_note": gather_note, "engine_options": extra_opts,
                    "hipgraph": bool(args.graph), "winograd_for_3x3s1": {0: "off", 1: "F(2,3)", 2: "F(4,3)"}.get(args.winograd, "F(2,3)")},
         "windows": {"count": len(windows), "steps_each": args.steps, "timed_s_total": round(total, 3),
                     "value_is": "median window",

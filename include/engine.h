@@ -62,6 +62,8 @@ public:
     //   "device"          HIP device ordinal (default: current device)
     //   "fuse"            1/0  fold activation / residual add into the conv epilogue (default 1)
     //   "alias_cat"       1/0  producers write straight into torch.cat outputs (default 1)
+    //   "arena"           1/0  intermediate operands share one HBM arena by lifetime (default 1); 0 = one allocation per operand,
+    //                          as the reference does (src/engine_impl.cpp:465-482)
     //   "fuse_upsample"   1/0  a 1x1 conv that consumes cat(upsample(x), skip) reads x at the source pixel; the upsample launch
     //                          and its output disappear (default 1; needs "fuse" and "alias_cat")
     //   "winograd"        0/1/2  3x3 stride-1 convs: 1 (default) fused Winograd F(2,3) where it is the faster kernel, as

@@ -19,7 +19,7 @@ typedef struct SiEngine SiEngine;
 /* Engine::Engine / ~Engine */
 int si_engine_create(SiEngine** engine);
 int si_engine_destroy(SiEngine* engine);
-/* Engine::SetOption -- before load_model.  Keys: device, fuse, alias_cat, fuse_upsample, winograd, fp16, batch, graph, outputs_to_host
+/* Engine::SetOption -- before load_model.  Keys: device, fuse, alias_cat, fuse_upsample, arena, winograd, fp16, batch, graph, outputs_to_host
  * (include/engine.h documents the values) */
 int si_engine_set_option(SiEngine* engine, const char* key, int value);
 /* Engine::LoadModel / Release (reference src/engine_impl.cpp:16-75, :77-127) */
@@ -54,7 +54,8 @@ float si_engine_last_forward_ms(SiEngine* engine);
 int si_engine_profile(SiEngine* engine);
 int si_engine_profile_entry(SiEngine* engine, int index, const char** op_name, const char** op_type,
                             const char** kernel, float* ms, double* flops, double* bytes);
-/* text description of the launch schedule: "run <op>", "fused <op>", "alias <operand>" lines */
+/* text description of the launch schedule: "run <op>", "fused <op>", "alias <operand>" lines, then "arena_bytes <n>" (HBM held
+ * for intermediate operands, shared by lifetime) and "per_operand_bytes <n>" (what one allocation per operand would take) */
 int si_engine_schedule(SiEngine* engine, char* buf, size_t cap);
 
 /* Loader check: parse a .pnnx.param/.bin with THIS library's pnnx loader (optionally lowering

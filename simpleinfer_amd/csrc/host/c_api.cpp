@@ -156,6 +156,9 @@ int si_engine_schedule(SiEngine* e, char* buf, size_t cap) {
     for (auto& n : e->impl.ScheduledOps()) os << "run " << n << "\n";
     for (auto& n : e->impl.FusedOps()) os << "fused " << n << "\n";
     for (auto& n : e->impl.AliasedOperands()) os << "alias " << n << "\n";
+    size_t arena = 0, unshared = 0;
+    e->impl.ActivationFootprint(arena, unshared);
+    os << "arena_bytes " << arena << "\n" << "per_operand_bytes " << unshared << "\n";
     return copy_out(os.str(), buf, cap);
 }
 

@@ -53,6 +53,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "outputs_to_host") opt_outputs_to_host_ = value != 0;
     else if (key == "fp16") opt_fp16_ = value != 0;
     else if (key == "batch") opt_batch_ = value;  // > 0: re-batch the graph at load (the file bakes its batch into every shape)
+    else if (key == "arena") opt_arena_ = value != 0;  // 1 (default): intermediates share one arena by lifetime; 0: one hipMalloc each
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else {
@@ -670,7 +671,23 @@ Status EngineImpl::AliasConcats() {
 
 // ---- memory --------------------------------------------------------------------------------------
 Status EngineImpl::AllocateTensorMemory() {
-    // 1. every live operand that is not an alias and not a graph input gets its own HBM buffer
+    // 1. Every live operand that is not an alias gets HBM.  The reference mallocs each operand separately and never reuses
+    //    (src/engine_impl.cpp:465-482, "TODO" at :466).  Here graph inputs / outputs keep their own buffers (they outlive the
+    //    forward), and the intermediates are packed into ONE arena: two buffers may overlap in memory iff no launch of the plan
+    //    needs both -- a buffer lives from the first step that writes it (or any alias into it) to the last step that reads it.
+    struct Buf {
+        TensorNode* node;
+        size_t bytes, offset;
+        int first, last;
+    };
+    std::map<TensorNode*, size_t> buf_of;   // root buffer node -> index in bufs
+    std::vector<Buf> bufs;
+    auto root_of = [&](TensorNode* n) -> TensorNode* {
+        if (!n || !n->operand) return n;
+        auto al = aliases_.find(n->operand->name);
+        return al != aliases_.end() ? al->second.parent : n;
+    };
+    unshared_bytes_ = arena_bytes_ = 0;
     for (auto& kv : tensor_nodes_) {
         const std::string& name = kv.first;
         Tensor& t = kv.second->tensor;
@@ -680,14 +697,69 @@ Status EngineImpl::AllocateTensorMemory() {
             LOG(ERROR) << "operand [" << name << "] has no static shape";
             return Status::kErrorShape;
         }
-        void* p = nullptr;
-        SI_TRY_HIP(si_hip_malloc(&p, bytes), "hipMalloc operand");
-        device_allocs_.push_back(p);
-        if (input_tensor_nodes_.count(name)) {
-            input_buffers_[name] = p;  // staging for host inputs
+        const bool io = input_tensor_nodes_.count(name) || output_tensor_nodes_.count(name);
+        if (io || !opt_arena_) {
+            void* p = nullptr;
+            SI_TRY_HIP(si_hip_malloc(&p, bytes), "hipMalloc operand");
+            device_allocs_.push_back(p);
+            if (input_tensor_nodes_.count(name)) input_buffers_[name] = p;  // staging for host inputs
+            if (output_tensor_nodes_.count(name)) own_output_ptrs_[name] = p;
+            t.SetView(p, MemoryType::kDevice, 0);
+            if (!io) unshared_bytes_ += bytes, arena_bytes_ += bytes;
+            continue;
         }
-        if (output_tensor_nodes_.count(name)) own_output_ptrs_[name] = p;
-        t.SetView(p, MemoryType::kDevice, 0);
+        buf_of[kv.second] = bufs.size();
+        bufs.push_back(Buf{kv.second, (bytes + 255) & ~size_t(255), 0, -1, -1});
+        unshared_bytes_ += bytes;
+    }
+    if (!bufs.empty()) {
+        auto touch = [&](TensorNode* n, int step) {
+            auto it = buf_of.find(root_of(n));
+            if (it == buf_of.end()) return;
+            Buf& b = bufs[it->second];
+            if (b.first < 0) b.first = step;
+            b.last = step;
+        };
+        for (size_t i = 0; i < plan_.size(); ++i) {
+            Layer* L = plan_[i].layer;
+            std::vector<TensorNode*> extra;
+            L->ExtraReads(extra);
+            for (TensorNode* n : L->InputNodes()) touch(n, (int)i);
+            for (TensorNode* n : extra) touch(n, (int)i);
+            for (TensorNode* n : L->OutputNodes()) touch(n, (int)i);
+        }
+        // buffers no step of the plan touches (operands only a fused-away operator produced) live for the whole forward
+        for (Buf& b : bufs)
+            if (b.first < 0) { b.first = 0; b.last = (int)plan_.size(); }
+        // greedy by size: place each buffer at the lowest offset that is free during its whole life
+        std::vector<size_t> order(bufs.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return bufs[x].bytes != bufs[y].bytes ? bufs[x].bytes > bufs[y].bytes : x < y; });
+        std::vector<size_t> placed;
+        size_t total = 0;
+        for (size_t bi : order) {
+            Buf& b = bufs[bi];
+            std::vector<std::pair<size_t, size_t>> busy;   // [offset, end) of placed buffers alive at the same time
+            for (size_t pj : placed) {
+                const Buf& o = bufs[pj];
+                if (o.first <= b.last && b.first <= o.last) busy.push_back(std::make_pair(o.offset, o.offset + o.bytes));
+            }
+            std::sort(busy.begin(), busy.end());
+            size_t off = 0;
+            for (auto& iv : busy) {
+                if (off + b.bytes <= iv.first) break;
+                if (iv.second > off) off = iv.second;
+            }
+            b.offset = off;
+            if (off + b.bytes > total) total = off + b.bytes;
+            placed.push_back(bi);
+        }
+        void* arena = nullptr;
+        SI_TRY_HIP(si_hip_malloc(&arena, total), "hipMalloc activation arena");
+        device_allocs_.push_back(arena);
+        arena_bytes_ = total;
+        for (Buf& b : bufs) b.node->tensor.SetView(static_cast<char*>(arena) + b.offset, MemoryType::kDevice, 0);
+        LOG(INFO) << "activation arena: " << total << " bytes for " << bufs.size() << " operands (" << unshared_bytes_ << " without sharing)";
     }
     // 2. aliases point into their concat buffer
     for (auto& kv : aliases_) {

@@ -77,6 +77,8 @@ public:
     std::vector<std::string> ScheduledOps() const;
     std::vector<std::string> FusedOps() const;
     std::vector<std::string> AliasedOperands() const;
+    // bytes of HBM held for intermediate operands: with lifetime sharing, and what one allocation per operand would take
+    void ActivationFootprint(size_t& arena_bytes, size_t& per_operand_bytes) const { arena_bytes = arena_bytes_; per_operand_bytes = unshared_bytes_; }
 
 private:
     struct Step {
@@ -100,6 +102,7 @@ private:
     bool opt_fuse_ = true;
     bool opt_alias_cat_ = true;
     bool opt_fuse_upsample_ = true;
+    bool opt_arena_ = true;      // intermediate operands share one HBM arena by lifetime (0: one allocation per operand, as the reference)
     bool opt_graph_ = false;
     bool opt_outputs_to_host_ = true;
     int opt_winograd_ = 1;
@@ -125,6 +128,7 @@ private:
     std::map<std::string, Alias> aliases_;   // operand name -> slice of a concat buffer
 
     std::vector<void*> device_allocs_;
+    size_t arena_bytes_ = 0, unshared_bytes_ = 0;   // footprint with / without lifetime sharing (statistics)
     std::map<std::string, Tensor> user_inputs_;     // what Input() bound (host or device alias)
     std::map<std::string, Tensor> user_outputs_;    // what Output() bound (caller-owned device buffers)
     std::map<std::string, void*> own_output_ptrs_;  // the engine's own buffer of every output operand

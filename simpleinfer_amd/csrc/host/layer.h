@@ -56,6 +56,9 @@ public:
     virtual const char* KernelName() const { return "none"; }
     // algorithmic cost of one Forward with the currently bound nodes
     virtual double Flops() const { return 0.0; }
+    // tensors a layer reads besides its bound input nodes (fusion hooks: a conv's residual, its upsampled source); the engine's
+    // memory planner needs every reader of a buffer
+    virtual void ExtraReads(std::vector<TensorNode*>& nodes) const { (void)nodes; }
     // fp16 storage (Engine option "fp16"): can this layer run with the storage types its bound nodes now have?  Asked once, at
     // LoadModel, so that an unsupported combination is a load-time Status with a reason instead of a failing first Forward().
     // Default: fine when no bound tensor is fp16, or when inputs and outputs are all fp16.

@@ -33,6 +33,10 @@ public:
 
     virtual const char* KernelName() const override;
     virtual bool HalfStorageOk(std::string& why) const override;
+    virtual void ExtraReads(std::vector<TensorNode*>& nodes) const override {
+        if (residual_node_) nodes.push_back(residual_node_);
+        if (up_node_) nodes.push_back(up_node_);
+    }
     int WinogradTile(const SiConv2dDesc& d) const;
     virtual double Flops() const override;
     virtual double Bytes() const override;
