@@ -1021,19 +1021,24 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         {"conv_igemm_f32_kernel<128, 64, 2, 2, false>", "conv_igemm_f32_kernel<128, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<64, 64, 2, 2, false>", "conv_igemm_f32_kernel<64, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<128, 32, 4, 1, false>", "conv_igemm_f32_kernel<128, 32, 4, 1, true>"}};
+    // exactly as rocprofv3 prints the instantiation (minus the namespace): <BM, BN, WM, WN, NBUF, PADK, UPS>
     static const char* fast_names[11] = {
-        "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 2>", "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 2>",
-        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 2>",   "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 2>",
-        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1>",   "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 1>",
-        "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 1>",  "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 1>",
-        "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 2>",  "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>",
-        "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1>"};
+        "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 2, false, false>", "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 2, false, false>",
+        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 2, false, false>",   "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 2, false, false>",
+        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false>",   "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 1, false, false>",
+        "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 1, false, false>",  "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 1, false, false>",
+        "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 2, false, false>",  "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, false>",
+        "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, false>"};
     if (si_conv_smallc_ok(d)) return si_conv_smallc_name(d);
     if (si_conv_depthwise_ok(d)) return si_conv_depthwise_name(d);
     SiConv2dDesc eff = conv_effective(d);
     d = &eff;
     const int v = conv_variant(d);
-    if (conv_fast_ok(d, in)) return fast_names[v];
+    if (conv_fast_ok(d, in)) {
+        if ((d->ic / d->groups) % 32 != 0)   // zero-padded K: the PADK instantiations of the two default tiles
+            return (d->oc / d->groups) <= 32 ? "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, true, false>" : "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, true, false>";
+        return fast_names[v];
+    }
     static const int generic_of[11] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3};
     return names[generic_of[v]][conv_vec_a(d, in) ? 1 : 0];
 }

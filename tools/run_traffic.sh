@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 REPO=$PWD
 for C in FETCH_SIZE WRITE_SIZE; do
   cd /tmp
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/raw_$C" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-aux --profile-passes 1 "$@" > "$OUT/bench_$C.json" 2> "$OUT/stderr_$C.txt" || true
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/raw_$C" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --min-time 0 --max-windows 1 --no-cpu-baseline --no-aux --profile-passes 1 "$@" > "$OUT/bench_$C.json" 2> "$OUT/stderr_$C.txt" || true
   cd "$REPO"
   find "$OUT/raw_$C" -name "*counter_collection.csv" -exec cp {} "$OUT/counters_$C.csv" \;
   rm -rf "$OUT/raw_$C"
@@ -42,7 +42,9 @@ for k, v in res.items():
     w = v.get("WRITE_SIZE", 0.0) * 1024.0
     final[k] = {"hbm_bytes_per_launch": round(f + w), "fetch_bytes": round(f), "write_bytes": round(w), "launches": v.get("launches", 0),
                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950)"}
+import os
+final["_recorded_at"] = os.environ.get("SI_COMMIT", "unknown commit")
 json.dump(final, open(out + "/traffic.json", "w"), indent=1)
-for k, v in sorted(final.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
+for k, v in sorted(((k, v) for k, v in final.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
     print(k, v["hbm_bytes_per_launch"] / 1e6, "MB/launch", v["launches"])
 PY
