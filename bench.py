@@ -349,14 +349,6 @@ def main():
                 gather_mode = "rccl"
                 if share and world > 1:
                     sys.exit("bench.py: RCCL cannot run two ranks on one device")
-        if gather_mode == "rccl":
-            import torch  # plumbing only: process group, barrier, the RCCL all-gather
-            torch.cuda.set_device(dev)
-            dist = sd.init_process_group("nccl", device_index=dev)
-            e.forward()
-            optr, _ = e.extract_ptr(oname)
-            og = sd.OverlappedGather(sd.as_torch(optr, oshape, dev))
-
         def step():
             if sf is not None:
                 # Forward() writes this step's [B/G, rows, 85] slab straight into its place in one of three gathered buffers
@@ -406,8 +398,48 @@ def main():
                 theirs = np.array([int(v.item()) for v in allt], np.uint64)
                 sums = sums >> np.uint64(1)
             if not np.array_equal(sums, theirs) or int(sums[rank]) == 0:
-                sys.exit("bench.py: rank %d: the gathered buffer does not hold every rank's slab (%s vs %s)" % (rank, sums, theirs))
+                raise RuntimeError("rank %d: the gathered buffer does not hold every rank's slab (%s vs %s)" % (rank, sums, theirs))
 
+        def setup_rccl():
+            nonlocal torch, dist, og
+            import torch as _torch  # plumbing only: process group, barrier, the RCCL all-gather
+            torch = _torch
+            torch.cuda.set_device(dev)
+            dist = sd.init_process_group("nccl", device_index=dev)
+            e.bind_output(oname, None)
+            e.forward()
+            optr, _ = e.extract_ptr(oname)
+            og = sd.OverlappedGather(sd.as_torch(optr, oshape, dev))
+
+        if gather_mode == "rccl":
+            setup_rccl()
+
+        # warm-up; with the direct gather in `auto` mode it doubles as the acceptance test of that path: every rank reports
+        # whether its steps ran and its gathered buffer checks out, and unless ALL do, all fall back to RCCL together
+        if sf is not None and args.gather == "auto":
+            ok = 1
+            try:
+                for _ in range(max(args.warmup, 2)):
+                    step()
+                fence()
+                slab_checksums()
+                fence()
+            except Exception as ex:  # noqa: BLE001 -- any failure of the optional path means "use the fallback"
+                ok = 0
+                gather_note = "direct gather failed its warm-up check (%s)" % ex
+            all_ok = min(b[0] for b in group.allgather_bytes(bytes([ok])))
+            if not all_ok:
+                if gather_note is None:
+                    gather_note = "direct gather failed its warm-up check on another rank"
+                try:
+                    sf.close()
+                except Exception:  # noqa: BLE001
+                    pass
+                sf = None
+                gather_mode = "rccl"
+                if share and world > 1:
+                    sys.exit("bench.py: RCCL cannot run two ranks on one device")
+                setup_rccl()
         for _ in range(args.warmup):
             step()
         fence()

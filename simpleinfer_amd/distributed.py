@@ -31,6 +31,8 @@ def init_process_group(backend: str, device_index: int = None):
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")          # a lone process (SI_BENCH_FORCE_DIST=1) is rank 0 of 1
+        os.environ.setdefault("WORLD_SIZE", "1")
         kw = {}
         if backend == "nccl" and device_index is not None:
             kw["device_id"] = torch.device("cuda", device_index)
