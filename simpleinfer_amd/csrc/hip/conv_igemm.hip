@@ -279,29 +279,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
 
-// Diagnostic build only (-DSI_DIAG_STAMPS, tools/conv_diag.py): per-workgroup s_memtime / s_memrealtime stamps at the phase
-// boundaries of the fast kernel, written to a buffer of their own that nothing else reads.  In the product build no stamp
-// executes and the macros expand to nothing.
-
-#ifdef SI_DIAG_STAMPS
-__device__ unsigned long long si_diag_stamps[65536 * 8];
-#define SI_STAMP_DECL unsigned long long st_[8]
-#define SI_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
-#define SI_STAMP_RT(i) st_[i] = __builtin_amdgcn_s_memrealtime()
-#define SI_STAMP_FLUSH()                                                                                        \
-    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 65536) {                                            \
-        unsigned hw_, xcc_;                                                                                     \
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                       \
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                     \
-        st_[7] = ((unsigned long long)xcc_ << 32) | hw_;                                                        \
-        for (int i_ = 0; i_ < 8; ++i_) si_diag_stamps[(size_t)blockIdx.x * 8 + i_] = st_[i_];                   \
-    }
-#else
-#define SI_STAMP_DECL
-#define SI_STAMP(i)
-#define SI_STAMP_RT(i)
-#define SI_STAMP_FLUSH()
-#endif
+SI_STAMP_ARRAY(si_diag_stamps);   // diagnostic build only (si_hip_internal.h)
 
 template <int BM, int BN, int WM, int WN, bool VEC_A>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
@@ -692,20 +670,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31, m0 + BM <= a.M, yolo_img, bias_pre);
     SI_STAMP(5);
     SI_STAMP_RT(6);
-    SI_STAMP_FLUSH();
+    SI_STAMP_FLUSH(si_diag_stamps);
 }
 
 #ifdef SI_DIAG_STAMPS
 }  // namespace
-extern "C" int si_hip_diag_stamps_read(unsigned long long* host, size_t count) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(si_diag_stamps), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
-}
-extern "C" int si_hip_diag_stamps_clear(void) {
-    void* p = nullptr;
-    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(si_diag_stamps));
-    if (e != hipSuccess) return (int)e;
-    return (int)hipMemset(p, 0, sizeof(unsigned long long) * 65536 * 8);
-}
+SI_STAMP_ACCESSORS(si_diag_stamps, si_hip_diag_stamps_read, si_hip_diag_stamps_clear)
 namespace {
 #endif
 

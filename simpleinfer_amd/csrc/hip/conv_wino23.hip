@@ -66,6 +66,11 @@ __device__ __forceinline__ float wino_act(int act, float v, float p) {
 
 constexpr int CB = 16;  // input channels per staged block
 
+#ifndef SI_WINO_ABLATE   // diagnostic builds only (timing experiments, wrong results): 1 no patch prefetch after block 0,
+#define SI_WINO_ABLATE 0  // 2 no filter loads after the first, 4 no commit writes after block 0, 8 no output stores
+#endif
+SI_STAMP_ARRAY(si_diag_stamps_wino);   // diagnostic build only (si_hip_internal.h)
+
 // LOG_TBW: log2 of tiles per block row (the workgroup's 32 tiles form a TBH x TBW block).
 template <int LOG_TBW>
 __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
@@ -86,6 +91,9 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     constexpr int LDS_FLOATS = 2 * BUF > XCH ? 2 * BUF : XCH;
 
     __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
+    SI_STAMP_DECL;
+    SI_STAMP_RT(0);
+    SI_STAMP(1);
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -194,152 +202,33 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
 
     f32x4 bcur[4], bnxt[4];
     auto load_b = [&](f32x4 (&dst)[4], int cb, int half) {
+        if ((SI_WINO_ABLATE & 2) && (cb | half)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = bcur[q];
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = ub[b_index(q, cb, half)];
     };
 
     prefetch(0);
+    SI_STAMP(2);
     commit(0);
     load_b(bcur, 0, 0);
     __syncthreads();
+    SI_STAMP(3);
 
     // software pipeline: the patch rows of step s+1 are read from LDS before the MFMAs of step s are issued, and within a
     // block the filter loads are issued BEFORE the (slower, HBM) patch prefetch so that waiting for the filter values
     // never waits for the patch (vmcnt retires in order)
     float2 da[2], db[2];
     const float *pa = pa0, *pb = pb0;
-    auto read_d = [&](int s) {
-        const float2* qa = reinterpret_cast<const float2*>(pa + (2 * s) * PLANE);
-        const float2* qb = reinterpret_cast<const float2*>(pb + (2 * s) * PLANE);
         da[0] = qa[0]; da[1] = qa[1]; db[0] = qb[0]; db[1] = qb[1];
     };
     for (int cb = 0; cb < ncb; ++cb) {
         const int buf = cb & 1;
         pa = pa0 + buf * BUF;
         pb = pb0 + buf * BUF;
-        read_d(0);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half == 0) {
-                load_b(bnxt, cb, 1);
-                if (cb + 1 < ncb) prefetch(cb + 1);
-            } else if (cb + 1 < ncb) {
-                load_b(bnxt, cb + 1, 0);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int s = half * 4 + k;
-                const float t0 = da[0].x + sg * db[0].x;
-                const float t1 = da[0].y + sg * db[0].y;
-                const float t2 = da[1].x + sg * db[1].x;
-                const float t3 = da[1].y + sg * db[1].y;
-                if (s + 1 < CB / 2) read_d(s + 1);
-                float v[4];
-                v[0] = t0 - t2;
-                v[1] = t1 + t2;
-                v[2] = t2 - t1;
-                v[3] = t1 - t3;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], bcur[q][k], acc[q], 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bcur[q] = bnxt[q];
-        }
-        // the other buffer was last read one block ago and a barrier has passed since: fill it, then one barrier
-        if (cb + 1 < ncb) commit(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- output transform.  Column half in registers (winograd_helper.cpp:582-590): Z0 = m0+m1+m2, Z1 = m1-m2-m3.
-    // Every wave parks its Z[jc][e] (32 values) in LDS as [wave][lane][XLS] with 8 ds_write_b128; after ONE barrier wave w
-    // finishes output row i = w & 1 of output column jc = w >> 1 for every tile: the row half across the four plane rows
-    // (:592-615), Y0 = Z(r0)+Z(r1)+Z(r2), Y1 = Z(r1)-Z(r2)-Z(r3), then bias / activation / residual.
-    float* xch = patch;
-    {
-        f32x4* mine = reinterpret_cast<f32x4*>(xch + (wave * 64 + lane) * XLS);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 z0, z1;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = 4 * g + k;
-                z0[k] = (acc[0][e] + acc[1][e]) + acc[2][e];
-                z1[k] = (acc[1][e] - acc[2][e]) - acc[3][e];
-            }
-            mine[g] = z0;       // float index jc*16 + e
-            mine[4 + g] = z1;
-        }
-    }
-    __syncthreads();
-    const int i_out = wave & 1, jc = wave >> 1;
-    // activation / residual combination resolved once per workgroup: the loop body is straight-line code
-    auto finish = [&](auto act1, auto act2, auto has_res) {
-#pragma clang fp contract(off)  // every instantiation must round alike (bit-exact batch sharding)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 zr[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) zr[r] = *reinterpret_cast<const f32x4*>(xch + (r * 64 + lane) * XLS + jc * 16 + 4 * g);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = 4 * g + k;
-                const float y = (i_out == 0) ? (zr[0][k] + zr[1][k]) + zr[2][k] : (zr[1][k] - zr[2][k]) - zr[3][k];
-                // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh
-                const int m = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const int tr = m >> LOG_TBW, tc = m & (TBW - 1);
-                const int R = row0 + tr;
-                const int txg = col0 + tc;
-                if (R < a.rows_total && txg < a.tw && ocok) {
-                    int img = img0, ty = ty0 + tr;
-                    while (ty >= a.th) {
-                        ty -= a.th;
-                        ++img;
-                    }
-                    const int oy = 2 * ty + i_out, ox = 2 * txg + jc;
-                    if (oy < a.oh && ox < a.ow) {
-                        const size_t pix = (size_t)(img * a.oh + oy) * a.ow + ox;
-                        float vv = y + bv;
-                        vv = decltype(act1)::value < 0 ? wino_act(a.act1, vv, a.act_param)
-                                                       : (decltype(act1)::value == SI_ACT_SILU ? vv * __builtin_amdgcn_rcpf(1.0f + __expf(-vv))
-                                                          : (decltype(act1)::value == SI_ACT_RELU ? fmaxf(vv, 0.0f) : vv));
-                        if (decltype(has_res)::value) vv += a.res[pix * a.res_ld + o];
-                        vv = decltype(act2)::value < 0 ? wino_act(a.act2, vv, a.act_param)
-                                                       : (decltype(act2)::value == SI_ACT_RELU ? fmaxf(vv, 0.0f) : vv);
-                        a.out[pix * a.out_ld + o] = vv;
-                    }
-                }
-            }
-        }
-    };
-    using IC = std::integral_constant<int, 0>;
-    (void)sizeof(IC);
-    const bool res = a.res != nullptr;
-    if (a.act1 == SI_ACT_SILU && a.act2 == SI_ACT_NONE) {
-        if (res) finish(std::integral_constant<int, SI_ACT_SILU>{}, std::integral_constant<int, SI_ACT_NONE>{}, std::true_type{});
-        else finish(std::integral_constant<int, SI_ACT_SILU>{}, std::integral_constant<int, SI_ACT_NONE>{}, std::false_type{});
-    } else if (a.act1 == SI_ACT_RELU && a.act2 == SI_ACT_NONE && !res) {
-        finish(std::integral_constant<int, SI_ACT_RELU>{}, std::integral_constant<int, SI_ACT_NONE>{}, std::false_type{});
-    } else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_RELU && res) {
-        finish(std::integral_constant<int, SI_ACT_NONE>{}, std::integral_constant<int, SI_ACT_RELU>{}, std::true_type{});
-    } else if (res) {
-        finish(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{}, std::true_type{});
-    } else {
-        finish(std::integral_constant<int, -1>{}, std::integral_constant<int, -1>{}, std::false_type{});
-    }
-}
-
-template <int LOG_TBW>
-int launch_wino(WinoArgs a, hipStream_t s) {
-    constexpr int TBW = 1 << LOG_TBW;
-    constexpr int TBH = 32 / TBW;
-    a.col_blocks = (a.tw + TBW - 1) / TBW;
-    a.oc_blocks = (a.oc + 31) / 32;
-    const int row_blocks = (a.rows_total + TBH - 1) / TBH;
-    a.spatial_blocks = a.col_blocks * row_blocks;
-    const long long nblocks = (long long)((a.spatial_blocks + 7) / 8) * 8 * a.oc_blocks;
-    if (nblocks > 0x7fffffffLL) return SI_E_UNSUPPORTED;
-    dim3 grid((unsigned)nblocks, 1, 1);
     hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW>), grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }

@@ -120,4 +120,38 @@ __device__ __forceinline__ void si_yolo_tile_one_image(const Args& a, float* out
     }
 }
 
+// ---- diagnostic build only (-DSI_DIAG_STAMPS; tools/conv_diag.py): per-workgroup s_memtime / s_memrealtime stamps at the phase
+// boundaries of a kernel, written to a __device__ array of their own that nothing else reads.  In the product build no stamp
+// executes and every macro expands to nothing.  Slots: [0] realtime at start, [1..5] cycle stamps, [6] realtime at end, [7] hw id.
+#ifdef SI_DIAG_STAMPS
+#define SI_STAMP_ARRAY(name) __device__ unsigned long long name[65536 * 8]
+#define SI_STAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define SI_STAMP(i) st_[i] = __builtin_amdgcn_s_memtime()
+#define SI_STAMP_RT(i) st_[i] = __builtin_amdgcn_s_memrealtime()
+#define SI_STAMP_FLUSH(name)                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 65536) {                                            \
+        unsigned hw_, xcc_;                                                                                     \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                       \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                                     \
+        st_[7] = ((unsigned long long)xcc_ << 32) | hw_;                                                        \
+        for (int i_ = 0; i_ < 8; ++i_) name[(size_t)blockIdx.x * 8 + i_] = st_[i_];                             \
+    }
+#define SI_STAMP_ACCESSORS(name, read_fn, clear_fn)                                                                              \
+    extern "C" int read_fn(unsigned long long* host, size_t count) {                                                             \
+        return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(name), count * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);   \
+    }                                                                                                                            \
+    extern "C" int clear_fn(void) {                                                                                              \
+        void* p_ = nullptr;                                                                                                      \
+        hipError_t e_ = hipGetSymbolAddress(&p_, HIP_SYMBOL(name));                                                              \
+        if (e_ != hipSuccess) return (int)e_;                                                                                    \
+        return (int)hipMemset(p_, 0, sizeof(unsigned long long) * 65536 * 8);                                                    \
+    }
+#else
+#define SI_STAMP_ARRAY(name) static_assert(true, "")
+#define SI_STAMP_DECL
+#define SI_STAMP(i)
+#define SI_STAMP_RT(i)
+#define SI_STAMP_FLUSH(name)
+#endif
+
 #endif  // SI_HIP_INTERNAL_H_
