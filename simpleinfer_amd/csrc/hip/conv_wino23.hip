@@ -7,16 +7,22 @@
 // only if the transformed tensors (4x the activation size) never touch HBM.  This kernel keeps everything on chip:
 //
 //   * a workgroup owns 32 Winograd tiles (TBH x TBW, rows of tiles counted across the whole batch) x 32 output
-//     channels.  Per 16-channel block it stages the raw input patches of its tiles in LDS (channel-major, so the MFMA
-//     operand reads below are plain ds_read_b32 with immediate offsets);
+//     channels.  Per 16-channel block every thread fetches the four patch rows of one (tile row, pixel, 4 channels) item,
+//     forms the ROW half of B^T d B in registers -- t_r = d[ja] +- d[jb] for the four plane rows r, the formulas of
+//     winograd_helper.cpp:188-239 -- and stores the four results channel-major in LDS;
 //   * wave r (0..3) owns plane ROW r of the 4x4 transform domain: for its tile (lane&31) and channel (2*step + lane>>5)
-//     it reads the two patch rows it needs (8 values), forms t = d[ja] +- d[jb] and V[r][0..3] in 8 VALU ops -- the
-//     B^T d B formulas of winograd_helper.cpp:188-239 -- and feeds them straight into 32x32x2 MFMAs as the A operand.
-//     The B operand is the pre-transformed filter U = G g G^T ([plane][ic][oc], oc contiguous: one 256-byte row pair
-//     per MFMA), streamed from L2 through registers one step ahead;
-//   * after the channel loop each wave applies the column half of A^T M A in registers, the four waves exchange the
-//     row half through LDS (reusing the patch buffer), and the 2x2 outputs get bias / activation / residual and go
-//     out as 128-byte channel rows.
+//     it reads the four pixels of row r with two ds_read_b64, forms V[r][0..3] in 4 VALU ops (the column half) and feeds them
+//     straight into four 32x32x2 MFMAs as the A operand.  The B operand is the pre-transformed filter U = G g G^T
+//     ([plane][ic][oc], oc contiguous), streamed from L2 through registers half a block ahead;
+//   * the loop is software-pipelined by hand (round 2; the stamps of tools/conv_diag.py --algo wino showed one wave alone
+//     reaching only 48 % of the MFMA rate with the LDS latency and the transform exposed after every four MFMAs): the
+//     operands of step s+1 are transformed and the pixels of step s+2 requested between the MFMAs of step s; the staging
+//     stores of the next block are spread over the MFMA gaps of steps 4 and 5, its global loads have a whole block to land,
+//     and the one barrier per block sits behind three issued MFMAs;
+//   * after the channel loop each wave applies the column half of A^T M A in registers and parks the result in LDS
+//     transposed to [plane row][output column][tile][oc]; after one barrier wave w finishes output (row w&1, column w>>1)
+//     of every tile: lane = (tile, 4 channels), so the row half, bias / activation / residual and the store work on float4s
+//     and a wave stores eight 128-byte channel rows per instruction.
 //
 // Tile-block shape is chosen per layer so the tile grid is covered without waste: 4x8 tiles for >= 16 tiles per row
 // (feature maps >= 32 wide), 8x4 for 8..15... (see wino_pick).  Tile rows are counted over (image, tile row)
@@ -47,9 +53,10 @@ struct WinoArgs {
     int th, tw;          // tiles per image column / row
     int rows_total;      // n * th
     int col_blocks, oc_blocks, spatial_blocks;
-    unsigned in_bytes;
+    unsigned in_bytes, u_bytes;
     int act1, act2;
     float act_param;
+    int vec_out;         // out (and res) rows are 16-byte aligned: float4 stores
 };
 
 __device__ __forceinline__ float wino_act(int act, float v, float p) {
@@ -66,29 +73,30 @@ __device__ __forceinline__ float wino_act(int act, float v, float p) {
 
 constexpr int CB = 16;  // input channels per staged block
 
-#ifndef SI_WINO_ABLATE   // diagnostic builds only (timing experiments, wrong results): 1 no patch prefetch after block 0,
-#define SI_WINO_ABLATE 0  // 2 no filter loads after the first, 4 no commit writes after block 0, 8 no output stores
+#ifndef SI_WINO_ABLATE   // diagnostic builds only (timing experiments, wrong results): 1 no patch loads after block 0,
+#define SI_WINO_ABLATE 0  // 2 no filter loads after the first, 4 no staging stores after block 0, 8 no output stores
 #endif
 SI_STAMP_ARRAY(si_diag_stamps_wino);   // diagnostic build only (si_hip_internal.h)
+
+#define SI_WINO_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 // LOG_TBW: log2 of tiles per block row (the workgroup's 32 tiles form a TBH x TBW block).
 template <int LOG_TBW>
 __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     constexpr int TBW = 1 << LOG_TBW;
     constexpr int TBH = 32 / TBW;
-    constexpr int PW = 2 * TBW + 2;          // staged pixels per slot row
-    constexpr int PWP = PW;                  // even row pitch: every patch row of a tile starts 8-byte aligned (ds_read_b64)
-    constexpr int SLOTS = 4 * TBH;           // slot = j * TBH + tr  (j = patch row 0..3)
-    // floats per staged channel, padded to 2 (mod 8): the commit writes the four channels of a 16-byte vector to four
+    constexpr int PW = 2 * TBW + 2;          // staged pixels per tile row: 2 * TBW of its own and two of halo
+    constexpr int PWP = PW;                  // even row pitch: every tile's four pixels start 8-byte aligned (ds_read_b64)
+    constexpr int SLOTS = 4 * TBH;           // slot = r * TBH + tr  (r = plane row 0..3)
+    // floats per staged channel, padded to 2 (mod 8): the staging stores of a 16-byte vector's four channels go to four
     // planes (4*PLANE apart = 8 banks apart), conflict free within a 32-lane group
     constexpr int PLANE = ((SLOTS * PWP + 5) / 8) * 8 + 2;
-    constexpr int NVEC = SLOTS * PW * (CB / 4);
-    constexpr int PFV = (NVEC + 255) / 256;  // 16-byte vectors per thread per block
-    static_assert(PLANE % 2 == 0, "8-byte aligned patch rows");
+    static_assert(PLANE % 2 == 0, "8-byte aligned tile pixels");
     constexpr int BUF = CB * PLANE;          // one staged channel block; two alternate, so a block costs ONE barrier
-    constexpr int XLS = 36;                  // exchange: floats per lane (32 used); XLS/4 odd keeps ds_*_b128 conflict free
-    constexpr int XCH = 4 * 64 * XLS;
+    constexpr int XCH = 4 * 2 * 32 * 32;     // exchange: [plane row][output column][tile][oc]
     constexpr int LDS_FLOATS = 2 * BUF > XCH ? 2 * BUF : XCH;
+    constexpr int NHALO = TBH * 2 * 4;       // halo items: (tile row, pixel 2*TBW or 2*TBW+1, 4 channels)
+    constexpr int HALO_WAVES = (NHALO + 63) / 64;
 
     __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
     SI_STAMP_DECL;
@@ -111,88 +119,89 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     const int row0 = by * TBH;               // first flattened tile row of the block
     const int col0 = bc * TBW;               // first tile column
     const int oc0 = ocb * 32;
-    // this lane's output channel and its bias, loaded up front (not at the head of the epilogue)
-    const int o = oc0 + ((int)threadIdx.x & 31);
-    const bool ocok = o < a.oc;
-    const float bv = (a.bias && ocok) ? a.bias[o] : 0.0f;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
 
-    // the block's first tile row as (image, tile row): one wave-uniform division, reused by the staging slots and the stores
+    // the block's first tile row as (image, tile row): one wave-uniform division, reused by the staging items and the stores
     const int img0 = row0 / a.th;
     const int ty0 = row0 - img0 * a.th;
+    const unsigned row_pitch = (unsigned)(a.iw * a.in_ld * 4);
 
-    // ---- per-thread staging slots: byte offset of channel block 0 (the LDS destination is recomputed at commit time)
-    unsigned g_off[PFV];
-#pragma unroll
-    for (int q = 0; q < PFV; ++q) {
-        const int v = tid + q * 256;
-        g_off[q] = 0xFFFFFF00u;
-        if (v < NVEC) {
-            const int cq = v & 3;
-            const int rest = v >> 2;
-            const int slot = rest / PW;
-            const int px = rest - slot * PW;
-            const int j = slot / TBH;
-            const int tr = slot - j * TBH;
-            const int R = row0 + tr;
-            if (R < a.rows_total) {
-                int img = img0, ty = ty0 + tr;  // tr < TBH <= 16: a couple of subtractions instead of a division
-                while (ty >= a.th) {
-                    ty -= a.th;
-                    ++img;
-                }
-                const int y = 2 * ty - a.pad + j;
-                const int x = 2 * col0 - a.pad + px;
-                if ((unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw)
-                    g_off[q] = (unsigned)((img * a.ih + y) * a.iw + x) * (unsigned)(a.in_ld * 4) + (unsigned)(cq * 16);
-            }
+    // ---- staging items.  Core: thread -> (tile row, one of the 2*TBW own pixels, 4 channels); halo: the first NHALO threads
+    // -> (tile row, one of the two halo pixels, 4 channels).  An item is the byte offset of patch row 0 (it may lie before
+    // the tensor when that row is padding; only valid rows use it) and a 4-bit mask of the rows inside the image.
+    auto make_item = [&](int tr, int px, int cq, unsigned& base, unsigned& rows) {
+        int img = img0, ty = ty0 + tr;       // tr < TBH <= 16: a couple of subtractions instead of a division
+        while (ty >= a.th) {
+            ty -= a.th;
+            ++img;
         }
+        const int y0 = 2 * ty - a.pad, x = 2 * col0 - a.pad + px;
+        const bool ok = row0 + tr < a.rows_total && (unsigned)x < (unsigned)a.iw;
+        rows = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rows |= (ok && (unsigned)(y0 + j) < (unsigned)a.ih) ? (1u << j) : 0u;
+        base = (unsigned)((img * a.ih + y0) * a.iw + x) * (unsigned)(a.in_ld * 4) + (unsigned)(cq * 16);
+    };
+    const int c_cq = tid & 3, c_px = (tid >> 2) & (2 * TBW - 1), c_tr = tid >> (LOG_TBW + 3);
+    const int h_cq = tid & 3, h_px = 2 * TBW + ((tid >> 2) & 1), h_tr = (tid >> 3) & (TBH - 1);
+    const bool halo_wave = wave < HALO_WAVES;            // wave-uniform
+    const bool halo_lane = tid < NHALO;
+    unsigned c_base, c_rows, h_base = 0, h_rows = 0;
+    make_item(c_tr, c_px, c_cq, c_base, c_rows);
+    if (halo_wave) {
+        make_item(h_tr, h_px, h_cq, h_base, h_rows);
+        if (!halo_lane) h_rows = 0;
     }
+    // LDS destinations (floats) of channel 0 / plane row 0 of each item
+    const int c_dst = (c_cq * 4) * PLANE + c_tr * PWP + c_px;
+    const int h_dst = (h_cq * 4) * PLANE + h_tr * PWP + h_px;
 
-    u32x4 pre[PFV];
-    auto prefetch = [&](int cb) {
+    u32x4 cpre[4], hpre[4];
+    auto fetch = [&](u32x4 (&dst)[4], unsigned base, unsigned rows, int cb) {
 #pragma unroll
-        for (int q = 0; q < PFV; ++q) {
-            const unsigned off = g_off[q] == 0xFFFFFF00u ? 0xFFFFFF00u : g_off[q] + (unsigned)(cb * CB * 4);
-            pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const unsigned off = ((rows >> j) & 1u) ? base + (unsigned)j * row_pitch + (unsigned)(cb * CB * 4) : 0xFFFFFF00u;
+            dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
         }
     };
-    auto commit = [&](int buf) {
+    // the row half of B^T d B (winograd_helper.cpp:188-239):  r=0: d0 - d2   r=1: d1 + d2   r=2: d2 - d1   r=3: d1 - d3,
+    // computed where it is stored (rows r_lo..r_hi-1 of one item: 4 channels to 4 planes each)
+    auto store_rows = [&](const u32x4 (&p)[4], int dst, auto r_lo, auto r_hi) {
+        const f32x4 d0 = __builtin_bit_cast(f32x4, p[0]), d1 = __builtin_bit_cast(f32x4, p[1]);
+        const f32x4 d2 = __builtin_bit_cast(f32x4, p[2]), d3 = __builtin_bit_cast(f32x4, p[3]);
 #pragma unroll
-        for (int q = 0; q < PFV; ++q) {
-            const int v = tid + q * 256;
-            if (v < NVEC) {
-                const int rest = v >> 2;
-                const int slot = rest / PW;
-                const int dst = buf * BUF + ((v & 3) * 4) * PLANE + slot * PWP + (rest - slot * PW);
-                const f32x4 f = __builtin_bit_cast(f32x4, pre[q]);
-                patch[dst] = f[0];
-                patch[dst + PLANE] = f[1];
-                patch[dst + 2 * PLANE] = f[2];
-                patch[dst + 3 * PLANE] = f[3];
-            }
+        for (int r = 0; r < 4; ++r) {
+            if (r < decltype(r_lo)::value || r >= decltype(r_hi)::value) continue;
+            const f32x4 f = r == 0 ? d0 - d2 : (r == 1 ? d1 + d2 : (r == 2 ? d2 - d1 : d1 - d3));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) patch[dst + k * PLANE + r * TBH * PWP] = f[k];
         }
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
 
-    // ---- this wave's plane row r = wave: t = d[ja] + sg * d[jb]   (winograd_helper.cpp:188-239)
-    //   r=0: d0 - d2    r=1: d1 + d2    r=2: d2 - d1    r=3: d1 - d3
-    const int ja = (wave == 0) ? 0 : ((wave == 2) ? 2 : 1);
-    const int jb = (wave == 0 || wave == 1) ? 2 : ((wave == 2) ? 1 : 3);
-    const float sg = (wave == 1) ? 1.0f : -1.0f;
+    // ---- this wave's plane row r = wave; its lane's tile and channel parity
     const int tr_l = l31 >> LOG_TBW, tc_l = l31 & (TBW - 1);
-    const float* pa0 = patch + lh * PLANE + (ja * TBH + tr_l) * PWP + 2 * tc_l;
-    const float* pb0 = patch + lh * PLANE + (jb * TBH + tr_l) * PWP + 2 * tc_l;
+    const int rd0 = lh * PLANE + (wave * TBH + tr_l) * PWP + 2 * tc_l;
+    int rd1 = rd0 + 2;
+    // two ds_read_b64 (2 LDS cycles each); merged into one ds_read2_b64 they would take 8
+    asm volatile("" : "+v"(rd1));
+    rd1 &= ~1;                               // (still 8-byte aligned, which the compiler can no longer see)
 
     // B operand: filter image U2[plane][cb][oc tile][half][oc%32][lane half][4]: for one (plane, 16-channel block, 32-wide
     // oc tile, half) the 64 lanes' float4s are 1 KB contiguous; element k of lane (o, h) is U[plane][cb*16 + (half*4+k)*2 + h][o],
-    // i.e. the B value of MFMA step s = half*4 + k.  One fully coalesced dwordx4 load feeds four MFMAs.
+    // i.e. the B value of MFMA step s = half*4 + k.  One fully coalesced dwordx4 load feeds four MFMAs.  The 1 KB piece is
+    // addressed by a scalar offset, the lane by one shared VGPR.
     const int noct = a.oc / 32;
     const int ncb = a.ic / CB;
-    const f32x4* ub = reinterpret_cast<const f32x4*>(a.u) + l31 * 2 + lh;
-    auto b_index = [&](int q, int cb, int half) -> size_t {
-        return ((((size_t)(4 * wave + q) * ncb + cb) * noct + (oc0 / 32)) * 2 + half) * 64;
-    };
+    const unsigned u_lane = (unsigned)(l31 * 2 + lh) * 16u;
+    unsigned u_plane[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) u_plane[q] = (unsigned)(((4 * wave + q) * ncb * noct + (oc0 / 32)) * 2) * 1024u;
+    const unsigned u_cb = (unsigned)(noct * 2) * 1024u;
 
     f32x16 acc[4];
 #pragma unroll
@@ -208,28 +217,219 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
             return;
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = ub[b_index(q, cb, half)];
+        for (int q = 0; q < 4; ++q)
+            dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, u_lane, u_plane[q] + (unsigned)cb * u_cb + (unsigned)half * 1024u, 0));
     };
 
-    prefetch(0);
-    SI_STAMP(2);
-    commit(0);
+    // ---- prologue: block 0 staged, block 1 in flight, the filter values of the first half loaded
+    fetch(cpre, c_base, c_rows, 0);
+    fetch(hpre, h_base, h_rows, 0);
     load_b(bcur, 0, 0);
+    SI_STAMP(2);
+    store_rows(cpre, c_dst, I0{}, I4{});
+    if (halo_wave && halo_lane) store_rows(hpre, h_dst, I0{}, I4{});
+    fetch(cpre, c_base, ncb > 1 ? c_rows : 0u, 1);
+    fetch(hpre, h_base, ncb > 1 ? h_rows : 0u, 1);
     __syncthreads();
     SI_STAMP(3);
 
-    // software pipeline: the patch rows of step s+1 are read from LDS before the MFMAs of step s are issued, and within a
-    // block the filter loads are issued BEFORE the (slower, HBM) patch prefetch so that waiting for the filter values
-    // never waits for the patch (vmcnt retires in order)
-    float2 da[2], db[2];
-    const float *pa = pa0, *pb = pb0;
-        da[0] = qa[0]; da[1] = qa[1]; db[0] = qb[0]; db[1] = qb[1];
+    // ---- channel loop.  tq: the four row-r pixels of the lane's tile for the step after next (in flight); va / vb: the A operands
+    // of even / odd steps.
+    float2 tq[2];
+    float va[4], vb[4];
+    auto read_t = [&](int o0, int o1, int s) {
+        tq[0] = *reinterpret_cast<const float2*>(patch + o0 + (2 * s) * PLANE);
+        tq[1] = *reinterpret_cast<const float2*>(patch + o1 + (2 * s) * PLANE);
     };
-    for (int cb = 0; cb < ncb; ++cb) {
-        const int buf = cb & 1;
-        pa = pa0 + buf * BUF;
-        pb = pb0 + buf * BUF;
+    auto col_transform = [&](float (&v)[4]) {   // the column half: V[r][0..3] from t0..t3
+        const float t0 = tq[0].x, t1 = tq[0].y, t2 = tq[1].x, t3 = tq[1].y;
+        v[0] = t0 - t2;
+        v[1] = t1 + t2;
+        v[2] = t2 - t1;
+        v[3] = t1 - t3;
+    };
+    read_t(rd0, rd1, 0);
+    col_transform(va);
+    read_t(rd0, rd1, 1);
+
+    // one 16-channel block: 8 steps of four MFMAs.  `more` (compile time): another block follows, so this one also stages it.
+    auto block = [&](int cb, auto more_t) {
+        constexpr bool more = decltype(more_t)::value;
+        const int buf = cb & 1, nbuf = buf ^ 1;
+        const int p0 = rd0 + buf * BUF, p1 = rd1 + buf * BUF;
+        const int n0 = rd0 + nbuf * BUF, n1 = rd1 + nbuf * BUF;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float(&vc)[4] = (s & 1) ? vb : va;
+            float(&vn)[4] = (s & 1) ? va : vb;
+            const int k = s & 3;
+            if (s == 0) load_b(bnxt, cb, 1);
+            if (s == 4 && more) load_b(bnxt, cb + 1, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[0], bcur[0][k], acc[0], 0, 0, 0);
+            SI_WINO_FENCE();
+            // operands of the next step (step 0 of the next block after step 7), then the request for the one after it
+            if (s < 7 || more) col_transform(vn);
+            if (s < 6) read_t(p0, p1, s + 2);
+            else if (more) read_t(n0, n1, s - 6);          // the barrier of step 5 has passed
+            SI_WINO_FENCE();
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[1], bcur[1][k], acc[1], 0, 0, 0);
+            SI_WINO_FENCE();
+            // staging of block cb+1, spread over the MFMA gaps of steps 4 and 5
+            if (more && !(SI_WINO_ABLATE & 4)) {
+                if (s == 4) store_rows(cpre, nbuf * BUF + c_dst, I0{}, I2{});
+                if (s == 5) store_rows(cpre, nbuf * BUF + c_dst, I2{}, I4{});
+                SI_WINO_FENCE();
+            }
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[2], bcur[2][k], acc[2], 0, 0, 0);
+            SI_WINO_FENCE();
+            if (more && !(SI_WINO_ABLATE & 4) && halo_wave) {
+                if (s == 4 && halo_lane) store_rows(hpre, nbuf * BUF + h_dst, I0{}, I2{});
+                if (s == 5 && halo_lane) store_rows(hpre, nbuf * BUF + h_dst, I2{}, I4{});
+                SI_WINO_FENCE();
+            }
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[3], bcur[3][k], acc[3], 0, 0, 0);
+            SI_WINO_FENCE();
+            if (s == 5 && more) {
+                // the registers are free again: block cb+2 has a whole block to arrive; then the block's one barrier
+                // (issued unconditionally -- past the last block, and for the halo of a wave that carries none, with every row
+                // masked off: a masked load moves no bytes, and a load behind a branch would make the compiler's vmcnt for the
+                // filter values wait for these loads too)
+                if (!(SI_WINO_ABLATE & 1)) {
+                    const bool live = cb + 2 < ncb;
+                    fetch(cpre, c_base, live ? c_rows : 0u, cb + 2);
+                    fetch(hpre, h_base, live ? h_rows : 0u, cb + 2);
+                }
+                __syncthreads();
+                SI_WINO_FENCE();
+            }
+            if (k == 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bcur[q] = bnxt[q];
+            }
+        }
+    };
+    for (int cb = 0; cb + 1 < ncb; ++cb) block(cb, std::true_type{});
+    block(ncb - 1, std::false_type{});
+    SI_STAMP(4);
+
+    // ---- output transform.  Column half in registers (winograd_helper.cpp:582-590): Z0 = m0+m1+m2, Z1 = m1-m2-m3, parked in LDS
+    // as [plane row][output column jc][tile][oc] (32 scalar stores of 32 consecutive floats per half wave).  After ONE barrier
+    // wave w finishes output row i = w & 1 of output column jc = w >> 1: lane = (tile 8*i4 + lane/8, channels 4*(lane&7)..+3)
+    // reads the four plane rows as float4s and applies the row half (:592-615), Y0 = Z(r0)+Z(r1)+Z(r2), Y1 = Z(r1)-Z(r2)-Z(r3),
+    // then bias / activation / residual.
+    const int quad = lane & 7;
+    f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + oc0 + 4 * quad);
+    __syncthreads();                          // every wave has read its last pixels: the patch buffers become the exchange
+    float* xz = patch;
+    {
+        float* mine = xz + (wave * 64 + 4 * lh) * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh
+            const int m = (e & 3) + 8 * (e >> 2);
+            mine[m * 32] = (acc[0][e] + acc[1][e]) + acc[2][e];
+            mine[(32 + m) * 32] = (acc[1][e] - acc[2][e]) - acc[3][e];
+        }
+    }
+    __syncthreads();
+    const int i_out = wave & 1, jc = wave >> 1;
+    // activation / residual combination resolved once per workgroup: the loop body is straight-line code
+    auto finish = [&](auto act1, auto act2, auto has_res, auto vec) {
+#pragma clang fp contract(off)  // every instantiation must round alike (bit-exact batch sharding)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const int t = (lane >> 3) + 8 * i4;
+            f32x4 zr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zr[r] = *reinterpret_cast<const f32x4*>(xz + ((r * 2 + jc) * 32 + t) * 32 + 4 * quad);
+            const f32x4 y = (i_out == 0) ? (zr[0] + zr[1]) + zr[2] : (zr[1] - zr[2]) - zr[3];
+            const int tr = t >> LOG_TBW, tc = t & (TBW - 1);
+            const int txg = col0 + tc;
+            if (row0 + tr >= a.rows_total || txg >= a.tw) continue;
+            int img = img0, ty = ty0 + tr;
+            while (ty >= a.th) {
+                ty -= a.th;
+                ++img;
+            }
+            const int oy = 2 * ty + i_out, ox = 2 * txg + jc;
+            if (oy >= a.oh || ox >= a.ow) continue;
+            const size_t pix = (size_t)(img * a.oh + oy) * a.ow + ox;
+            f32x4 rv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (decltype(has_res)::value) {
+                const float* rp = a.res + pix * a.res_ld + oc0 + 4 * quad;
+                if (decltype(vec)::value) rv = *reinterpret_cast<const f32x4*>(rp);
+                else rv = f32x4{rp[0], rp[1], rp[2], rp[3]};
+            }
+            f32x4 o4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float vv = y[k] + bv[k];
+                vv = decltype(act1)::value < 0 ? wino_act(a.act1, vv, a.act_param)
+                                               : (decltype(act1)::value == SI_ACT_SILU ? vv * __builtin_amdgcn_rcpf(1.0f + __expf(-vv))
+                                                  : (decltype(act1)::value == SI_ACT_RELU ? fmaxf(vv, 0.0f) : vv));
+                if (decltype(has_res)::value) vv += rv[k];
+                vv = decltype(act2)::value < 0 ? wino_act(a.act2, vv, a.act_param)
+                                               : (decltype(act2)::value == SI_ACT_RELU ? fmaxf(vv, 0.0f) : vv);
+                o4[k] = vv;
+            }
+            float* op = a.out + pix * a.out_ld + oc0 + 4 * quad;
+            if ((SI_WINO_ABLATE & 8) && o4[0] != 123.456f) continue;
+            if (decltype(vec)::value) {
+                *reinterpret_cast<f32x4*>(op) = o4;
+            } else {
+                op[0] = o4[0]; op[1] = o4[1]; op[2] = o4[2]; op[3] = o4[3];
+            }
+        }
+    };
+    using SiluT = std::integral_constant<int, SI_ACT_SILU>;
+    using ReluT = std::integral_constant<int, SI_ACT_RELU>;
+    using NoneT = std::integral_constant<int, SI_ACT_NONE>;
+    using AnyT = std::integral_constant<int, -1>;
+    const bool res = a.res != nullptr;
+    if (!a.vec_out) {
+        if (res) finish(AnyT{}, AnyT{}, std::true_type{}, std::false_type{});
+        else finish(AnyT{}, AnyT{}, std::false_type{}, std::false_type{});
+    } else if (a.act1 == SI_ACT_SILU && a.act2 == SI_ACT_NONE) {
+        if (res) finish(SiluT{}, NoneT{}, std::true_type{}, std::true_type{});
+        else finish(SiluT{}, NoneT{}, std::false_type{}, std::true_type{});
+    } else if (a.act1 == SI_ACT_RELU && a.act2 == SI_ACT_NONE && !res) {
+        finish(ReluT{}, NoneT{}, std::false_type{}, std::true_type{});
+    } else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_RELU && res) {
+        finish(NoneT{}, ReluT{}, std::true_type{}, std::true_type{});
+    } else if (res) {
+        finish(AnyT{}, AnyT{}, std::true_type{}, std::true_type{});
+    } else {
+        finish(AnyT{}, AnyT{}, std::false_type{}, std::true_type{});
+    }
+    SI_STAMP(5);
+    SI_STAMP_RT(6);
+    SI_STAMP_FLUSH(si_diag_stamps_wino);
+}
+
+#ifdef SI_DIAG_STAMPS
+}  // namespace
+SI_STAMP_ACCESSORS(si_diag_stamps_wino, si_hip_diag_stamps_read_wino, si_hip_diag_stamps_clear_wino)
+namespace {
+#endif
+
+template <int LOG_TBW>
+int launch_wino(WinoArgs a, hipStream_t s) {
+    constexpr int TBW = 1 << LOG_TBW;
+    constexpr int TBH = 32 / TBW;
+    a.col_blocks = (a.tw + TBW - 1) / TBW;
+    a.oc_blocks = (a.oc + 31) / 32;
+    const int row_blocks = (a.rows_total + TBH - 1) / TBH;
+    a.spatial_blocks = a.col_blocks * row_blocks;
+    const long long nblocks = (long long)((a.spatial_blocks + 7) / 8) * 8 * a.oc_blocks;
+    if (nblocks > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    dim3 grid((unsigned)nblocks, 1, 1);
+#ifdef SI_DIAG_STAMPS   // residency experiments: extra dynamic LDS per workgroup
+    static const int extra_lds = [] { const char* e = getenv("SI_WINO_EXTRA_LDS"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW>), grid, dim3(256), (size_t)extra_lds, s, a);
+#else
     hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW>), grid, dim3(256), 0, s, a);
+#endif
     return (int)hipGetLastError();
 }
 
@@ -325,6 +525,9 @@ extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, 
     if (d->in_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
     const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull;
     if (in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+    const unsigned long long u_bytes = 16ull * d->ic * d->oc * 4ull;
+    if (u_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+    if (d->has_bias && (reinterpret_cast<uintptr_t>(bias) & 15) != 0) return SI_E_UNSUPPORTED;
     if (d->oh != d->ih + 2 * d->pt - 2 || d->ow != d->iw + 2 * d->pl - 2) return SI_E_BADARG;
 
     WinoArgs a;
@@ -336,6 +539,9 @@ extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, 
     a.rows_total = d->n * a.th;
     a.col_blocks = a.oc_blocks = a.spatial_blocks = 0;
     a.in_bytes = (unsigned)in_bytes;
+    a.u_bytes = (unsigned)u_bytes;
+    a.vec_out = (reinterpret_cast<uintptr_t>(out) & 15) == 0 && d->out_ld % 4 == 0 &&
+                (!d->has_residual || ((reinterpret_cast<uintptr_t>(residual) & 15) == 0 && d->res_ld % 4 == 0));
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
 
     hipStream_t s = static_cast<hipStream_t>(stream);
