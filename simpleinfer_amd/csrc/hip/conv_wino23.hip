@@ -80,9 +80,11 @@ SI_STAMP_ARRAY(si_diag_stamps_wino);   // diagnostic build only (si_hip_internal
 
 #define SI_WINO_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// LOG_TBW: log2 of tiles per block row (the workgroup's 32 tiles form a TBH x TBW block).
-template <int LOG_TBW>
-__global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
+// LOG_TBW: log2 of tiles per block row (the workgroup's 32 tiles form a TBH x TBW block).  OCG: 32-channel output groups per
+// workgroup (1 or 2): with two, every transformed input value feeds eight MFMAs instead of four and the patches are fetched
+// half as often, at the price of 128 accumulator registers (two waves per SIMD instead of three).
+template <int LOG_TBW, int OCG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 - OCG))) void conv_wino23_kernel(const WinoArgs a) {
     constexpr int TBW = 1 << LOG_TBW;
     constexpr int TBH = 32 / TBW;
     constexpr int PW = 2 * TBW + 2;          // staged pixels per tile row: 2 * TBW of its own and two of halo
@@ -93,10 +95,12 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     constexpr int PLANE = ((SLOTS * PWP + 5) / 8) * 8 + 2;
     static_assert(PLANE % 2 == 0, "8-byte aligned tile pixels");
     constexpr int BUF = CB * PLANE;          // one staged channel block; two alternate, so a block costs ONE barrier
-    constexpr int XCH = 4 * 2 * 32 * 32;     // exchange: [plane row][output column][tile][oc]
+    constexpr int OCW = 32 * OCG;            // output channels per workgroup
+    constexpr int XCH = 4 * 2 * 32 * OCW;    // exchange: [plane row][output column][tile][oc]
+    constexpr int RING = OCG == 1 ? 4 : 2;   // filter values are requested RING steps (1024 MFMA cycles) before their step
     constexpr int LDS_FLOATS = 2 * BUF > XCH ? 2 * BUF : XCH;
-    constexpr int NHALO = TBH * 2 * 4;       // halo items: (tile row, pixel 2*TBW or 2*TBW+1, 4 channels)
-    constexpr int HALO_WAVES = (NHALO + 63) / 64;
+    constexpr int NHALO = TBH * 2 * 4 * 4;   // halo loads: (tile row, pixel 2*TBW or 2*TBW+1, 4 channels, patch row)
+    constexpr int HR = (NHALO + 255) / 256;  // ... per thread
 
     __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
     SI_STAMP_DECL;
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     const int bc = sb - by * a.col_blocks;
     const int row0 = by * TBH;               // first flattened tile row of the block
     const int col0 = bc * TBW;               // first tile column
-    const int oc0 = ocb * 32;
+    const int oc0 = ocb * OCW;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
@@ -145,20 +149,29 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
         base = (unsigned)((img * a.ih + y0) * a.iw + x) * (unsigned)(a.in_ld * 4) + (unsigned)(cq * 16);
     };
     const int c_cq = tid & 3, c_px = (tid >> 2) & (2 * TBW - 1), c_tr = tid >> (LOG_TBW + 3);
-    const int h_cq = tid & 3, h_px = 2 * TBW + ((tid >> 2) & 1), h_tr = (tid >> 3) & (TBH - 1);
-    const bool halo_wave = wave < HALO_WAVES;            // wave-uniform
-    const bool halo_lane = tid < NHALO;
-    unsigned c_base, c_rows, h_base = 0, h_rows = 0;
+    unsigned c_base, c_rows;
     make_item(c_tr, c_px, c_cq, c_base, c_rows);
-    if (halo_wave) {
-        make_item(h_tr, h_px, h_cq, h_base, h_rows);
-        if (!halo_lane) h_rows = 0;
-    }
-    // LDS destinations (floats) of channel 0 / plane row 0 of each item
+    // LDS destination (floats) of channel 0 / plane row 0 of the item
     const int c_dst = (c_cq * 4) * PLANE + c_tr * PWP + c_px;
-    const int h_dst = (h_cq * 4) * PLANE + h_tr * PWP + h_px;
+    // Halo: a QUAD of lanes shares one item, lane j of it fetching patch row j alone; the row transform then takes its two
+    // rows from the quad by DPP (4 staging registers instead of 16 for a column only one thread in eight would own).
+    const int h_j = tid & 3;
+    const float h_sign = h_j == 1 ? 1.0f : -1.0f;
+    unsigned h_off[HR];
+    int h_dst[HR];
+    bool h_live[HR];
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+        const int hv = tid + 256 * i;
+        const int h_cq = (hv >> 2) & 3, h_px = 2 * TBW + ((hv >> 4) & 1), h_tr = (hv >> 5) & (TBH - 1);
+        unsigned base, rows;
+        make_item(h_tr, h_px, h_cq, base, rows);
+        h_live[i] = hv < NHALO;
+        h_off[i] = (h_live[i] && ((rows >> h_j) & 1u)) ? base + (unsigned)h_j * row_pitch : 0xFFFFFF00u;
+        h_dst[i] = (h_cq * 4) * PLANE + (h_j * TBH + h_tr) * PWP + h_px;   // plane row j is the one this lane produces
+    }
 
-    u32x4 cpre[4], hpre[4];
+    u32x4 cpre[4], hpre[HR];
     auto fetch = [&](u32x4 (&dst)[4], unsigned base, unsigned rows, int cb) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -179,6 +192,31 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
             for (int k = 0; k < 4; ++k) patch[dst + k * PLANE + r * TBH * PWP] = f[k];
         }
     };
+    auto fetch_halo = [&](int cb, bool live) {
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            const unsigned off = (live && h_off[i] != 0xFFFFFF00u) ? h_off[i] + (unsigned)(cb * CB * 4) : 0xFFFFFF00u;
+            hpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+        }
+    };
+    // lane j of a quad:  t_j = d[ja] +- d[jb]  with (ja, jb) = (0,2) (1,2) (2,1) (1,3): two quad permutes and one fma per value
+    auto store_halo = [&](int buf_off) {
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int d = (int)hpre[i][k];
+                const float da = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(d, 0x64, 0xF, 0xF, false));   // quad_perm [0,1,2,1]
+                const float db = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(d, 0xDA, 0xF, 0xF, false));   // quad_perm [2,2,1,3]
+                t[k] = da + h_sign * db;
+            }
+            if (h_live[i]) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) patch[buf_off + h_dst[i] + k * PLANE] = t[k];
+            }
+        }
+    };
     using I0 = std::integral_constant<int, 0>;
     using I2 = std::integral_constant<int, 2>;
     using I4 = std::integral_constant<int, 4>;
@@ -191,45 +229,35 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     asm volatile("" : "+v"(rd1));
     rd1 &= ~1;                               // (still 8-byte aligned, which the compiler can no longer see)
 
-    // B operand: filter image U2[plane][cb][oc tile][half][oc%32][lane half][4]: for one (plane, 16-channel block, 32-wide
-    // oc tile, half) the 64 lanes' float4s are 1 KB contiguous; element k of lane (o, h) is U[plane][cb*16 + (half*4+k)*2 + h][o],
-    // i.e. the B value of MFMA step s = half*4 + k.  One fully coalesced dwordx4 load feeds four MFMAs.  The 1 KB piece is
-    // addressed by a scalar offset, the lane by one shared VGPR.
+    // B operand: filter image U2[plane row][cb][oc tile][step][oc%32][lane half][plane column]: for one (plane row, 16-channel
+    // block, 32-wide oc tile, step) the 64 lanes' float4s are 1 KB contiguous; element q of lane (o, h) is
+    // U[4*row + q][cb*16 + 2*step + h][o], i.e. the B values of the step's four MFMAs.  One fully coalesced dwordx4 load per
+    // output group and step, addressed by a scalar offset and one VGPR shared by all of them.
     const int noct = a.oc / 32;
     const int ncb = a.ic / CB;
     const unsigned u_lane = (unsigned)(l31 * 2 + lh) * 16u;
-    unsigned u_plane[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) u_plane[q] = (unsigned)(((4 * wave + q) * ncb * noct + (oc0 / 32)) * 2) * 1024u;
-    const unsigned u_cb = (unsigned)(noct * 2) * 1024u;
+    const unsigned u_row = (unsigned)(wave * ncb * noct + oc0 / 32) * 8192u;      // (row, cb 0, first oc tile, step 0)
+    const unsigned u_cb = (unsigned)noct * 8192u;
 
-    f32x16 acc[4];
+    f32x16 acc[OCG][4];
+    f32x4 ring[RING][OCG];
+    auto load_b = [&](int slot, int cb, int step) {
+        if ((SI_WINO_ABLATE & 2) && (cb | step)) return;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[q][e] = 0.0f;
-
-    f32x4 bcur[4], bnxt[4];
-    auto load_b = [&](f32x4 (&dst)[4], int cb, int half) {
-        if ((SI_WINO_ABLATE & 2) && (cb | half)) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = bcur[q];
-            return;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            dst[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, u_lane, u_plane[q] + (unsigned)cb * u_cb + (unsigned)half * 1024u, 0));
+        for (int g = 0; g < OCG; ++g)
+            ring[slot][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, u_lane, u_row + (unsigned)cb * u_cb + (unsigned)(g * 8 + step) * 1024u, 0));
     };
 
-    // ---- prologue: block 0 staged, block 1 in flight, the filter values of the first half loaded
+    // ---- prologue: block 0 staged, block 1 in flight, the filter values of the first RING steps requested
     fetch(cpre, c_base, c_rows, 0);
-    fetch(hpre, h_base, h_rows, 0);
-    load_b(bcur, 0, 0);
+    fetch_halo(0, true);
+#pragma unroll
+    for (int i = 0; i < RING; ++i) load_b(i, 0, i);
     SI_STAMP(2);
     store_rows(cpre, c_dst, I0{}, I4{});
-    if (halo_wave && halo_lane) store_rows(hpre, h_dst, I0{}, I4{});
+    store_halo(0);
     fetch(cpre, c_base, ncb > 1 ? c_rows : 0u, 1);
-    fetch(hpre, h_base, ncb > 1 ? h_rows : 0u, 1);
+    fetch_halo(1, ncb > 1);
     __syncthreads();
     SI_STAMP(3);
 
@@ -252,27 +280,31 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     col_transform(va);
     read_t(rd0, rd1, 1);
 
-    // one 16-channel block: 8 steps of four MFMAs.  `more` (compile time): another block follows, so this one also stages it.
-    auto block = [&](int cb, auto more_t) {
+    // one 16-channel block: 8 steps of 4 * OCG MFMAs.  Compile-time flags: `more` -- another block follows, so this one also
+    // stages it; `first` -- the accumulators start from the literal zero (no 64 * OCG register writes up front).
+    auto block = [&](int cb, auto more_t, auto first_t) {
         constexpr bool more = decltype(more_t)::value;
+        constexpr bool first = decltype(first_t)::value;
         const int buf = cb & 1, nbuf = buf ^ 1;
         const int p0 = rd0 + buf * BUF, p1 = rd1 + buf * BUF;
         const int n0 = rd0 + nbuf * BUF, n1 = rd1 + nbuf * BUF;
+        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float(&vc)[4] = (s & 1) ? vb : va;
             float(&vn)[4] = (s & 1) ? va : vb;
-            const int k = s & 3;
-            if (s == 0) load_b(bnxt, cb, 1);
-            if (s == 4 && more) load_b(bnxt, cb + 1, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[0], bcur[0][k], acc[0], 0, 0, 0);
+            const int slot = s % RING;
+            auto mfma = [&](int g, int q) {
+                acc[g][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[q], ring[slot][g][q], (first && s == 0) ? zero : acc[g][q], 0, 0, 0);
+            };
+            mfma(0, 0);
             SI_WINO_FENCE();
             // operands of the next step (step 0 of the next block after step 7), then the request for the one after it
             if (s < 7 || more) col_transform(vn);
             if (s < 6) read_t(p0, p1, s + 2);
             else if (more) read_t(n0, n1, s - 6);          // the barrier of step 5 has passed
             SI_WINO_FENCE();
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[1], bcur[1][k], acc[1], 0, 0, 0);
+            mfma(0, 1);
             SI_WINO_FENCE();
             // staging of block cb+1, spread over the MFMA gaps of steps 4 and 5
             if (more && !(SI_WINO_ABLATE & 4)) {
@@ -280,57 +312,69 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
                 if (s == 5) store_rows(cpre, nbuf * BUF + c_dst, I2{}, I4{});
                 SI_WINO_FENCE();
             }
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[2], bcur[2][k], acc[2], 0, 0, 0);
+            mfma(0, 2);
             SI_WINO_FENCE();
-            if (more && !(SI_WINO_ABLATE & 4) && halo_wave) {
-                if (s == 4 && halo_lane) store_rows(hpre, nbuf * BUF + h_dst, I0{}, I2{});
-                if (s == 5 && halo_lane) store_rows(hpre, nbuf * BUF + h_dst, I2{}, I4{});
+            if (more && !(SI_WINO_ABLATE & 4) && s == 5) {
+                store_halo(nbuf * BUF);
                 SI_WINO_FENCE();
             }
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[3], bcur[3][k], acc[3], 0, 0, 0);
+            mfma(0, 3);
+            if (OCG == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mfma(OCG - 1, q);
+            }
             SI_WINO_FENCE();
+            // the step's filter registers are free: request the values of step s + RING
+            if (s + RING < 8) load_b(slot, cb, s + RING);
+            else if (more) load_b(slot, cb + 1, s + RING - 8);
             if (s == 5 && more) {
-                // the registers are free again: block cb+2 has a whole block to arrive; then the block's one barrier
+                // the staging registers are free too: block cb+2 has a whole block to arrive; then the block's one barrier
                 // (issued unconditionally -- past the last block, and for the halo of a wave that carries none, with every row
                 // masked off: a masked load moves no bytes, and a load behind a branch would make the compiler's vmcnt for the
                 // filter values wait for these loads too)
                 if (!(SI_WINO_ABLATE & 1)) {
                     const bool live = cb + 2 < ncb;
                     fetch(cpre, c_base, live ? c_rows : 0u, cb + 2);
-                    fetch(hpre, h_base, live ? h_rows : 0u, cb + 2);
+                    fetch_halo(cb + 2, live);
                 }
                 __syncthreads();
-                SI_WINO_FENCE();
             }
-            if (k == 3) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bcur[q] = bnxt[q];
-            }
+            SI_WINO_FENCE();
         }
     };
-    for (int cb = 0; cb + 1 < ncb; ++cb) block(cb, std::true_type{});
-    block(ncb - 1, std::false_type{});
+    if (ncb == 1) {
+        block(0, std::false_type{}, std::true_type{});
+    } else {
+        block(0, std::true_type{}, std::true_type{});
+        for (int cb = 1; cb + 1 < ncb; ++cb) block(cb, std::true_type{}, std::false_type{});
+        block(ncb - 1, std::false_type{}, std::false_type{});
+    }
     SI_STAMP(4);
 
     // ---- output transform.  Column half in registers (winograd_helper.cpp:582-590): Z0 = m0+m1+m2, Z1 = m1-m2-m3, parked in LDS
-    // as [plane row][output column jc][tile][oc] (32 scalar stores of 32 consecutive floats per half wave).  After ONE barrier
-    // wave w finishes output row i = w & 1 of output column jc = w >> 1: lane = (tile 8*i4 + lane/8, channels 4*(lane&7)..+3)
+    // as [plane row][output column jc][tile][oc] (scalar stores of 32 consecutive floats per half wave).  After ONE barrier
+    // wave w finishes output row i = w & 1 of output column jc = w >> 1: a lane takes four channels of TPI tiles per pass,
     // reads the four plane rows as float4s and applies the row half (:592-615), Y0 = Z(r0)+Z(r1)+Z(r2), Y1 = Z(r1)-Z(r2)-Z(r3),
     // then bias / activation / residual.
-    const int quad = lane & 7;
+    constexpr int QPT = OCW / 4;              // float4s per tile
+    constexpr int TPI = 64 / QPT;             // tiles per pass
+    const int quad = lane & (QPT - 1);
     f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
     if (a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + oc0 + 4 * quad);
     __syncthreads();                          // every wave has read its last pixels: the patch buffers become the exchange
     float* xz = patch;
     {
-        float* mine = xz + (wave * 64 + 4 * lh) * 32 + l31;
+        float* mine = xz + (wave * 64 + 4 * lh) * OCW + l31;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh
-            const int m = (e & 3) + 8 * (e >> 2);
-            mine[m * 32] = (acc[0][e] + acc[1][e]) + acc[2][e];
-            mine[(32 + m) * 32] = (acc[1][e] - acc[2][e]) - acc[3][e];
-        }
+        for (int g = 0; g < OCG; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh
+                const int m = (e & 3) + 8 * (e >> 2);
+                mine[m * OCW + g * 32] = (acc[g][0][e] + acc[g][1][e]) + acc[g][2][e];
+                mine[(32 + m) * OCW + g * 32] = (acc[g][1][e] - acc[g][2][e]) - acc[g][3][e];
+                if ((e & 3) == 3) SI_WINO_FENCE();   // (keeps the accumulator reads from being hoisted into 64 * OCG live VGPRs)
+            }
     }
     __syncthreads();
     const int i_out = wave & 1, jc = wave >> 1;
@@ -338,11 +382,11 @@ __global__ __launch_bounds__(256) void conv_wino23_kernel(const WinoArgs a) {
     auto finish = [&](auto act1, auto act2, auto has_res, auto vec) {
 #pragma clang fp contract(off)  // every instantiation must round alike (bit-exact batch sharding)
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
-            const int t = (lane >> 3) + 8 * i4;
+        for (int i4 = 0; i4 < 32 / TPI; ++i4) {
+            const int t = lane / QPT + TPI * i4;
             f32x4 zr[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) zr[r] = *reinterpret_cast<const f32x4*>(xz + ((r * 2 + jc) * 32 + t) * 32 + 4 * quad);
+            for (int r = 0; r < 4; ++r) zr[r] = *reinterpret_cast<const f32x4*>(xz + ((r * 2 + jc) * 32 + t) * OCW + 4 * quad);
             const f32x4 y = (i_out == 0) ? (zr[0] + zr[1]) + zr[2] : (zr[1] - zr[2]) - zr[3];
             const int tr = t >> LOG_TBW, tc = t & (TBW - 1);
             const int txg = col0 + tc;
@@ -413,12 +457,12 @@ SI_STAMP_ACCESSORS(si_diag_stamps_wino, si_hip_diag_stamps_read_wino, si_hip_dia
 namespace {
 #endif
 
-template <int LOG_TBW>
+template <int LOG_TBW, int OCG>
 int launch_wino(WinoArgs a, hipStream_t s) {
     constexpr int TBW = 1 << LOG_TBW;
     constexpr int TBH = 32 / TBW;
     a.col_blocks = (a.tw + TBW - 1) / TBW;
-    a.oc_blocks = (a.oc + 31) / 32;
+    a.oc_blocks = a.oc / (32 * OCG);
     const int row_blocks = (a.rows_total + TBH - 1) / TBH;
     a.spatial_blocks = a.col_blocks * row_blocks;
     const long long nblocks = (long long)((a.spatial_blocks + 7) / 8) * 8 * a.oc_blocks;
@@ -426,9 +470,9 @@ int launch_wino(WinoArgs a, hipStream_t s) {
     dim3 grid((unsigned)nblocks, 1, 1);
 #ifdef SI_DIAG_STAMPS   // residency experiments: extra dynamic LDS per workgroup
     static const int extra_lds = [] { const char* e = getenv("SI_WINO_EXTRA_LDS"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW>), grid, dim3(256), (size_t)extra_lds, s, a);
+    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW, OCG>), grid, dim3(256), (size_t)extra_lds, s, a);
 #else
-    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW, OCG>), grid, dim3(256), 0, s, a);
 #endif
     return (int)hipGetLastError();
 }
@@ -505,13 +549,12 @@ extern "C" int si_hip_conv2d_wino23_pack_weight_host(const SiConv2dDesc* d, cons
                 const float a68 = g[6] + g[8];
                 t[12] = g[6]; t[13] = (a68 + g[7]) * r2; t[14] = (a68 - g[7]) * r2; t[15] = g[8];
             }
-            // U2[plane][cb][oc tile][half][oc%32][lane half][4]   (see the kernel's B operand comment)
+            // U2[plane row][cb][oc tile][step][oc%32][lane half][plane column]   (see the kernel's B operand comment)
             const int cb = c / 16, cl = c % 16;
             const int step = cl / 2, h = cl % 2;
-            const int half = step / 4, k = step % 4;
             const int ncb = ic / 16, noct = oc / 32;
             for (int q = 0; q < 16; ++q)
-                u[((((((size_t)q * ncb + cb) * noct + o / 32) * 2 + half) * 32 + o % 32) * 2 + h) * 4 + k] = t[q];
+                u[((((((size_t)(q / 4) * ncb + cb) * noct + o / 32) * 8 + step) * 32 + o % 32) * 2 + h) * 4 + q % 4] = t[q];
         }
     return 0;
 }
@@ -546,7 +589,20 @@ extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, 
 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int l = wino_pick_log_tbw(a.tw, a.rows_total);
-    if (l == 3) return launch_wino<3>(a, s);
-    if (l == 2) return launch_wino<2>(a, s);
-    return launch_wino<1>(a, s);
+    // Two output groups per workgroup pay where the channel loop is long and the grid still covers the chip (MI355X, sustained:
+    // 20x20x256 batch 32 0.0848 -> 0.0736 ms, 14x14x256 batch 64 0.0750 -> 0.0706; at 128 channels and below, or under
+    // ~1.5 workgroups per CU, one group with three waves per SIMD is faster: 40x40x128 0.0705 vs 0.0755, 80x80x64 0.0717 vs
+    // 0.0778).  SI_WINO_OCG=1 / =2 forces either (development switch).
+    static const int ocg_force = [] { const char* e = getenv("SI_WINO_OCG"); return e ? atoi(e) : 0; }();
+    const int tbw = 1 << l, tbh = 32 / tbw;
+    const long long wgs2 = (long long)((a.tw + tbw - 1) / tbw) * ((a.rows_total + tbh - 1) / tbh) * (d->oc / 64);
+    const bool two = d->oc % 64 == 0 && (ocg_force == 2 || (ocg_force == 0 && d->ic >= 256 && wgs2 >= 384));
+    if (two) {
+        if (l == 3) return launch_wino<3, 2>(a, s);
+        if (l == 2) return launch_wino<2, 2>(a, s);
+        return launch_wino<1, 2>(a, s);
+    }
+    if (l == 3) return launch_wino<3, 1>(a, s);
+    if (l == 2) return launch_wino<2, 1>(a, s);
+    return launch_wino<1, 1>(a, s);
 }
