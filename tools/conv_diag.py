@@ -117,6 +117,8 @@ def main():
         _, per_cu = np.unique(cu_key[raw.reshape(tiles, 8)[:, 6] != 0], return_counts=True)
         med = lambda a: float(np.median(a))
         total_pipe = len(s) * mfma_cyc                        # pipe cycles per SIMD column (one wave of each wg per SIMD)
+        if wino:   # persistent workgroups walk several tiles: count the executed MFMA work itself (64 flop / clk / SIMD)
+            total_pipe = flops / 2.25 / 64.0 / 4.0
         if wino:
             flops_exec = flops / 2.25
             print("   (Winograd: executes %.1f GFLOP of MFMA work for %.1f GFLOP of direct convolution)" % (flops_exec / 1e9, flops / 1e9))
