@@ -55,6 +55,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "batch") opt_batch_ = value;  // > 0: re-batch the graph at load (the file bakes its batch into every shape)
     else if (key == "arena") opt_arena_ = value != 0;  // 1 (default): intermediates share one arena by lifetime; 0: one hipMalloc each
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
+    else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else {
         LOG(ERROR) << "unknown engine option [" << key << "]";
@@ -142,7 +143,11 @@ Status EngineImpl::CreateContext() {
 Status EngineImpl::DestroyContext() {
     if (ev_start_) si_hip_event_destroy(ev_start_);
     if (ev_stop_) si_hip_event_destroy(ev_stop_);
-    ev_start_ = ev_stop_ = nullptr;
+    if (ev_fork_) si_hip_event_destroy(ev_fork_);
+    if (ev_join_) si_hip_event_destroy(ev_join_);
+    ev_start_ = ev_stop_ = ev_fork_ = ev_join_ = nullptr;
+    delete side_context_;
+    side_context_ = nullptr;
     delete context_;
     context_ = nullptr;
     return Status::kSuccess;
@@ -360,6 +365,51 @@ Status EngineImpl::CreatePipeline() {
     }
     plan_ = order;
     if (opt_alias_cat_) CHECK_STATUS(AliasConcats());
+    if (opt_detect_stream_) CHECK_STATUS(PlanDetectStream());
+    return Status::kSuccess;
+}
+
+// Option "detect_stream": a Detect level only needs its own feature map, and the two finer maps are final well before the last
+// PAN layer.  Each such level is launched on a second stream right after the step that completes its input (fork: an event on
+// the main stream), beside the layers that follow; the Detect step launches the remaining level and joins (the main stream
+// waits for the side stream's event).  The output tensor is a graph output with its own allocation, so early writes into it
+// touch nothing the arena shares.  Under hipGraph capture the side stream joins the capture through the same events.
+Status EngineImpl::PlanDetectStream() {
+    for (size_t di = 0; di < plan_.size(); ++di) {
+        YoloDetect* det = dynamic_cast<YoloDetect*>(plan_[di].layer);
+        if (!det) continue;
+        if (det->OutputNodes().size() != 1 || !det->OutputNodes()[0]->operand ||
+            !output_tensor_nodes_.count(det->OutputNodes()[0]->operand->name))
+            continue;   // only when Detect writes a graph output (own buffer)
+        unsigned mask = 0;
+        std::vector<int> producer(det->InputNodes().size(), -1);
+        for (size_t k = 0; k < det->InputNodes().size(); ++k) {
+            TensorNode* n = det->InputNodes()[k];
+            if (!n || !n->operand || aliases_.count(n->operand->name)) continue;   // a view into a concat buffer has several writers
+            bool aliased_into = false;
+            for (auto& kv : aliases_) aliased_into = aliased_into || kv.second.parent == n;
+            if (aliased_into) continue;
+            for (size_t j = 0; j < di; ++j) {
+                std::vector<TensorNode*> outs = plan_[j].layer->OutputNodes();
+                if (std::find(outs.begin(), outs.end(), n) != outs.end()) producer[k] = (int)j;
+            }
+            // Worth a fork / join only for a level with real work (MI355X, YOLOv5s same-box A/B: batch 32 +1.3 %, batch 8 +-0,
+            // batch 1 -3 %: two more graph edges against launches of a few microseconds)
+            const double level_flops = 2.0 * (double)n->tensor.NumElements() * det->num_elements_;
+            if (producer[k] >= 0 && producer[k] + 1 < (int)di && (level_flops >= 4e9 || opt_detect_stream_ >= 2)) mask |= 1u << k;   // something runs in between
+        }
+        if (!mask) continue;
+        if (!side_context_) {
+            side_context_ = new Context;
+            CHECK_STATUS(side_context_->Init(context_->device()));
+            SI_TRY_HIP(si_hip_event_create(&ev_fork_), "event create");
+            SI_TRY_HIP(si_hip_event_create(&ev_join_), "event create");
+        }
+        det->SetEarlyLevels(side_context_, mask);
+        for (size_t k = 0; k < producer.size(); ++k)
+            if ((mask >> k) & 1u) plan_[producer[k]].detect_levels.push_back((int)k);
+        LOG(INFO) << "detect_stream: levels mask " << mask << " of [" << plan_[di].op->name << "] launch on the side stream";
+    }
     return Status::kSuccess;
 }
 
@@ -879,11 +929,30 @@ Status EngineImpl::UploadInputs() {
 }
 
 Status EngineImpl::LaunchAll() {
-    for (const Step& s : plan_) {
+    YoloDetect* early_detect = nullptr;   // the Detect layer with levels in flight on the side stream
+    for (size_t i = 0; i < plan_.size(); ++i) {
+        const Step& s = plan_[i];
         Status ret = s.layer->Forward();
         if (Status::kSuccess != ret) {
             LOG(ERROR) << "layer [" << s.op->name << "] forward fail";
             return ret;
+        }
+        if (side_context_ && early_detect && s.layer == early_detect) {
+            // join: everything after Detect (and the end of the forward) waits for the side stream's levels
+            SI_TRY_HIP(si_hip_event_record(ev_join_, side_context_->stream()), "event record");
+            SI_TRY_HIP(si_hip_stream_wait_event(context_->stream(), ev_join_), "stream wait");
+            early_detect = nullptr;
+        }
+        if (side_context_ && !s.detect_levels.empty()) {
+            // fork: the side stream may start once this step is done
+            SI_TRY_HIP(si_hip_event_record(ev_fork_, context_->stream()), "event record");
+            SI_TRY_HIP(si_hip_stream_wait_event(side_context_->stream(), ev_fork_), "stream wait");
+            for (size_t j = i + 1; j < plan_.size() && !early_detect; ++j) {
+                YoloDetect* d = dynamic_cast<YoloDetect*>(plan_[j].layer);
+                if (d && d->EarlyLevels()) early_detect = d;
+            }
+            if (!early_detect) return Status::kFail;
+            for (int level : s.detect_levels) CHECK_STATUS(early_detect->ForwardLevel(level));
         }
     }
     return Status::kSuccess;
@@ -986,11 +1055,17 @@ Status EngineImpl::Profile(std::vector<LayerProfile>& layers) {
     for (auto& e : ev) SI_TRY_HIP(si_hip_event_create(&e), "event create");
     Status ret = Status::kSuccess;
     si_hip_event_record(ev[0], stream);
+    // (per-layer timing: Detect runs whole on the main stream here, whatever "detect_stream" says)
+    std::vector<std::pair<YoloDetect*, unsigned>> early;
+    for (const Step& st : plan_)
+        if (YoloDetect* d = dynamic_cast<YoloDetect*>(st.layer))
+            if (d->EarlyLevels()) { early.push_back(std::make_pair(d, d->EarlyLevels())); d->SetEarlyLevels(nullptr, 0); }
     for (size_t i = 0; i < plan_.size() && ret == Status::kSuccess; ++i) {
         ret = plan_[i].layer->Forward();
         si_hip_event_record(ev[i + 1], stream);
     }
     si_hip_stream_sync(stream);
+    for (auto& e : early) e.first->SetEarlyLevels(side_context_, e.second);
     if (ret == Status::kSuccess) {
         for (size_t i = 0; i < plan_.size(); ++i) {
             LayerProfile p;

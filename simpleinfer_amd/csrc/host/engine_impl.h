@@ -84,7 +84,9 @@ private:
     struct Step {
         Layer* layer = nullptr;
         const pnnx::Operator* op = nullptr;
+        std::vector<int> detect_levels;   // Detect levels whose input this step completes (option "detect_stream")
     };
+    Status PlanDetectStream();
 
     Status FuseEpilogues(std::vector<Step>& order);
     Status FuseSiblingConvs(std::vector<Step>& order);
@@ -107,9 +109,13 @@ private:
     bool opt_outputs_to_host_ = true;
     int opt_winograd_ = 1;
     int opt_batch_ = 0;          // > 0: serve this batch whatever batch the file was traced with
+    int opt_detect_stream_ = 1;        // Detect's early levels on a second stream beside the layers that follow their inputs: 0 never, 1 for levels with enough work, 2 always
     bool opt_fp16_ = false;      // fp16 storage for internal activations and weights (BASELINE.json configs[3])
 
     Context* context_ = nullptr;
+    Context* side_context_ = nullptr;        // second stream (option "detect_stream"); created with the first plan that uses it
+    si_event_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    bool in_profile_ = false;                // Profile() times layers one by one on the main stream: no side launches
     pnnx::Graph* graph_ = nullptr;
 
     std::map<std::string, Layer*> layers_;

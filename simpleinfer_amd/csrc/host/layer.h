@@ -59,6 +59,8 @@ public:
     // tensors a layer reads besides its bound input nodes (fusion hooks: a conv's residual, its upsampled source); the engine's
     // memory planner needs every reader of a buffer
     virtual void ExtraReads(std::vector<TensorNode*>& nodes) const { (void)nodes; }
+    // the stream this layer's launches go to (its context's)
+    si_stream_t LaunchStream() const { return Stream(); }
     // fp16 storage (Engine option "fp16"): can this layer run with the storage types its bound nodes now have?  Asked once, at
     // LoadModel, so that an unsupported combination is a load-time Status with a reason instead of a failing first Forward().
     // Default: fine when no bound tensor is fp16, or when inputs and outputs are all fp16.

@@ -120,17 +120,60 @@ Status YoloDetect::Validate() {
     return Status::kSuccess;
 }
 
+void YoloDetect::SetEarlyLevels(Context* side, unsigned mask) {
+    early_mask_ = side ? mask : 0u;
+    for (int i = 0; i < num_spatial_sizes; ++i) conv_2d_layer_[i].SetContext(((early_mask_ >> i) & 1u) ? side : context_);
+}
+
+Status YoloDetect::PrepareDevice() {
+    if (device_ready_) return Status::kSuccess;
+    for (int i = 0; i < num_spatial_sizes; ++i) {
+        CHECK_STATUS(CheckHip(grids_dev_[i].Upload(grids_[i].data(), grids_[i].size() * sizeof(float)), "upload grid"));
+        CHECK_STATUS(CheckHip(anchor_grids_dev_[i].Upload(anchor_grids_[i].data(), anchor_grids_[i].size() * sizeof(float)), "upload anchors"));
+    }
+    device_ready_ = true;
+    return Status::kSuccess;
+}
+
+// one level: 1x1 conv with the decode + concat in its epilogue (one launch), or conv + decode kernel where that form is not available
+Status YoloDetect::LaunchLevel(int i, const Tensor& in, Tensor& out, int rows_total, int row_off) {
+    Dims4 d;
+    if (!GetDims4(in, d) || d.h != level_h_[i] || d.w != level_w_[i]) return Status::kErrorShape;
+    if (fuse_decode_) {
+        SiYoloLevel lv;
+        lv.na = num_anchor_grid_levels_; lv.ne = num_classes_info_; lv.rows_total = rows_total; lv.row_off = row_off;
+        lv.stride = strides_[i];
+        const Status fs = conv_2d_layer_[i].ForwardYolo(in, lv, grids_dev_[i].As<float>(), anchor_grids_dev_[i].As<float>(), out);
+        if (fs != Status::kUnsupport) return fs;
+    }
+    CHECK_STATUS(spatial_output[i].Allocate(DataType::kFloat32, {d.n, d.h, d.w, num_elements_}));
+    CHECK_STATUS(conv_2d_layer_[i].Forward(in, spatial_output[i]));
+    return CheckHip(si_hip_yolo_decode_f32(spatial_output[i].Data<float>(), d.n, d.h, d.w, num_anchor_grid_levels_, num_classes_info_,
+                                           grids_dev_[i].As<float>(), anchor_grids_dev_[i].As<float>(), strides_[i], out.Data<float>(),
+                                           rows_total, row_off, conv_2d_layer_[i].LaunchStream()),
+                    "YoloDetect decode");
+}
+
+Status YoloDetect::ForwardLevel(int level) {
+    if (level < 0 || level >= num_spatial_sizes || (int)input_tensor_nodes_.size() != num_spatial_sizes || output_tensor_nodes_.size() != 1)
+        return Status::kErrorShape;
+    const Tensor& in = input_tensor_nodes_[level]->tensor;
+    Tensor& out = output_tensor_nodes_[0]->tensor;
+    if (in.GetMemoryType() != MemoryType::kDevice || out.GetMemoryType() != MemoryType::kDevice || IsHalf(out)) return Status::kUnsupport;
+    CHECK_STATUS(PrepareDevice());
+    const std::vector<int> os = out.ShapeAs(3);
+    if (os[2] != num_classes_info_) return Status::kErrorShape;
+    int row_off = 0;
+    for (int i = 0; i < level; ++i) row_off += level_h_[i] * level_w_[i] * num_anchor_grid_levels_;
+    if (row_off + level_h_[level] * level_w_[level] * num_anchor_grid_levels_ > os[1]) return Status::kErrorShape;
+    return LaunchLevel(level, in, out, os[1], row_off);
+}
+
 Status YoloDetect::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
     if ((int)inputs.size() != num_spatial_sizes) return Status::kErrorShape;
     return RunOnDevice({&inputs[0], &inputs[1], &inputs[2]}, {&output},
                        [this](const std::vector<Tensor>& in, std::vector<Tensor>& out) {
-        if (!device_ready_) {
-            for (int i = 0; i < num_spatial_sizes; ++i) {
-                CHECK_STATUS(CheckHip(grids_dev_[i].Upload(grids_[i].data(), grids_[i].size() * sizeof(float)), "upload grid"));
-                CHECK_STATUS(CheckHip(anchor_grids_dev_[i].Upload(anchor_grids_[i].data(), anchor_grids_[i].size() * sizeof(float)), "upload anchors"));
-            }
-            device_ready_ = true;
-        }
+        CHECK_STATUS(PrepareDevice());
         if (IsHalf(out[0])) return Status::kUnsupport;  // detections are always fp32 (features may be fp16)
         const std::vector<int> os = out[0].ShapeAs(3);
         const int rows_total = os[1];
@@ -151,28 +194,9 @@ Status YoloDetect::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
         }
         int row_off = 0;
         for (int i = 0; i < num_spatial_sizes; ++i) {
-            Dims4 d;
-            if (!GetDims4(in[i], d) || d.h != level_h_[i] || d.w != level_w_[i]) return Status::kErrorShape;
-            if (fuse_decode_) {
-                // one launch: 1x1 conv with the decode + concat in its epilogue
-                SiYoloLevel lv;
-                lv.na = num_anchor_grid_levels_; lv.ne = num_classes_info_; lv.rows_total = rows_total; lv.row_off = row_off;
-                lv.stride = strides_[i];
-                const Status fs = conv_2d_layer_[i].ForwardYolo(in[i], lv, grids_dev_[i].As<float>(), anchor_grids_dev_[i].As<float>(), out[0]);
-                if (fs == Status::kSuccess) {
-                    row_off += d.h * d.w * num_anchor_grid_levels_;
-                    continue;
-                }
-                if (fs != Status::kUnsupport) return fs;
-            }
-            CHECK_STATUS(spatial_output[i].Allocate(DataType::kFloat32, {d.n, d.h, d.w, num_elements_}));
-            CHECK_STATUS(conv_2d_layer_[i].Forward(in[i], spatial_output[i]));
-            CHECK_STATUS(CheckHip(si_hip_yolo_decode_f32(spatial_output[i].Data<float>(), d.n, d.h, d.w, num_anchor_grid_levels_,
-                                                         num_classes_info_, grids_dev_[i].As<float>(),
-                                                         anchor_grids_dev_[i].As<float>(), strides_[i], out[0].Data<float>(),
-                                                         rows_total, row_off, Stream()),
-                                  "YoloDetect decode"));
-            row_off += d.h * d.w * num_anchor_grid_levels_;
+            // (a level the engine has already launched on the side stream this forward is skipped here)
+            if (!((early_mask_ >> i) & 1u)) CHECK_STATUS(LaunchLevel(i, in[i], out[0], rows_total, row_off));
+            row_off += level_h_[i] * level_w_[i] * num_anchor_grid_levels_;
         }
         return row_off == rows_total ? Status::kSuccess : Status::kErrorShape;
     });

@@ -19,6 +19,11 @@ public:
     virtual Status Deinit() override;
     virtual Status Validate() override;
     virtual Status Forward(const std::vector<Tensor>& inputs, Tensor& output) override;
+    // Engine option "detect_stream": the levels in `mask` launch on `side`'s stream as soon as the engine has their input
+    // (ForwardLevel, called by the engine right after the producing step); Forward() then launches only the others.
+    void SetEarlyLevels(Context* side, unsigned mask);
+    unsigned EarlyLevels() const { return early_mask_; }
+    Status ForwardLevel(int level);   // on the bound (device) tensors
     virtual bool HalfStorageOk(std::string& why) const override;
     virtual const char* KernelName() const override {
         const bool half = !input_tensor_nodes_.empty() && IsHalf(input_tensor_nodes_[0]->tensor);
@@ -50,6 +55,9 @@ public:
 private:
     DeviceBuffer grids_dev_[num_spatial_sizes], anchor_grids_dev_[num_spatial_sizes];
     bool device_ready_ = false;
+    unsigned early_mask_ = 0;
+    Status PrepareDevice();
+    Status LaunchLevel(int i, const Tensor& in, Tensor& out, int rows_total, int row_off);
 };
 
 }  // namespace SimpleInfer

@@ -135,6 +135,25 @@ def test_upsample_read_at_the_source_is_bit_identical(si, tmp_path):
     assert [L["kernel"] for L in e0.profile()].count("upsample_nearest") == 2
 
 
+@pytest.mark.parametrize("graph", [0, 1])
+def test_detect_levels_on_a_second_stream_are_bit_identical(si, tmp_path, graph):
+    """Option detect_stream (on by default): the two finer Detect levels launch on a second stream right after the step that completes their
+    feature map (fork / join by events, captured into the hipGraph the same way); nothing else changes -- same launches, same
+    bits, forward after forward, and per-layer profiling still sees Detect as one step."""
+    pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(2, 160), "dets")
+    x = si.modelgen.synth_input((2, 160, 160, 3))
+    e0, oname, ref = _run(si, pp, bp, x, graph=graph, detect_stream=0)
+    e1, _, got = _run(si, pp, bp, x, graph=graph, detect_stream=2)   # (1, the default, only forks for levels of 4 GFLOP and up)
+    assert_exact(got, ref, "detect_stream vs single stream")
+    for _ in range(4):   # (with graph=1 the second forward captures, the later ones replay)
+        e1.forward()
+        assert_exact(e1.extract(oname), ref, "repeated forwards with detect_stream")
+    assert e1.schedule()["run"] == e0.schedule()["run"]
+    assert [L["kernel"] for L in e1.profile()] == [L["kernel"] for L in e0.profile()]
+    e1.forward()
+    assert_exact(e1.extract(oname), ref, "forward after a profile pass")
+
+
 @pytest.mark.parametrize("name", ["yolov5s_160", "resnet18_small", "mobilenetv3_small_96", "toy_yolo"])
 def test_activation_arena_changes_nothing_but_the_footprint(si, tmp_path, name):
     """Intermediate operands share one HBM arena by lifetime (the reference allocates every operand and never reuses,
