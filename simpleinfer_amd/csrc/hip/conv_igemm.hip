@@ -254,10 +254,11 @@ __device__ __forceinline__ void epilogue_yolo(const ConvArgs& a, f32x16 (&acc)[T
 // `yolo_img` >= 0: the tile also lies inside that one image (Detect decode takes its straight-line form)
 // `bias_pre`: this lane's TN bias values, loaded before the K loop (their latency is otherwise paid at the head of the
 // epilogue, by every workgroup of a round at the same time)
-template <int TM, int TN>
+// YMODE: -1 the Detect form is a runtime switch (generic kernel), 0 never, 1 always (the Detect instantiation of the fast kernel)
+template <int TM, int TN, int YMODE = -1>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior = false,
                                          int yolo_img = -1, const float* bias_pre = nullptr) {
-    if (a.ymode) {
+    if (YMODE == 1 || (YMODE < 0 && a.ymode)) {
         if (yolo_img >= 0) si_yolo_tile_one_image<TM, TN>(a, a.out, acc, mrow0, ocol0, yolo_img);
         else epilogue_yolo<TM, TN>(a, acc, mrow0, ocol0);
         return;
@@ -448,7 +449,9 @@ constexpr unsigned OOB_B = 0x80000000u;  // weights are < 2 GB; + kt*128 cannot 
 // channel check costs the ordinary layers nothing (it was worth 0.5 % of the YOLOv5s step inside the shared loop)
 // UPS: the dual-source pointwise form (ConvArgs::up); its own instantiation, so the ordinary layers carry neither the extra row
 // offsets nor the per-K-tile source select
-template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false, bool UPS = false>
+// YOLO: the Detect form (decode + concat in the epilogue); its own instantiation, so a profile lists Detect's three launches --
+// which run on the engine's second stream beside other layers -- apart from the ordinary ones
+template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false, bool UPS = false, bool YOLO = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
@@ -663,11 +666,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     SI_STAMP(4);
 
     int yolo_img = -1;
-    if (a.ymode && m0 + BM <= a.M) {
+    if (YOLO && m0 + BM <= a.M) {
         const int img = m0 / a.ohow;
         if (m0 - img * a.ohow + BM <= a.ohow) yolo_img = img;
     }
-    epilogue<TM, TN>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31, m0 + BM <= a.M, yolo_img, bias_pre);
+    epilogue<TM, TN, YOLO ? 1 : 0>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31, m0 + BM <= a.M, yolo_img, bias_pre);
     SI_STAMP(5);
     SI_STAMP_RT(6);
     SI_STAMP_FLUSH(si_diag_stamps);
@@ -686,7 +689,15 @@ int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
     b.n_tiles = (a.ocg + BN - 1) / BN;
     const int chunks = (b.m_tiles + 7) / 8;
     dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
-    if (a.up) {
+    if (a.ymode) {
+        // Detect: the default tile only
+        if constexpr (NBUF == 1 && BM == 64 && BN == 64) {
+            if (a.icg % 32 != 0 || a.up) return SI_E_UNSUPPORTED;
+            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, true>), grid, dim3(256), 0, s, b);
+        } else {
+            return SI_E_UNSUPPORTED;
+        }
+    } else if (a.up) {
         // dual-source pointwise conv (consumer of cat(upsample(x), skip)): the two default tiles only
         if constexpr (NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32))) {
             if (a.icg % 32 != 0 || !a.pointwise) return SI_E_UNSUPPORTED;
@@ -929,7 +940,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
         a.in_bytes = (unsigned)((unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull);
         hipStream_t fs = static_cast<hipStream_t>(stream);
         // a zero-padded K axis only exists in the two default tiles (SI_CONV_VARIANT is ignored for those layers)
-        const int variant = (a.icg % 32 != 0 || a.up) ? ((d->oc / d->groups) <= 32 ? 10 : 4) : conv_variant(d);
+        const int variant = a.ymode ? 4 : (a.icg % 32 != 0 || a.up) ? ((d->oc / d->groups) <= 32 ? 10 : 4) : conv_variant(d);
         switch (variant) {
             case 0: return launch_fast<128, 128, 2, 2, 2>(a, d->groups, fs);
             case 1: return launch_fast<128, 64, 2, 2, 2>(a, d->groups, fs);
@@ -991,14 +1002,14 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         {"conv_igemm_f32_kernel<128, 64, 2, 2, false>", "conv_igemm_f32_kernel<128, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<64, 64, 2, 2, false>", "conv_igemm_f32_kernel<64, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<128, 32, 4, 1, false>", "conv_igemm_f32_kernel<128, 32, 4, 1, true>"}};
-    // exactly as rocprofv3 prints the instantiation (minus the namespace): <BM, BN, WM, WN, NBUF, PADK, UPS>
+    // exactly as rocprofv3 prints the instantiation (minus the namespace): <BM, BN, WM, WN, NBUF, PADK, UPS, YOLO>
     static const char* fast_names[11] = {
-        "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 2, false, false>", "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 2, false, false>",
-        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 2, false, false>",   "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 2, false, false>",
-        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false>",   "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 1, false, false>",
-        "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 1, false, false>",  "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 1, false, false>",
-        "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 2, false, false>",  "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, false>",
-        "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, false>"};
+        "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 2, false, false, false>", "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 2, false, false, false>",
+        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 2, false, false, false>",   "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 2, false, false, false>",
+        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false>",   "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 1, false, false, false>",
+        "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 1, false, false, false>",  "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 1, false, false, false>",
+        "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 2, false, false, false>",  "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, false, false>",
+        "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, false, false>"};
     if (si_conv_smallc_ok(d)) return si_conv_smallc_name(d);
     if (si_conv_depthwise_ok(d)) return si_conv_depthwise_name(d);
     SiConv2dDesc eff = conv_effective(d);
@@ -1006,7 +1017,7 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
     const int v = conv_variant(d);
     if (conv_fast_ok(d, in)) {
         if ((d->ic / d->groups) % 32 != 0)   // zero-padded K: the PADK instantiations of the two default tiles
-            return (d->oc / d->groups) <= 32 ? "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, true, false>" : "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, true, false>";
+            return (d->oc / d->groups) <= 32 ? "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, true, false, false>" : "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, true, false, false>";
         return fast_names[v];
     }
     static const int generic_of[11] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3};

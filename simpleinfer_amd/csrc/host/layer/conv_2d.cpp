@@ -423,7 +423,7 @@ const char* Conv2d::KernelName() const {
     if (mode == 2) return "conv_stem_f16_kernel";
     const int tile = WinogradTile(d);
     if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
-    if (up_node_) return d.oc <= 32 ? "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, true>" : "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, true>";
+    if (up_node_) return d.oc <= 32 ? "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, true, false>" : "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, true, false>";
     return si_hip_conv2d_kernel_name(&d, in.Data<float>());
 }
 

@@ -129,6 +129,10 @@ def main():
         print("   start of workgroups after the first: p50 %.1f us  p90 %.1f us  max %.1f us" % (med(start), float(np.percentile(start, 90)), start.max()))
         print("   cycles per workgroup (median): prologue %.0f  fill %.0f  loop %.0f (MFMA alone %d = %.0f %% of it)  epilogue %.0f  | total %.0f"
               % (med(pro), med(fill), med(loop), mfma_cyc, 100.0 * mfma_cyc / med(loop), med(epi), med(s[:, 5] - s[:, 1])))
+        fr = start < 2.0   # the workgroups of the first round: nothing to overlap their prologue with
+        if fr.any() and not wino:
+            print("   first round (%d workgroups): prologue %.0f  fill %.0f cycles -> first MFMA %.1f us after the launch; the others: prologue %.0f"
+                  % (int(fr.sum()), med(pro[fr]), med(fill[fr]), med((s[:, 3] - s[:, 1])[fr]) / (clock * 1e3), med(pro[~fr]) if (~fr).any() else 0.0))
         print("   MFMA pipe busy over the span: %.1f %%   (at 2.4 GHz and 100 %% the launch would take %.1f us)"
               % (100.0 * total_pipe / (256.0 * span_cyc), flops / 157.3e12 * 1e6))
         if args.timeline:
