@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     const int c_cq = tid & 3, c_px = (tid >> 2) & (2 * TBW - 1), c_tr = tid >> (LOG_TBW + 3);
     unsigned c_base, c_rows;
     make_item(c_tr, c_px, c_cq, c_base, c_rows);
+    c_base += row_pitch;                     // offset of patch row 1 (see fetch)
     // LDS destination (floats) of channel 0 / plane row 0 of the item
     const int c_dst = (c_cq * 4) * PLANE + c_tr * PWP + c_px;
     // Halo: a QUAD of lanes shares one item, lane j of it fetching patch row j alone; the row transform then takes its two
@@ -172,11 +173,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     }
 
     u32x4 cpre[4], hpre[HR];
+    // (the patch row and the channel block ride in the instruction's SCALAR offset, which the range check does not see: a lane
+    // costs one select per load -- its item's offset, or the out-of-range one when that row is masked)
+    // `base` is the offset of patch row ONE (never before the tensor: pad <= 1); row 0 is one pitch below it, per lane, and only
+    // where that row exists -- the hardware adds the scalar offset in 64 bits, so a wrapped "negative" lane offset would not come back
     auto fetch = [&](u32x4 (&dst)[4], unsigned base, unsigned rows, int cb) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned off = ((rows >> j) & 1u) ? base + (unsigned)j * row_pitch + (unsigned)(cb * CB * 4) : 0xFFFFFF00u;
-            dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+            const unsigned off = ((rows >> j) & 1u) ? (j == 0 ? base - row_pitch : base) : 0xFFFFFF00u;
+            dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, (unsigned)(j == 0 ? 0 : j - 1) * row_pitch + (unsigned)(cb * CB * 4), 0);
         }
     };
     // the row half of B^T d B (winograd_helper.cpp:188-239):  r=0: d0 - d2   r=1: d1 + d2   r=2: d2 - d1   r=3: d1 - d3,
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     auto fetch_halo = [&](int cb, bool live) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
-            const unsigned off = (live && h_off[i] != 0xFFFFFF00u) ? h_off[i] + (unsigned)(cb * CB * 4) : 0xFFFFFF00u;
-            hpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+            const unsigned off = live ? h_off[i] : 0xFFFFFF00u;
+            hpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, (unsigned)(cb * CB * 4), 0);
         }
     };
     // lane j of a quad:  t_j = d[ja] +- d[jb]  with (ja, jb) = (0,2) (1,2) (2,1) (1,3): two quad permutes and one fma per value

@@ -163,6 +163,20 @@ def test_winograd_fused_epilogue_and_strides(hops, orc):
         hops.conv2d_winograd(rng_uniform(75, (1, 8, 8, 12), -1, 1), rng_uniform(76, (32, 12, 3, 3)), None)  # ic % 16 != 0
 
 
+def test_winograd_64_channel_workgroups_and_unaligned_outputs():
+    """The 64-output-channel form of the kernel (two accumulator groups per wave; picked by itself only for ic >= 256 on large
+    grids) is forced onto every eligible shape of the two tests above in a child process (the switch is read once per process):
+    same parity bars, same bit-exact batch invariance, the strided / offset-output cases included."""
+    import os, subprocess, sys
+    env = dict(os.environ, SI_WINO_OCG="2")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "test_winograd_vs_reference_path or test_winograd_fused_epilogue_and_strides"],
+                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
 # F(4x4, 3x3): same shapes (tile-block shapes 2x8 / 4x4 / 8x2 / 16x1, clipped 4x4 stores on odd sizes, image-spanning
 # blocks) plus maps smaller than one tile.  Parity target stays the reference's Winograd pipeline; the fp64 bound shows
 # the larger tile costs about one digit (measured <= 1e-5 of the output scale) and stays far inside 1e-4.
