@@ -210,21 +210,23 @@ int Graph::load(const std::string& parampath, const std::string& binpath) {
                 a.shape.clear();
                 for (const auto& d : dims) a.shape.push_back(std::stoi(d));
                 if (a.shape.empty()) continue;
-                size_t count = 1;
-                for (int d : a.shape) count *= (size_t)d;
-                const size_t bytes = count * type_elemsize(a.type);
                 const std::string entry = op->name + "." + key.substr(1);
                 const size_t have = zip.get_file_size(entry);
                 if (have == 0) continue;  // no such entry: attribute keeps shape, no data
-                if (have != bytes) fprintf(stderr, "pnnx: %s holds %zu bytes, expected %zu\n", entry.c_str(), have, bytes);
-                a.data.resize(bytes);
-                if (have >= bytes) {
-                    std::vector<char> tmp(have);
-                    zip.read_file(entry, tmp.data());
-                    std::copy(tmp.begin(), tmp.begin() + bytes, a.data.begin());
-                } else {
-                    zip.read_file(entry, a.data.data());
+                // the byte count the shape implies must be the entry's, checked BEFORE anything is sized by it (a corrupt
+                // shape must not drive an allocation; the layer that needs the data then fails its own size check at Init)
+                size_t count = 1;
+                bool sane = true;
+                for (int d : a.shape) {
+                    if (d <= 0 || count > have) { sane = false; break; }
+                    count *= (size_t)d;
                 }
+                if (!sane || count * type_elemsize(a.type) != have) {
+                    fprintf(stderr, "pnnx: %s holds %zu bytes, its shape says otherwise: ignored\n", entry.c_str(), have);
+                    continue;
+                }
+                a.data.resize(have);
+                zip.read_file(entry, a.data.data());
             } else if (key[0] == '$') {
                 op->inputnames.resize(op->inputs.size());
                 for (size_t j = 0; j < op->inputs.size(); ++j)
