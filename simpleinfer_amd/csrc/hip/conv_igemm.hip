@@ -74,6 +74,7 @@ struct ConvArgs {
     int Kp;                     // kh*kw*icg_pad
     int M;                      // n*oh*ow
     int ohow;
+    unsigned mg_ohow, mg_ow;    // floor(2^32 / d) for the two per-row divisions of the fast kernel's prologue (see fast_div)
     int m_tiles, n_tiles;
     int act1, act2;
     float act_param;
@@ -442,6 +443,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
 // * loads are raw buffer loads: an out-of-image tap (or a row past M / past OC) is an out-of-range offset
 //   and the hardware returns zeros -- no branches around the loads.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// n / d for 0 <= n < 2^32 with mg = floor(2^32 / d) (0xFFFFFFFF for d = 1): mulhi gives the quotient or one less, one
+// correction step makes it exact -- 5 instructions instead of the ~40 of an emulated integer division, twice per staged row
+__device__ __forceinline__ int fast_div(int n, int d, unsigned mg) {
+    unsigned q = __umulhi((unsigned)n, mg);
+    if ((unsigned)n - q * (unsigned)d >= (unsigned)d) ++q;
+    return (int)q;
+}
 constexpr unsigned OOB_A = 0xFFFFFF00u;  // >= any legal num_records
 constexpr unsigned OOB_B = 0x80000000u;  // weights are < 2 GB; + kt*128 cannot wrap
 
@@ -500,9 +508,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         if (UPS) {
             u_off[i] = OOB_A;
             if (m < a.M) {
-                const int img = m / a.ohow;
+                const int img = fast_div(m, a.ohow, a.mg_ohow);
                 const int rem = m - img * a.ohow;
-                const int oy = rem / a.ow;
+                const int oy = fast_div(rem, a.ow, a.mg_ow);
                 const int ox = rem - oy * a.ow;
                 // upsample.cpp:85-92: src = clamp(int(float(dst) * (1 / scale)), 0, in - 1)
                 int sy = (int)((float)oy * a.up_inv_h), sx = (int)((float)ox * a.up_inv_w);
@@ -516,9 +524,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
             a_off[i] = (unsigned)m * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16);
             a_mask[i] = 1ull;
         } else if (m < a.M) {
-            const int img = m / a.ohow;
+            const int img = fast_div(m, a.ohow, a.mg_ohow);
             const int rem = m - img * a.ohow;
-            const int oy = rem / a.ow;
+            const int oy = fast_div(rem, a.ow, a.mg_ow);
             const int ox = rem - oy * a.ow;
             const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
             // modulo-2^32 arithmetic: (tap-0 pixel may lie before the tensor start; adding the tap delta brings
@@ -906,6 +914,8 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     a.Kp = d->kh * d->kw * a.icg_pad;
     a.M = d->n * d->oh * d->ow;
     a.ohow = d->oh * d->ow;
+    a.mg_ohow = a.ohow > 1 ? (unsigned)(0x100000000ull / (unsigned)a.ohow) : 0xFFFFFFFFu;
+    a.mg_ow = d->ow > 1 ? (unsigned)(0x100000000ull / (unsigned)d->ow) : 0xFFFFFFFFu;
     a.m_tiles = a.n_tiles = 0;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
     a.cb_major = conv_cb_major(d) ? 1 : 0;

@@ -53,6 +53,7 @@ struct WinoArgs {
     int th, tw;          // tiles per image column / row
     int rows_total;      // n * th
     int col_blocks, oc_blocks, spatial_blocks;
+    unsigned mg_chunk, mg_cols, mg_th;   // floor(2^32 / d) of the block decode's three divisors (wino_div)
     unsigned in_bytes, u_bytes;
     int act1, act2;
     float act_param;
@@ -72,6 +73,13 @@ __device__ __forceinline__ float wino_act(int act, float v, float p) {
 }
 
 constexpr int CB = 16;  // input channels per staged block
+
+// n / d for 0 <= n < 2^32 with mg = floor(2^32 / d) (0xFFFFFFFF for d = 1): the high product is the quotient or one less
+__device__ __forceinline__ int wino_div(int n, int d, unsigned mg) {
+    unsigned q = __umulhi((unsigned)n, mg);
+    if ((unsigned)n - q * (unsigned)d >= (unsigned)d) ++q;
+    return (int)q;
+}
 
 #ifndef SI_WINO_ABLATE   // diagnostic builds only (timing experiments, wrong results): 1 no patch loads after block 0,
 #define SI_WINO_ABLATE 0  // 2 no filter loads after the first, 4 no staging stores after block 0, 8 no output stores
@@ -113,12 +121,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     // block id -> (spatial block, oc block): the oc blocks of one spatial block share blockIdx % 8, i.e. one XCD and its
     // L2, because they all stage the same input patches (placement is a speed hint only)
     const int per_chunk = 8 * a.oc_blocks;
-    const int chunk = blockIdx.x / per_chunk;
+    const int chunk = wino_div((int)blockIdx.x, per_chunk, a.mg_chunk);
     const int rr = blockIdx.x - chunk * per_chunk;
     const int sb = chunk * 8 + (rr & 7);
     const int ocb = rr >> 3;
     if (sb >= a.spatial_blocks) return;
-    const int by = sb / a.col_blocks;
+    const int by = wino_div(sb, a.col_blocks, a.mg_cols);
     const int bc = sb - by * a.col_blocks;
     const int row0 = by * TBH;               // first flattened tile row of the block
     const int col0 = bc * TBW;               // first tile column
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
 
     // the block's first tile row as (image, tile row): one wave-uniform division, reused by the staging items and the stores
-    const int img0 = row0 / a.th;
+    const int img0 = wino_div(row0, a.th, a.mg_th);
     const int ty0 = row0 - img0 * a.th;
     const unsigned row_pitch = (unsigned)(a.iw * a.in_ld * 4);
 
@@ -470,6 +478,10 @@ int launch_wino(WinoArgs a, hipStream_t s) {
     a.oc_blocks = a.oc / (32 * OCG);
     const int row_blocks = (a.rows_total + TBH - 1) / TBH;
     a.spatial_blocks = a.col_blocks * row_blocks;
+    auto magic = [](int d) { return d > 1 ? (unsigned)(0x100000000ull / (unsigned)d) : 0xFFFFFFFFu; };
+    a.mg_chunk = magic(8 * a.oc_blocks);
+    a.mg_cols = magic(a.col_blocks);
+    a.mg_th = magic(a.th);
     const long long nblocks = (long long)((a.spatial_blocks + 7) / 8) * 8 * a.oc_blocks;
     if (nblocks > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     dim3 grid((unsigned)nblocks, 1, 1);
