@@ -135,20 +135,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
 
-    // the block's first tile row as (image, tile row): one wave-uniform division, reused by the staging items and the stores
-    const int img0 = wino_div(row0, a.th, a.mg_th);
-    const int ty0 = row0 - img0 * a.th;
     const unsigned row_pitch = (unsigned)(a.iw * a.in_ld * 4);
 
     // ---- staging items.  Core: thread -> (tile row, one of the 2*TBW own pixels, 4 channels); halo: the first NHALO threads
     // -> (tile row, one of the two halo pixels, 4 channels).  An item is the byte offset of patch row 0 (it may lie before
     // the tensor when that row is padding; only valid rows use it) and a 4-bit mask of the rows inside the image.
     auto make_item = [&](int tr, int px, int cq, unsigned& base, unsigned& rows) {
-        int img = img0, ty = ty0 + tr;       // tr < TBH <= 16: a couple of subtractions instead of a division
-        while (ty >= a.th) {
-            ty -= a.th;
-            ++img;
-        }
+        const int img = wino_div(row0 + tr, a.th, a.mg_th);   // (image, tile row) of the item's flattened tile row, branch free
+        const int ty = row0 + tr - img * a.th;
         const int y0 = 2 * ty - a.pad, x = 2 * col0 - a.pad + px;
         const bool ok = row0 + tr < a.rows_total && (unsigned)x < (unsigned)a.iw;
         rows = 0;
@@ -404,11 +398,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
             const int tr = t >> LOG_TBW, tc = t & (TBW - 1);
             const int txg = col0 + tc;
             if (row0 + tr >= a.rows_total || txg >= a.tw) continue;
-            int img = img0, ty = ty0 + tr;
-            while (ty >= a.th) {
-                ty -= a.th;
-                ++img;
-            }
+            const int img = wino_div(row0 + tr, a.th, a.mg_th);
+            const int ty = row0 + tr - img * a.th;
             const int oy = 2 * ty + i_out, ox = 2 * txg + jc;
             if (oy >= a.oh || ox >= a.ow) continue;
             const size_t pix = (size_t)(img * a.oh + oy) * a.ow + ox;
