@@ -48,6 +48,7 @@ struct ConvArgsH {
     int icg, ocg, oc;
     int Kp;                     // kh*kw*icg
     int M, ohow;
+    unsigned mg_ohow, mg_ow;    // floor(2^32 / d) of the two per-row divisions of the prologue (fast_div_h)
     int m_tiles, n_tiles;
     int act1, act2;
     float act_param;
@@ -61,6 +62,13 @@ struct ConvArgsH {
     const float* ygrid;
     const float* yanchor;
 };
+
+// n / d for 0 <= n < 2^32 with mg = floor(2^32 / d) (0xFFFFFFFF for d = 1): the high product is the quotient or one less
+__device__ __forceinline__ int fast_div_h(int n, int d, unsigned mg) {
+    unsigned q = __umulhi((unsigned)n, mg);
+    if ((unsigned)n - q * (unsigned)d >= (unsigned)d) ++q;
+    return (int)q;
+}
 
 __device__ __forceinline__ float act_h(int act, float v, float p) {
     switch (act) {
@@ -248,9 +256,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
             a_off[i] = (unsigned)m * (unsigned)(a.in_ld * 2) + (unsigned)(kv * 16);
             a_mask[i] = 1ull;
         } else if (m < a.M) {
-            const int img = m / a.ohow;
+            const int img = fast_div_h(m, a.ohow, a.mg_ohow);
             const int rem = m - img * a.ohow;
-            const int oy = rem / a.ow;
+            const int oy = fast_div_h(rem, a.ow, a.mg_ow);
             const int ox = rem - oy * a.ow;
             const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
             a_off[i] = (unsigned)((img * a.ih + y0) * a.iw + x0) * (unsigned)(a.in_ld * 2) + (unsigned)(kv * 16);
@@ -437,6 +445,8 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     a.Kp = d->kh * d->kw * a.icg;
     a.M = d->n * d->oh * d->ow;
     a.ohow = d->oh * d->ow;
+    a.mg_ohow = a.ohow > 1 ? (unsigned)(0x100000000ull / (unsigned)a.ohow) : 0xFFFFFFFFu;
+    a.mg_ow = d->ow > 1 ? (unsigned)(0x100000000ull / (unsigned)d->ow) : 0xFFFFFFFFu;
     a.m_tiles = a.n_tiles = 0;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
     a.in_bytes = (unsigned)in_bytes;
