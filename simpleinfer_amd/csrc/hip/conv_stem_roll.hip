@@ -36,6 +36,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef SI_STEM_ABLATE
 #define SI_STEM_ABLATE 0
 #endif
+#ifndef SI_STEM_EXP   // development: 1 compile-time epilogue, 2 padded weight pitch (no operand swap), 4 literal-zero first step
+#define SI_STEM_EXP 7
+#endif
 
 namespace {
 
@@ -70,12 +73,20 @@ __device__ __forceinline__ float stem_act(int act, float v, float p) {
 
 // NW waves, each PB blocks of 16 output pixels along W; NT 32-wide output-channel tiles per wave; KH x KW kernel, 3 channels,
 // stride 2.
-template <int NW, int PB, int NT, int KH, int KW, typename OutT, bool VEC>
+// EP: the epilogue known at compile time -- 1: bias + SiLU, 2: bias + ReLU (no residual, no second activation: the YOLOv5 / ResNet
+// stems; straight-line code), 0: anything (runtime switches per tile).
+template <int NW, int PB, int NT, int KH, int KW, typename OutT, bool VEC, int EP = 0>
 __global__ __launch_bounds__(NW * 64) void conv_stem_roll_kernel(const StemArgs a) {
     constexpr int C = 3, S = 2, PXS = S * C;
     constexpr int KWC = KW * C, K = KH * KWC, STEPS = (K + 3) / 4;
     constexpr int NR = KH + S;               // ring slots: the KH rows of the current output row + the S incoming ones
     constexpr int WLD = 32 * NT;
+    // LDS pitch of a weight row.  Two 32-channel tiles: 16 floats of padding put rows k and k + 1 sixteen banks apart, so the two
+    // k of a 32-lane group read their 16 channels from disjoint banks with no operand swap (ResNet stem 0.178 -> 0.163 ms).  One
+    // tile: the padded image costs the wide instantiation its second resident workgroup (0.237 -> 0.297 ms), so there lanes with
+    // odd k read the two 16-channel halves in the opposite order and swap them back in registers.
+    constexpr bool PADW = (SI_STEM_EXP & 2) && NT == 2;
+    constexpr int WLP = WLD + (PADW ? 16 : 0);
     constexpr int NTHR = NW * 64, TOW = 16 * PB * NW;
     constexpr int NOC = 2 * NT;              // 16-channel MFMA column tiles per wave
     constexpr int VPT = ((3 + (TOW - 1) * PXS + KWC + 3) / 4 + NTHR - 1) / NTHR;   // 16-byte vectors per thread per staged row
@@ -92,8 +103,10 @@ __global__ __launch_bounds__(NW * 64) void conv_stem_roll_kernel(const StemArgs 
     {
         const int nvec = STEPS * 4 * WLD / 4;
         const float4* src = reinterpret_cast<const float4*>(a.w);
-        float4* dst = reinterpret_cast<float4*>(wl);
-        for (int i = tid; i < nvec; i += NTHR) dst[i] = src[i];
+        for (int i = tid; i < nvec; i += NTHR) {
+            const int row = i / (WLD / 4), c4 = i - row * (WLD / 4);
+            *reinterpret_cast<float4*>(wl + row * WLP + c4 * 4) = src[i];
+        }
     }
     // the MFMA runs with the weights as its A operand: a lane's 4 accumulator registers are 4 CONSECUTIVE CHANNELS
     // (u * 16 + 4 * kq + e) of ONE pixel (l15), so the epilogue stores 16 bytes per lane and tile
@@ -170,6 +183,12 @@ __global__ __launch_bounds__(NW * 64) void conv_stem_roll_kernel(const StemArgs 
             OutT* const opix = static_cast<OutT*>(a.out) + pix * a.out_ld;
             f32x4 v = accv + bv[u];
             if (SI_STEM_ABLATE & 2) {
+            } else if (EP == 1 && (SI_STEM_EXP & 1)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[q]));
+            } else if (EP == 2 && (SI_STEM_EXP & 1)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.0f);
             } else if (simple && a.act1 == SI_ACT_SILU) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[q]));
@@ -223,7 +242,7 @@ __global__ __launch_bounds__(NW * 64) void conv_stem_roll_kernel(const StemArgs 
                 if (sl >= NR) sl -= NR;
                 rowoff[ky] = sl * a.row_len;
             }
-            if (compute) {
+            if (compute && !(SI_STEM_EXP & 4)) {
 #pragma unroll
                 for (int h = 0; h < PB; ++h)
 #pragma unroll
@@ -249,21 +268,27 @@ __global__ __launch_bounds__(NW * 64) void conv_stem_roll_kernel(const StemArgs 
                     float av[PB];
 #pragma unroll
                     for (int h = 0; h < PB; ++h) av[h] = ring[px_base + h * 16 * PXS + off];
-                    // B: lanes with odd k read the two halves of each 32-channel tile in the opposite order (bank spread), then swap
                     float b[NOC];
-                    const bool odd = kq & 1;
-                    const float* const wrow = wl + (k0 + kq) * WLD + l15;
+                    const float* const wrow = wl + (k0 + kq) * WLP + l15;
+                    if (PADW) {
 #pragma unroll
-                    for (int u = 0; u < NOC; u += 2) {
-                        const float r0 = wrow[u * 16 + (odd ? 16 : 0)];
-                        const float r1 = wrow[u * 16 + (odd ? 0 : 16)];
-                        b[u] = odd ? r1 : r0;
-                        b[u + 1] = odd ? r0 : r1;
+                        for (int u = 0; u < NOC; ++u) b[u] = wrow[u * 16];
+                    } else {
+                        const bool odd = kq & 1;
+#pragma unroll
+                        for (int u = 0; u < NOC; u += 2) {
+                            const float r0 = wrow[u * 16 + (odd ? 16 : 0)];
+                            const float r1 = wrow[u * 16 + (odd ? 0 : 16)];
+                            b[u] = odd ? r1 : r0;
+                            b[u + 1] = odd ? r0 : r1;
+                        }
                     }
+                    // (the first step accumulates onto the literal zero: no register writes to clear the row's accumulators)
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int h = 0; h < PB; ++h)
 #pragma unroll
-                        for (int u = 0; u < NOC; ++u) cur[h][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u], av[h], cur[h][u], 0, 0, 0);
+                        for (int u = 0; u < NOC; ++u) cur[h][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u], av[h], (s == 0 && (SI_STEM_EXP & 4)) ? zero : cur[h][u], 0, 0, 0);
                 }
                 if (drain && s >= 1 && (s - 1) % EVERY == 0 && (s - 1) / EVERY < TILES) {
                     constexpr int dummy = 0;
@@ -328,14 +353,14 @@ inline bool stem_shape(const SiConv2dDesc* d, StemShape& s) {
 
 inline int stem_steps(const StemShape& s) { return (s.kh * s.kw * 3 + 3) / 4; }
 
-template <int NW, int PB, int NT, int KH, int KW, typename OutT>
+template <int NW, int PB, int NT, int KH, int KW, typename OutT, int EP = 0>
 int launch_roll(StemArgs a, bool vec, hipStream_t st) {
-    constexpr int S = 2, C = 3, KWC = KW * C, K = KH * KWC, STEPS = (K + 3) / 4, NR = KH + S, WLD = 32 * NT, TOW = 16 * PB * NW;
+    constexpr int S = 2, C = 3, KWC = KW * C, K = KH * KWC, STEPS = (K + 3) / 4, NR = KH + S, WLD = 32 * NT + (((SI_STEM_EXP & 2) && NT == 2) ? 16 : 0), TOW = 16 * PB * NW;
     a.w_tiles = (a.ow + TOW - 1) / TOW;
     a.row_len = (3 + (TOW - 1) * S * C + KWC + 3) / 4 * 4;
     const size_t lds = ((size_t)NR * a.row_len + (size_t)STEPS * 4 * WLD) * sizeof(float);
     if (lds > 160 * 1024) return SI_E_UNSUPPORTED;
-    auto kern = vec ? conv_stem_roll_kernel<NW, PB, NT, KH, KW, OutT, true> : conv_stem_roll_kernel<NW, PB, NT, KH, KW, OutT, false>;
+    auto kern = vec ? conv_stem_roll_kernel<NW, PB, NT, KH, KW, OutT, true, EP> : conv_stem_roll_kernel<NW, PB, NT, KH, KW, OutT, false, EP>;
     if (hipError_t e = si_allow_dynamic_lds(kern, lds); e != hipSuccess) return (int)e;
     const int per_cu = si_resident_blocks(kern, NW * 64, lds);
     const long long slots = 256LL * per_cu;
@@ -415,11 +440,19 @@ static int stemroll_launch_t(const SiConv2dDesc* d, const float* in, const float
     if (in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
     a.in_bytes = (unsigned)in_bytes;
     const bool vec = d->in_ld == 3 && (d->iw * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    // the two stems of the path get their epilogue at compile time (YOLOv5: SiLU; ResNet: ReLU)
+    const bool plain = !d->has_residual && d->act2 == SI_ACT_NONE;
     if (s.kh == 6) {
-        if (stem_wide(d)) return launch_roll<4, 5, 1, 6, 6, OutT>(a, vec, st);
+        if (stem_wide(d)) {
+            if (plain && d->act1 == SI_ACT_SILU) return launch_roll<4, 5, 1, 6, 6, OutT, 1>(a, vec, st);
+            return launch_roll<4, 5, 1, 6, 6, OutT>(a, vec, st);
+        }
         return s.nt == 1 ? launch_roll<4, 2, 1, 6, 6, OutT>(a, vec, st) : launch_roll<4, 2, 2, 6, 6, OutT>(a, vec, st);
     }
-    if (s.kh == 7) return s.nt == 1 ? launch_roll<4, 2, 1, 7, 7, OutT>(a, vec, st) : launch_roll<4, 2, 2, 7, 7, OutT>(a, vec, st);
+    if (s.kh == 7) {
+        if (s.nt == 2 && plain && d->act1 == SI_ACT_RELU) return launch_roll<4, 2, 2, 7, 7, OutT, 2>(a, vec, st);
+        return s.nt == 1 ? launch_roll<4, 2, 1, 7, 7, OutT>(a, vec, st) : launch_roll<4, 2, 2, 7, 7, OutT>(a, vec, st);
+    }
     return s.nt == 1 ? launch_roll<4, 2, 1, 3, 3, OutT>(a, vec, st) : launch_roll<4, 2, 2, 3, 3, OutT>(a, vec, st);
 }
 
