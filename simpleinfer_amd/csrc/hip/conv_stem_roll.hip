@@ -31,13 +31,21 @@
 #pragma clang fp contract(off)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
 // development ablations (tools/build_exp.sh): 1 no output stores, 2 no activation, 4 no row fetch in the loop
 #ifndef SI_STEM_ABLATE
 #define SI_STEM_ABLATE 0
 #endif
-#ifndef SI_STEM_EXP   // development: 1 compile-time epilogue, 2 padded weight pitch (no operand swap), 4 literal-zero first step
-#define SI_STEM_EXP 7
+// (development switch: two waves per SIMD promised to the compiler, accumulators in the unified VGPR file, no v_accvgpr_read per
+// value in the epilogue: 0.2100 -> 0.2080 ms, ResNet18 stem 0.1448 -> 0.1431; not worth a non-default register contract)
+#if defined(SI_STEM_UNIFIED_REGS)
+#define SI_STEM_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define SI_STEM_WAVES_ATTR
+#endif
+#ifndef SI_STEM_EXP   // development: 1 compile-time epilogue, 2 padded weight pitch (no operand swap), 4 literal-zero first step,
+#define SI_STEM_EXP 15   // 8 buffer stores with scalar tile offsets
 #endif
 
 namespace {
@@ -55,6 +63,7 @@ struct StemArgs {
     int rc;              // output rows per task
     int w_tiles, row_chunks, tasks;
     unsigned in_bytes;
+    unsigned out_bytes;  // extent of `out` when it fits a buffer resource with 16-byte aligned rows, else 0
     int act1, act2;
     float act_param;
 };
@@ -76,7 +85,7 @@ __device__ __forceinline__ float stem_act(int act, float v, float p) {
 // EP: the epilogue known at compile time -- 1: bias + SiLU, 2: bias + ReLU (no residual, no second activation: the YOLOv5 / ResNet
 // stems; straight-line code), 0: anything (runtime switches per tile).
 template <int NW, int PB, int NT, int KH, int KW, typename OutT, bool VEC, int EP = 0>
-__global__ __launch_bounds__(NW * 64) void conv_stem_roll_kernel(const StemArgs a) {
+__global__ __launch_bounds__(NW * 64) SI_STEM_WAVES_ATTR void conv_stem_roll_kernel(const StemArgs a) {
     constexpr int C = 3, S = 2, PXS = S * C;
     constexpr int KWC = KW * C, K = KH * KWC, STEPS = (K + 3) / 4;
     constexpr int NR = KH + S;               // ring slots: the KH rows of the current output row + the S incoming ones
@@ -122,9 +131,12 @@ __global__ __launch_bounds__(NW * 64) void conv_stem_roll_kernel(const StemArgs 
     auto load_row = [&](int img, int y, int e, bool live) -> f32x4 {
         const bool yok = live && (unsigned)y < (unsigned)a.ih;
         if (VEC) {
-            unsigned off = ((unsigned)((img * a.ih + y) * row_floats + e)) * 4u;  // modulo 2^32
-            if (!(yok && e >= 0 && e + 3 < row_floats)) off = 0xFFFFFF00u;        // out-of-range offset: the hardware returns 0
-            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+            // the lane's part of the address is its float index in the row (or the out-of-range offset: the hardware returns 0),
+            // the row's part a scalar offset (the range check does not see it; valid rows keep it inside the tensor)
+            const bool ok = yok && e >= 0 && e + 3 < row_floats;
+            const unsigned off = ok ? (unsigned)e * 4u : 0xFFFFFF00u;
+            const unsigned row = (unsigned)y < (unsigned)a.ih ? (unsigned)((img * a.ih + y) * row_floats) * 4u : 0u;   // wave-uniform
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, row, 0));
         }
         f32x4 v;
 #pragma unroll
@@ -175,7 +187,37 @@ __global__ __launch_bounds__(NW * 64) void conv_stem_roll_kernel(const StemArgs 
         // 16x16 C/D map with the weights as A: row (channel) = 4 * (lane >> 4) + e, column (pixel) = lane & 15.
         const bool simple = a.res == nullptr && a.act2 == SI_ACT_NONE;
         const bool vst = (a.out_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && sizeof(OutT) == 4;
+        // The compile-time epilogues store through a buffer resource: the lane's part of the address (its pixel inside a 16-pixel
+        // block, its 4 channels) is one VGPR computed once per task, the tile's part (image row, block, channel tile) a scalar
+        // offset -- the 64-bit pixel index and pointer arithmetic cost ~15 vector instructions per tile, a third of what a row
+        // issues beside its MFMAs.  A pixel block past the row's end, or a channel group past oc, stores to the out-of-range offset.
+        constexpr bool bst = EP != 0 && (SI_STEM_EXP & 8) && sizeof(OutT) == 4;   // (the launcher picks EP != 0 only with out_bytes != 0)
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+        const unsigned st_lane = (unsigned)(((wave * PB * 16 + l15) * a.out_ld + 4 * kq) * 4);
+        unsigned st_mask = 0;                         // bit h * NOC + u: this lane's (pixel block h, channel tile u) lies inside the tensor
+#pragma unroll
+        for (int h = 0; h < PB; ++h)
+#pragma unroll
+            for (int u = 0; u < NOC; ++u)
+                if (ox0 + (wave * PB + h) * 16 + l15 < a.ow && u * 16 + 4 * kq + 3 < a.oc) st_mask |= 1u << (h * NOC + u);
         auto epilogue_tile = [&](const f32x4& accv, int h, int u, int oy) {
+            if constexpr (bst) {
+                f32x4 v = accv + bv[u];
+                if (EP == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[q]));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.0f);
+                }
+                const unsigned row = (unsigned)((img * a.oh + oy) * a.ow + ox0) * (unsigned)(a.out_ld * 4);   // wave-uniform
+                const unsigned soff = row + (unsigned)(h * 16 * a.out_ld * 4 + u * 64);
+                // (the tile's offset is ADDED to the lane's, not passed as the instruction's scalar offset: a 16-byte store with an SGPR
+                // offset reads its data registers one cycle late, and with the next tile's arithmetic right behind it the last
+                // four lanes of every 16 stored the next tile's first value -- 1216 wrong elements in 3.3 M on image 31 of 32)
+                const unsigned voff = ((st_mask >> (h * NOC + u)) & 1u) ? st_lane + soff : 0xFFFFFF00u;
+                if (!(SI_STEM_ABLATE & 1)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, v), rs_out, voff, 0, 0);
+            } else {
             const int ox = ox0 + (wave * PB + h) * 16 + l15;
             const int o = u * 16 + 4 * kq;
             if (ox >= a.ow || o >= a.oc) return;
@@ -211,6 +253,7 @@ __global__ __launch_bounds__(NW * 64) void conv_stem_roll_kernel(const StemArgs 
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (o + q < a.oc) opix[o + q] = si_store_cast<OutT>(v[q]);
+            }
             }
         };
 
@@ -439,9 +482,12 @@ static int stemroll_launch_t(const SiConv2dDesc* d, const float* in, const float
     const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull;
     if (in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
     a.in_bytes = (unsigned)in_bytes;
+    // extent of the output as the kernel addresses it (the last pixel's row may be a view into a wider concat buffer: out_ld)
+    const unsigned long long out_bytes = ((unsigned long long)d->n * d->oh * d->ow - 1ull) * d->out_ld * 4ull + (unsigned long long)d->oc * 4ull;
+    a.out_bytes = (out_bytes < 0xFFFFFF00ull && d->out_ld % 4 == 0 && d->oc % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? (unsigned)out_bytes : 0u;
     const bool vec = d->in_ld == 3 && (d->iw * 3) % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     // the two stems of the path get their epilogue at compile time (YOLOv5: SiLU; ResNet: ReLU)
-    const bool plain = !d->has_residual && d->act2 == SI_ACT_NONE;
+    const bool plain = !d->has_residual && d->act2 == SI_ACT_NONE && a.out_bytes != 0;
     if (s.kh == 6) {
         if (stem_wide(d)) {
             if (plain && d->act1 == SI_ACT_SILU) return launch_roll<4, 5, 1, 6, 6, OutT, 1>(a, vec, st);

@@ -532,6 +532,19 @@ def test_stem_rolling_window_kernel(hops, orc, n, ih, iw, oc, k, p, act, strided
     (3, 5, 7, 32, 96, 32, (2.0, 2.0), False),       # upsampled tensor second; <= 32 output channels (the 128x32 tile)
     (1, 4, 6, 32, 32, 96, (3.0, 2.0), True),        # non-square scale: the index rule with inv = 1/3
 ])
+def test_stem_full_size_batch_position_invariance(hops):
+    """The YOLOv5s stem at its bench size (32 x 640 x 640 x 3): images 0, 1 and 31 of the batch are bit-identical to the same image
+    run alone.  (Regression: 16-byte buffer stores with an SGPR offset read their data registers late; with the next tile's
+    arithmetic right behind them 1216 of 3.3 M elements of image 31 were wrong -- and nothing at test sizes showed it.)"""
+    rng = np.random.default_rng(0)
+    x = rng.random((32, 640, 640, 3), dtype=np.float32)
+    w = (rng.random((32, 3, 6, 6), dtype=np.float32) - 0.5) * 0.3
+    b = rng.random(32, dtype=np.float32) - 0.5
+    full = hops.conv2d(x, w, b, (2, 2), (2, 2), act1="silu")
+    for i in (0, 1, 31):
+        assert_exact(hops.conv2d(x[i:i + 1], w, b, (2, 2), (2, 2), act1="silu")[0], full[i], "stem image %d alone vs in the batch" % i)
+
+
 def test_conv_reads_upsampled_source(hops, orc, n, lh, lw, cl, cs, oc, scale, up_first):
     """si_hip_conv2d_upcat_f32 against the reference's three passes restated (Upsample::Forward, Cat::Forward, the 1x1 conv): BIT
     exact versus this library's own unfused kernels on the materialised concat, within the bar of the oracle."""
