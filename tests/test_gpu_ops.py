@@ -527,11 +527,6 @@ def test_stem_rolling_window_kernel(hops, orc, n, ih, iw, oc, k, p, act, strided
         assert_exact(one[0], got[n - 1], "stem: batch position")
 
 
-@pytest.mark.parametrize("n,lh,lw,cl,cs,oc,scale,up_first", [
-    (2, 10, 10, 64, 32, 64, (2.0, 2.0), True),      # the YOLOv5 PAN form: cat([upsample(x), skip])
-    (3, 5, 7, 32, 96, 32, (2.0, 2.0), False),       # upsampled tensor second; <= 32 output channels (the 128x32 tile)
-    (1, 4, 6, 32, 32, 96, (3.0, 2.0), True),        # non-square scale: the index rule with inv = 1/3
-])
 def test_stem_full_size_batch_position_invariance(hops):
     """The YOLOv5s stem at its bench size (32 x 640 x 640 x 3): images 0, 1 and 31 of the batch are bit-identical to the same image
     run alone.  (Regression: 16-byte buffer stores with an SGPR offset read their data registers late; with the next tile's
@@ -545,6 +540,11 @@ def test_stem_full_size_batch_position_invariance(hops):
         assert_exact(hops.conv2d(x[i:i + 1], w, b, (2, 2), (2, 2), act1="silu")[0], full[i], "stem image %d alone vs in the batch" % i)
 
 
+@pytest.mark.parametrize("n,lh,lw,cl,cs,oc,scale,up_first", [
+    (2, 10, 10, 64, 32, 64, (2.0, 2.0), True),      # the YOLOv5 PAN form: cat([upsample(x), skip])
+    (3, 5, 7, 32, 96, 32, (2.0, 2.0), False),       # upsampled tensor second; <= 32 output channels (the 128x32 tile)
+    (1, 4, 6, 32, 32, 96, (3.0, 2.0), True),        # non-square scale: the index rule with inv = 1/3
+])
 def test_conv_reads_upsampled_source(hops, orc, n, lh, lw, cl, cs, oc, scale, up_first):
     """si_hip_conv2d_upcat_f32 against the reference's three passes restated (Upsample::Forward, Cat::Forward, the 1x1 conv): BIT
     exact versus this library's own unfused kernels on the materialised concat, within the bar of the oracle."""
