@@ -459,7 +459,11 @@ constexpr unsigned OOB_B = 0x80000000u;  // weights are < 2 GB; + kt*128 cannot 
 // offsets nor the per-K-tile source select
 // YOLO: the Detect form (decode + concat in the epilogue); its own instantiation, so a profile lists Detect's three launches --
 // which run on the engine's second stream beside other layers -- apart from the ordinary ones
-template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false, bool UPS = false, bool YOLO = false>
+// PW: plain pointwise layers (1x1, stride 1, no padding, whole 32-channel K blocks): a row's offset is fixed and never before
+// the tensor, so the K-tile's channel offset rides in the load's SCALAR offset and a K-tile costs no vector instruction for
+// addressing (the general form spends ~12 per K-tile on tap masks and offset adds -- on the vector issue port the short-K layers
+// are bound by)
+template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false, bool UPS = false, bool YOLO = false, bool PW = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
@@ -519,7 +523,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
                 u_off[i] = (unsigned)((img * a.up_ih + sy) * a.up_iw + sx) * (unsigned)(a.up_ld * 4) + (unsigned)(kv * 16);
             }
         }
-        if (m < a.M && a.pointwise) {
+        if (PW) {
+            a_off[i] = m < a.M ? (unsigned)m * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16) : OOB_A;
+        } else if (m < a.M && a.pointwise) {
             // 1x1, stride 1, no padding: output pixel m IS input pixel m -- no index decomposition, one always-valid tap
             a_off[i] = (unsigned)m * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16);
             a_mask[i] = 1ull;
@@ -568,6 +574,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     int cb = 0, ky = 0, kx = 0;
 
     auto load_tile = [&](int kt) {
+        if (PW) {
+            const unsigned kb = (unsigned)kt * (BK * 4);   // the K-tile's 32 channels: the same 128 bytes further in both operands
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off[i], kb, 0);
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], kb, 0);
+            return;
+        }
         const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * 32) * 4u;
         const int tapbit = ky * a.kw + kx;
         const bool cok = !PADK || cb * 32 + kv * 4 < a.icg;  // false only in the zero-padded tail block of a 1x1 conv
@@ -586,7 +600,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         }
         const unsigned kb = (unsigned)kt * (BK * 4);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i] + kb, 0, 0);
+        for (int i = 0; i < B_IT; ++i) pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], kb, 0);
         if (++kx == a.kw) {
             kx = 0;
             if (++ky == a.kh) {
@@ -720,6 +734,12 @@ int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
         else
             return SI_E_UNSUPPORTED;
     } else {
+        if constexpr (NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32))) {
+            if (a.pointwise) {   // the two default tiles have the pointwise instantiation
+                hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, false, true>), grid, dim3(256), 0, s, b);
+                return (int)hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), 0, s, b);
     }
     return (int)hipGetLastError();
@@ -1012,7 +1032,9 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         {"conv_igemm_f32_kernel<128, 64, 2, 2, false>", "conv_igemm_f32_kernel<128, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<64, 64, 2, 2, false>", "conv_igemm_f32_kernel<64, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<128, 32, 4, 1, false>", "conv_igemm_f32_kernel<128, 32, 4, 1, true>"}};
-    // exactly as rocprofv3 prints the instantiation (minus the namespace): <BM, BN, WM, WN, NBUF, PADK, UPS, YOLO>
+    // as rocprofv3 prints the instantiation (minus the namespace) up to the last argument: <BM, BN, WM, WN, NBUF, PADK, UPS, YOLO>;
+    // the trailing PW argument is left off, so a profile groups a tile's general and pointwise instantiations as ONE kernel (the
+    // same launches every earlier profile of this kernel covered)
     static const char* fast_names[11] = {
         "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 2, false, false, false>", "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 2, false, false, false>",
         "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 2, false, false, false>",   "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 2, false, false, false>",
