@@ -177,14 +177,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     u32x4 cpre[4], hpre[HR];
     // (the patch row and the channel block ride in the instruction's SCALAR offset, which the range check does not see: a lane
     // costs one select per load -- its item's offset, or the out-of-range one when that row is masked)
-    // `base` is the offset of patch row ONE (never before the tensor: pad <= 1); row 0 is one pitch below it, per lane, and only
-    // where that row exists -- the hardware adds the scalar offset in 64 bits, so a wrapped "negative" lane offset would not come back
-    auto fetch = [&](u32x4 (&dst)[4], unsigned base, unsigned rows, int cb) {
+    // Per-lane load offsets, fixed for the workgroup: patch row j of the core item (row 0 is one pitch below row 1, whose offset
+    // is never before the tensor: pad <= 1 -- the hardware adds the scalar offset in 64 bits, so a wrapped "negative" lane offset
+    // would not come back), or the out-of-range offset where that row is padding.  The patch row (rows 1..3) and the channel block
+    // ride in the SCALAR offset, which the range check does not see; a fetch past the last block goes through a descriptor of
+    // zero records (`live` false), so every staging load is issued unconditionally and costs no vector instruction.
+    unsigned c_off[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned off = ((rows >> j) & 1u) ? (j == 0 ? base - row_pitch : base) : 0xFFFFFF00u;
-            dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, (unsigned)(j == 0 ? 0 : j - 1) * row_pitch + (unsigned)(cb * CB * 4), 0);
-        }
+    for (int j = 0; j < 4; ++j) c_off[j] = ((c_rows >> j) & 1u) ? (j == 0 ? c_base - row_pitch : c_base) : 0xFFFFFF00u;
+    const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, 0, 0x00020000);
+    auto fetch = [&](u32x4 (&dst)[4], int cb, bool live) {
+        const __amdgpu_buffer_rsrc_t rs = live ? rs_in : rs_none;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, c_off[j], (unsigned)(j == 0 ? 0 : j - 1) * row_pitch + (unsigned)(cb * CB * 4), 0);
     };
     // the row half of B^T d B (winograd_helper.cpp:188-239):  r=0: d0 - d2   r=1: d1 + d2   r=2: d2 - d1   r=3: d1 - d3,
     // computed where it is stored (rows r_lo..r_hi-1 of one item: 4 channels to 4 planes each)
@@ -202,14 +208,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     auto fetch_halo = [&](int cb, bool live) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
-            const unsigned off = live ? h_off[i] : 0xFFFFFF00u;
-            hpre[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, (unsigned)(cb * CB * 4), 0);
+            hpre[i] = __builtin_amdgcn_raw_buffer_load_b128(live ? rs_in : rs_none, h_off[i], (unsigned)(cb * CB * 4), 0);
         }
     };
     // lane j of a quad:  t_j = d[ja] +- d[jb]  with (ja, jb) = (0,2) (1,2) (2,1) (1,3): two quad permutes and one fma per value
     auto store_halo = [&](int buf_off) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
+            if (wave * 64 + 256 * i >= NHALO) continue;   // (wave-uniform: a wave without halo lanes skips the permutes too)
             float t[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -256,14 +262,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     };
 
     // ---- prologue: block 0 staged, block 1 in flight, the filter values of the first RING steps requested
-    fetch(cpre, c_base, c_rows, 0);
+    fetch(cpre, 0, true);
     fetch_halo(0, true);
 #pragma unroll
     for (int i = 0; i < RING; ++i) load_b(i, 0, i);
     SI_STAMP(2);
     store_rows(cpre, c_dst, I0{}, I4{});
     store_halo(0);
-    fetch(cpre, c_base, ncb > 1 ? c_rows : 0u, 1);
+    fetch(cpre, 1, ncb > 1);
     fetch_halo(1, ncb > 1);
     __syncthreads();
     SI_STAMP(3);
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
                 // filter values wait for these loads too)
                 if (!(SI_WINO_ABLATE & 1)) {
                     const bool live = cb + 2 < ncb;
-                    fetch(cpre, c_base, live ? c_rows : 0u, cb + 2);
+                    fetch(cpre, cb + 2, live);
                     fetch_halo(cb + 2, live);
                 }
                 __syncthreads();
