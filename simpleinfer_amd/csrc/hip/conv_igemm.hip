@@ -149,6 +149,22 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[T
             const int mb = mrow0 + t * 32;
             float* const op = obase + (size_t)mb * old;
             const float* const rp = HAS_RES ? a.res + (size_t)mb * a.res_ld + oc_abs : nullptr;
+            if (ACT1 == SI_ACT_SILU && ACT2 == SI_ACT_NONE && !HAS_RES) {
+                // SiLU on PAIRS of rows with the packed fp32 instructions (v_pk_add / v_pk_mul: two values per issue slot, each
+                // component rounded exactly like the scalar form, so the bits are the scalar path's): bias add, the -log2(e)
+                // scale, the + 1 and the final product take 4 vector issues per pair instead of 8; v_exp / v_rcp stay scalar.
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int c0 = (e & 3) + 8 * (e >> 2);   // rows c0 and c0 + 1 (e and e + 1 never straddle a group of 4)
+                    const f32x2 v = f32x2{acc[t][u][e], acc[t][u][e + 1]} + f32x2{bv, bv};
+                    const f32x2 x = v * f32x2{-1.44269504088896340736f, -1.44269504088896340736f};
+                    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])} + f32x2{1.0f, 1.0f};
+                    const f32x2 o = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                    if (INTERIOR || mb + c0 < a.M) op[c0 * old] = o[0];
+                    if (INTERIOR || mb + c0 + 1 < a.M) op[(c0 + 1) * old] = o[1];
+                }
+            } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = (e & 3) + 8 * (e >> 2);  // row of the 32x32 C/D map (plus 4 * (lane >> 5), already in mrow0)
@@ -157,6 +173,7 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[T
                     if (HAS_RES) v += rp[c * a.res_ld];
                     op[c * old] = act_fn<ACT2>(v, a.act_param);
                 }
+            }
             }
         }
     }
