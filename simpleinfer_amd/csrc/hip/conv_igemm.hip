@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
                 u_off[i] = (unsigned)((img * a.up_ih + sy) * a.up_iw + sx) * (unsigned)(a.up_ld * 4) + (unsigned)(kv * 16);
             }
         }
-        if (PW) {
+        if (PW || UPS) {   // (the dual-source form is pointwise by construction)
             a_off[i] = m < a.M ? (unsigned)m * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16) : OOB_A;
         } else if (m < a.M && a.pointwise) {
             // 1x1, stride 1, no padding: output pixel m IS input pixel m -- no index decomposition, one always-valid tap
@@ -591,10 +591,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     int cb = 0, ky = 0, kx = 0;
 
     auto load_tile = [&](int kt) {
-        if (PW) {
+        if (PW || UPS) {
             const unsigned kb = (unsigned)kt * (BK * 4);   // the K-tile's 32 channels: the same 128 bytes further in both operands
+            // UPS: K-tiles [up_cb0, up_cb1) come from the low-resolution tensor at the row's source pixel (wave-uniform choice)
+            const bool from_up = UPS && kt >= a.up_cb0 && kt < a.up_cb1;
+            if (from_up) {
+                const unsigned du = (unsigned)(kt - a.up_cb0) * 128u;
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off[i], kb, 0);
+                for (int i = 0; i < A_IT; ++i) pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_up, u_off[i], du, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) pa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, a_off[i], kb, 0);
+            }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) pb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, b_off[i], kb, 0);
             return;
