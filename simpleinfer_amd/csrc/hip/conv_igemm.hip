@@ -75,6 +75,7 @@ struct ConvArgs {
     int M;                      // n*oh*ow
     int ohow;
     unsigned mg_ohow, mg_ow;    // floor(2^32 / d) for the two per-row divisions of the fast kernel's prologue (see fast_div)
+    unsigned mg_chunk;          // ... and for the block decode's division by 8 * n_tiles
     int m_tiles, n_tiles;
     int act1, act2;
     float act_param;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 
     const int g = blockIdx.y;
     const int per_chunk = 8 * a.n_tiles;
-    const int chunk = blockIdx.x / per_chunk;
+    const int chunk = fast_div((int)blockIdx.x, per_chunk, a.mg_chunk);
     const int r = blockIdx.x - chunk * per_chunk;
     const int m_tile = chunk * 8 + (r & 7);
     const int n_tile = r >> 3;
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
                 u_off[i] = (unsigned)((img * a.up_ih + sy) * a.up_iw + sx) * (unsigned)(a.up_ld * 4) + (unsigned)(kv * 16);
             }
         }
-        if (PW || UPS) {   // (the dual-source form is pointwise by construction)
+        if (PW || UPS || YOLO) {   // (the dual-source and Detect forms are pointwise by construction)
             a_off[i] = m < a.M ? (unsigned)m * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16) : OOB_A;
         } else if (m < a.M && a.pointwise) {
             // 1x1, stride 1, no padding: output pixel m IS input pixel m -- no index decomposition, one always-valid tap
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     int cb = 0, ky = 0, kx = 0;
 
     auto load_tile = [&](int kt) {
-        if (PW || UPS) {
+        if (PW || UPS || YOLO) {
             const unsigned kb = (unsigned)kt * (BK * 4);   // the K-tile's 32 channels: the same 128 bytes further in both operands
             // UPS: K-tiles [up_cb0, up_cb1) come from the low-resolution tensor at the row's source pixel (wave-uniform choice)
             const bool from_up = UPS && kt >= a.up_cb0 && kt < a.up_cb1;
@@ -734,6 +735,7 @@ int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
     ConvArgs b = a;
     b.m_tiles = (a.M + BM - 1) / BM;
     b.n_tiles = (a.ocg + BN - 1) / BN;
+    b.mg_chunk = (unsigned)(0x100000000ull / (unsigned)(8 * b.n_tiles));
     const int chunks = (b.m_tiles + 7) / 8;
     dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
     if (a.ymode) {
@@ -986,7 +988,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     }
     if (yolo) {
         // the decode epilogue lives in the fast kernel only; the layer falls back to conv + decode otherwise
-        if (!conv_fast_ok(d, in) || d->groups != 1 || d->has_residual || yolo->na * yolo->ne != d->oc) return SI_E_UNSUPPORTED;
+        if (!conv_fast_ok(d, in) || d->groups != 1 || d->has_residual || yolo->na * yolo->ne != d->oc || !a.pointwise || d->ic % 32 != 0) return SI_E_UNSUPPORTED;
         a.ymode = 1; a.yna = yolo->na; a.yne = yolo->ne; a.yrows_total = yolo->rows_total; a.yrow_off = yolo->row_off;
         a.ystride = yolo->stride; a.ygrid = ygrid; a.yanchor = yanchor;
     }
