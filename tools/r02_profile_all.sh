@@ -1,4 +1,4 @@
-export SI_COMMIT=0fe8754
+export SI_COMMIT=16c3178
 bash tools/run_rocprof.sh r02c_prof > /dev/null 2>&1
 bash tools/run_traffic.sh r02c_traffic > gpurun_out/r02c_traffic_stdout.txt 2>&1
 python bench.py > gpurun_out/r02c_bench_default.json 2> gpurun_out/r02c_bench_default.err
