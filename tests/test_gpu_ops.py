@@ -527,6 +527,36 @@ def test_stem_rolling_window_kernel(hops, orc, n, ih, iw, oc, k, p, act, strided
         assert_exact(one[0], got[n - 1], "stem: batch position")
 
 
+@pytest.mark.parametrize("n,h,w,ic,oc", [(32, 80, 80, 64, 64), (32, 40, 40, 128, 128), (32, 20, 20, 256, 256), (32, 160, 160, 32, 32),
+                                          (64, 14, 14, 256, 256), (64, 7, 7, 512, 512)])
+def test_winograd_full_size_batch_position_invariance(hops, n, h, w, ic, oc):
+    """The Winograd layers of YOLOv5s (batch 32) and ResNet18 (batch 64) at bench size: an image run alone gives the bits it has
+    inside the batch (at 256 channels the batch takes the 64-channel workgroup form and the single image the 32-channel one),
+    and two launches of the batch agree."""
+    rng = np.random.default_rng(1)
+    x = rng.random((n, h, w, ic), dtype=np.float32) - 0.5
+    wt = (rng.random((oc, ic, 3, 3), dtype=np.float32) - 0.5) * 0.2
+    b = rng.random(oc, dtype=np.float32) - 0.5
+    full = hops.conv2d_winograd(x, wt, b, (1, 1), act1="silu")
+    for i in (0, 1, n // 2, n - 1):
+        assert_exact(hops.conv2d_winograd(x[i:i + 1], wt, b, (1, 1), act1="silu")[0], full[i], "image %d alone vs in the batch" % i)
+    assert_exact(hops.conv2d_winograd(x, wt, b, (1, 1), act1="silu"), full, "run to run")
+
+
+@pytest.mark.parametrize("n,h,w,ic,oc,k,s,p", [(32, 80, 80, 128, 128, 1, 1, 0), (32, 160, 160, 64, 64, 1, 1, 0), (32, 160, 160, 32, 32, 1, 1, 0),
+                                                (32, 20, 20, 1024, 512, 1, 1, 0), (32, 80, 80, 128, 256, 3, 2, 1), (32, 320, 320, 32, 64, 3, 2, 1)])
+def test_implicit_gemm_full_size_batch_position_invariance(hops, n, h, w, ic, oc, k, s, p):
+    """The same for the implicit-GEMM kernel's pointwise and general instantiations at YOLOv5s batch-32 layer sizes."""
+    rng = np.random.default_rng(2)
+    x = rng.random((n, h, w, ic), dtype=np.float32) - 0.5
+    wt = (rng.random((oc, ic, k, k), dtype=np.float32) - 0.5) * 0.2
+    b = rng.random(oc, dtype=np.float32) - 0.5
+    full = hops.conv2d(x, wt, b, (s, s), (p, p), act1="silu")
+    for i in (0, 1, n // 2, n - 1):
+        assert_exact(hops.conv2d(x[i:i + 1], wt, b, (s, s), (p, p), act1="silu")[0], full[i], "image %d alone vs in the batch" % i)
+    assert_exact(hops.conv2d(x, wt, b, (s, s), (p, p), act1="silu"), full, "run to run")
+
+
 def test_stem_full_size_batch_position_invariance(hops):
     """The YOLOv5s stem at its bench size (32 x 640 x 640 x 3): images 0, 1 and 31 of the batch are bit-identical to the same image
     run alone.  (Regression: 16-byte buffer stores with an SGPR offset read their data registers late; with the next tile's
