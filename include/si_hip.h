@@ -153,8 +153,10 @@ const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);
  * and evaluation order), 2.25x fewer MFMA flops than the direct kernel.
  * Eligibility (shape only): 3x3, stride 1, dilation 1, groups 1, pad 0 or 1 on all sides (the reference's condition,
  * conv_2d.cpp:183-187) and ic % 16 == 0, oc % 32 == 0.  The filter is pre-transformed once with
- * si_hip_conv2d_wino23_pack_weight_host into U = G g G^T laid out [16][ic][oc] (replaces
- * Conv3x3s1Winograd23TransformKernelPack4, winograd_helper.cpp:40-143). */
+ * si_hip_conv2d_wino23_pack_weight_host into U = G g G^T, 16 * ic * oc floats in the kernel's own operand order
+ * ([plane row][ic / 16][oc / 32][step][oc % 32][ic parity][plane column]: opaque to the caller; replaces
+ * Conv3x3s1Winograd23TransformKernelPack4, winograd_helper.cpp:40-143).  `bias` must be 16-byte aligned; `out` /
+ * `residual` rows that are not get scalar stores. */
 int si_hip_conv2d_wino23_eligible(const SiConv2dDesc* d);
 /* eligible AND measured faster than si_hip_conv2d_f32 on MI355X (currently: ic >= 32) */
 int si_hip_conv2d_wino23_preferred(const SiConv2dDesc* d);
