@@ -341,7 +341,7 @@ def main():
         sf = og = None
         if gather_mode == "p2p":
             try:
-                sf = shard.ShardedForward(e, oname, group, dev, slots=3)   # collective: every rank succeeds or none does
+                sf = shard.ShardedForward(e, oname, group, dev, slots=4)   # collective: every rank succeeds or none does
             except shard.ShardError as ex:
                 if args.gather == "p2p":
                     raise

@@ -33,14 +33,15 @@ public:
     // rank.  `engine` must have a model loaded with device-resident outputs (SetOption("outputs_to_host", 0)); its
     // output operand `output_name` is re-bound into this object's gathered buffers (Engine::Output).
     Status Init(const std::string& group_name, int rank, int world, Engine* engine, const std::string& output_name,
-                int slots = 3, double timeout_s = 60.0);
+                int slots = 4, double timeout_s = 60.0);
     // engine->Forward() into this step's slot, start the fan-out of the slab to every peer (asynchronous), and complete
     // the PREVIOUS step's gather (wait for its copies + node barrier).
     Status Forward();
     // complete the gather of the last Forward()
     Status Flush();
-    // device tensor [world * b, ...] holding every rank's slab of the most recently completed step; valid until two
-    // more Forward() calls
+    // device tensor [world * b, ...] holding every rank's slab of the most recently completed step.  With the default 4
+    // slots it stays valid through the NEXT Forward() and is overwritten during the one after (a consumer may read it
+    // asynchronously while the next step computes); with 3 slots only until the next Forward() (include/si_shard.h)
     Status Gathered(Tensor& gathered) const;
     Status Release();  // collective
 

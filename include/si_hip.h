@@ -140,9 +140,19 @@ typedef struct SiConv2dUpsampledSource {
 int si_hip_conv2d_upcat_f32(const SiConv2dDesc* d, const float* in, const SiConv2dUpsampledSource* up,
                             const float* w_packed, const float* bias, float* out, int split_oc, float* out2,
                             int out2_ld, si_stream_t stream);
+/* 1 when si_hip_conv2d_upcat_f32 can serve this problem given 16-byte aligned buffers (shapes, strides, channel
+ * granularity, both tensors below 4 GiB; up->src is not looked at), else 0.  A scheduler that wants to drop the
+ * upsample launch asks this BEFORE doing so: the fused form has no fallback at Forward() time. */
+int si_hip_conv2d_upcat_supported(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up);
 /* name of the kernel instantiation si_hip_conv2d_f32 would launch for this problem (as rocprofv3 prints
  * it, minus the namespace), so profiles can be joined with per-layer timings */
 const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);
+/* Tile policy of si_hip_conv2d_f32's implicit-GEMM kernels.  The default (variant < 0) picks the workgroup tile from the
+ * launch size and the CU count (small batches run 32-row tiles on the 16x16x4 MFMA so that the chip is covered); a
+ * variant id 0..15 (table in conv_igemm.hip) forces one tile for every later launch of this process -- tuning sweeps and
+ * the tests that hold every tile to the same bits.  The tile never changes a result: all tiles accumulate an output
+ * element as one fma chain in the same k order.  Returns the previous setting. */
+int si_hip_conv2d_set_tile_variant(int variant);
 
 /* ---- Winograd F(2x2,3x3) for 3x3 stride-1 convolutions --------------------------------------------------------
  * One fused kernel replacing the reference's four-pass Conv2d::ForwardWinograd23 (src/layer/conv_2d.cpp:382-487):

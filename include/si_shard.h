@@ -15,14 +15,20 @@
  *                  links; a ring would move 7 slabs over one link per GPU).  The producer writes its slab in
  *                  place (si_gather_slab is where Engine::Output binds), so the local copy costs nothing.
  *
- * Step protocol (slot = step % slots, slots >= 3 for the overlapped form):
+ * Step protocol (slot = step % slots, slots >= 3 for the overlapped form, 4 by default):
  *     bind the engine's output to si_gather_slab(g, slot); Forward()
  *     si_gather_push(g, slot, engine_stream)        asynchronous fan-out behind the producer's work
  *     si_gather_complete(g, previous slot)          waits for MY pushes of the previous step, then the node
  *                                                    barrier: every rank's slab of that step is now in
  *                                                    si_gather_buffer(g, previous slot)
- * A consumer must be done with a completed slot before it calls si_gather_complete two more times (the slot
- * is then pushed into again).  With slots == 1 call push and complete back to back (no overlap).
+ * How long a completed slot may be read.  Call C(t) the si_gather_complete of step t (made during step t + 1).  Step
+ * s + slots is pushed into the slot of step s, and a peer may start that step as soon as it has left the barrier of
+ * C(s + slots - 2), i.e. as soon as THIS rank has ENTERED that call.  So after C(s) returns, the slot of step s is
+ * stable until this rank makes its (slots - 2)-th FURTHER si_gather_complete call: with 3 slots only until the next
+ * call (a consumer must have finished reading before the next step completes), with 4 slots -- the default of
+ * ShardedEngine / ShardedForward -- through one more whole step, the room an asynchronous consumer (device NMS on the
+ * gathered tensor while the next Forward runs) needs.  With
+ * slots == 1 call push and complete back to back (no overlap).
  *
  * Return value: 0 on success; positive hipError_t / negative SI_E_* from the HIP layer (include/si_hip.h); or
  * SI_SHARD_E_* below.

@@ -87,7 +87,7 @@ def conv_desc(x_shape, w_shape, stride=(1, 1), padding=(0, 0), dilation=(1, 1), 
 
 def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, path="auto",
            q1_bug=False, acc64=True):
-    """path: auto (reference dispatch) | im2col | winograd | naive"""
+    """path: auto (reference dispatch) | im2col | winograd | naive | chain (the device kernel's fma order)"""
     x, w_oihw = _f32(x), _f32(w_oihw)
     bias = None if bias is None else _f32(bias)
     d, oh, ow = conv_desc(x.shape, w_oihw.shape, stride, padding, dilation, groups, bias is not None)
@@ -101,6 +101,8 @@ def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
         rc = L.orc_conv2d_winograd23(C.byref(d), _p(x), _p(w_oihw), _p(bias), _p(out), 1 if q1_bug else 0)
     elif path == "naive":
         rc = L.orc_conv2d_naive(C.byref(d), _p(x), _p(w_oihw), _p(bias), _p(out), 1 if acc64 else 0)
+    elif path == "chain":   # the device implicit-GEMM kernel's fma chain (bit-exact predictor, not a reference algorithm)
+        rc = L.orc_conv2d_chain(C.byref(d), _p(x), _p(w_oihw), _p(bias), _p(out))
     else:
         raise ValueError(path)
     if rc != 0:

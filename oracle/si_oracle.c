@@ -442,6 +442,82 @@ int orc_conv2d_naive(const OrcConv2d* p, const float* in, const float* w_oihw,
     return 0;
 }
 
+/* NOT a reference algorithm: the accumulation order of the DEVICE's fp32
+ * implicit-GEMM convolution (simpleinfer_amd/csrc/hip/conv_igemm.hip),
+ * restated as a scalar fmaf chain.  gfx950's fp32 MFMAs round exactly like
+ * a sequential fma chain over k (tools/mfma_chain_test.hip), so this loop
+ * predicts the kernel's output BIT FOR BIT, whatever workgroup tile or MFMA
+ * shape a launch uses -- the instrument behind the engine's claim that an
+ * image's bits do not depend on the batch it rides in.  Order of k:
+ *   - channel-block major (c/32, kh, kw, c%32) when ic/groups is a multiple
+ *     of 32 and the kernel is larger than 1x1, else (kh, kw, c) with the
+ *     channel axis padded to x4 (x32 for ungrouped 1x1 convs whose channel
+ *     count is a multiple of 4, >= 8);
+ *   - inside every 16-wide block of that sequence: j, 4+j, 8+j, 12+j for
+ *     j = 0..3.
+ * Out-of-image taps and pad channels are fma(0, w, acc) = acc on the device
+ * and skipped here.  Bias is one separate add after the chain.
+ * Ungrouped / plain grouped convolutions only (not the merged-group, stem,
+ * depthwise or Winograd kernels, which have their own orders). */
+int orc_conv2d_chain(const OrcConv2d* p, const float* in, const float* w_oihw,
+                     const float* bias, float* out) {
+    int oh, ow;
+    orc_conv2d_out_shape(p, &oh, &ow);
+    const int G = p->groups, icg = p->ic / G, ocg = p->oc / G;
+    const int ntaps = p->kh * p->kw;
+    int icp = (icg + 3) & ~3;
+    if (ntaps == 1 && G == 1 && icg % 4 == 0 && icg % 32 != 0 && icg >= 8) icp = (icg + 31) / 32 * 32;
+    const int cbm = (icg % 32 == 0) && ntaps > 1;
+    const int Kp = ntaps * icp, Kt = (Kp + 31) / 32 * 32;
+    /* device k -> (tap, channel) or -1 */
+    int* ktap = (int*)malloc(sizeof(int) * (size_t)Kt);
+    int* kch = (int*)malloc(sizeof(int) * (size_t)Kt);
+    if (!ktap || !kch) { free(ktap); free(kch); return -1; }
+    int n = 0;
+    for (int k0 = 0; k0 < Kt; k0 += 16)
+        for (int j = 0; j < 4; ++j)
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + 4 * q + j;
+                int tap = -1, c = -1;
+                if (k < Kp) {
+                    if (cbm) {
+                        const int blk = k >> 5, cb = blk / ntaps;
+                        tap = blk - cb * ntaps;
+                        c = cb * 32 + (k & 31);
+                    } else {
+                        tap = k / icp;
+                        c = k - tap * icp;
+                    }
+                    if (c >= icg) tap = -1;
+                }
+                ktap[n] = tap;
+                kch[n] = c;
+                ++n;
+            }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < p->n; ++b)
+        for (int y = 0; y < oh; ++y)
+            for (int x = 0; x < ow; ++x)
+                for (int o = 0; o < p->oc; ++o) {
+                    const int g = o / ocg;
+                    float acc = 0.0f;
+                    for (int i = 0; i < Kt; ++i) {
+                        if (ktap[i] < 0) continue;
+                        const int ky = ktap[i] / p->kw, kx = ktap[i] - ky * p->kw;
+                        const int iy = y * p->sh - p->pt + ky * p->dh, ix = x * p->sw - p->pl + kx * p->dw;
+                        if (iy < 0 || iy >= p->ih || ix < 0 || ix >= p->iw) continue;
+                        const float a = in[(((size_t)b * p->ih + iy) * p->iw + ix) * p->ic + g * icg + kch[i]];
+                        const float wv = w_oihw[(((size_t)o * icg + kch[i]) * p->kh + ky) * p->kw + kx];
+                        acc = fmaf(a, wv, acc);
+                    }
+                    if (p->use_bias && bias) acc = acc + bias[o];
+                    out[(((size_t)b * oh + y) * ow + x) * p->oc + o] = acc;
+                }
+    free(ktap);
+    free(kch);
+    return 0;
+}
+
 /* ========================================================================
  * Other layers
  * ======================================================================== */

@@ -91,6 +91,11 @@ int orc_conv2d_winograd23(const OrcConv2d* p, const float* in,
  * with a double accumulator (acc64 != 0) or the tests' float accumulator. */
 int orc_conv2d_naive(const OrcConv2d* p, const float* in, const float* w_oihw,
                      const float* bias, float* out, int acc64);
+/* NOT a reference algorithm: the device implicit-GEMM kernel's accumulation
+ * order as a scalar fmaf chain (bit-exact predictor of conv_igemm.hip; see
+ * the definition).  */
+int orc_conv2d_chain(const OrcConv2d* p, const float* in, const float* w_oihw,
+                     const float* bias, float* out);
 
 /* ---- other layers ------------------------------------------------------- */
 

@@ -108,7 +108,9 @@ def hip():
         "si_hip_conv2d_split_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_upcat_f32": (i, [C.POINTER(SiConv2dDesc), vp, C.POINTER(SiConv2dUpsampledSource), vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_yolo_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),
+        "si_hip_conv2d_upcat_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dUpsampledSource)]),
         "si_hip_conv2d_kernel_name": (C.c_char_p, [C.POINTER(SiConv2dDesc), vp]),
+        "si_hip_conv2d_set_tile_variant": (i, [i]),
         "si_hip_linear_f32": (i, [vp, i, i, vp, vp, i, vp, vp]),
         "si_hip_maxpool2d_f32": (i, [C.POINTER(SiPool2dDesc), vp, vp, vp]),
         "si_hip_adaptive_avgpool2d_f32": (i, [vp, i, i, i, i, i, vp, i, i, i, vp]),

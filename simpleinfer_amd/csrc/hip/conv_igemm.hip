@@ -30,6 +30,8 @@
 // tile, not a different sum).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 
 #include "si_hip.h"
@@ -112,6 +114,24 @@ __device__ __forceinline__ float apply_act(int act, float v, float p) {
     }
 }
 
+// The two fp32 MFMA tiles the kernels use.  Both round like ONE sequential fma chain over k (tools/mfma_chain_test.hip, measured:
+// v_mfma_f32_32x32x2_f32, v_mfma_f32_16x16x4_f32 and a scalar fmaf loop agree bit for bit), so a kernel on 16x16 tiles that feeds
+// k in the same order as one on 32x32 tiles produces the same bits per output element -- the tile policy may follow the batch
+// size without breaking the engine's batch-invariance contract.
+//   32x32x2: A/B operand of lane l = row (l & 31), k = l >> 5;   C/D: col = l & 31, row = (e&3) + 8*(e>>2) + 4*(l>>5), 16 registers
+//   16x16x4: A/B operand of lane l = row (l & 15), k = l >> 4;   C/D: col = l & 15, row = e + 4*(l>>4),             4 registers
+template <int MT> struct Mma;
+template <> struct Mma<32> {
+    typedef f32x16 acc_t;
+    static constexpr int NE = 16;
+    __device__ static __forceinline__ constexpr int row(int e) { return (e & 3) + 8 * (e >> 2); }
+};
+template <> struct Mma<16> {
+    typedef f32x4 acc_t;
+    static constexpr int NE = 4;
+    __device__ static __forceinline__ constexpr int row(int e) { return e; }
+};
+
 // ---- epilogue shared by the kernels.  32x32 C/D map: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
 // Each store instruction writes two 128-byte row segments (lanes 0-31 / 32-63).  The activation switch
 // is resolved once per workgroup, not per element.
@@ -133,12 +153,13 @@ __device__ __forceinline__ float act_fn(float v, float p) {
 // The straight-line epilogue: one activation known at compile time, residual yes / no and "every row of the tile is inside
 // M" (all tiles but the last) resolved once per workgroup, row offsets c*ld computed once -- per element this leaves
 // bias add, activation, (residual load + add), one store.
-template <int TM, int TN, int ACT1, int ACT2, bool HAS_RES, bool INTERIOR>
-__device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0,
+template <int MT, int TM, int TN, int ACT1, int ACT2, bool HAS_RES, bool INTERIOR>
+__device__ __forceinline__ void epilogue_lean(const ConvArgs& a, typename Mma<MT>::acc_t (&acc)[TM][TN], int g, int mrow0, int ocol0,
                                               const float* bias_pre) {
+    constexpr int NE = Mma<MT>::NE;
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
-        const int o = ocol0 + u * 32;  // channel inside the group
+        const int o = ocol0 + u * MT;  // channel inside the group
         if (o >= a.ocg) continue;
         const int oc_abs = g * a.ocg + o;
         const float bv = bias_pre ? bias_pre[u] : (a.bias ? a.bias[oc_abs] : 0.0f);
@@ -147,7 +168,7 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[T
         const int old = second ? a.out2_ld : a.out_ld;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            const int mb = mrow0 + t * 32;
+            const int mb = mrow0 + t * MT;
             float* const op = obase + (size_t)mb * old;
             const float* const rp = HAS_RES ? a.res + (size_t)mb * a.res_ld + oc_abs : nullptr;
             if (ACT1 == SI_ACT_SILU && ACT2 == SI_ACT_NONE && !HAS_RES) {
@@ -156,8 +177,8 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[T
                 // scale, the + 1 and the final product take 4 vector issues per pair instead of 8; v_exp / v_rcp stay scalar.
                 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const int c0 = (e & 3) + 8 * (e >> 2);   // rows c0 and c0 + 1 (e and e + 1 never straddle a group of 4)
+                for (int e = 0; e < NE; e += 2) {
+                    const int c0 = Mma<MT>::row(e);   // rows c0 and c0 + 1 (e and e + 1 never straddle a group of 4)
                     const f32x2 v = f32x2{acc[t][u][e], acc[t][u][e + 1]} + f32x2{bv, bv};
                     const f32x2 x = v * f32x2{-1.44269504088896340736f, -1.44269504088896340736f};
                     const f32x2 d = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])} + f32x2{1.0f, 1.0f};
@@ -167,8 +188,8 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[T
                 }
             } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int c = (e & 3) + 8 * (e >> 2);  // row of the 32x32 C/D map (plus 4 * (lane >> 5), already in mrow0)
+            for (int e = 0; e < NE; ++e) {
+                const int c = Mma<MT>::row(e);  // row of the C/D map (plus 4 * (lane >> 5) or 4 * (lane >> 4), already in mrow0)
                 if (INTERIOR || mb + c < a.M) {
                     float v = act_fn<ACT1>(acc[t][u][e] + bv, a.act_param);
                     if (HAS_RES) v += rp[c * a.res_ld];
@@ -180,26 +201,26 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, f32x16 (&acc)[T
     }
 }
 
-template <int TM, int TN, int ACT1, int ACT2 = SI_ACT_NONE>
-__device__ __forceinline__ void epilogue_pick(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior,
+template <int MT, int TM, int TN, int ACT1, int ACT2 = SI_ACT_NONE>
+__device__ __forceinline__ void epilogue_pick(const ConvArgs& a, typename Mma<MT>::acc_t (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior,
                                               const float* bias_pre) {
     if (a.res) {
-        if (interior) epilogue_lean<TM, TN, ACT1, ACT2, true, true>(a, acc, g, mrow0, ocol0, bias_pre);
-        else epilogue_lean<TM, TN, ACT1, ACT2, true, false>(a, acc, g, mrow0, ocol0, bias_pre);
+        if (interior) epilogue_lean<MT, TM, TN, ACT1, ACT2, true, true>(a, acc, g, mrow0, ocol0, bias_pre);
+        else epilogue_lean<MT, TM, TN, ACT1, ACT2, true, false>(a, acc, g, mrow0, ocol0, bias_pre);
     } else {
-        if (interior) epilogue_lean<TM, TN, ACT1, ACT2, false, true>(a, acc, g, mrow0, ocol0, bias_pre);
-        else epilogue_lean<TM, TN, ACT1, ACT2, false, false>(a, acc, g, mrow0, ocol0, bias_pre);
+        if (interior) epilogue_lean<MT, TM, TN, ACT1, ACT2, false, true>(a, acc, g, mrow0, ocol0, bias_pre);
+        else epilogue_lean<MT, TM, TN, ACT1, ACT2, false, false>(a, acc, g, mrow0, ocol0, bias_pre);
     }
 }
 
 // generic epilogue: any act1 / act2 combination (runtime switches per element)
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue_generic(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0) {
+template <int MT, int TM, int TN>
+__device__ __forceinline__ void epilogue_generic(const ConvArgs& a, typename Mma<MT>::acc_t (&acc)[TM][TN], int g, int mrow0, int ocol0) {
     const bool has_bias = a.bias != nullptr;
     const bool has_res = a.res != nullptr;
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
-        const int o = ocol0 + u * 32;
+        const int o = ocol0 + u * MT;
         if (o >= a.ocg) continue;
         const int oc_abs = g * a.ocg + o;
         const float bv = has_bias ? a.bias[oc_abs] : 0.0f;
@@ -209,10 +230,10 @@ __device__ __forceinline__ void epilogue_generic(const ConvArgs& a, f32x16 (&acc
         const int old = second ? a.out2_ld : a.out_ld;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            const int mb = mrow0 + t * 32;
+            const int mb = mrow0 + t * MT;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
+            for (int e = 0; e < Mma<MT>::NE; ++e) {
+                const int m = mb + Mma<MT>::row(e);
                 if (m < a.M) {
                     float v = acc[t][u][e] + bv;
                     v = apply_act(a.act1, v, a.act_param);
@@ -274,25 +295,27 @@ __device__ __forceinline__ void epilogue_yolo(const ConvArgs& a, f32x16 (&acc)[T
 // `bias_pre`: this lane's TN bias values, loaded before the K loop (their latency is otherwise paid at the head of the
 // epilogue, by every workgroup of a round at the same time)
 // YMODE: -1 the Detect form is a runtime switch (generic kernel), 0 never, 1 always (the Detect instantiation of the fast kernel)
-template <int TM, int TN, int YMODE = -1>
-__device__ __forceinline__ void epilogue(const ConvArgs& a, f32x16 (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior = false,
+template <int TM, int TN, int YMODE = -1, int MT = 32>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, typename Mma<MT>::acc_t (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior = false,
                                          int yolo_img = -1, const float* bias_pre = nullptr) {
-    if (YMODE == 1 || (YMODE < 0 && a.ymode)) {
-        if (yolo_img >= 0) si_yolo_tile_one_image<TM, TN>(a, a.out, acc, mrow0, ocol0, yolo_img);
-        else epilogue_yolo<TM, TN>(a, acc, mrow0, ocol0);
-        return;
+    if constexpr (MT == 32) {   // (the Detect form exists on the 32x32 tile only)
+        if (YMODE == 1 || (YMODE < 0 && a.ymode)) {
+            if (yolo_img >= 0) si_yolo_tile_one_image<TM, TN>(a, a.out, acc, mrow0, ocol0, yolo_img);
+            else epilogue_yolo<TM, TN>(a, acc, mrow0, ocol0);
+            return;
+        }
     }
     // the shapes the YOLOv5 / ResNet graphs produce get straight-line code; the rest is generic
     if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_SILU) {
-        epilogue_pick<TM, TN, SI_ACT_SILU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        epilogue_pick<MT, TM, TN, SI_ACT_SILU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
     } else if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_NONE) {
-        epilogue_pick<TM, TN, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        epilogue_pick<MT, TM, TN, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior, bias_pre);
     } else if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_RELU) {
-        epilogue_pick<TM, TN, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        epilogue_pick<MT, TM, TN, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
     } else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_RELU) {  // ResNet: conv -> add -> ReLU
-        epilogue_pick<TM, TN, SI_ACT_NONE, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        epilogue_pick<MT, TM, TN, SI_ACT_NONE, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
     } else {
-        epilogue_generic<TM, TN>(a, acc, g, mrow0, ocol0);
+        epilogue_generic<MT, TM, TN>(a, acc, g, mrow0, ocol0);
     }
 }
 
@@ -430,19 +453,24 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs a) {
         const float* As = lds[cur] + (wm * TM * 32 + l31) * LDS_LD + lh * 4;
         const float* Bs = lds[cur] + BM * LDS_LD + (wn * TN * 32 + l31) * LDS_LD + lh * 4;
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            f32x4 fa[TM], fb[TN];
+        for (int p = 0; p < BK / 16; ++p) {   // the canonical k order (see the fast kernel's K-tile loop)
+            f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f32x4*>(As + t * 32 * LDS_LD + q * 8);
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f32x4*>(Bs + u * 32 * LDS_LD + q * 8);
+                for (int t = 0; t < TM; ++t) fa[h][t] = *reinterpret_cast<const f32x4*>(As + t * 32 * LDS_LD + p * 16 + h * 8);
+#pragma unroll
+                for (int u = 0; u < TN; ++u) fb[h][u] = *reinterpret_cast<const f32x4*>(Bs + u * 32 * LDS_LD + p * 16 + h * 8);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int t = 0; t < TM; ++t)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int u = 0; u < TN; ++u)
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[u][j], acc[t][u], 0, 0, 0);
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int u = 0; u < TN; ++u)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][t][j], fb[h][u][j], acc[t][u], 0, 0, 0);
         }
 
         if (kt + 1 < nk) store_tile(cur ^ 1);
@@ -481,12 +509,17 @@ constexpr unsigned OOB_B = 0x80000000u;  // weights are < 2 GB; + kt*128 cannot 
 // the tensor, so the K-tile's channel offset rides in the load's SCALAR offset and a K-tile costs no vector instruction for
 // addressing (the general form spends ~12 per K-tile on tap masks and offset adds -- on the vector issue port the short-K layers
 // are bound by)
-template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false, bool UPS = false, bool YOLO = false, bool PW = false>
+// MT: the MFMA tile, 32 (v_mfma_f32_32x32x2_f32) or 16 (v_mfma_f32_16x16x4_f32: workgroup tiles of 32 rows for launches that
+// would otherwise leave most of the chip without a wave, i.e. small batches; same bits, see Mma / the K-tile loop)
+template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false, bool UPS = false, bool YOLO = false, bool PW = false, int MT = 32>
 __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
-    constexpr int TM = BM / WM / 32;
-    constexpr int TN = BN / WN / 32;
+    static_assert(MT == 32 || MT == 16, "MFMA tile");
+    static_assert(BM % 32 == 0 && BN % 32 == 0 && BM % (WM * MT) == 0 && BN % (WN * MT) == 0, "tile shape");
+    static_assert(MT == 32 || !YOLO, "the Detect epilogue exists on the 32x32 tile only");
+    constexpr int TM = BM / WM / MT;
+    constexpr int TN = BN / WN / MT;
     constexpr int A_IT = BM / 32;
     constexpr int B_IT = BN / 32;
 
@@ -648,15 +681,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     const int wave = tid >> 6;
     const int lane = tid & 63;
     const int wm = wave / WN, wn = wave - wm * WN;
-    const int l31 = lane & 31, lh = lane >> 5;
+    const int lrow = lane & (MT - 1), lk = lane / MT;   // operand row and k slot of this lane (Mma<MT>)
 
-    f32x16 acc[TM][TN];
+    typename Mma<MT>::acc_t acc[TM][TN];
 #pragma unroll
     for (int t = 0; t < TM; ++t)
 #pragma unroll
         for (int u = 0; u < TN; ++u)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.0f;
+            for (int e = 0; e < Mma<MT>::NE; ++e) acc[t][u][e] = 0.0f;
 
     const int nk = a.Kp / BK;  // icg_pad % 32 == 0
 
@@ -665,7 +698,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     float bias_pre[TN];
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
-        const int o = n0 + wn * TN * 32 + l31 + u * 32;
+        const int o = n0 + wn * TN * MT + lrow + u * MT;
         bias_pre[u] = (a.bias && o < a.ocg) ? a.bias[g * a.ocg + o] : 0.0f;
     }
     SI_STAMP(2);
@@ -677,26 +710,52 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         const int cur = NBUF == 2 ? (kt & 1) : 0;
         if (kt + 1 < nk) load_tile(kt + 1);
 
-        const float* As = lds[cur] + (wm * TM * 32 + l31) * LDS_LD + lh * 4;
-        const float* Bs = lds[cur] + BM * LDS_LD + (wn * TN * 32 + l31) * LDS_LD + lh * 4;
+        const float* As = lds[cur] + (wm * TM * MT + lrow) * LDS_LD + lk * 4;
+        const float* Bs = lds[cur] + BM * LDS_LD + (wn * TN * MT + lrow) * LDS_LD + lk * 4;
+        // CANONICAL K ORDER (every fp32 implicit-GEMM kernel of this file, so that they agree bit for bit): inside each 16-wide
+        // block of a K-tile an output element accumulates k = j, 4+j, 8+j, 12+j for j = 0..3.  On the 16x16x4 MFMA that is one
+        // 16-byte read per operand row (lane group g = lane >> 4 reads k = 4g..4g+3; MFMA j takes register j and chains the four
+        // groups in order); on the 32x32x2 MFMA it is two reads (k = 4h.. and 8+4h.., h = lane >> 5) whose MFMAs alternate.
 #pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            f32x4 fa[TM], fb[TN];
+        for (int p = 0; p < BK / 16; ++p) {
+            if constexpr (MT == 32) {
+                f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-            for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f32x4*>(As + t * 32 * LDS_LD + q * 8);
+                for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f32x4*>(Bs + u * 32 * LDS_LD + q * 8);
-            // raised priority around the MFMA cluster: +0.5-1.2 % on YOLOv5s (same-box A/B; per cdna_hip_programming.md T5 the
-            // effect is on how hipcc places the cluster relative to the LDS reads and barriers, not the s_setprio itself)
-            __builtin_amdgcn_s_setprio(1);
+                    for (int t = 0; t < TM; ++t) fa[h][t] = *reinterpret_cast<const f32x4*>(As + t * 32 * LDS_LD + p * 16 + h * 8);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                    for (int u = 0; u < TN; ++u) fb[h][u] = *reinterpret_cast<const f32x4*>(Bs + u * 32 * LDS_LD + p * 16 + h * 8);
+                }
+                // raised priority around the MFMA cluster: +0.5-1.2 % on YOLOv5s (same-box A/B; per cdna_hip_programming.md T5 the
+                // effect is on how hipcc places the cluster relative to the LDS reads and barriers, not the s_setprio itself)
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int t = 0; t < TM; ++t)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int u = 0; u < TN; ++u)
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t][j], fb[u][j], acc[t][u], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int t = 0; t < TM; ++t)
+#pragma unroll
+                            for (int u = 0; u < TN; ++u)
+                                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[h][t][j], fb[h][u][j], acc[t][u], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                f32x4 fa[TM], fb[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f32x4*>(As + t * 16 * LDS_LD + p * 16);
+#pragma unroll
+                for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f32x4*>(Bs + u * 16 * LDS_LD + p * 16);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int u = 0; u < TN; ++u)
+                            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t][j], fb[u][j], acc[t][u], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
         }
 
         if (NBUF == 2) {
@@ -718,7 +777,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         const int img = m0 / a.ohow;
         if (m0 - img * a.ohow + BM <= a.ohow) yolo_img = img;
     }
-    epilogue<TM, TN, YOLO ? 1 : 0>(a, acc, g, m0 + wm * TM * 32 + 4 * lh, n0 + wn * TN * 32 + l31, m0 + BM <= a.M, yolo_img, bias_pre);
+    epilogue<TM, TN, YOLO ? 1 : 0, MT>(a, acc, g, m0 + wm * TM * MT + 4 * lk, n0 + wn * TN * MT + lrow, m0 + BM <= a.M, yolo_img, bias_pre);
     SI_STAMP(5);
     SI_STAMP_RT(6);
     SI_STAMP_FLUSH(si_diag_stamps);
@@ -730,7 +789,7 @@ SI_STAMP_ACCESSORS(si_diag_stamps, si_hip_diag_stamps_read, si_hip_diag_stamps_c
 namespace {
 #endif
 
-template <int BM, int BN, int WM, int WN, int NBUF>
+template <int BM, int BN, int WM, int WN, int NBUF, int MT = 32>
 int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
     ConvArgs b = a;
     b.m_tiles = (a.M + BM - 1) / BM;
@@ -738,36 +797,38 @@ int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
     b.mg_chunk = (unsigned)(0x100000000ull / (unsigned)(8 * b.n_tiles));
     const int chunks = (b.m_tiles + 7) / 8;
     dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
+    // the tiles that carry every instantiation (pointwise / dual-source / zero-padded K): the two defaults and the 16x16-MFMA ones
+    constexpr bool kFull = (MT == 32 && NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32))) || MT == 16;
     if (a.ymode) {
         // Detect: the default tile only
-        if constexpr (NBUF == 1 && BM == 64 && BN == 64) {
+        if constexpr (MT == 32 && NBUF == 1 && BM == 64 && BN == 64) {
             if (a.icg % 32 != 0 || a.up) return SI_E_UNSUPPORTED;
             hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, true>), grid, dim3(256), 0, s, b);
         } else {
             return SI_E_UNSUPPORTED;
         }
     } else if (a.up) {
-        // dual-source pointwise conv (consumer of cat(upsample(x), skip)): the two default tiles only
-        if constexpr (NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32))) {
+        // dual-source pointwise conv (consumer of cat(upsample(x), skip))
+        if constexpr (kFull) {
             if (a.icg % 32 != 0 || !a.pointwise) return SI_E_UNSUPPORTED;
-            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, true>), grid, dim3(256), 0, s, b);
+            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, true, false, false, MT>), grid, dim3(256), 0, s, b);
         } else {
             return SI_E_UNSUPPORTED;
         }
     } else if (a.icg % 32 != 0) {
-        // zero-padded K (1x1 convs with a channel count that is not a multiple of 32): the two default tiles carry the check
-        if constexpr (NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32)))
-            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, true>), grid, dim3(256), 0, s, b);
+        // zero-padded K (1x1 convs with a channel count that is not a multiple of 32)
+        if constexpr (kFull)
+            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, true, false, false, false, MT>), grid, dim3(256), 0, s, b);
         else
             return SI_E_UNSUPPORTED;
     } else {
-        if constexpr (NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32))) {
-            if (a.pointwise) {   // the two default tiles have the pointwise instantiation
-                hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, false, true>), grid, dim3(256), 0, s, b);
+        if constexpr (kFull) {
+            if (a.pointwise) {
+                hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, false, true, MT>), grid, dim3(256), 0, s, b);
                 return (int)hipGetLastError();
             }
         }
-        hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF>), grid, dim3(256), 0, s, b);
+        hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, false, false, MT>), grid, dim3(256), 0, s, b);
     }
     return (int)hipGetLastError();
 }
@@ -797,16 +858,64 @@ inline int round_up4(int v) { return (v + 3) & ~3; }
 // when a layer only has a few hundred tiles; it beats the 128x128 double-buffered tile on every shape
 // (6.7 ms vs 10.6 ms summed over the net).  Layers with <= 32 output channels use 128x32.
 //   id: 0 128x128x2  1 128x64x2  2 64x64x2  3 128x32x2  4 64x64x1  5 64x128x1  6 128x64x1  7 128x128x1
-//       8 64x128x2  10 128x32x1        (BM x BN x LDS stages)
-static int conv_variant(const SiConv2dDesc* d) {
-    static const int forced = [] {
-        const char* e = getenv("SI_CONV_VARIANT");  // development override
-        return e ? atoi(e) : -1;
+//       8 64x128x2  10 128x32x1        (BM x BN x LDS stages; 32x32x2 MFMA)
+//       11 32x64x2  12 32x32x2  13 32x64x1  14 32x32x1  15 64x32x2  16 64x32x1  17 64x64x1  18 32x128x1     (16x16x4 MFMA, round 3)
+static constexpr int kConvVariants = 19;
+static int si_cu_count() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
     }();
-    if (forced >= 0 && forced <= 10) return forced;
-    const int ocg = d->oc / d->groups;
-    return ocg <= 32 ? 10 : 4;
+    return cus;
 }
+static std::atomic<int> g_forced_variant{-2};   // -2: not yet initialised from the environment, -1: policy
+static int conv_forced_variant() {
+    int v = g_forced_variant.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char* e = getenv("SI_CONV_VARIANT");  // development override
+        v = e ? atoi(e) : -1;
+        if (v < 0 || v >= kConvVariants || v == 9) v = -1;
+        int expected = -2;
+        g_forced_variant.compare_exchange_strong(expected, v);
+        v = g_forced_variant.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+// The policy (round 3; tools/tile_sweep.py on MI355X, sustained, every YOLOv5s implicit-GEMM shape at batch 4 / 8 / 16 / 32:
+// profiles/r03_tile_sweep.txt).  What decides is how many workgroups a launch has against the 256 CUs, counted in 64x64 tiles:
+//   * >= 4800 tiles: the 64x64 tile, on the 16x16x4 MFMA (four accumulator chains per wave instead of one: the large 3x3
+//     stride-2 layers run 3-6 % faster than on the 32x32x2 MFMA, the rest the same);
+//   * 1200 .. 4800: half tiles -- 64x32 for pointwise layers, 32x64 for the others (2-6 % over 64x64);
+//   * below: 32x32 (a 20x20 layer at batch 32 has 800 64x64-tiles, at batch 4 a hundred: -14 % ... -40 %), except 3x3 layers
+//     with 600+ tiles, which still prefer 32x64;
+//   * <= 32 output channels per group: 64x32.
+// Whatever is chosen, the bits are the same (Mma, tests/test_gpu_tiles.py).
+static int conv_variant(const SiConv2dDesc* d) {
+    const int forced = conv_forced_variant();
+    if (forced >= 0) return forced;
+    const int ocg = d->oc / d->groups;
+    if (ocg <= 32) return 16;
+    const long long M = (long long)d->n * d->oh * d->ow;
+    const long long tiles64 = ((M + 63) / 64) * ((ocg + 63) / 64) * d->groups;
+    const bool pointwise = d->kh == 1 && d->kw == 1;
+    // (thresholds in units of the 256-CU part they were measured on)
+    const long long cus = si_cu_count();
+    if (tiles64 * 256 >= 4800 * cus) return 17;
+    if (tiles64 * 256 >= 1200 * cus) return pointwise ? 16 : 13;
+    if (!pointwise && tiles64 * 256 >= 600 * cus) return 13;
+    return 14;
+}
+// the generic kernel (any channel count) has four tiles: 0 128x128, 1 128x64, 2 64x64, 3 128x32; a forced variant maps to the
+// nearest one, the policy is the round-1 rule (these layers are latency / HBM bound)
+static int conv_generic_tile(const SiConv2dDesc* d) {
+    static const int generic_of[kConvVariants] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2};
+    const int forced = conv_forced_variant();
+    if (forced >= 0) return generic_of[forced];
+    return (d->oc / d->groups) <= 32 ? 3 : 2;
+}
+// the variants that have the pointwise / dual-source / zero-padded-K instantiations (launch_fast: kFull)
+static bool conv_variant_full(int v) { return v == 4 || v == 10 || (v >= 11 && v < kConvVariants); }
 
 // General grouped convolution with few channels per group (ForwardIm2ColWithGroup, reference src/layer/conv_2d.cpp:285-380: one
 // Eigen expression per group): 4, 8 or 16 input channels per group.  G = 32 / (ic / groups) neighbouring groups are contiguous
@@ -911,6 +1020,22 @@ extern "C" int si_hip_conv2d_pack_weight_host(const SiConv2dDesc* d, const float
     return 0;
 }
 
+// everything si_hip_conv2d_upcat_f32 requires of a problem EXCEPT the pointers' alignment (shape-only, so a scheduler can ask
+// before any buffer exists): a plain pointwise conv on the fast path, 32-channel granularity, both tensors below 4 GiB
+static bool conv_upcat_shape_ok(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up) {
+    if (!d || !up || d->groups != 1 || d->ic <= 0 || d->oc <= 0) return false;
+    const bool pointwise = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow;
+    if (!pointwise || d->has_residual) return false;
+    if (up->c <= 0 || up->c % 32 != 0 || up->c0 % 32 != 0 || up->c0 + up->c > d->ic || up->ld % 4 != 0 || up->ih <= 0 || up->iw <= 0) return false;
+    if (!conv_fast_ok(d, nullptr)) return false;   // (a null pointer is 16-byte aligned: sizes, strides and channel counts only)
+    const unsigned long long ub = (unsigned long long)d->n * up->ih * up->iw * up->ld * 4ull;
+    return ub < 0xFFFFFF00ull;
+}
+
+extern "C" int si_hip_conv2d_upcat_supported(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up) {
+    return conv_upcat_shape_ok(d, up) ? 1 : 0;
+}
+
 struct SplitOut {
     float* out2;
     int out2_ld, split;
@@ -974,11 +1099,9 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     a.up = nullptr; a.up_ih = a.up_iw = a.up_ld = a.up_cb0 = a.up_cb1 = 0; a.up_inv_h = a.up_inv_w = 0.f; a.up_bytes = 0;
     if (up) {
         // channels [c0, c0 + c) of this 1x1 conv's input are nn.Upsample(nearest) of up->src: read them at the source
-        if (!up->src || !a.pointwise || d->groups != 1 || yolo || up->c <= 0 || up->c % 32 != 0 || up->c0 % 32 != 0 || up->c0 + up->c > d->ic ||
-            up->ld % 4 != 0 || (reinterpret_cast<uintptr_t>(up->src) & 15) != 0 || up->ih <= 0 || up->iw <= 0 || !conv_fast_ok(d, in))
+        if (!up->src || yolo || !conv_upcat_shape_ok(d, up) || (reinterpret_cast<uintptr_t>(up->src) & 15) != 0 || !conv_fast_ok(d, in))
             return SI_E_UNSUPPORTED;
         const unsigned long long ub = (unsigned long long)d->n * up->ih * up->iw * up->ld * 4ull;
-        if (ub >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
         a.up = up->src; a.up_ih = up->ih; a.up_iw = up->iw; a.up_ld = up->ld; a.up_cb0 = up->c0 / 32; a.up_cb1 = (up->c0 + up->c) / 32;
         a.up_inv_h = up->inv_scale_h; a.up_inv_w = up->inv_scale_w; a.up_bytes = (unsigned)ub;
     }
@@ -997,7 +1120,9 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
         a.in_bytes = (unsigned)((unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull);
         hipStream_t fs = static_cast<hipStream_t>(stream);
         // a zero-padded K axis only exists in the two default tiles (SI_CONV_VARIANT is ignored for those layers)
-        const int variant = a.ymode ? 4 : (a.icg % 32 != 0 || a.up) ? ((d->oc / d->groups) <= 32 ? 10 : 4) : conv_variant(d);
+        int variant = conv_variant(d);
+        if (a.ymode) variant = 4;   // Detect: the default tile only
+        else if ((a.icg % 32 != 0 || a.up) && !conv_variant_full(variant)) variant = (d->oc / d->groups) <= 32 ? 10 : 4;
         switch (variant) {
             case 0: return launch_fast<128, 128, 2, 2, 2>(a, d->groups, fs);
             case 1: return launch_fast<128, 64, 2, 2, 2>(a, d->groups, fs);
@@ -1008,6 +1133,14 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
             case 6: return launch_fast<128, 64, 2, 2, 1>(a, d->groups, fs);
             case 7: return launch_fast<128, 128, 2, 2, 1>(a, d->groups, fs);
             case 8: return launch_fast<64, 128, 2, 2, 2>(a, d->groups, fs);
+            case 11: return launch_fast<32, 64, 2, 2, 2, 16>(a, d->groups, fs);
+            case 12: return launch_fast<32, 32, 2, 2, 2, 16>(a, d->groups, fs);
+            case 13: return launch_fast<32, 64, 2, 2, 1, 16>(a, d->groups, fs);
+            case 14: return launch_fast<32, 32, 2, 2, 1, 16>(a, d->groups, fs);
+            case 15: return launch_fast<64, 32, 2, 2, 2, 16>(a, d->groups, fs);
+            case 16: return launch_fast<64, 32, 2, 2, 1, 16>(a, d->groups, fs);
+            case 17: return launch_fast<64, 64, 2, 2, 1, 16>(a, d->groups, fs);
+            case 18: return launch_fast<32, 128, 2, 2, 1, 16>(a, d->groups, fs);
             default: return launch_fast<128, 32, 4, 1, 1>(a, d->groups, fs);
         }
     }
@@ -1015,10 +1148,10 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
     const bool vec_a = conv_vec_a(d, in);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int G = d->groups;
-    switch (conv_variant(d)) {
-        case 0: case 7: return launch<128, 128, 2, 2>(a, G, vec_a, s);
-        case 1: case 6: return launch<128, 64, 2, 2>(a, G, vec_a, s);
-        case 2: case 4: case 5: case 8: return launch<64, 64, 2, 2>(a, G, vec_a, s);
+    switch (conv_generic_tile(d)) {
+        case 0: return launch<128, 128, 2, 2>(a, G, vec_a, s);
+        case 1: return launch<128, 64, 2, 2>(a, G, vec_a, s);
+        case 2: return launch<64, 64, 2, 2>(a, G, vec_a, s);
         default: return launch<128, 32, 4, 1>(a, G, vec_a, s);
     }
 }
@@ -1052,6 +1185,12 @@ extern "C" int si_hip_conv2d_yolo_f32(const SiConv2dDesc* d, const float* in, co
     return conv2d_dispatch(d, in, w_packed, bias, nullptr, detect_out, stream, level, grid_hwa2, anchor_hwa2);
 }
 
+extern "C" int si_hip_conv2d_set_tile_variant(int variant) {
+    const int prev = conv_forced_variant();
+    g_forced_variant.store((variant >= 0 && variant < kConvVariants && variant != 9) ? variant : -1, std::memory_order_relaxed);
+    return prev;
+}
+
 extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in) {
     if (!d || d->groups <= 0) return "invalid";
     static const char* names[4][2] = {
@@ -1059,26 +1198,31 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
         {"conv_igemm_f32_kernel<128, 64, 2, 2, false>", "conv_igemm_f32_kernel<128, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<64, 64, 2, 2, false>", "conv_igemm_f32_kernel<64, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<128, 32, 4, 1, false>", "conv_igemm_f32_kernel<128, 32, 4, 1, true>"}};
-    // as rocprofv3 prints the instantiation (minus the namespace) up to the last argument: <BM, BN, WM, WN, NBUF, PADK, UPS, YOLO>;
-    // the trailing PW argument is left off, so a profile groups a tile's general and pointwise instantiations as ONE kernel (the
-    // same launches every earlier profile of this kernel covered)
-    static const char* fast_names[11] = {
-        "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 2, false, false, false>", "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 2, false, false, false>",
-        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 2, false, false, false>",   "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 2, false, false, false>",
-        "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false>",   "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 1, false, false, false>",
-        "conv_igemm_f32_fast_kernel<128, 64, 2, 2, 1, false, false, false>",  "conv_igemm_f32_fast_kernel<128, 128, 2, 2, 1, false, false, false>",
-        "conv_igemm_f32_fast_kernel<64, 128, 2, 2, 2, false, false, false>",  "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, false, false>",
-        "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, false, false>"};
+    // as rocprofv3 prints the instantiation (minus the namespace) up to the YOLO argument: <BM, BN, WM, WN, NBUF, PADK, UPS, YOLO>;
+    // the trailing PW and MT arguments are left off, so a profile groups a tile's general and pointwise instantiations as ONE
+    // kernel (the same launches every earlier profile of this kernel covered); the 16x16-MFMA tiles are told apart by BM
+    static const int tile_of[kConvVariants][5] = {{128, 128, 2, 2, 2}, {128, 64, 2, 2, 2}, {64, 64, 2, 2, 2}, {128, 32, 4, 1, 2}, {64, 64, 2, 2, 1},
+                                                  {64, 128, 2, 2, 1},  {128, 64, 2, 2, 1}, {128, 128, 2, 2, 1}, {64, 128, 2, 2, 2}, {128, 32, 4, 1, 1},
+                                                  {128, 32, 4, 1, 1},  {32, 64, 2, 2, 2},  {32, 32, 2, 2, 2}, {32, 64, 2, 2, 1},  {32, 32, 2, 2, 1},
+                                                  {64, 32, 2, 2, 2},   {64, 32, 2, 2, 1},   {64, 64, 2, 2, 1}, {32, 128, 2, 2, 1}};
+    static char fast_names[kConvVariants][2][96];
+    static const bool named = [] {
+        for (int v = 0; v < kConvVariants; ++v)
+            for (int pk = 0; pk < 2; ++pk)
+                snprintf(fast_names[v][pk], sizeof(fast_names[v][pk]), "conv_igemm_f32_fast_kernel<%d, %d, %d, %d, %d, %s, false, false>", tile_of[v][0],
+                         tile_of[v][1], tile_of[v][2], tile_of[v][3], tile_of[v][4], pk ? "true" : "false");
+        return true;
+    }();
+    (void)named;
     if (si_conv_smallc_ok(d)) return si_conv_smallc_name(d);
     if (si_conv_depthwise_ok(d)) return si_conv_depthwise_name(d);
     SiConv2dDesc eff = conv_effective(d);
     d = &eff;
-    const int v = conv_variant(d);
+    int v = conv_variant(d);
     if (conv_fast_ok(d, in)) {
-        if ((d->ic / d->groups) % 32 != 0)   // zero-padded K: the PADK instantiations of the two default tiles
-            return (d->oc / d->groups) <= 32 ? "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, true, false, false>" : "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, true, false, false>";
-        return fast_names[v];
+        const bool padk = (d->ic / d->groups) % 32 != 0;   // zero-padded K: the PADK instantiation (kFull tiles only)
+        if (padk && !conv_variant_full(v)) v = (d->oc / d->groups) <= 32 ? 10 : 4;
+        return fast_names[v][padk ? 1 : 0];
     }
-    static const int generic_of[11] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3};
-    return names[generic_of[v]][conv_vec_a(d, in) ? 1 : 0];
+    return names[conv_generic_tile(d)][conv_vec_a(d, in) ? 1 : 0];
 }

@@ -21,6 +21,9 @@ namespace SimpleInfer {
 
 namespace {
 
+// option "streams" = 0 (auto): two lanes from this batch on
+constexpr int kAutoLanesMinBatch = 1 << 30;
+
 // built-in operator types whose kernels honour a pixel stride on inputs and outputs
 bool HonoursPixelStride(const std::string& type) {
     static const std::set<std::string> ok = {
@@ -57,6 +60,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
+    else if (key == "streams") opt_streams_ = value;  // 2: two half-batch lanes on two streams, 1: one stream, 0 (default): auto
     else {
         LOG(ERROR) << "unknown engine option [" << key << "]";
         return Status::kUnsupport;
@@ -100,8 +104,31 @@ Status EngineImpl::LoadModel(const std::string& parampath, const std::string& bi
             return ret;
         }
     }
-    const Stage stages[] = {{"CreateTensorNodes", &EngineImpl::CreateTensorNodes},
-                            {"CreateLayers", &EngineImpl::CreateLayers},
+    param_path_ = parampath;
+    bin_path_ = binpath;
+    {
+        Status ret = CreateTensorNodes();
+        if (Status::kSuccess != ret) {
+            LOG(ERROR) << "CreateTensorNodes fail";
+            Release();
+            return ret;
+        }
+    }
+    int lanes = 1;
+    {
+        Status ret = PlanLanes(lanes);
+        if (Status::kSuccess == ret && lanes > 1) {
+            ret = LoadLanes(lanes);
+            if (Status::kSuccess == ret) ret = AllocateTensorMemory();   // graph inputs / outputs only: the lanes own the rest
+        }
+        if (Status::kSuccess != ret) {
+            LOG(ERROR) << "lane setup fail";
+            Release();
+            return ret;
+        }
+        if (lanes > 1) return Status::kSuccess;
+    }
+    const Stage stages[] = {{"CreateLayers", &EngineImpl::CreateLayers},
                             {"CreatePipeline", &EngineImpl::CreatePipeline},
                             {"AllocateTensorMemory", &EngineImpl::AllocateTensorMemory}};
     for (const Stage& s : stages) {
@@ -123,6 +150,8 @@ Status EngineImpl::LoadModel(const std::string& parampath, const std::string& bi
 
 Status EngineImpl::Release() {
     if (context_ && context_->stream()) si_hip_stream_sync(context_->stream());
+    CHECK_STATUS(DestroyGraphCache());   // (a captured graph references the lanes' streams and buffers)
+    CHECK_STATUS(DestroyLanes());
     CHECK_STATUS(DeallocateTensorMemory());
     CHECK_STATUS(DestroyPipeline());
     CHECK_STATUS(DestroyLayers());
@@ -413,9 +442,16 @@ Status EngineImpl::PlanDetectStream() {
     return Status::kSuccess;
 }
 
-Status EngineImpl::DestroyPipeline() {
+// A cached graph exec may still be in flight (ForwardAsync without Sync): wait for the stream before destroying any.
+Status EngineImpl::DestroyGraphCache() {
+    if (!graph_cache_.empty() && context_ && context_->stream()) si_hip_stream_sync(context_->stream());
     for (auto& g : graph_cache_) si_hip_graph_destroy(g.second);
     graph_cache_.clear();
+    return Status::kSuccess;
+}
+
+Status EngineImpl::DestroyPipeline() {
+    CHECK_STATUS(DestroyGraphCache());
     forward_count_ = 0;
     plan_.clear();
     fused_ops_.clear();
@@ -622,7 +658,7 @@ Status EngineImpl::FuseUpsampleIntoConvs(std::vector<Step>& order) {
             if (!c || c->type != "nn.Conv2d") { ok = false; break; }
             if (sibling_ops_.count(c->name)) continue;
             Conv2d* conv = index.count(c) ? dynamic_cast<Conv2d*>(order[index[c]].layer) : nullptr;
-            if (!conv || !conv->CanReadUpsampled(c0, us[3]) || conv->UpsampledSource()) { ok = false; break; }
+            if (!conv || conv->UpsampledSource() || !conv->CanReadUpsampledFrom(up->InputNodes()[0], c0, up->scale_factor_h_, up->scale_factor_w_)) { ok = false; break; }
             readers.push_back(conv);
         }
         // ... and every sibling-fused secondary must have its primary among them
@@ -742,6 +778,7 @@ Status EngineImpl::AllocateTensorMemory() {
         const std::string& name = kv.first;
         Tensor& t = kv.second->tensor;
         if (dead_operands_.count(name) || aliases_.count(name)) continue;
+        if (!lanes_.empty() && !input_tensor_nodes_.count(name) && !output_tensor_nodes_.count(name)) continue;   // the lanes own the intermediates
         const size_t bytes = t.ByteSize();
         if (bytes == 0) {
             LOG(ERROR) << "operand [" << name << "] has no static shape";
@@ -840,6 +877,116 @@ Status EngineImpl::DeallocateTensorMemory() {
     return Status::kSuccess;
 }
 
+
+// ---- lanes (option "streams") ---------------------------------------------------------------------
+// Two half-batch engines on two streams instead of one full-batch engine on one: while one lane is in a layer's tail (the last,
+// partial round of workgroups, the epilogue stores) the other lane's workgroups fill the idle CUs.  Measured on MI355X,
+// YOLOv5s batch 32, same box, hipGraph replay: +4.9 % (tools/two_stream_exp.py).  Every operator of the
+// path is per-image, so a lane is simply this model re-batched to N / 2 (the "batch" option's rule) that reads
+// and writes slab views of this engine's input and output buffers; results are bit-identical to the one-stream schedule because
+// no kernel's per-element arithmetic depends on the batch (tests/test_gpu_tiles.py, tests/test_gpu_engine.py).
+Status EngineImpl::PlanLanes(int& lanes) {
+    lanes = 1;
+    if (is_lane_ || opt_streams_ == 1) return Status::kSuccess;
+    int batch = 0;
+    bool ok = !input_tensor_nodes_.empty() && !output_tensor_nodes_.empty();
+    for (auto& kv : input_tensor_nodes_) {
+        const std::vector<int>& sh = kv.second->tensor.Shape();
+        if (sh.size() < 2 || (batch != 0 && sh[0] != batch)) ok = false;
+        else batch = sh[0];
+    }
+    for (auto& kv : output_tensor_nodes_) {
+        const std::vector<int>& sh = kv.second->tensor.Shape();
+        if (sh.size() < 2 || sh[0] != batch) ok = false;
+    }
+    ok = ok && batch >= 2 && batch % 2 == 0;
+    if (opt_streams_ >= 2) {
+        if (!ok) {
+            LOG(ERROR) << "streams=2 needs an even batch that is dimension 0 of every graph input and output";
+            return Status::kUnsupport;
+        }
+        lanes = 2;
+        return Status::kSuccess;
+    }
+    // auto: where the same-box A/B wins (profiles/r03_ab_streams.txt)
+    if (ok && batch >= kAutoLanesMinBatch) lanes = 2;
+    return Status::kSuccess;
+}
+
+Status EngineImpl::LoadLanes(int lanes) {
+    int batch = input_tensor_nodes_.begin()->second->tensor.Shape()[0];
+    for (int l = 0; l < lanes; ++l) {
+        EngineImpl* lane = new EngineImpl;
+        lanes_.push_back(lane);
+        lane->is_lane_ = true;
+        lane->opt_device_ = context_->device();
+        lane->opt_fuse_ = opt_fuse_;
+        lane->opt_alias_cat_ = opt_alias_cat_;
+        lane->opt_fuse_upsample_ = opt_fuse_upsample_;
+        lane->opt_arena_ = opt_arena_;
+        lane->opt_winograd_ = opt_winograd_;
+        lane->opt_detect_stream_ = opt_detect_stream_;
+        lane->opt_fp16_ = opt_fp16_;
+        lane->opt_graph_ = false;             // this engine captures both lanes in ONE graph
+        lane->opt_outputs_to_host_ = false;   // ... and owns the host mirrors
+        lane->opt_streams_ = 1;
+        lane->opt_batch_ = batch / lanes;
+        CHECK_STATUS(lane->LoadModel(param_path_, bin_path_));
+        si_event_t ev = nullptr;
+        SI_TRY_HIP(si_hip_event_create(&ev), "event create");
+        lane_done_.push_back(ev);
+    }
+    if (!ev_fork_) SI_TRY_HIP(si_hip_event_create(&ev_fork_), "event create");
+    LOG(INFO) << "streams: " << lanes << " lanes of batch " << batch / lanes;
+    return Status::kSuccess;
+}
+
+Status EngineImpl::DestroyLanes() {
+    for (EngineImpl* lane : lanes_) delete lane;
+    lanes_.clear();
+    for (si_event_t ev : lane_done_) si_hip_event_destroy(ev);
+    lane_done_.clear();
+    return Status::kSuccess;
+}
+
+namespace {
+// lane `l` of `n`: the contiguous slab of images [l * N / n, (l + 1) * N / n) of a batch-major tensor, as a non-owning view
+Tensor SlabView(const Tensor& t, int l, int n) {
+    std::vector<int> shape = t.Shape();
+    const size_t rows = t.NumElements() / (size_t)shape.back();   // pixels (rank 4) / rows of the last dimension
+    const size_t slab_bytes = rows / (size_t)n * (size_t)t.PixelStride() * ElementSize(t.GetDataType());
+    shape[0] /= n;
+    Tensor v(t.GetDataType(), shape, MemoryType::kDevice, false);
+    v.SetView(static_cast<char*>(t.RawData()) + (size_t)l * slab_bytes, MemoryType::kDevice, t.PixelStride() == t.Shape().back() ? 0 : t.PixelStride());
+    return v;
+}
+}  // namespace
+
+// hand every lane its slab of the (already resolved) input and output tensors of this engine
+Status EngineImpl::BindLanes() {
+    const int n = (int)lanes_.size();
+    for (int l = 0; l < n; ++l) {
+        for (auto& kv : input_tensor_nodes_) CHECK_STATUS(lanes_[l]->Input(kv.first, SlabView(kv.second->tensor, l, n)));
+        for (auto& kv : output_tensor_nodes_) CHECK_STATUS(lanes_[l]->Output(kv.first, SlabView(kv.second->tensor, l, n)));
+    }
+    return Status::kSuccess;
+}
+
+// fork: every lane's stream waits for this engine's stream (the input upload); join: this stream waits for every lane.  Under
+// hipGraph capture the lanes' streams join the capture through the fork event, so ONE replayed graph holds both branches.
+Status EngineImpl::LaunchLanes() {
+    si_stream_t stream = context_->stream();
+    SI_TRY_HIP(si_hip_event_record(ev_fork_, stream), "event record");
+    for (size_t l = 0; l < lanes_.size(); ++l) {
+        SI_TRY_HIP(si_hip_stream_wait_event(lanes_[l]->context_->stream(), ev_fork_), "stream wait");
+        CHECK_STATUS(lanes_[l]->ForwardAsync());
+        lanes_[l]->forward_pending_ = false;   // (the lane's own start / stop events may sit inside a capture: never read)
+        SI_TRY_HIP(si_hip_event_record(lane_done_[l], lanes_[l]->context_->stream()), "event record");
+    }
+    for (size_t l = 0; l < lanes_.size(); ++l) SI_TRY_HIP(si_hip_stream_wait_event(stream, lane_done_[l]), "stream wait");
+    return Status::kSuccess;
+}
+
 // ---- I/O -----------------------------------------------------------------------------------------
 const std::vector<std::string> EngineImpl::InputNames() {
     std::vector<std::string> ret;
@@ -929,6 +1076,7 @@ Status EngineImpl::UploadInputs() {
 }
 
 Status EngineImpl::LaunchAll() {
+    if (!lanes_.empty()) return LaunchLanes();
     YoloDetect* early_detect = nullptr;   // the Detect layer with levels in flight on the side stream
     for (size_t i = 0; i < plan_.size(); ++i) {
         const Step& s = plan_[i];
@@ -975,7 +1123,7 @@ Status EngineImpl::Sync() {
 }
 
 Status EngineImpl::ForwardAsync() {
-    if (nullptr == context_ || plan_.empty()) {
+    if (nullptr == context_ || (plan_.empty() && lanes_.empty())) {
         LOG(ERROR) << "Forward before a successful LoadModel";
         return Status::kFail;
     }
@@ -983,6 +1131,7 @@ Status EngineImpl::ForwardAsync() {
     si_stream_t stream = context_->stream();
     CHECK_STATUS(UploadInputs());
     CHECK_STATUS(BindOutputs());
+    if (!lanes_.empty()) CHECK_STATUS(BindLanes());
 
     SI_TRY_HIP(si_hip_event_record(ev_start_, stream), "event record");
     if (opt_graph_ && forward_count_ > 0) {
@@ -1006,6 +1155,8 @@ Status EngineImpl::ForwardAsync() {
             SI_TRY_HIP(rc, "end capture");
             constexpr size_t kMaxGraphs = 8;
             if (graph_cache_.size() >= kMaxGraphs) {
+                // the evicted exec may be the one a not-yet-synchronised ForwardAsync() launched: let the stream drain first
+                SI_TRY_HIP(si_hip_stream_sync(stream), "stream sync");
                 si_hip_graph_destroy(graph_cache_.back().second);
                 graph_cache_.pop_back();
             }
@@ -1047,10 +1198,22 @@ Status EngineImpl::Extract(const std::string& name, Tensor& output) {
 
 Status EngineImpl::Profile(std::vector<LayerProfile>& layers) {
     layers.clear();
-    if (nullptr == context_ || plan_.empty()) return Status::kFail;
+    if (nullptr == context_ || (plan_.empty() && lanes_.empty())) return Status::kFail;
     si_stream_t stream = context_->stream();
     CHECK_STATUS(UploadInputs());
     CHECK_STATUS(BindOutputs());
+    if (!lanes_.empty()) {
+        // per-launch durations are measured WITHOUT the overlap: one lane after the other, each layer between two events (as
+        // Detect's side-stream levels are, below).  A layer appears once per lane, with that lane's FLOPs and bytes.
+        CHECK_STATUS(BindLanes());
+        SI_TRY_HIP(si_hip_stream_sync(stream), "stream sync");
+        for (EngineImpl* lane : lanes_) {
+            std::vector<LayerProfile> part;
+            CHECK_STATUS(lane->Profile(part));
+            layers.insert(layers.end(), part.begin(), part.end());
+        }
+        return Status::kSuccess;
+    }
     std::vector<si_event_t> ev(plan_.size() + 1, nullptr);
     for (auto& e : ev) SI_TRY_HIP(si_hip_event_create(&e), "event create");
     Status ret = Status::kSuccess;
@@ -1085,18 +1248,21 @@ Status EngineImpl::Profile(std::vector<LayerProfile>& layers) {
 void* EngineImpl::Stream() { return context_ ? context_->stream() : nullptr; }
 
 std::vector<std::string> EngineImpl::ScheduledOps() const {
+    if (!lanes_.empty()) return lanes_[0]->ScheduledOps();
     std::vector<std::string> out;
     for (const Step& s : plan_) out.push_back(s.op->name);
     return out;
 }
 
 std::vector<std::string> EngineImpl::FusedOps() const {
+    if (!lanes_.empty()) return lanes_[0]->FusedOps();
     std::vector<std::string> out(fused_ops_.begin(), fused_ops_.end());
     out.insert(out.end(), sibling_ops_.begin(), sibling_ops_.end());
     return out;
 }
 
 std::vector<std::string> EngineImpl::AliasedOperands() const {
+    if (!lanes_.empty()) return lanes_[0]->AliasedOperands();
     std::vector<std::string> out;
     for (auto& kv : aliases_) out.push_back(kv.first);
     return out;

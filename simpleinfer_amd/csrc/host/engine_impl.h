@@ -78,7 +78,12 @@ public:
     std::vector<std::string> FusedOps() const;
     std::vector<std::string> AliasedOperands() const;
     // bytes of HBM held for intermediate operands: with lifetime sharing, and what one allocation per operand would take
-    void ActivationFootprint(size_t& arena_bytes, size_t& per_operand_bytes) const { arena_bytes = arena_bytes_; per_operand_bytes = unshared_bytes_; }
+    void ActivationFootprint(size_t& arena_bytes, size_t& per_operand_bytes) const {
+        arena_bytes = arena_bytes_;
+        per_operand_bytes = unshared_bytes_;
+        for (const EngineImpl* lane : lanes_) arena_bytes += lane->arena_bytes_, per_operand_bytes += lane->unshared_bytes_;
+    }
+    int Lanes() const { return lanes_.empty() ? 1 : (int)lanes_.size(); }
 
 private:
     struct Step {
@@ -98,6 +103,14 @@ private:
     Status BindOutputs();
     Status LaunchAll();
 
+    // option "streams" = 2: the batch runs as two half-batch LANES on two streams (see LoadLanes)
+    Status PlanLanes(int& lanes);
+    Status LoadLanes(int lanes);
+    Status BindLanes();
+    Status LaunchLanes();
+    Status DestroyLanes();
+    Status DestroyGraphCache();
+
 private:
     // options
     int opt_device_ = -1;
@@ -111,6 +124,7 @@ private:
     int opt_batch_ = 0;          // > 0: serve this batch whatever batch the file was traced with
     int opt_detect_stream_ = 1;        // Detect's early levels on a second stream beside the layers that follow their inputs: 0 never, 1 for levels with enough work, 2 always
     bool opt_fp16_ = false;      // fp16 storage for internal activations and weights (BASELINE.json configs[3])
+    int opt_streams_ = 0;        // 2: two half-batch lanes on two streams; 1: one stream; 0 (default): 2 where it was measured faster
 
     Context* context_ = nullptr;
     Context* side_context_ = nullptr;        // second stream (option "detect_stream"); created with the first plan that uses it
@@ -124,6 +138,13 @@ private:
     std::map<std::string, TensorNode*> output_tensor_nodes_;
 
     std::vector<Step> plan_;
+
+    // lanes: child engines serving one contiguous slab of the batch each, on their own streams, reading / writing slab views of
+    // THIS engine's input and output buffers; this engine then has no layers of its own
+    std::vector<EngineImpl*> lanes_;
+    std::vector<si_event_t> lane_done_;
+    bool is_lane_ = false;
+    std::string param_path_, bin_path_;
     std::set<std::string> fused_ops_;        // operator names folded into a conv epilogue
     std::set<std::string> sibling_ops_;      // convs computed by a sibling conv's launch
     std::set<std::string> dead_operands_;    // operands that no longer exist after fusion

@@ -362,6 +362,23 @@ bool Conv2d::CanReadUpsampled(int c0, int c) const {
            residual_node_ == nullptr && algo_ != Algo::kWinograd23 && algo_ != Algo::kWinograd43;
 }
 
+// ... and the kernel's own preconditions on THIS problem (tensor sizes below 4 GiB, strides), asked with the shapes the bound
+// nodes have: once the engine drops the upsample launch there is no unfused schedule to fall back to at Forward() time
+bool Conv2d::CanReadUpsampledFrom(const TensorNode* low, int c0, float scale_h, float scale_w) const {
+    Dims4 lo, di, dout;
+    if (!low || input_tensor_nodes_.size() != 1 || output_tensor_nodes_.empty()) return false;
+    if (!GetDims4(low->tensor, lo) || !GetDims4(input_tensor_nodes_[0]->tensor, di) || !GetDims4(output_tensor_nodes_[0]->tensor, dout)) return false;
+    if (IsHalf(low->tensor) || IsHalf(input_tensor_nodes_[0]->tensor) || !CanReadUpsampled(c0, lo.c) || scale_h <= 0.f || scale_w <= 0.f) return false;
+    SiConv2dDesc d = MakeDesc(input_tensor_nodes_[0]->tensor, output_tensor_nodes_[0]->tensor);
+    d.in_ld = di.c;   // (the concat buffer is dense: the conv's input IS the concat output)
+    if (sibling_) d.oc = out_channels_ + sibling_->out_channels_;
+    SiConv2dUpsampledSource up;
+    memset(&up, 0, sizeof(up));
+    up.ih = lo.h; up.iw = lo.w; up.c = lo.c; up.ld = lo.c; up.c0 = c0;
+    up.inv_scale_h = 1.0f / scale_h; up.inv_scale_w = 1.0f / scale_w;
+    return si_hip_conv2d_upcat_supported(&d, &up) == 1;
+}
+
 void Conv2d::SetUpsampledSource(TensorNode* low, int c0, float scale_h, float scale_w) {
     up_node_ = low;
     up_c0_ = c0;

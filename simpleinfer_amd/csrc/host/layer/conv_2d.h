@@ -58,6 +58,7 @@ public:
     // engine fusion hook: channels [c0, c0 + low->C) of this 1x1 conv's input (a torch.cat output) are nn.Upsample(nearest) of
     // `low`; the conv reads them from `low` at the source pixel and the upsample / concat copy never run
     bool CanReadUpsampled(int c0, int c) const;
+    bool CanReadUpsampledFrom(const TensorNode* low, int c0, float scale_h, float scale_w) const;
     void SetUpsampledSource(TensorNode* low, int c0, float scale_h, float scale_w);
     TensorNode* UpsampledSource() const { return up_node_; }
 

@@ -143,17 +143,25 @@ int si_group_barrier(SiNodeGroup* g) {
     if (!g) return SI_SHARD_E_BADARG;
     if (g->world == 1) return 0;
     ShmHeader* h = g->hdr;
+    // a rank that timed out leaves its arrival in `count` behind: the group is dead from then on (every later barrier on
+    // every rank fails instead of releasing with fewer than `world` arrivals)
+    if (h->failed.load(std::memory_order_acquire)) return SI_SHARD_E_PEER;
     const uint32_t gen = h->gen.load(std::memory_order_acquire);
     if (h->count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)g->world) {
         h->count.store(0, std::memory_order_relaxed);
         h->gen.fetch_add(1, std::memory_order_acq_rel);
-        return 0;
+        return h->failed.load(std::memory_order_acquire) ? SI_SHARD_E_PEER : 0;
     }
-    const bool ok = wait_until([&] { return h->gen.load(std::memory_order_acquire) != gen; }, g->timeout_s);
+    const bool ok = wait_until([&] { return h->gen.load(std::memory_order_acquire) != gen || h->failed.load(std::memory_order_acquire) != 0; },
+                               g->timeout_s);
     if (!ok) {
         h->failed.store(1, std::memory_order_release);
         LOG(ERROR) << "si_group_barrier: rank " << g->rank << " timed out after " << g->timeout_s << " s";
         return SI_SHARD_E_TIMEOUT;
+    }
+    if (h->failed.load(std::memory_order_acquire)) {
+        LOG(ERROR) << "si_group_barrier: rank " << g->rank << ": another rank timed out, the group is dead";
+        return SI_SHARD_E_PEER;
     }
     return 0;
 }

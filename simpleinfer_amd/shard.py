@@ -73,7 +73,7 @@ class DirectGather:
     """include/si_shard.h SiDirectGather: `slots` gathered buffers [world][slab_bytes] per rank; every step each rank
     pushes its slab into the same slot of every peer with one device-to-device copy per peer."""
 
-    def __init__(self, group: NodeGroup, device: int, slab_bytes: int, slots: int = 3):
+    def __init__(self, group: NodeGroup, device: int, slab_bytes: int, slots: int = 4):
         self._h = _native.host()
         self.group = group
         self._d = C.c_void_p()
@@ -102,7 +102,7 @@ class ShardedForward:
     """The step of the sharded path (the Python twin of SimpleInfer::ShardedEngine, include/shard.h): Forward() into this
     step's slot, start the fan-out, complete the previous step's gather."""
 
-    def __init__(self, engine, output_name: str, group: NodeGroup, device: int, slots: int = 3):
+    def __init__(self, engine, output_name: str, group: NodeGroup, device: int, slots: int = 4):
         self.e, self.oname = engine, output_name
         shape = engine.operand_shape(output_name)
         self.local_shape = tuple(shape)

@@ -28,6 +28,16 @@ def test_direct_gather_between_processes_is_bit_exact(gpu, tmp_path, world, slot
     assert res["shape"][0] == 2 * world
 
 
+def test_gathered_tensor_survives_the_next_step_with_default_slots(gpu, tmp_path):
+    """include/si_shard.h slot lifetime: with the default 4 slots the gathered tensor handed out after Forward(s) is still
+    step s-1's after Forward(s+1) -- a slow consumer on one rank while the others run ahead (3 ranks sharing the device)."""
+    from simpleinfer_amd import launch
+    code, out = launch.spawn_ranks([sys.executable, CHILD, "slow_consumer", str(tmp_path)], 3, timeout=300)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert code == 0 and lines, out
+    assert json.loads(lines[-1])["ok"] == [1, 1, 1]
+
+
 def _bench(*args, env_extra=None, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})

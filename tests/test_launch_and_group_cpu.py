@@ -41,6 +41,17 @@ def test_launcher_stops_the_other_ranks_when_one_fails():
     assert time.time() - t0 < 30, "rank 0 (sleeping 60 s) was not stopped"
 
 
+def test_a_timed_out_barrier_kills_the_group_on_every_rank(native_libs, tmp_path):
+    """si_group_barrier: rank 0 times out (-103) while rank 1 is late; rank 1's barrier then fails with SI_SHARD_E_PEER (-105)
+    instead of completing with rank 0's stale arrival, and every later barrier on both ranks fails too."""
+    code, _ = _spawn("dead_group", 2, tmp_path)
+    assert code == 0
+    c0 = json.load(open(tmp_path / "codes0.json"))
+    c1 = json.load(open(tmp_path / "codes1.json"))
+    assert c0[0] == -103 and all(c in (-103, -105) for c in c0[1:]), c0
+    assert c1 == [-105, -105, -105], c1
+
+
 def test_group_rejects_bad_arguments(native_libs):
     import ctypes as C
     _, host = native_libs

@@ -1,4 +1,5 @@
-export SI_COMMIT=16c3178
+# provenance stamped into profiles/traffic*.json: the commit this tree is at (the GPU box has no .git: pass SI_COMMIT in)
+export SI_COMMIT=${SI_COMMIT:-$(git rev-parse --short HEAD 2>/dev/null || echo unknown)}
 bash tools/run_rocprof.sh r02c_prof > /dev/null 2>&1
 bash tools/run_traffic.sh r02c_traffic > gpurun_out/r02c_traffic_stdout.txt 2>&1
 python bench.py > gpurun_out/r02c_bench_default.json 2> gpurun_out/r02c_bench_default.err
