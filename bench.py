@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--global-batch", type=int, default=0, help="total images per step over all GPUs (strong scaling): per-GPU batch = B / N")
     ap.add_argument("--gather", default="auto", choices=["auto", "p2p", "rccl"],
                     help="N > 1 output all-gather: p2p = direct IPC fan-out (include/si_shard.h), rccl = torch.distributed, auto = p2p with RCCL fallback")
-    ap.add_argument("--min-time", type=float, default=2.0, help="repeat the K-step timed window until this many seconds are accumulated")
+    ap.add_argument("--min-time", type=float, default=10.0, help="repeat the K-step timed window until this many seconds are accumulated (BASELINE.md section 3: >= 10 s)")
     ap.add_argument("--max-windows", type=int, default=200)
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--model", default="yolov5s", choices=["yolov5s", "resnet18", "mobilenetv3"])
@@ -63,8 +63,8 @@ def parse():
     ap.add_argument("--fp16", type=int, default=0, help="1: fp16 storage / fp16 MFMA path (BASELINE.json configs[3]); the headline metric is fp32 (default 0)")
     ap.add_argument("--no-aux", action="store_true", help="skip the host-I/O and post-processing side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=32, help="images in the batch-1 CPU baseline sample")
-    ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the batched CPU baseline samples (BASELINE.md section 3)")
+    ap.add_argument("--cpu-images", type=int, default=24, help="images in the batch-1 CPU baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=16, help="batch of the batched CPU baseline samples (BASELINE.md section 3); the three CPU legs together are bounded to ~20 s")
     ap.add_argument("--cpu-threads", type=int, default=16, help="oracle threads (reference uses 16 intra-op)")
     ap.add_argument("--profile-passes", type=int, default=3)
     ap.add_argument("--layers", action="store_true", help="print the per-layer table to stderr")
@@ -82,38 +82,66 @@ def build_model(mg, name, batch, size):
     return mg.build_resnet18(batch, sz), (batch, sz, sz, 3)
 
 
+def _physical_cores():
+    """distinct (package, core) pairs of /proc/cpuinfo: hardware threads beyond that are SMT siblings"""
+    try:
+        cores, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        if cores:
+            return len(cores)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def cpu_baseline(args, mg, td):
-    """The oracle (CPU restatement of the reference's Eigen/highway path, kind "port") timed on this box's host cores, on
-    bounded samples of the same workload.  Three records:
+    """The oracle -- an UNOPTIMISED scalar-class restatement of the reference's Eigen/highway CPU path (kind "port"; plain C loops
+    built with -ffp-contract=off, no cache blocking: it exists to check results, not to be fast) -- timed on this box's host cores
+    on bounded samples of the same workload (~20 s for the three legs together).  A reported baseline, not a target:
       cpu_baseline           `--cpu-threads` threads (16 = the reference's intra-op pool, engine_impl.cpp:133), batch-1 forwards
-      cpu_baseline_batched   the same threads, one forward of a batch-`--cpu-batch` model (the metric's batch)
-      cpu_baseline_all_cores every hardware thread of the box, the same batched forward"""
+      cpu_baseline_batched   the same threads, one forward of a batch-`--cpu-batch` model
+      cpu_baseline_all_cores one thread per PHYSICAL core (threads bound to cores), the same batched forward"""
+    # thread placement must be in the environment before libgomp initialises (the oracle is loaded lazily, below)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from oracle import orc
     name = _cpu_name()
-    what = ("CPU restatement of SimpleInfer's Eigen/highway path (Winograd F(2,3)+pack4 GEMM for 3x3 s1, im2col GEMM "
+    what = ("unoptimised CPU restatement of SimpleInfer's Eigen/highway path (Winograd F(2,3)+pack4 GEMM for 3x3 s1, im2col GEMM "
             "otherwise, unfused passes)")
 
-    def sample(batch, forwards, threads):
+    def sample(batch, forwards, threads, budget_s):
         orc.lib().orc_set_num_threads(threads)
         b, shape = build_model(mg, args.model, batch, args.size)
         pp, bp = os.path.join(td, "cpu%d.pnnx.param" % batch), os.path.join(td, "cpu%d.pnnx.bin" % batch)
         b.save(pp, bp)
         x = mg.synth_input(shape)
         t0 = time.perf_counter()
+        done = 0
         for _ in range(forwards):
             orc.run_graph(pp, bp, {"0": x})
+            done += 1
+            if time.perf_counter() - t0 >= budget_s:
+                break
         dt = time.perf_counter() - t0
-        return {"value": round(batch * forwards / dt, 4), "unit": "images/sec", "cores": int(orc.lib().orc_num_threads()),
+        return {"value": round(batch * done / dt, 4), "unit": "images/sec", "cores": int(orc.lib().orc_num_threads()),
                 "kind": "port",
                 "sample": "%d forward(s) of %s %dx%d fp32 batch %d, %s, %.1f s, host %s"
-                          % (forwards, args.model, shape[1], shape[2], batch, what, dt, name)}
+                          % (done, args.model, shape[1], shape[2], batch, what, dt, name)}
 
-    out = {"cpu_baseline": sample(1, max(args.cpu_images, 1), args.cpu_threads)}
+    out = {"cpu_baseline": sample(1, max(args.cpu_images, 1), args.cpu_threads, 8.0)}
     if args.cpu_batch > 1:
-        out["cpu_baseline_batched"] = sample(args.cpu_batch, 1, args.cpu_threads)
-        ncpu = os.cpu_count() or args.cpu_threads
-        if ncpu != args.cpu_threads:
-            out["cpu_baseline_all_cores"] = sample(args.cpu_batch, 1, ncpu)
+        out["cpu_baseline_batched"] = sample(args.cpu_batch, 1, args.cpu_threads, 6.0)
+        ncore = _physical_cores()
+        if ncore > args.cpu_threads:
+            out["cpu_baseline_all_cores"] = sample(min(args.cpu_batch, 8), 1, ncore, 6.0)
     return out
 
 
@@ -131,61 +159,116 @@ PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E
 
 
+def _template_of(kernel):
+    return kernel.split("<", 1)[0]
+
+
+def _traffic_table(fp16):
+    tpath = os.path.join(ROOT, "profiles", "traffic_fp16.json" if fp16 else "traffic.json")
+    if not os.path.exists(tpath):
+        return {}, None
+    try:
+        table = json.load(open(tpath))
+    except Exception:
+        return {}, None
+    # PMC counters cannot be collected from inside this process: the figures are the ones tools/run_traffic.sh recorded
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes) for these instantiations, not a measurement of this run
+    return table, "profiles/%s (recorded at %s)" % (os.path.basename(tpath), table.get("_recorded_at", "an earlier round"))
+
+
+def _traffic_of(table, name):
+    rec = table.get(name)
+    if rec is None:
+        # a profile name may drop trailing template arguments the profiler prints: launch-weighted mean over the
+        # instantiations that share the prefix
+        stem = name.rstrip(">")
+        hits = [v for k, v in table.items() if k.startswith(stem) and isinstance(v, dict)]
+        n = sum(v.get("launches", 0) for v in hits)
+        if n:
+            return round(sum(v["hbm_bytes_per_launch"] * v.get("launches", 0) for v in hits) / n)
+        return None
+    return rec.get("hbm_bytes_per_launch") if isinstance(rec, dict) else rec
+
+
+WINOGRAD_MULT_REDUCTION = {"conv_wino23_kernel": 2.25, "conv_wino43_kernel": 4.0}   # direct multiplies per executed multiply
+
+
 def roofline_from_profile(passes, fp16=False):
-    """passes: list of per-layer profile lists (same schedule).  Groups conv launches by kernel instantiation.
-    fp32: the dominant kernel is priced against the fp32 MFMA peak with direct-conv FLOPs.  fp16: the matrix cores are
-    16x faster and every YOLOv5s layer is bound by memory, so the dominant kernel is priced against HBM with its
-    algorithmic bytes (input + output + weights of each launch)."""
-    agg = {}
+    """passes: list of per-layer profile lists (same schedule).  The dominant KERNEL is the conv kernel template with the
+    largest total time (all its instantiations: one source kernel whose tile / MFMA shape follows the launch size); it is
+    priced as SUM of algorithmic work / SUM of launch durations, and every instantiation -- the names are exactly what
+    rocprofv3 --kernel-trace prints -- is listed beside it with its own launches, average duration, algorithmic bytes and
+    PMC traffic, so the rocprof summary under profiles/ can be checked row by row.
+    fp32: priced against the fp32 MFMA peak with direct-conv FLOPs; a Winograd kernel executes 2.25x (4x)
+    fewer multiplies than it is credited with, so its line also carries frac_executed_mfma = frac / 2.25.
+    fp16: every YOLOv5s layer is bound by memory, so the kernel is priced against HBM with its algorithmic bytes."""
+    inst = {}
     for layers in passes:
         for L in layers:
             if not L["kernel"].startswith("conv_") or L["flops"] <= 0 or L["type"] == "models.yolo.Detect":
                 continue
-            a = agg.setdefault(L["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            a = inst.setdefault(L["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
             a["ms"] += L["ms"]
             a["flops"] += L["flops"]
             a["bytes"] += L["bytes"]
             a["launches"] += 1
-    if not agg:
-        return None, agg
-    name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    if not inst:
+        return None, inst
+    tmpl = {}
+    for k, v in inst.items():
+        t = tmpl.setdefault(_template_of(k), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        for f in ("ms", "flops", "bytes", "launches"):
+            t[f] += v[f]
+    name, a = max(tmpl.items(), key=lambda kv: kv[1]["ms"])
+    npass = max(len(passes), 1)
     avg_ms = a["ms"] / a["launches"]
     flops_per_launch = a["flops"] / a["launches"]
+    bytes_per_launch = a["bytes"] / a["launches"]
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-    traffic = None
-    traffic_source = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_fp16.json" if fp16 else "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            table = json.load(open(tpath))
-            rec = table.get(name)
-            if rec is None:
-                # the profile's kernel name drops trailing template arguments the profiler prints (e.g. the K-block width
-                # of conv_igemm_f16_kernel): launch-weighted mean over the instantiations that share the prefix
-                stem = name.rstrip(">")
-                hits = [v for k, v in table.items() if k.startswith(stem) and isinstance(v, dict)]
-                n = sum(v.get("launches", 0) for v in hits)
-                if n:
-                    rec = {"hbm_bytes_per_launch": round(sum(v["hbm_bytes_per_launch"] * v.get("launches", 0) for v in hits) / n)}
-            traffic = rec.get("hbm_bytes_per_launch") if isinstance(rec, dict) else rec
-            if traffic is not None:
-                # PMC counters cannot be collected from inside this process: the figure is the one recorded by
-                # tools/run_traffic.sh (rocprofv3 --pmc passes) for this kernel, not a measurement of this run
-                traffic_source = "profiles/%s (recorded at %s)" % (os.path.basename(tpath), table.get("_recorded_at", "an earlier round"))
-        except Exception:
-            traffic = None
+    table, traffic_source = _traffic_table(fp16)
+    rows, tsum, tn = [], 0.0, 0
+    for k, v in sorted(inst.items(), key=lambda kv: -kv[1]["ms"]):
+        if _template_of(k) != name:
+            continue
+        tr = _traffic_of(table, k)
+        if tr is not None:
+            tsum += tr * v["launches"]
+            tn += v["launches"]
+        ims = v["ms"] / v["launches"]
+        row = {"kernel": k, "launches_per_step": v["launches"] // npass, "avg_launch_ms": round(ims, 4),
+               "algorithmic_bytes": round(v["bytes"] / v["launches"]), "traffic": tr,
+               "traffic_over_algorithmic": round(tr / (v["bytes"] / v["launches"]), 3) if tr else None}
+        if fp16:
+            row["gbs"] = round(v["bytes"] / v["launches"] / (ims * 1e-3) / 1e9, 1)
+            row["frac"] = round(row["gbs"] / PEAK_HBM_GBS, 4)
+        else:
+            row["tflops"] = round(v["flops"] / v["launches"] / (ims * 1e-3) / 1e12, 2)
+            row["frac"] = round(row["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        rows.append(row)
+    # launch-weighted over the instantiations that have a recorded figure (None when none has)
+    traffic = round(tsum / tn) if tn else None
+    label = name + (" (all %d instantiations)" % len(rows) if len(rows) > 1 else "")
+    if len(rows) == 1:
+        label = rows[0]["kernel"]
+    common = {"kernel": label, "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+              "algorithmic_bytes": round(bytes_per_launch), "launches_per_step": a["launches"] // npass,
+              "avg_launch_ms": round(avg_ms, 4), "instantiations": rows}
     if fp16:
-        bytes_per_launch = a["bytes"] / a["launches"]
         gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                "launches_per_step": a["launches"] // max(len(passes), 1), "avg_launch_ms": round(avg_ms, 4),
+        roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
                 "mbytes_per_launch": round(bytes_per_launch / 1e6, 2), "tflops": round(achieved, 1),
-                "frac_of_f16_mfma_peak": round(achieved / PEAK_F16_MFMA_TFLOPS, 4)}, agg
-    return {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "launches_per_step": a["launches"] // max(len(passes), 1), "avg_launch_ms": round(avg_ms, 4),
-            "gflop_per_launch": round(flops_per_launch / 1e9, 3)}, agg
+                "frac_of_f16_mfma_peak": round(achieved / PEAK_F16_MFMA_TFLOPS, 4)}
+    else:
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "gflop_per_launch": round(flops_per_launch / 1e9, 3)}
+        red = WINOGRAD_MULT_REDUCTION.get(name)
+        if red:
+            # `achieved` credits the kernel with DIRECT-convolution FLOPs (SURVEY.md 8d), so frac can exceed 1; the matrix
+            # pipe's own utilisation is the executed work: direct / 2.25 for F(2,3), / 4 for F(4,3)
+            roof["frac_executed_mfma"] = round(achieved / red / PEAK_FP32_MFMA_TFLOPS, 4)
+            roof["note"] = "Winograd: frac counts direct-conv FLOPs; frac_executed_mfma = frac / %.2f is the matrix pipe's share" % red
+    roof.update(common)
+    return roof, inst
 
 
 def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x):
@@ -199,15 +282,20 @@ def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x):
     e2 = si.Engine(device=dev, outputs_to_host=1, graph=args.graph, winograd=args.winograd, fp16=args.fp16)
     e2.load_model(pp, bp)
     e2.input(e2.input_names()[0], x)
-    e2.forward()
+    for _ in range(3):   # the first Forward builds the sliced pipeline, the second pins the borrowed input buffer in place
+        e2.forward()
     H.si_hip_device_sync()
+    hsteps = max(steps, 12)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for _ in range(hsteps):
         e2.forward()
     H.si_hip_device_sync()
     dt = time.perf_counter() - t0
-    aux["host_io"] = {"value": round(args.batch * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3),
-                      "note": "input uploaded from host memory and outputs copied back on every Forward (PCIe-inclusive); not `value`"}
+    aux["host_io"] = {"value": round(args.batch * hsteps / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / hsteps * 1e3, 3),
+                      "note": "the reference's calling convention (bench/bench_yolo.cpp:20-28): Input() borrows a HOST tensor that is "
+                              "uploaded on every Forward(), Extract() returns host memory (PCIe-inclusive: 4.9 MB up + 8.6 MB down per "
+                              "image); one synchronous Forward() pipelines batch slices over an upload stream, a compute stream and a "
+                              "download stream (engine option host_slices); not `value`"}
     e2.release()
     if args.model == "yolov5s" and len(oshape) == 3:
         n, rows, ne = oshape
@@ -246,6 +334,108 @@ def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x):
                                       "[n,25200,85] slab: detector-like synthetic predictions; 'degenerate' = this run's random-init "
                                       "network output, where nearly every row passes the 0.25 filter in one class"}
     return aux
+
+
+def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
+    """The application around Forward() in the reference's test-yolo (test/test_yolo/test_yolo.cpp:299-438) as a pipelined
+    stream of batches, every stage on the device except the resize the reference leaves to cv::resize: per batch the host holds
+    u8 BGR images already resized to the letterbox target; they are uploaded (u8: 39 MB per 32 images instead of 157 MB of fp32)
+    on a copy stream into one of TWO device buffers while the previous batch computes; on the engine's stream: letterbox (pad /
+    BGR->RGB / cast / divide by 255, :220-259) into the engine's input, Forward(), confidence filter + sort + per-class NMS
+    (:337-428), and the boxes (7 KB per image) come back.  Reported: images/sec end to end and its ratio to the device-resident
+    Forward() rate of the same run.  Random-init weights put every row near confidence 0.25, so the confidence threshold is set
+    where 3 % of the rows pass (~750 candidates per image, what a trained detector yields), and says so."""
+    import ctypes as C
+    n, size = args.batch, args.size
+    rows, ne = oshape[1], oshape[2]
+    hr, wr, scale, pt, pl = hipops.letterbox_geometry(480, 640, size, size)   # 4:3 camera frames
+    img_bytes = hr * wr * 3
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (2, n, hr, wr, 3), dtype=np.uint8)
+    pinned, dev_u8, dev_in = [], [], []
+    for k in range(2):
+        hp = C.c_void_p()
+        assert H.si_hip_host_alloc(C.byref(hp), n * img_bytes) == 0
+        C.memmove(hp, frames[k].ctypes.data, n * img_bytes)
+        pinned.append(hp)
+        dev_u8.append(hipops.DeviceBuffer(n * img_bytes))
+        dev_in.append(hipops.DeviceBuffer(n * size * size * 3 * 4))
+    max_det = 300
+    wsb = H.si_hip_yolo_postprocess_workspace_bytes(n, rows, ne)
+    ws, dets, cnt = hipops.DeviceBuffer(wsb), hipops.DeviceBuffer(n * max_det * 6 * 4), hipops.DeviceBuffer(n * 4)
+    hdets = [C.c_void_p(), C.c_void_p()]
+    for k in range(2):
+        assert H.si_hip_host_alloc(C.byref(hdets[k]), n * max_det * 6 * 4 + n * 4) == 0
+    copy_stream = C.c_void_p()
+    assert H.si_hip_stream_create(C.byref(copy_stream)) == 0
+    ev_up = [C.c_void_p(), C.c_void_p()]
+    ev_used = [C.c_void_p(), C.c_void_p()]
+    ev_done = [C.c_void_p(), C.c_void_p()]
+    for evs in (ev_up, ev_used, ev_done):
+        for k in range(2):
+            H.si_hip_event_create(C.byref(evs[k]))
+    es = e.stream()
+    optr, _ = e.extract_ptr(oname)
+
+    def upload(k):
+        H.si_hip_stream_wait_event(copy_stream, ev_used[k])          # the letterbox of two batches ago has read this buffer
+        H.si_hip_memcpy_h2d(dev_u8[k].ptr, pinned[k], n * img_bytes, copy_stream)
+        H.si_hip_event_record(ev_up[k], copy_stream)
+
+    def compute(k, thr):
+        H.si_hip_stream_wait_event(es, ev_up[k])
+        for b in range(n):
+            H.si_hip_letterbox_u8_f32(dev_u8[k].ptr + b * img_bytes, hr, wr, dev_in[k].ptr + b * size * size * 3 * 4, size, size, pt, pl, es)
+        H.si_hip_event_record(ev_used[k], es)
+        e.input_device(iname, dev_in[k].ptr)
+        e.forward_async()
+        rc = H.si_hip_yolo_postprocess_f32(optr, n, rows, ne, thr, 0.45, 0, None, dets.ptr, cnt.ptr, max_det, ws.ptr, wsb, es)
+        if rc != 0:
+            raise RuntimeError("si_hip_yolo_postprocess_f32 rc=%d" % rc)
+        H.si_hip_memcpy_d2h(hdets[k], dets.ptr, n * max_det * 6 * 4, es)
+        H.si_hip_memcpy_d2h(C.c_void_p(hdets[k].value + n * max_det * 6 * 4), cnt.ptr, n * 4, es)
+        H.si_hip_event_record(ev_done[k], es)
+
+    for k in range(2):
+        H.si_hip_event_record(ev_used[k], es)
+    # threshold where 3 % of the rows of this network's output pass
+    upload(0)
+    compute(0, 2.0)
+    e.sync()
+    pred = hipops.DeviceBuffer.view(optr, n * rows * ne * 4).to_numpy((n, rows, ne))
+    conf = pred[..., 4] * pred[..., 5:].max(axis=-1)
+    thr = float(np.quantile(conf, 0.97))
+    upload(1)
+    for it in range(4):            # warm-up
+        compute((it + 1) % 2, thr)
+        upload(it % 2)
+    e.sync()
+    steps = max(args.steps, 20)
+    t0 = time.perf_counter()
+    for it in range(steps):
+        k = (it + 1) % 2
+        compute(k, thr)
+        upload(1 - k)              # the next batch goes up while this one computes
+        if it > 0:
+            H.si_hip_event_sync(ev_done[1 - k])   # the previous batch's boxes are on the host
+    e.sync()
+    dt = time.perf_counter() - t0
+    kept = np.ctypeslib.as_array(C.cast(C.c_void_p(hdets[k].value + n * max_det * 6 * 4), C.POINTER(C.c_int32)), shape=(n,)).mean()
+    for k in range(2):
+        H.si_hip_host_free(pinned[k]); H.si_hip_host_free(hdets[k])
+        dev_u8[k].free(); dev_in[k].free()
+    for evs in (ev_up, ev_used, ev_done):
+        for k in range(2):
+            H.si_hip_event_destroy(evs[k])
+    H.si_hip_stream_destroy(copy_stream)
+    value = n * steps / dt
+    return {"value": round(value, 2), "unit": "images/sec", "ms_per_batch": round(dt / steps * 1e3, 3),
+            "ratio_to_device_resident": round(value / rate_resident, 4), "boxes_kept_per_image": round(float(kept), 1),
+            "confidence_threshold": round(thr, 4), "bytes_up_per_image": img_bytes, "bytes_down_per_image": max_det * 24 + 4,
+            "note": "test-yolo's flow (test_yolo.cpp:299-438) pipelined: u8 letterbox-target frames (480x640 -> %dx%d, padded to %dx%d on the "
+                    "device) uploaded double-buffered on a copy stream, device letterbox -> Forward -> device filter / sort / NMS, boxes "
+                    "downloaded; threshold at the 97th percentile of this random-init network's confidences (3 %% of rows pass, as with "
+                    "a trained detector); not `value`" % (hr, wr, size, size)}
 
 
 def self_launch(args):
@@ -319,6 +509,11 @@ def main():
 
     mg = si.modelgen
     with tempfile.TemporaryDirectory(prefix="si_bench_r%d_" % rank) as td:
+        # the CPU legs run FIRST (bounded, ~20 s): the GPU leg is then the long, uninterrupted tail of the run
+        cpu = {"cpu_baseline": None}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, mg, td)
+
         builder, shape = build_model(mg, args.model, args.batch, args.size)
         pp, bp = os.path.join(td, "m.pnnx.param"), os.path.join(td, "m.pnnx.bin")
         builder.save(pp, bp)
@@ -332,6 +527,7 @@ def main():
             sys.exit("bench.py: %s cannot be loaded with these options (%s)%s" % (
                 args.model, ex, "; the fp16 storage path has no kernels for some of its layers -- see the engine's log line above" if args.fp16 else ""))
         iname, oname = e.input_names()[0], e.output_names()[0]
+        lanes = e.schedule().get("lanes", 1)   # 2: the batch runs as two half-batch lanes on two streams (engine option "streams")
         # global batch = per-GPU batch * world; this rank's slab gets its own seed (distinct images)
         x = mg.synth_input(shape, seed=1 + rank)
         dx = hipops.DeviceBuffer.from_numpy(x)
@@ -427,7 +623,14 @@ def main():
             except Exception as ex:  # noqa: BLE001 -- any failure of the optional path means "use the fallback"
                 ok = 0
                 gather_note = "direct gather failed its warm-up check (%s)" % ex
-            all_ok = min(b[0] for b in group.allgather_bytes(bytes([ok])))
+            # the vote goes through a FRESH rendezvous: a warm-up that failed with a timeout leaves `group` dead (a timed-out
+            # barrier poisons it), and a vote read from its stale bytes would mean nothing
+            try:
+                vote = shard.NodeGroup(shard.default_group_name() + "_vote", rank, world, timeout_s=180.0)
+                all_ok = min(b[0] for b in vote.allgather_bytes(bytes([ok])))
+                vote.close()
+            except shard.ShardError as ex:
+                sys.exit("bench.py: rank %d: the ranks could not agree on the gather path (%s)" % (rank, ex))
             if not all_ok:
                 if gather_note is None:
                     gather_note = "direct gather failed its warm-up check on another rank"
@@ -447,6 +650,8 @@ def main():
             slab_checksums()
             fence()
 
+        if sf is not None:
+            sf.gather.stats(reset=True)
         windows = []
         fwd_ms = 0.0
         total = 0.0
@@ -461,6 +666,20 @@ def main():
             total += dt
             if total >= args.min_time or len(windows) >= args.max_windows:
                 break
+        gather_diag = None
+        if sf is not None:
+            # where a step's time went: host waits inside si_gather_complete (0 = the fan-out hid behind the next step's
+            # compute) and the device time of the peer copies; every rank reports, rank 0 prints its own and the worst
+            gs = sf.gather.stats()
+            waits = group.allgather_f64(gs["gather_wait_ms"])
+            copies = group.allgather_f64(gs["peer_copy_ms"] or 0.0)
+            gather_diag = dict(gs)
+            gather_diag.update({"gather_wait_ms_max_over_ranks": round(float(waits.max()), 4),
+                                "peer_copy_ms_max_over_ranks": round(float(copies.max()), 4),
+                                "slab_mbytes": round(sf.gather.slab_bytes / 1e6, 2), "slots": sf.gather.slots,
+                                "copy_engine": "hipMemcpyDtoDAsync per peer on its own stream; HSA_ENABLE_SDMA=%s (unset / 1: SDMA engines, "
+                                               "0: blit kernels that take CUs from the convs -- a rocprofv3 kernel trace shows them as "
+                                               "__amd_rocclr_copyBuffer)" % os.environ.get("HSA_ENABLE_SDMA", "unset")})
         if use_dist:
             slab_checksums()
         wsorted = sorted(windows)
@@ -485,10 +704,9 @@ def main():
         aux = {}
         if rank == 0 and world == 1 and not args.no_aux:
             aux = aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x)
-
-        cpu = {"cpu_baseline": None}
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, mg, td)
+            if args.model == "yolov5s" and len(oshape) == 3 and not args.fp16:
+                aux["app_pipeline"] = app_pipeline(args, si, hipops, H, e, iname, oname, oshape, args.batch * args.steps / dt)
+                e.input_device(iname, dx.ptr)
 
         if sf is not None:
             group.barrier()
@@ -519,7 +737,7 @@ def main():
                                                             args.batch * world,
                                                             (", every step's output slab all-gathered (%s), overlapped with the next step" % gather_text) if use_dist else ""),
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                   "gather": gather_mode, "gather_note": gather_note, "engine_options": extra_opts,
+                   "gather": gather_mode, "gather_note": gather_note, "engine_options": extra_opts, "lanes": lanes,
                    "hipgraph": bool(args.graph), "winograd_for_3x3s1": {0: "off", 1: "F(2,3)", 2: "F(4,3)"}.get(args.winograd, "F(2,3)")},
         "windows": {"count": len(windows), "steps_each": args.steps, "timed_s_total": round(total, 3),
                     "value_is": "median window",
@@ -528,6 +746,9 @@ def main():
                     "ms_per_step_max": round(wsorted[-1] / args.steps * 1e3, 3),
                     "ms_per_step_first": round(windows[0] / args.steps * 1e3, 3)},
         "forward_kernel_ms_per_step": round(fwd_ms_per_step, 3),
+        "gather": gather_diag,
+        "step_bound": (None if gather_diag is None else
+                       ("gather" if gather_diag["gather_wait_ms_max_over_ranks"] > 0.1 * (dt / args.steps * 1e3) else "compute")),
         "gflop_per_image": round(flops_step / args.batch / 1e9, 3),
         "frac_of_mfma_ceiling": round(value / world / ceiling, 4),
         "roofline": roof,

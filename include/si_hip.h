@@ -57,6 +57,8 @@ int si_hip_malloc(void** ptr, size_t bytes);
 int si_hip_free(void* ptr);
 int si_hip_host_alloc(void** ptr, size_t bytes); /* pinned */
 int si_hip_host_free(void* ptr);
+int si_hip_host_register(void* ptr, size_t bytes); /* pin caller-owned host memory in place (hipHostRegister) */
+int si_hip_host_unregister(void* ptr);
 int si_hip_memset_async(void* ptr, int value, size_t bytes, si_stream_t stream);
 int si_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, si_stream_t stream);
 int si_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, si_stream_t stream);
@@ -79,6 +81,11 @@ int si_hip_ipc_get_mem_handle(void* dptr, void* handle);
 int si_hip_ipc_open_mem_handle(const void* handle, void** dptr);
 int si_hip_ipc_close_mem_handle(void* dptr);
 int si_hip_enable_peer_access(int peer_device); /* current device -> peer_device; 0 when already enabled or same device */
+/* A device index only means something inside one process (HIP_VISIBLE_DEVICES may differ per rank); the PCI bus id
+ * ("0000:c1:00.0", buf of >= 16 bytes) names the GPU for every process of the node.  _by_pci_bus_id: index of the
+ * visible device with that id, -1 when it is hidden from this process. */
+int si_hip_device_pci_bus_id(int device, char* buf, int len);
+int si_hip_device_by_pci_bus_id(const char* bus_id);
 /* stream capture -> executable graph (replaces the CGraph pipeline of
  * src/engine_impl.cpp:336-437 for launch-bound small batches) */
 int si_hip_graph_begin_capture(si_stream_t stream);
@@ -144,9 +151,11 @@ int si_hip_conv2d_upcat_f32(const SiConv2dDesc* d, const float* in, const SiConv
  * granularity, both tensors below 4 GiB; up->src is not looked at), else 0.  A scheduler that wants to drop the
  * upsample launch asks this BEFORE doing so: the fused form has no fallback at Forward() time. */
 int si_hip_conv2d_upcat_supported(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up);
-/* name of the kernel instantiation si_hip_conv2d_f32 would launch for this problem (as rocprofv3 prints
- * it, minus the namespace), so profiles can be joined with per-layer timings */
+/* name of the kernel instantiation si_hip_conv2d_f32 would launch for this problem (exactly as rocprofv3 prints
+ * it, minus the namespace), so profiles can be joined with per-layer timings.  _form: 0 si_hip_conv2d_f32 /
+ * _split_f32, 1 si_hip_conv2d_upcat_f32, 2 si_hip_conv2d_yolo_f32 */
 const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);
+const char* si_hip_conv2d_kernel_name_form(const SiConv2dDesc* d, const float* in, int form);
 /* Tile policy of si_hip_conv2d_f32's implicit-GEMM kernels.  The default (variant < 0) picks the workgroup tile from the
  * launch size and the CU count (small batches run 32-row tiles on the 16x16x4 MFMA so that the chip is covered); a
  * variant id 0..15 (table in conv_igemm.hip) forces one tile for every later launch of this process -- tuning sweeps and

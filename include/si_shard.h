@@ -77,6 +77,23 @@ void* si_gather_slab(SiDirectGather* gather, int slot);   /* = buffer + rank x s
 int si_gather_push(SiDirectGather* gather, int slot, si_stream_t producer_stream);
 int si_gather_complete(SiDirectGather* gather, int slot); /* collective */
 
+/* Where a step's time went, accumulated since the last reset -- what tells a reader of an N > 1 benchmark line whether the
+ * steps were compute- or gather-bound:
+ *   wait_copies_ms_total   host time si_gather_complete spent waiting for THIS rank's peer copies of the slot (0 when the
+ *                          fan-out finished behind the next step's compute: the overlap worked)
+ *   wait_barrier_ms_total  ... and then in the node barrier (waiting for the slowest rank)
+ *   copy_ms_total / copies device time from "slab ready" to "landed in the peer", per peer copy: slab_bytes / that is the
+ *                          achieved per-link rate when the copy stream was idle (xGMI: ~153 GB/s per link peak) */
+typedef struct SiGatherStats {
+    double wait_copies_ms_total;
+    double wait_barrier_ms_total;
+    double copy_ms_total;
+    double copy_ms_max;
+    long long completes;
+    long long copies;
+} SiGatherStats;
+int si_gather_stats(SiDirectGather* gather, SiGatherStats* out, int reset);
+
 #ifdef __cplusplus
 }
 #endif

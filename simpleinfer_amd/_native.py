@@ -70,6 +70,8 @@ def hip():
         "si_hip_free": (i, [vp]),
         "si_hip_host_alloc": (i, [C.POINTER(vp), sz]),
         "si_hip_host_free": (i, [vp]),
+        "si_hip_host_register": (i, [vp, sz]),
+        "si_hip_host_unregister": (i, [vp]),
         "si_hip_memset_async": (i, [vp, i, sz, vp]),
         "si_hip_memcpy_h2d": (i, [vp, vp, sz, vp]),
         "si_hip_memcpy_d2h": (i, [vp, vp, sz, vp]),
@@ -88,6 +90,8 @@ def hip():
         "si_hip_ipc_open_mem_handle": (i, [vp, C.POINTER(vp)]),
         "si_hip_ipc_close_mem_handle": (i, [vp]),
         "si_hip_enable_peer_access": (i, [i]),
+        "si_hip_device_pci_bus_id": (i, [i, C.c_char_p, i]),
+        "si_hip_device_by_pci_bus_id": (i, [C.c_char_p]),
         "si_hip_graph_begin_capture": (i, [vp]),
         "si_hip_graph_end_capture": (i, [vp, C.POINTER(vp)]),
         "si_hip_graph_launch": (i, [vp, vp]),
@@ -110,6 +114,7 @@ def hip():
         "si_hip_conv2d_yolo_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),
         "si_hip_conv2d_upcat_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dUpsampledSource)]),
         "si_hip_conv2d_kernel_name": (C.c_char_p, [C.POINTER(SiConv2dDesc), vp]),
+        "si_hip_conv2d_kernel_name_form": (C.c_char_p, [C.POINTER(SiConv2dDesc), vp, i]),
         "si_hip_conv2d_set_tile_variant": (i, [i]),
         "si_hip_linear_f32": (i, [vp, i, i, vp, vp, i, vp, vp]),
         "si_hip_maxpool2d_f32": (i, [C.POINTER(SiPool2dDesc), vp, vp, vp]),
@@ -155,6 +160,12 @@ def hip():
     L._si_signatures = sig
     _hip = L
     return L
+
+
+class SiGatherStats(C.Structure):
+    """include/si_shard.h"""
+    _fields_ = [("wait_copies_ms_total", C.c_double), ("wait_barrier_ms_total", C.c_double), ("copy_ms_total", C.c_double),
+                ("copy_ms_max", C.c_double), ("completes", C.c_longlong), ("copies", C.c_longlong)]
 
 
 def host():
@@ -209,6 +220,7 @@ def host():
         "si_gather_slab": (vp, [vp, i]),
         "si_gather_push": (i, [vp, i, vp]),
         "si_gather_complete": (i, [vp, i]),
+        "si_gather_stats": (i, [vp, C.POINTER(SiGatherStats), i]),
     }
     for name, (res, args) in list(sig.items()) + list(shard.items()):
         fn = getattr(L, name)

@@ -30,6 +30,7 @@
 // tile, not a different sum).
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -157,6 +158,53 @@ template <int MT, int TM, int TN, int ACT1, int ACT2, bool HAS_RES, bool INTERIO
 __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, typename Mma<MT>::acc_t (&acc)[TM][TN], int g, int mrow0, int ocol0,
                                               const float* bias_pre) {
     constexpr int NE = Mma<MT>::NE;
+    if constexpr (MT == 16 && TN % 2 == 0) {
+        // 16x16 tiles in PAIRS along the channels: a lane holds, per register, one value of the left tile (A) and one of the right
+        // tile (B) for row e + 4g (g = its 16-lane group).  v_permlane16_swap trades A's odd groups with B's even groups, after
+        // which a register holds 32 CONSECUTIVE channels of one row in lanes 0-31 and of another row in lanes 32-63: every store
+        // instruction then writes two whole 128-byte row segments, as the 32x32 tile's does, instead of four 64-byte ones (which
+        // cost the strided concat-slice outputs of the C3 blocks 8-10 % of the layer).  Same arithmetic per element, so same bits.
+        const int lg = (int)(threadIdx.x & 63) >> 4;
+        const int hsel = lg & 1;                  // after the swap this lane stores the left (0) / right (1) half of the 32 channels
+        const int rbase = mrow0 - 4 * lg + 8 * (lg >> 1);   // ... of row rbase + e (first register) and rbase + 4 + e (second)
+#pragma unroll
+        for (int u = 0; u < TN; u += 2) {
+            const int o_l = ocol0 + u * 16, o_r = o_l + 16;   // this lane's channels in the two tiles
+            const float bv_l = bias_pre ? bias_pre[u] : ((a.bias && o_l < a.ocg) ? a.bias[g * a.ocg + o_l] : 0.0f);
+            const float bv_r = bias_pre ? bias_pre[u + 1] : ((a.bias && o_r < a.ocg) ? a.bias[g * a.ocg + o_r] : 0.0f);
+            const int o = o_l + 16 * hsel;        // the channel this lane stores
+            const bool live = o < a.ocg;
+            const int oc_abs = g * a.ocg + (live ? o : 0);
+            const bool second = a.out2 != nullptr && oc_abs >= a.split;
+            float* const obase = second ? a.out2 + (oc_abs - a.split) : a.out + oc_abs;
+            const int old = second ? a.out2_ld : a.out_ld;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                const int mb = rbase + t * 16;
+                float* const op = obase + (size_t)mb * old;
+                const float* const rp = HAS_RES ? a.res + (size_t)mb * a.res_ld + oc_abs : nullptr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float vl = act_fn<ACT1>(acc[t][u][e] + bv_l, a.act_param);
+                    const float vr = act_fn<ACT1>(acc[t][u + 1][e] + bv_r, a.act_param);
+                    // (inline assembly: with __builtin_amdgcn_permlane16_swap hipcc 7.2 used the FIRST result for both halves in this
+                    // function -- the second result's register was reused as an address before its store; the s_nop covers the
+                    // VALU-write -> permlane-read hazard the compiler otherwise pads)
+                    float x = vl, y = vr;
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+                    if (live && (INTERIOR || mb + e < a.M)) {
+                        if (HAS_RES) x += rp[e * a.res_ld];
+                        op[e * old] = act_fn<ACT2>(x, a.act_param);
+                    }
+                    if (live && (INTERIOR || mb + 4 + e < a.M)) {
+                        if (HAS_RES) y += rp[(4 + e) * a.res_ld];
+                        op[(4 + e) * old] = act_fn<ACT2>(y, a.act_param);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
         const int o = ocol0 + u * MT;  // channel inside the group
@@ -859,8 +907,9 @@ inline int round_up4(int v) { return (v + 3) & ~3; }
 // (6.7 ms vs 10.6 ms summed over the net).  Layers with <= 32 output channels use 128x32.
 //   id: 0 128x128x2  1 128x64x2  2 64x64x2  3 128x32x2  4 64x64x1  5 64x128x1  6 128x64x1  7 128x128x1
 //       8 64x128x2  10 128x32x1        (BM x BN x LDS stages; 32x32x2 MFMA)
-//       11 32x64x2  12 32x32x2  13 32x64x1  14 32x32x1  15 64x32x2  16 64x32x1  17 64x64x1  18 32x128x1     (16x16x4 MFMA, round 3)
-static constexpr int kConvVariants = 19;
+//       11 32x64x2  12 32x32x2  13 32x64x1  14 32x32x1  15 64x32x2  16 64x32x1  17 64x64x1  18 32x128x1  19 64x32x1 as 4x1 waves
+//       (16x16x4 MFMA, round 3)
+static constexpr int kConvVariants = 20;
 static int si_cu_count() {
     static const int cus = [] {
         int dev = 0, n = 0;
@@ -886,30 +935,43 @@ static int conv_forced_variant() {
 // profiles/r03_tile_sweep.txt).  What decides is how many workgroups a launch has against the 256 CUs, counted in 64x64 tiles:
 //   * >= 4800 tiles: the 64x64 tile, on the 16x16x4 MFMA (four accumulator chains per wave instead of one: the large 3x3
 //     stride-2 layers run 3-6 % faster than on the 32x32x2 MFMA, the rest the same);
-//   * 1200 .. 4800: half tiles -- 64x32 for pointwise layers, 32x64 for the others (2-6 % over 64x64);
+//   * 1200 .. 4800: half tiles -- 64x32 (as four 16x32 waves) for pointwise layers, 32x64 for the others (2-6 % over 64x64);
 //   * below: 32x32 (a 20x20 layer at batch 32 has 800 64x64-tiles, at batch 4 a hundred: -14 % ... -40 %), except 3x3 layers
 //     with 600+ tiles, which still prefer 32x64;
-//   * <= 32 output channels per group: 64x32.
+//   * <= 32 output channels per group: 64x32 (four 16x32 waves: 32 consecutive channels per store, see epilogue_lean).
+// In the network (same-box interleaved A/B of whole policies, tools/ab_policy.sh, profiles/r03_ab_policy.txt): YOLOv5s batch 32
+// 7232-7308 img/s with the round-2 rule (64x64 / 128x32 on the 32x32x2 MFMA everywhere) -> 7513-7517 with this one.
 // Whatever is chosen, the bits are the same (Mma, tests/test_gpu_tiles.py).
 static int conv_variant(const SiConv2dDesc* d) {
     const int forced = conv_forced_variant();
     if (forced >= 0) return forced;
+    // development: SI_CONV_POLICY="oc32,bigG,bigP,midG,midP,smallG,small" overrides the seven classes' variants (G: general, P: pointwise)
+    static const std::array<int, 7> cls = [] {
+        std::array<int, 7> c = {19, 17, 17, 13, 19, 13, 14};
+        if (const char* e = getenv("SI_CONV_POLICY")) {
+            int v[7];
+            if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) == 7)
+                for (int i = 0; i < 7; ++i)
+                    if (v[i] >= 0 && v[i] < kConvVariants && v[i] != 9) c[(size_t)i] = v[i];
+        }
+        return c;
+    }();
     const int ocg = d->oc / d->groups;
-    if (ocg <= 32) return 16;
+    if (ocg <= 32) return cls[0];
     const long long M = (long long)d->n * d->oh * d->ow;
     const long long tiles64 = ((M + 63) / 64) * ((ocg + 63) / 64) * d->groups;
     const bool pointwise = d->kh == 1 && d->kw == 1;
     // (thresholds in units of the 256-CU part they were measured on)
     const long long cus = si_cu_count();
-    if (tiles64 * 256 >= 4800 * cus) return 17;
-    if (tiles64 * 256 >= 1200 * cus) return pointwise ? 16 : 13;
-    if (!pointwise && tiles64 * 256 >= 600 * cus) return 13;
-    return 14;
+    if (tiles64 * 256 >= 4800 * cus) return pointwise ? cls[2] : cls[1];
+    if (tiles64 * 256 >= 1200 * cus) return pointwise ? cls[4] : cls[3];
+    if (!pointwise && tiles64 * 256 >= 600 * cus) return cls[5];
+    return cls[6];
 }
 // the generic kernel (any channel count) has four tiles: 0 128x128, 1 128x64, 2 64x64, 3 128x32; a forced variant maps to the
 // nearest one, the policy is the round-1 rule (these layers are latency / HBM bound)
 static int conv_generic_tile(const SiConv2dDesc* d) {
-    static const int generic_of[kConvVariants] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2};
+    static const int generic_of[kConvVariants] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2};
     const int forced = conv_forced_variant();
     if (forced >= 0) return generic_of[forced];
     return (d->oc / d->groups) <= 32 ? 3 : 2;
@@ -1141,6 +1203,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
             case 16: return launch_fast<64, 32, 2, 2, 1, 16>(a, d->groups, fs);
             case 17: return launch_fast<64, 64, 2, 2, 1, 16>(a, d->groups, fs);
             case 18: return launch_fast<32, 128, 2, 2, 1, 16>(a, d->groups, fs);
+            case 19: return launch_fast<64, 32, 4, 1, 1, 16>(a, d->groups, fs);
             default: return launch_fast<128, 32, 4, 1, 1>(a, d->groups, fs);
         }
     }
@@ -1191,26 +1254,30 @@ extern "C" int si_hip_conv2d_set_tile_variant(int variant) {
     return prev;
 }
 
-extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in) {
+// The kernel instantiation a launch of this problem runs, exactly as rocprofv3 prints it (minus the namespace):
+// conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, PADK, UPS, YOLO, PW, MT>.  form: 0 si_hip_conv2d_f32 / _split_f32,
+// 1 si_hip_conv2d_upcat_f32 (dual-source), 2 si_hip_conv2d_yolo_f32 (Detect epilogue).
+extern "C" const char* si_hip_conv2d_kernel_name_form(const SiConv2dDesc* d, const float* in, int form) {
     if (!d || d->groups <= 0) return "invalid";
     static const char* names[4][2] = {
         {"conv_igemm_f32_kernel<128, 128, 2, 2, false>", "conv_igemm_f32_kernel<128, 128, 2, 2, true>"},
         {"conv_igemm_f32_kernel<128, 64, 2, 2, false>", "conv_igemm_f32_kernel<128, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<64, 64, 2, 2, false>", "conv_igemm_f32_kernel<64, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<128, 32, 4, 1, false>", "conv_igemm_f32_kernel<128, 32, 4, 1, true>"}};
-    // as rocprofv3 prints the instantiation (minus the namespace) up to the YOLO argument: <BM, BN, WM, WN, NBUF, PADK, UPS, YOLO>;
-    // the trailing PW and MT arguments are left off, so a profile groups a tile's general and pointwise instantiations as ONE
-    // kernel (the same launches every earlier profile of this kernel covered); the 16x16-MFMA tiles are told apart by BM
-    static const int tile_of[kConvVariants][5] = {{128, 128, 2, 2, 2}, {128, 64, 2, 2, 2}, {64, 64, 2, 2, 2}, {128, 32, 4, 1, 2}, {64, 64, 2, 2, 1},
-                                                  {64, 128, 2, 2, 1},  {128, 64, 2, 2, 1}, {128, 128, 2, 2, 1}, {64, 128, 2, 2, 2}, {128, 32, 4, 1, 1},
-                                                  {128, 32, 4, 1, 1},  {32, 64, 2, 2, 2},  {32, 32, 2, 2, 2}, {32, 64, 2, 2, 1},  {32, 32, 2, 2, 1},
-                                                  {64, 32, 2, 2, 2},   {64, 32, 2, 2, 1},   {64, 64, 2, 2, 1}, {32, 128, 2, 2, 1}};
-    static char fast_names[kConvVariants][2][96];
+    static const int tile_of[kConvVariants][6] = {{128, 128, 2, 2, 2, 32}, {128, 64, 2, 2, 2, 32}, {64, 64, 2, 2, 2, 32}, {128, 32, 4, 1, 2, 32},
+                                                  {64, 64, 2, 2, 1, 32},   {64, 128, 2, 2, 1, 32}, {128, 64, 2, 2, 1, 32}, {128, 128, 2, 2, 1, 32},
+                                                  {64, 128, 2, 2, 2, 32},  {128, 32, 4, 1, 1, 32}, {128, 32, 4, 1, 1, 32}, {32, 64, 2, 2, 2, 16},
+                                                  {32, 32, 2, 2, 2, 16},   {32, 64, 2, 2, 1, 16},  {32, 32, 2, 2, 1, 16},  {64, 32, 2, 2, 2, 16},
+                                                  {64, 32, 2, 2, 1, 16},   {64, 64, 2, 2, 1, 16},  {32, 128, 2, 2, 1, 16}, {64, 32, 4, 1, 1, 16}};
+    // [variant][instantiation]: 0 general, 1 pointwise, 2 zero-padded K, 3 dual-source, 4 Detect
+    static char fast_names[kConvVariants][5][112];
     static const bool named = [] {
+        static const char* flags[5] = {"false, false, false, false", "false, false, false, true", "true, false, false, false",
+                                       "false, true, false, false", "false, false, true, false"};
         for (int v = 0; v < kConvVariants; ++v)
-            for (int pk = 0; pk < 2; ++pk)
-                snprintf(fast_names[v][pk], sizeof(fast_names[v][pk]), "conv_igemm_f32_fast_kernel<%d, %d, %d, %d, %d, %s, false, false>", tile_of[v][0],
-                         tile_of[v][1], tile_of[v][2], tile_of[v][3], tile_of[v][4], pk ? "true" : "false");
+            for (int k = 0; k < 5; ++k)
+                snprintf(fast_names[v][k], sizeof(fast_names[v][k]), "conv_igemm_f32_fast_kernel<%d, %d, %d, %d, %d, %s, %d>", tile_of[v][0],
+                         tile_of[v][1], tile_of[v][2], tile_of[v][3], tile_of[v][4], flags[k], tile_of[v][5]);
         return true;
     }();
     (void)named;
@@ -1218,11 +1285,18 @@ extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const fl
     if (si_conv_depthwise_ok(d)) return si_conv_depthwise_name(d);
     SiConv2dDesc eff = conv_effective(d);
     d = &eff;
-    int v = conv_variant(d);
     if (conv_fast_ok(d, in)) {
-        const bool padk = (d->ic / d->groups) % 32 != 0;   // zero-padded K: the PADK instantiation (kFull tiles only)
-        if (padk && !conv_variant_full(v)) v = (d->oc / d->groups) <= 32 ? 10 : 4;
-        return fast_names[v][padk ? 1 : 0];
+        // the dispatch rule of conv2d_dispatch
+        int v = conv_variant(d);
+        const bool padk = (d->ic / d->groups) % 32 != 0;
+        const bool pointwise = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow;
+        if (form == 2) return fast_names[4][4];
+        if ((padk || form == 1) && !conv_variant_full(v)) v = (d->oc / d->groups) <= 32 ? 10 : 4;
+        if (form == 1) return fast_names[v][3];
+        if (padk) return fast_names[v][2];
+        return fast_names[v][(pointwise && conv_variant_full(v)) ? 1 : 0];
     }
     return names[conv_generic_tile(d)][conv_vec_a(d, in) ? 1 : 0];
 }
+
+extern "C" const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in) { return si_hip_conv2d_kernel_name_form(d, in, 0); }

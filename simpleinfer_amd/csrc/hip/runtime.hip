@@ -63,6 +63,14 @@ int si_hip_host_alloc(void** ptr, size_t bytes) {
     return 0;
 }
 int si_hip_host_free(void* ptr) { if (ptr) SI_HIP_TRY(hipHostFree(ptr)); return 0; }
+// pin caller-owned host memory in place (a borrowed Engine::Input buffer that is uploaded on every Forward): copies from it
+// then run asynchronously at the link rate instead of being staged through the runtime's bounce buffers
+int si_hip_host_register(void* ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return SI_E_BADARG;
+    SI_HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+int si_hip_host_unregister(void* ptr) { if (ptr) SI_HIP_TRY(hipHostUnregister(ptr)); return 0; }
 
 int si_hip_memset_async(void* ptr, int value, size_t bytes, si_stream_t s) {
     SI_HIP_TRY(hipMemsetAsync(ptr, value, bytes, (hipStream_t)s));
@@ -132,6 +140,19 @@ int si_hip_ipc_open_mem_handle(const void* handle, void** dptr) {
     return 0;
 }
 int si_hip_ipc_close_mem_handle(void* dptr) { if (dptr) SI_HIP_TRY(hipIpcCloseMemHandle(dptr)); return 0; }
+// the device's PCI bus id ("0000:c1:00.0"): what identifies a GPU ACROSS processes whose HIP_VISIBLE_DEVICES differ (a device
+// INDEX only means something inside one process)
+int si_hip_device_pci_bus_id(int device, char* buf, int len) {
+    if (!buf || len < 16) return SI_E_BADARG;
+    SI_HIP_TRY(hipDeviceGetPCIBusId(buf, len, device));
+    return 0;
+}
+// index of the visible device with this PCI bus id, or -1 (hidden from this process / unknown)
+int si_hip_device_by_pci_bus_id(const char* bus_id) {
+    int dev = -1;
+    if (!bus_id || hipDeviceGetByPCIBusId(&dev, bus_id) != hipSuccess) return -1;
+    return dev;
+}
 int si_hip_enable_peer_access(int peer_device) {
     int cur = -1;
     SI_HIP_TRY(hipGetDevice(&cur));

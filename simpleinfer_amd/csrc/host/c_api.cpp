@@ -159,6 +159,7 @@ int si_engine_schedule(SiEngine* e, char* buf, size_t cap) {
     size_t arena = 0, unshared = 0;
     e->impl.ActivationFootprint(arena, unshared);
     os << "arena_bytes " << arena << "\n" << "per_operand_bytes " << unshared << "\n";
+    os << "lanes " << e->impl.Lanes() << "\n";   // 2: the batch runs as two half-batch lanes on two streams (option "streams")
     return copy_out(os.str(), buf, cap);
 }
 

@@ -61,6 +61,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else if (key == "streams") opt_streams_ = value;  // 2: two half-batch lanes on two streams, 1: one stream, 0 (default): auto
+    else if (key == "host_slices") opt_host_slices_ = value;  // host tensors in and out: G pipelined batch slices per Forward(), 1 off, 0 (default) auto
     else {
         LOG(ERROR) << "unknown engine option [" << key << "]";
         return Status::kUnsupport;
@@ -151,6 +152,8 @@ Status EngineImpl::LoadModel(const std::string& parampath, const std::string& bi
 Status EngineImpl::Release() {
     if (context_ && context_->stream()) si_hip_stream_sync(context_->stream());
     CHECK_STATUS(DestroyGraphCache());   // (a captured graph references the lanes' streams and buffers)
+    CHECK_STATUS(DestroySlicer());
+    UnpinInputs();
     CHECK_STATUS(DestroyLanes());
     CHECK_STATUS(DeallocateTensorMemory());
     CHECK_STATUS(DestroyPipeline());
@@ -453,6 +456,7 @@ Status EngineImpl::DestroyGraphCache() {
 Status EngineImpl::DestroyPipeline() {
     CHECK_STATUS(DestroyGraphCache());
     forward_count_ = 0;
+    plan_warm_ = false;
     plan_.clear();
     fused_ops_.clear();
     sibling_ops_.clear();
@@ -885,10 +889,10 @@ Status EngineImpl::DeallocateTensorMemory() {
 // path is per-image, so a lane is simply this model re-batched to N / 2 (the "batch" option's rule) that reads
 // and writes slab views of this engine's input and output buffers; results are bit-identical to the one-stream schedule because
 // no kernel's per-element arithmetic depends on the batch (tests/test_gpu_tiles.py, tests/test_gpu_engine.py).
-Status EngineImpl::PlanLanes(int& lanes) {
-    lanes = 1;
-    if (is_lane_ || opt_streams_ == 1) return Status::kSuccess;
-    int batch = 0;
+// Can the batch be cut into contiguous slabs?  Every graph input and output must be batch-major (dimension 0 = the batch, rank >= 2);
+// every operator of the path is per-image, so nothing else is needed.
+bool EngineImpl::BatchSplittable(int& batch) const {
+    batch = 0;
     bool ok = !input_tensor_nodes_.empty() && !output_tensor_nodes_.empty();
     for (auto& kv : input_tensor_nodes_) {
         const std::vector<int>& sh = kv.second->tensor.Shape();
@@ -899,7 +903,14 @@ Status EngineImpl::PlanLanes(int& lanes) {
         const std::vector<int>& sh = kv.second->tensor.Shape();
         if (sh.size() < 2 || sh[0] != batch) ok = false;
     }
-    ok = ok && batch >= 2 && batch % 2 == 0;
+    return ok && batch >= 2;
+}
+
+Status EngineImpl::PlanLanes(int& lanes) {
+    lanes = 1;
+    if (is_lane_ || opt_streams_ == 1) return Status::kSuccess;
+    int batch = 0;
+    const bool ok = BatchSplittable(batch) && batch % 2 == 0;
     if (opt_streams_ >= 2) {
         if (!ok) {
             LOG(ERROR) << "streams=2 needs an even batch that is dimension 0 of every graph input and output";
@@ -927,7 +938,8 @@ Status EngineImpl::LoadLanes(int lanes) {
         lane->opt_winograd_ = opt_winograd_;
         lane->opt_detect_stream_ = opt_detect_stream_;
         lane->opt_fp16_ = opt_fp16_;
-        lane->opt_graph_ = false;             // this engine captures both lanes in ONE graph
+        lane->opt_graph_ = opt_graph_;        // every lane replays its OWN captured graph on its own stream; this engine only forks / joins
+                                              // (one graph holding both branches measured 10 % SLOWER than one stream: profiles/r03_ab_streams.txt)
         lane->opt_outputs_to_host_ = false;   // ... and owns the host mirrors
         lane->opt_streams_ = 1;
         lane->opt_batch_ = batch / lanes;
@@ -972,8 +984,8 @@ Status EngineImpl::BindLanes() {
     return Status::kSuccess;
 }
 
-// fork: every lane's stream waits for this engine's stream (the input upload); join: this stream waits for every lane.  Under
-// hipGraph capture the lanes' streams join the capture through the fork event, so ONE replayed graph holds both branches.
+// fork: every lane's stream waits for this engine's stream (the input upload); join: this stream waits for every lane.  With
+// option "graph" every lane replays its own captured graph between the two.
 Status EngineImpl::LaunchLanes() {
     si_stream_t stream = context_->stream();
     SI_TRY_HIP(si_hip_event_record(ev_fork_, stream), "event record");
@@ -984,6 +996,144 @@ Status EngineImpl::LaunchLanes() {
         SI_TRY_HIP(si_hip_event_record(lane_done_[l], lanes_[l]->context_->stream()), "event record");
     }
     for (size_t l = 0; l < lanes_.size(); ++l) SI_TRY_HIP(si_hip_stream_wait_event(stream, lane_done_[l]), "stream wait");
+    return Status::kSuccess;
+}
+
+// ---- the reference's host-tensor contract at speed (option "host_slices") -------------------------------------------------
+// Engine::Input borrows a HOST tensor that is read at Forward() time and Extract hands back host-visible memory (reference
+// src/engine_impl.cpp:522-555, bench/bench_yolo.cpp:20-28).  Done naively that is upload -> compute -> download in series:
+// YOLOv5s batch 32 moves 157 MB up and 274 MB down around 4.3 ms of kernels, 12.8 ms per Forward.  Here one synchronous
+// Forward() is a three-stage pipeline over G contiguous batch slices: slice g's images go up on an upload stream while slice
+// g-1 computes (ONE child engine of batch N / G runs the slices back to back on its own stream: same weights, same arena) and
+// slice g-2's output rows come down on a download stream into the pinned mirror Extract() returns.  What is left outside the
+// overlap is the first slice's upload and the last slice's download.  A borrowed input buffer that is handed over for a second
+// Forward is pinned in place (hipHostRegister) so its uploads run asynchronously at the link rate.  Bit-identical to the
+// unsliced schedule (per-image arithmetic; tests/test_gpu_engine.py::test_host_tensor_pipeline_*).
+int EngineImpl::PlanSlices() const {
+    if (is_lane_ || opt_host_slices_ == 1 || !opt_outputs_to_host_) return 1;
+    int batch = 0;
+    if (!BatchSplittable(batch)) return 1;
+    for (auto& kv : input_tensor_nodes_) {
+        auto u = user_inputs_.find(kv.first);
+        if (u == user_inputs_.end() || u->second.RawData() == nullptr || u->second.GetMemoryType() == MemoryType::kDevice) return 1;
+    }
+    if (!user_outputs_.empty()) return 1;   // caller-owned device outputs: not the host contract
+    if (opt_host_slices_ > 1) return batch % opt_host_slices_ == 0 ? opt_host_slices_ : 1;
+    // auto: slices of 8 images (MI355X, YOLOv5s: a batch-8 forward is still at 0.6 of the MFMA ceiling, and 8 images are 39 MB up /
+    // 69 MB down -- 0.7 / 1.3 ms of PCIe outside the overlap); at most 8 slices (one captured graph per slice under "graph")
+    if (batch < 16 || batch % 8 != 0) return 1;
+    int g = batch / 8;
+    while (g > 8 && g % 2 == 0) g /= 2;
+    return g <= 8 ? g : 1;
+}
+
+Status EngineImpl::DestroySlicer() {
+    delete slicer_;
+    slicer_ = nullptr;
+    slices_ = 0;
+    for (si_event_t e : ev_up_) si_hip_event_destroy(e);
+    for (si_event_t e : ev_done_) si_hip_event_destroy(e);
+    ev_up_.clear();
+    ev_done_.clear();
+    if (ev_down_all_) si_hip_event_destroy(ev_down_all_);
+    ev_down_all_ = nullptr;
+    delete up_context_;
+    delete down_context_;
+    up_context_ = down_context_ = nullptr;
+    return Status::kSuccess;
+}
+
+void EngineImpl::UnpinInputs() {
+    for (auto& kv : pinned_inputs_)
+        if (kv.second.registered) si_hip_host_unregister(const_cast<void*>(kv.second.ptr));
+    pinned_inputs_.clear();
+}
+
+Status EngineImpl::ForwardSliced(int slices) {
+    si_stream_t stream = context_->stream();
+    if (slicer_ == nullptr || slices_ != slices) {
+        CHECK_STATUS(DestroySlicer());
+        int batch = 0;
+        CHECK_BOOL(BatchSplittable(batch) && batch % slices == 0);
+        slicer_ = new EngineImpl;
+        slicer_->is_lane_ = true;
+        slicer_->opt_device_ = context_->device();
+        slicer_->opt_fuse_ = opt_fuse_;
+        slicer_->opt_alias_cat_ = opt_alias_cat_;
+        slicer_->opt_fuse_upsample_ = opt_fuse_upsample_;
+        slicer_->opt_arena_ = opt_arena_;
+        slicer_->opt_winograd_ = opt_winograd_;
+        slicer_->opt_detect_stream_ = opt_detect_stream_;
+        slicer_->opt_fp16_ = opt_fp16_;
+        slicer_->opt_graph_ = opt_graph_;          // one captured graph per slice (its I/O pointers key the cache)
+        slicer_->opt_outputs_to_host_ = false;
+        slicer_->opt_streams_ = 1;
+        slicer_->opt_batch_ = batch / slices;
+        CHECK_STATUS(slicer_->LoadModel(param_path_, bin_path_));
+        slices_ = slices;
+        up_context_ = new Context;
+        CHECK_STATUS(up_context_->Init(context_->device()));
+        down_context_ = new Context;
+        CHECK_STATUS(down_context_->Init(context_->device()));
+        ev_up_.assign((size_t)slices, nullptr);
+        ev_done_.assign((size_t)slices, nullptr);
+        for (auto& e : ev_up_) SI_TRY_HIP(si_hip_event_create(&e), "event create");
+        for (auto& e : ev_done_) SI_TRY_HIP(si_hip_event_create(&e), "event create");
+        SI_TRY_HIP(si_hip_event_create(&ev_down_all_), "event create");
+        if (!ev_fork_) SI_TRY_HIP(si_hip_event_create(&ev_fork_), "event create");
+        LOG(INFO) << "host_slices: " << slices << " pipelined slices of batch " << batch / slices;
+    }
+    // the engine's device-side input staging and its own output buffers, whole batch; the slices are views
+    for (auto& kv : input_tensor_nodes_) kv.second->tensor.SetView(input_buffers_[kv.first], MemoryType::kDevice, 0);
+    CHECK_STATUS(BindOutputs());
+    // a borrowed input seen for the second Forward in a row is pinned in place; a different pointer drops the old pin
+    for (auto& kv : input_tensor_nodes_) {
+        const Tensor& host = user_inputs_[kv.first];
+        Pinned& p = pinned_inputs_[kv.first];
+        if (p.ptr != host.RawData() || p.bytes != host.ByteSize()) {
+            if (p.registered) si_hip_host_unregister(const_cast<void*>(p.ptr));
+            p = Pinned();
+            p.ptr = host.RawData();
+            p.bytes = host.ByteSize();
+        }
+        if (++p.seen == 2 && !p.registered) {
+            p.registered = si_hip_host_register(const_cast<void*>(p.ptr), p.bytes) == 0;   // (failure: the uploads stay staged copies)
+            if (!p.registered) LOG(INFO) << "host_slices: could not pin the input buffer of [" << kv.first << "]; uploads stay staged";
+        }
+    }
+    SI_TRY_HIP(si_hip_event_record(ev_start_, stream), "event record");
+    // the upload stream starts behind whatever this engine's stream still holds (a previous ForwardAsync)
+    SI_TRY_HIP(si_hip_event_record(ev_fork_, stream), "event record");
+    SI_TRY_HIP(si_hip_stream_wait_event(up_context_->stream(), ev_fork_), "stream wait");
+    SI_TRY_HIP(si_hip_stream_wait_event(slicer_->context_->stream(), ev_fork_), "stream wait");
+    SI_TRY_HIP(si_hip_stream_wait_event(down_context_->stream(), ev_fork_), "stream wait");
+    for (int g = 0; g < slices; ++g) {
+        for (auto& kv : input_tensor_nodes_) {
+            const Tensor dst = SlabView(kv.second->tensor, g, slices);
+            const size_t bytes = dst.ByteSize();
+            const char* src = static_cast<const char*>(user_inputs_[kv.first].RawData()) + (size_t)g * bytes;
+            SI_TRY_HIP(si_hip_memcpy_h2d(dst.RawData(), src, bytes, up_context_->stream()), "input slice h2d");
+            CHECK_STATUS(slicer_->Input(kv.first, dst));
+        }
+        SI_TRY_HIP(si_hip_event_record(ev_up_[(size_t)g], up_context_->stream()), "event record");
+        SI_TRY_HIP(si_hip_stream_wait_event(slicer_->context_->stream(), ev_up_[(size_t)g]), "stream wait");
+        for (auto& kv : output_tensor_nodes_) CHECK_STATUS(slicer_->Output(kv.first, SlabView(kv.second->tensor, g, slices)));
+        CHECK_STATUS(slicer_->ForwardAsync());
+        slicer_->forward_pending_ = false;
+        SI_TRY_HIP(si_hip_event_record(ev_done_[(size_t)g], slicer_->context_->stream()), "event record");
+        SI_TRY_HIP(si_hip_stream_wait_event(down_context_->stream(), ev_done_[(size_t)g]), "stream wait");
+        for (auto& kv : output_tensor_nodes_) {
+            const Tensor src = SlabView(kv.second->tensor, g, slices);
+            const size_t bytes = src.ByteSize();
+            SI_TRY_HIP(si_hip_memcpy_d2h(static_cast<char*>(host_outputs_[kv.first]) + (size_t)g * bytes, src.RawData(), bytes,
+                                         down_context_->stream()), "output slice d2h");
+        }
+    }
+    SI_TRY_HIP(si_hip_event_record(ev_down_all_, down_context_->stream()), "event record");
+    SI_TRY_HIP(si_hip_stream_wait_event(stream, ev_down_all_), "stream wait");   // Sync() on this engine's stream covers the pipeline
+    SI_TRY_HIP(si_hip_event_record(ev_stop_, stream), "event record");
+    forward_pending_ = true;
+    ++forward_count_;
     return Status::kSuccess;
 }
 
@@ -1016,6 +1166,16 @@ Status EngineImpl::Input(const std::string& name, const Tensor& input) {
     if (input.NumElements() != it->second->tensor.NumElements() || input.GetDataType() != it->second->tensor.GetDataType()) {
         LOG(ERROR) << "tensor [" << name << "] does not match the model's input shape / type";
         return Status::kErrorShape;
+    }
+    // a previously borrowed buffer that was pinned in place (host_slices) is released to its owner NOW: the caller may free it
+    // as soon as this returns (reference contract: borrowed until the next Input() / Release, engine_impl.cpp:466-471,528)
+    auto pin = pinned_inputs_.find(name);
+    if (pin != pinned_inputs_.end() && pin->second.ptr != input.RawData()) {
+        if (pin->second.registered) {
+            if (up_context_) si_hip_stream_sync(up_context_->stream());
+            si_hip_host_unregister(const_cast<void*>(pin->second.ptr));
+        }
+        pinned_inputs_.erase(pin);
     }
     user_inputs_[name] = input;  // alias: the caller keeps ownership (reference engine_impl.cpp:528)
     return Status::kSuccess;
@@ -1129,12 +1289,13 @@ Status EngineImpl::ForwardAsync() {
     }
     si_hip_set_device(context_->device());
     si_stream_t stream = context_->stream();
+    if (const int slices = PlanSlices(); slices > 1) return ForwardSliced(slices);
     CHECK_STATUS(UploadInputs());
     CHECK_STATUS(BindOutputs());
     if (!lanes_.empty()) CHECK_STATUS(BindLanes());
 
     SI_TRY_HIP(si_hip_event_record(ev_start_, stream), "event record");
-    if (opt_graph_ && forward_count_ > 0) {
+    if (opt_graph_ && plan_warm_ && lanes_.empty()) {
         // a captured graph bakes pointers in: key the cache on where the device-resident inputs and the outputs are now
         std::vector<void*> key;
         for (auto& kv : input_tensor_nodes_) key.push_back(kv.second->tensor.RawData());
@@ -1164,8 +1325,10 @@ Status EngineImpl::ForwardAsync() {
         }
         SI_TRY_HIP(si_hip_graph_launch(exec, stream), "graph launch");
     } else {
-        // first call is always eager: it uploads weights and sizes scratch buffers
+        // the first pass over this engine's own plan is always eager: it uploads weights and sizes scratch buffers (a Forward
+        // served by the sliced host pipeline does not count: that ran the slicer's plan)
         CHECK_STATUS(LaunchAll());
+        plan_warm_ = true;
     }
     SI_TRY_HIP(si_hip_event_record(ev_stop_, stream), "event record");
 

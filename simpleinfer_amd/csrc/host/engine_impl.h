@@ -111,6 +111,13 @@ private:
     Status DestroyLanes();
     Status DestroyGraphCache();
 
+    // host-tensor contract at speed (option "host_slices"): see ForwardSliced
+    bool BatchSplittable(int& batch) const;
+    int PlanSlices() const;
+    Status ForwardSliced(int slices);
+    Status DestroySlicer();
+    void UnpinInputs();
+
 private:
     // options
     int opt_device_ = -1;
@@ -125,6 +132,7 @@ private:
     int opt_detect_stream_ = 1;        // Detect's early levels on a second stream beside the layers that follow their inputs: 0 never, 1 for levels with enough work, 2 always
     bool opt_fp16_ = false;      // fp16 storage for internal activations and weights (BASELINE.json configs[3])
     int opt_streams_ = 0;        // 2: two half-batch lanes on two streams; 1: one stream; 0 (default): 2 where it was measured faster
+    int opt_host_slices_ = 0;    // host inputs + host outputs: G batch slices pipelined over PCIe inside one Forward(); 1: off; 0 (default): auto
 
     Context* context_ = nullptr;
     Context* side_context_ = nullptr;        // second stream (option "detect_stream"); created with the first plan that uses it
@@ -145,6 +153,17 @@ private:
     std::vector<si_event_t> lane_done_;
     bool is_lane_ = false;
     std::string param_path_, bin_path_;
+
+    // the sliced host pipeline: ONE child engine of batch N / slices_ that runs the slices one after the other, an upload and a
+    // download stream beside it
+    EngineImpl* slicer_ = nullptr;
+    int slices_ = 0;
+    Context* up_context_ = nullptr;
+    Context* down_context_ = nullptr;
+    std::vector<si_event_t> ev_up_, ev_done_;
+    si_event_t ev_down_all_ = nullptr;
+    struct Pinned { const void* ptr = nullptr; size_t bytes = 0; int seen = 0; bool registered = false; };
+    std::map<std::string, Pinned> pinned_inputs_;   // borrowed host inputs that were pinned in place (hipHostRegister)
     std::set<std::string> fused_ops_;        // operator names folded into a conv epilogue
     std::set<std::string> sibling_ops_;      // convs computed by a sibling conv's launch
     std::set<std::string> dead_operands_;    // operands that no longer exist after fusion
@@ -166,6 +185,7 @@ private:
     // buffers (ShardedEngine, OverlappedGather) replay instead of re-capturing every Forward.  Small LRU.
     std::vector<std::pair<std::vector<void*>, si_graph_t>> graph_cache_;
     int forward_count_ = 0;
+    bool plan_warm_ = false;      // this engine's own plan has run eagerly once (weights uploaded): captures are allowed
     bool forward_pending_ = false;
 
     si_event_t ev_start_ = nullptr, ev_stop_ = nullptr;

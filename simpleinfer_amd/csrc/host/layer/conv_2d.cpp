@@ -440,8 +440,7 @@ const char* Conv2d::KernelName() const {
     if (mode == 2) return "conv_stem_f16_kernel";
     const int tile = WinogradTile(d);
     if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
-    if (up_node_) return d.oc <= 32 ? "conv_igemm_f32_fast_kernel<128, 32, 4, 1, 1, false, true, false>" : "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, true, false>";
-    return si_hip_conv2d_kernel_name(&d, in.Data<float>());
+    return si_hip_conv2d_kernel_name_form(&d, in.Data<float>(), up_node_ ? 1 : 0);
 }
 
 // 0 = implicit GEMM, 2 = fused Winograd F(2,3), 4 = fused Winograd F(4,3) for this layer's static shape

@@ -189,13 +189,15 @@ struct SiDirectGather {
     std::vector<si_event_t> ready;           // [slot] producer finished writing the slab
     std::vector<std::vector<si_event_t>> sent;  // [slot][rank] my slab of that slot has landed in that peer
     std::vector<char> pushed;                // [slot] a push is outstanding
+    SiGatherStats stats;                     // since the last reset
 };
 
 namespace {
 
 struct Advert {  // what a rank tells the others about itself
-    int32_t device;
+    int32_t device;   // its index of the device in ITS process (diagnostics only: indices are per process)
     int32_t ok;
+    char bus_id[32];  // the device's PCI bus id: the same GPU for every process, whatever HIP_VISIBLE_DEVICES each one has
     unsigned char handle[8][SI_IPC_HANDLE_BYTES];
 };
 static_assert(sizeof(Advert) <= SI_GROUP_MAX_BYTES, "advert must fit one group slot");
@@ -242,7 +244,9 @@ int si_gather_create(SiNodeGroup* g, int device, size_t slab_bytes, int slots, S
     Advert me;
     memset(&me, 0, sizeof(me));
     me.device = device;
+    memset(&d->stats, 0, sizeof(d->stats));
     int rc = si_hip_set_device(device);
+    if (rc == 0) rc = si_hip_device_pci_bus_id(device, me.bus_id, (int)sizeof(me.bus_id));
     for (int s = 0; rc == 0 && s < slots; ++s) {
         rc = si_hip_malloc(&d->mine[(size_t)s], slab_bytes * (size_t)world);
         if (rc == 0) rc = si_hip_memset_async(d->mine[(size_t)s], 0, slab_bytes * (size_t)world, nullptr);
@@ -259,9 +263,16 @@ int si_gather_create(SiNodeGroup* g, int device, size_t slab_bytes, int slots, S
 
     for (int p = 0; rc == 0 && p < world; ++p) {
         if (p == rank) continue;
-        if (all[(size_t)p].device != device) {
-            const int pe = si_hip_enable_peer_access(all[(size_t)p].device);
-            if (pe != 0) LOG(INFO) << "si_gather_create: peer access " << device << " -> " << all[(size_t)p].device << " not enabled (" << pe << "); relying on the IPC mapping";
+        // the peer's GPU, as THIS process numbers it (the peer's own index means nothing here when HIP_VISIBLE_DEVICES differs
+        // between ranks); a GPU hidden from this process cannot be named for hipDeviceEnablePeerAccess -- the IPC mapping below
+        // then has to carry the access by itself
+        char peer_bus[32];
+        memcpy(peer_bus, all[(size_t)p].bus_id, sizeof(peer_bus));
+        peer_bus[sizeof(peer_bus) - 1] = 0;
+        if (strcmp(peer_bus, me.bus_id) != 0) {
+            const int local = si_hip_device_by_pci_bus_id(peer_bus);
+            const int pe = local >= 0 ? si_hip_enable_peer_access(local) : -1;
+            if (pe != 0) LOG(INFO) << "si_gather_create: peer access " << me.bus_id << " -> " << peer_bus << " not enabled (" << pe << "); relying on the IPC mapping";
         }
         for (int s = 0; rc == 0 && s < slots; ++s) rc = si_hip_ipc_open_mem_handle(all[(size_t)p].handle[s], &d->peer[(size_t)p][(size_t)s]);
         if (rc == 0) rc = si_hip_stream_create(&d->stream[(size_t)p]);
@@ -316,15 +327,37 @@ int si_gather_push(SiDirectGather* d, int slot, si_stream_t producer) {
 int si_gather_complete(SiDirectGather* d, int slot) {
     if (!d || slot < 0 || slot >= d->slots) return SI_SHARD_E_BADARG;
     int rc = 0;
+    const double t0 = now_s();
     // a copy command completes with its bytes visible at system scope; the barrier then tells every rank that all peers'
     // pushes into ITS buffer are done; kernels launched afterwards see them
     // (only THIS slot's copies are waited for: a later slot's fan-out keeps running behind the next step's compute)
     if (d->pushed[(size_t)slot]) {
         for (si_event_t e : d->sent[(size_t)slot]) if (e && rc == 0) rc = si_hip_event_sync(e);
         d->pushed[(size_t)slot] = 0;
+        // how long each peer copy took behind the producer (ready -> landed); with an idle copy stream that is the copy itself
+        for (si_event_t e : d->sent[(size_t)slot]) {
+            float ms = 0.f;
+            if (e && rc == 0 && si_hip_event_elapsed_ms(d->ready[(size_t)slot], e, &ms) == 0 && ms > 0.f) {
+                d->stats.copy_ms_total += ms;
+                d->stats.copies += 1;
+                if (ms > d->stats.copy_ms_max) d->stats.copy_ms_max = ms;
+            }
+        }
     }
+    const double t1 = now_s();
     const int b = si_group_barrier(d->group);
+    const double t2 = now_s();
+    d->stats.completes += 1;
+    d->stats.wait_copies_ms_total += (t1 - t0) * 1e3;
+    d->stats.wait_barrier_ms_total += (t2 - t1) * 1e3;
     return rc != 0 ? rc : b;
+}
+
+int si_gather_stats(SiDirectGather* d, SiGatherStats* out, int reset) {
+    if (!d || !out) return SI_SHARD_E_BADARG;
+    *out = d->stats;
+    if (reset) memset(&d->stats, 0, sizeof(d->stats));
+    return 0;
 }
 
 }  // extern "C"

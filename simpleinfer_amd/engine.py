@@ -161,7 +161,7 @@ class Engine:
         out: Dict[str, List[str]] = {"run": [], "fused": [], "alias": []}
         for ln in buf.value.decode().splitlines():
             k, v = ln.split(" ", 1)
-            if k in ("arena_bytes", "per_operand_bytes"):
+            if k in ("arena_bytes", "per_operand_bytes", "lanes"):
                 out[k] = int(v)      # HBM held for intermediates: shared by lifetime / one allocation per operand
             else:
                 out[k].append(v)

@@ -92,6 +92,21 @@ class DirectGather:
     def complete(self, slot: int):
         _check(self._h.si_gather_complete(self._d, slot), "si_gather_complete")
 
+    def stats(self, reset: bool = False) -> dict:
+        """si_gather_stats: where the steps' time went since the last reset (host waits in si_gather_complete, device time of
+        the peer copies) -- per-step / per-copy averages and the achieved per-peer copy rate"""
+        st = _native.SiGatherStats()
+        _check(self._h.si_gather_stats(self._d, C.byref(st), 1 if reset else 0), "si_gather_stats")
+        n, c = max(int(st.completes), 1), int(st.copies)
+        out = {"gather_wait_copies_ms": round(st.wait_copies_ms_total / n, 4), "gather_wait_barrier_ms": round(st.wait_barrier_ms_total / n, 4),
+               "gather_wait_ms": round((st.wait_copies_ms_total + st.wait_barrier_ms_total) / n, 4), "completes": int(st.completes),
+               "peer_copies": c, "peer_copy_ms": None, "peer_copy_ms_max": None, "gather_gbps_per_peer": None}
+        if c:
+            out["peer_copy_ms"] = round(st.copy_ms_total / c, 4)
+            out["peer_copy_ms_max"] = round(st.copy_ms_max, 4)
+            out["gather_gbps_per_peer"] = round(self.slab_bytes / (st.copy_ms_total / c * 1e-3) / 1e9, 2)
+        return out
+
     def close(self):
         if self._d:
             d, self._d = self._d, C.c_void_p()
