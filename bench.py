@@ -384,8 +384,7 @@ def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
 
     def compute(k, thr):
         H.si_hip_stream_wait_event(es, ev_up[k])
-        for b in range(n):
-            H.si_hip_letterbox_u8_f32(dev_u8[k].ptr + b * img_bytes, hr, wr, dev_in[k].ptr + b * size * size * 3 * 4, size, size, pt, pl, es)
+        H.si_hip_letterbox_batch_u8_f32(dev_u8[k].ptr, n, img_bytes, hr, wr, dev_in[k].ptr, size, size, pt, pl, es)
         H.si_hip_event_record(ev_used[k], es)
         e.input_device(iname, dev_in[k].ptr)
         e.forward_async()

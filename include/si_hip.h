@@ -297,6 +297,11 @@ void si_letterbox_geometry(int height_origin, int width_origin, int height_new, 
  * with the caller.) */
 int si_hip_letterbox_u8_f32(const unsigned char* resized_bgr, int height_resize, int width_resize, float* out,
                             int height_new, int width_new, int padding_t, int padding_l, si_stream_t stream);
+/* ... for the n images of a batch that share one geometry (frames of one camera), image b at resized_bgr + b *
+ * image_stride_bytes, written to slots 0..n-1 of the NHWC input tensor `out`: one launch */
+int si_hip_letterbox_batch_u8_f32(const unsigned char* resized_bgr, int n, size_t image_stride_bytes, int height_resize,
+                                  int width_resize, float* out, int height_new, int width_new, int padding_t,
+                                  int padding_l, si_stream_t stream);
 /* Detection post-processing of test_yolo.cpp:337-428 on the device, for all images of a batch:
  *   confidence = pred[.,4] * max_k pred[.,5+k] (first maximum), kept when >= prob_threshold (:341-377);
  *   sorted by confidence, descending (:380; equal confidences are ordered by element index here, by an unstable

@@ -150,6 +150,7 @@ def hip():
         "si_hip_convert_f16_f32": (i, [vp, sz, i, i, vp, i, vp]),
         "si_letterbox_geometry": (None, [i, i, i, i, ip, ip, C.POINTER(f), ip, ip]),
         "si_hip_letterbox_u8_f32": (i, [vp, i, i, vp, i, i, i, i, vp]),
+        "si_hip_letterbox_batch_u8_f32": (i, [vp, i, sz, i, i, vp, i, i, i, i, vp]),
         "si_hip_yolo_postprocess_workspace_bytes": (sz, [i, i, i]),
         "si_hip_yolo_postprocess_f32": (i, [vp, i, i, i, f, f, i, vp, vp, vp, i, vp, sz, vp]),
     }

@@ -297,24 +297,24 @@ __device__ __forceinline__ void epilogue_generic(const ConvArgs& a, typename Mma
 // Detect head: sigmoid, grid / anchor decode and the concat into [N][rows_total][ne] in the conv epilogue
 // (reference src/layer/yolo_detect.cpp:223-266).  Output channel o = anchor*ne + e; pixel (y,x) of level rows
 // [H][W][anchor], so one pixel's na*ne outputs are contiguous: offset = ((img*rows_total + row_off + pix*na)*ne + o.
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue_yolo(const ConvArgs& a, f32x16 (&acc)[TM][TN], int mrow0, int ocol0) {
+template <int MT, int TM, int TN>
+__device__ __forceinline__ void epilogue_yolo(const ConvArgs& a, typename Mma<MT>::acc_t (&acc)[TM][TN], int mrow0, int ocol0) {
     const int per_pix = a.yna * a.yne;
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
-        const int o = ocol0 + u * 32;
+        const int o = ocol0 + u * MT;
         if (o >= a.ocg) continue;
         const float bv = a.bias ? a.bias[o] : 0.0f;
         const int anc = o / a.yne;
         const int e_ = o - anc * a.yne;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            const int mb = mrow0 + t * 32;
+            const int mb = mrow0 + t * MT;
             const int img0 = mb / a.ohow;
             const int pix0 = mb - img0 * a.ohow;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int dm = (e & 3) + 8 * (e >> 2);
+            for (int e = 0; e < Mma<MT>::NE; ++e) {
+                const int dm = Mma<MT>::row(e);
                 if (mb + dm < a.M) {
                     int pix = pix0 + dm, img = img0;
                     if (pix >= a.ohow) {  // tile rows may span several images when the level is tiny (2x2, 4x4 maps)
@@ -346,12 +346,10 @@ __device__ __forceinline__ void epilogue_yolo(const ConvArgs& a, f32x16 (&acc)[T
 template <int TM, int TN, int YMODE = -1, int MT = 32>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, typename Mma<MT>::acc_t (&acc)[TM][TN], int g, int mrow0, int ocol0, bool interior = false,
                                          int yolo_img = -1, const float* bias_pre = nullptr) {
-    if constexpr (MT == 32) {   // (the Detect form exists on the 32x32 tile only)
-        if (YMODE == 1 || (YMODE < 0 && a.ymode)) {
-            if (yolo_img >= 0) si_yolo_tile_one_image<TM, TN>(a, a.out, acc, mrow0, ocol0, yolo_img);
-            else epilogue_yolo<TM, TN>(a, acc, mrow0, ocol0);
-            return;
-        }
+    if (YMODE == 1 || (YMODE < 0 && a.ymode)) {
+        if (yolo_img >= 0) si_yolo_tile_one_image<TM, TN, ConvArgs, MT, typename Mma<MT>::acc_t>(a, a.out, acc, mrow0, ocol0, yolo_img);
+        else epilogue_yolo<MT, TM, TN>(a, acc, mrow0, ocol0);
+        return;
     }
     // the shapes the YOLOv5 / ResNet graphs produce get straight-line code; the rest is generic
     if (a.act2 == SI_ACT_NONE && a.act1 == SI_ACT_SILU) {
@@ -565,7 +563,6 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
     static_assert(MT == 32 || MT == 16, "MFMA tile");
     static_assert(BM % 32 == 0 && BN % 32 == 0 && BM % (WM * MT) == 0 && BN % (WN * MT) == 0, "tile shape");
-    static_assert(MT == 32 || !YOLO, "the Detect epilogue exists on the 32x32 tile only");
     constexpr int TM = BM / WM / MT;
     constexpr int TN = BN / WN / MT;
     constexpr int A_IT = BM / 32;
@@ -848,10 +845,10 @@ int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
     // the tiles that carry every instantiation (pointwise / dual-source / zero-padded K): the two defaults and the 16x16-MFMA ones
     constexpr bool kFull = (MT == 32 && NBUF == 1 && ((BM == 64 && BN == 64) || (BM == 128 && BN == 32))) || MT == 16;
     if (a.ymode) {
-        // Detect: the default tile only
-        if constexpr (MT == 32 && NBUF == 1 && BM == 64 && BN == 64) {
+        // Detect: the default tile and the 16x16-MFMA ones
+        if constexpr ((MT == 32 && NBUF == 1 && BM == 64 && BN == 64) || MT == 16) {
             if (a.icg % 32 != 0 || a.up) return SI_E_UNSUPPORTED;
-            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, true>), grid, dim3(256), 0, s, b);
+            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, true, false, MT>), grid, dim3(256), 0, s, b);
         } else {
             return SI_E_UNSUPPORTED;
         }
@@ -908,8 +905,8 @@ inline int round_up4(int v) { return (v + 3) & ~3; }
 //   id: 0 128x128x2  1 128x64x2  2 64x64x2  3 128x32x2  4 64x64x1  5 64x128x1  6 128x64x1  7 128x128x1
 //       8 64x128x2  10 128x32x1        (BM x BN x LDS stages; 32x32x2 MFMA)
 //       11 32x64x2  12 32x32x2  13 32x64x1  14 32x32x1  15 64x32x2  16 64x32x1  17 64x64x1  18 32x128x1  19 64x32x1 as 4x1 waves
-//       (16x16x4 MFMA, round 3)
-static constexpr int kConvVariants = 20;
+//       20 128x64x1  21 64x128x1     (16x16x4 MFMA, round 3)
+static constexpr int kConvVariants = 22;
 static int si_cu_count() {
     static const int cus = [] {
         int dev = 0, n = 0;
@@ -971,7 +968,7 @@ static int conv_variant(const SiConv2dDesc* d) {
 // the generic kernel (any channel count) has four tiles: 0 128x128, 1 128x64, 2 64x64, 3 128x32; a forced variant maps to the
 // nearest one, the policy is the round-1 rule (these layers are latency / HBM bound)
 static int conv_generic_tile(const SiConv2dDesc* d) {
-    static const int generic_of[kConvVariants] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2};
+    static const int generic_of[kConvVariants] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 2};
     const int forced = conv_forced_variant();
     if (forced >= 0) return generic_of[forced];
     return (d->oc / d->groups) <= 32 ? 3 : 2;
@@ -1183,7 +1180,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
         hipStream_t fs = static_cast<hipStream_t>(stream);
         // a zero-padded K axis only exists in the two default tiles (SI_CONV_VARIANT is ignored for those layers)
         int variant = conv_variant(d);
-        if (a.ymode) variant = 4;   // Detect: the default tile only
+        if (a.ymode && !(variant == 4 || variant >= 11)) variant = 4;   // Detect: the default tile or a 16x16-MFMA one
         else if ((a.icg % 32 != 0 || a.up) && !conv_variant_full(variant)) variant = (d->oc / d->groups) <= 32 ? 10 : 4;
         switch (variant) {
             case 0: return launch_fast<128, 128, 2, 2, 2>(a, d->groups, fs);
@@ -1204,6 +1201,8 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
             case 17: return launch_fast<64, 64, 2, 2, 1, 16>(a, d->groups, fs);
             case 18: return launch_fast<32, 128, 2, 2, 1, 16>(a, d->groups, fs);
             case 19: return launch_fast<64, 32, 4, 1, 1, 16>(a, d->groups, fs);
+            case 20: return launch_fast<128, 64, 2, 2, 1, 16>(a, d->groups, fs);
+            case 21: return launch_fast<64, 128, 2, 2, 1, 16>(a, d->groups, fs);
             default: return launch_fast<128, 32, 4, 1, 1>(a, d->groups, fs);
         }
     }
@@ -1268,7 +1267,8 @@ extern "C" const char* si_hip_conv2d_kernel_name_form(const SiConv2dDesc* d, con
                                                   {64, 64, 2, 2, 1, 32},   {64, 128, 2, 2, 1, 32}, {128, 64, 2, 2, 1, 32}, {128, 128, 2, 2, 1, 32},
                                                   {64, 128, 2, 2, 2, 32},  {128, 32, 4, 1, 1, 32}, {128, 32, 4, 1, 1, 32}, {32, 64, 2, 2, 2, 16},
                                                   {32, 32, 2, 2, 2, 16},   {32, 64, 2, 2, 1, 16},  {32, 32, 2, 2, 1, 16},  {64, 32, 2, 2, 2, 16},
-                                                  {64, 32, 2, 2, 1, 16},   {64, 64, 2, 2, 1, 16},  {32, 128, 2, 2, 1, 16}, {64, 32, 4, 1, 1, 16}};
+                                                  {64, 32, 2, 2, 1, 16},   {64, 64, 2, 2, 1, 16},  {32, 128, 2, 2, 1, 16}, {64, 32, 4, 1, 1, 16},
+                                                  {128, 64, 2, 2, 1, 16},  {64, 128, 2, 2, 1, 16}};
     // [variant][instantiation]: 0 general, 1 pointwise, 2 zero-padded K, 3 dual-source, 4 Detect
     static char fast_names[kConvVariants][5][112];
     static const bool named = [] {
@@ -1290,7 +1290,7 @@ extern "C" const char* si_hip_conv2d_kernel_name_form(const SiConv2dDesc* d, con
         int v = conv_variant(d);
         const bool padk = (d->ic / d->groups) % 32 != 0;
         const bool pointwise = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow;
-        if (form == 2) return fast_names[4][4];
+        if (form == 2) return fast_names[(v == 4 || v >= 11) ? v : 4][4];
         if ((padk || form == 1) && !conv_variant_full(v)) v = (d->oc / d->groups) <= 32 ? 10 : 4;
         if (form == 1) return fast_names[v][3];
         if (padk) return fast_names[v][2];

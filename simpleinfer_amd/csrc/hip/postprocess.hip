@@ -28,6 +28,30 @@ __global__ void letterbox_kernel(const unsigned char* __restrict__ src, int hr, 
     }
 }
 
+// the same for all images of a batch that share one geometry (frames of one camera): blockIdx.y = image, four consecutive
+// output floats per thread (one 16-byte store; H * W * 3 a multiple of 4)
+__global__ void letterbox_batch_kernel(const unsigned char* __restrict__ src, size_t src_stride, int hr, int wr, float* __restrict__ dst,
+                                       int H, int W, int pt, int pl) {
+    const int quads = H * W * 3 / 4;
+    const unsigned char* s = src + (size_t)blockIdx.y * src_stride;
+    float4* d = reinterpret_cast<float4*>(dst + (size_t)blockIdx.y * H * W * 3);
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = q * 4 + k;
+            const int c = i % 3;
+            const int x = (i / 3) % W;
+            const int y = i / (3 * W);
+            const int sy = y - pt, sx = x - pl;
+            float t = 114.0f;
+            if (sy >= 0 && sy < hr && sx >= 0 && sx < wr) t = (float)s[((size_t)sy * wr + sx) * 3 + (2 - c)];
+            v[k] = t / 255.0f;
+        }
+        d[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // ---- post-processing workspace ----------------------------------------------------------------
 // per image, cap = rows candidates, nbins = classes + 1 (bin = label + 1; label -1 = "no class"):
 //   count[n] | bin_count[n][nbins] | keep[n][cap]            (zeroed at the start of every call, one memset)
@@ -440,6 +464,26 @@ int si_hip_letterbox_u8_f32(const unsigned char* resized_bgr, int height_resize,
     hipLaunchKernelGGL(letterbox_kernel, dim3(si_grid_for((size_t)height_new * width_new * 3)), dim3(256), 0,
                        (hipStream_t)stream, resized_bgr, height_resize, width_resize, out, height_new, width_new,
                        padding_t, padding_l);
+    return (int)hipGetLastError();
+}
+
+int si_hip_letterbox_batch_u8_f32(const unsigned char* resized_bgr, int n, size_t image_stride_bytes, int height_resize, int width_resize,
+                                  float* out, int height_new, int width_new, int padding_t, int padding_l, si_stream_t stream) {
+    if (n < 0 || !out || height_new <= 0 || width_new <= 0 || height_resize < 0 || width_resize < 0) return SI_E_BADARG;
+    if ((height_resize > 0 && width_resize > 0) && !resized_bgr) return SI_E_BADARG;
+    if ((long long)height_new * width_new * 3 > 0x7fffffffLL || n > 65535) return SI_E_UNSUPPORTED;
+    if (n == 0) return 0;
+    if (((long long)height_new * width_new * 3) % 4 != 0 || (reinterpret_cast<uintptr_t>(out) & 15) != 0) {
+        for (int b = 0; b < n; ++b) {   // odd sizes: one launch per image
+            const int rc = si_hip_letterbox_u8_f32(resized_bgr + (size_t)b * image_stride_bytes, height_resize, width_resize,
+                                                   out + (size_t)b * height_new * width_new * 3, height_new, width_new, padding_t, padding_l, stream);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
+    const unsigned gx = si_grid_for((size_t)height_new * width_new * 3 / 4);
+    hipLaunchKernelGGL(letterbox_batch_kernel, dim3(gx > 512 ? 512 : gx, n), dim3(256), 0, (hipStream_t)stream, resized_bgr, image_stride_bytes,
+                       height_resize, width_resize, out, height_new, width_new, padding_t, padding_l);
     return (int)hipGetLastError();
 }
 

@@ -84,14 +84,16 @@ __device__ __forceinline__ unsigned si_pair_halves(float v0, float v1, bool odd)
 // box channels, two selects, one store.  Args: the conv kernels' argument structs (ocg, bias, yna, yne, ohow, ygrid,
 // yanchor, ystride, yrows_total, yrow_off).  C/D map of the 32x32 MFMA tile as everywhere: col = lane&31 (channel),
 // row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel).
+// MT: the MFMA tile the accumulators come from -- 32 (16 registers, rows (e&3) + 8*(e>>2)) or 16 (v_mfma_f32_16x16x4_f32: 4
+// registers, rows e; col = lane&15, + 4*(lane>>4) already in mrow0)
 typedef float si_f32x16 __attribute__((ext_vector_type(16)));
-template <int TM, int TN, typename Args>
-__device__ __forceinline__ void si_yolo_tile_one_image(const Args& a, float* out, si_f32x16 (&acc)[TM][TN], int mrow0, int ocol0, int img) {
+template <int TM, int TN, typename Args, int MT = 32, typename AccT = si_f32x16>
+__device__ __forceinline__ void si_yolo_tile_one_image(const Args& a, float* out, AccT (&acc)[TM][TN], int mrow0, int ocol0, int img) {
 #pragma clang fp contract(off)
     const int per_pix = a.yna * a.yne;
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
-        const int o = ocol0 + u * 32;
+        const int o = ocol0 + u * MT;
         const bool live = o < a.ocg;
         const int oo = live ? o : 0;
         const float bv = a.bias ? a.bias[oo] : 0.0f;
@@ -101,12 +103,12 @@ __device__ __forceinline__ void si_yolo_tile_one_image(const Args& a, float* out
         const float* const auxp = (is_xy ? a.ygrid + e_ : a.yanchor + (is_box ? e_ - 2 : 0)) + anc * 2;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            const int pix0 = mrow0 + t * 32 - img * a.ohow;
+            const int pix0 = mrow0 + t * MT - img * a.ohow;
             float* const op = out + ((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix0 * per_pix + oo;
             const float* const ap = auxp + (size_t)pix0 * a.yna * 2;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int dm = (e & 3) + 8 * (e >> 2);
+            for (int e = 0; e < (MT == 32 ? 16 : 4); ++e) {
+                const int dm = MT == 32 ? (e & 3) + 8 * (e >> 2) : e;
                 const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[t][u][e] + bv)));
                 float aux = 0.0f;
                 if (is_box) aux = ap[dm * a.yna * 2];

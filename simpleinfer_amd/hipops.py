@@ -455,6 +455,18 @@ def letterbox(resized_bgr, height_new, width_new, padding_t, padding_l):
     return dout.to_numpy((height_new, width_new, 3))
 
 
+def letterbox_batch(resized_bgr, height_new, width_new, padding_t, padding_l):
+    """si_hip_letterbox_batch_u8_f32: u8 BGR [n][hr][wr][3] -> float RGB [n][height_new][width_new][3] in one launch."""
+    H = _native.hip()
+    src = np.ascontiguousarray(resized_bgr, dtype=np.uint8)
+    n, hr, wr = int(src.shape[0]), int(src.shape[1]), int(src.shape[2])
+    dsrc = DeviceBuffer.from_numpy(src)
+    dout = DeviceBuffer(max(n * height_new * width_new * 3 * 4, 16))
+    _chk(H.si_hip_letterbox_batch_u8_f32(dsrc.ptr, n, hr * wr * 3, hr, wr, dout.ptr, height_new, width_new, padding_t, padding_l, None),
+         "si_hip_letterbox_batch_u8_f32")
+    return dout.to_numpy((n, height_new, width_new, 3))
+
+
 def yolo_postprocess(pred, prob_threshold=0.25, nms_threshold=0.45, agnostic=False, adjust=None, max_det=None,
                      pred_dev=None):
     """Device post-processing of test_yolo.cpp:337-428.  pred [n][rows][ne] -> list (one per image) of float arrays

@@ -442,6 +442,16 @@ def test_letterbox_exact(hops, orc):
     hr, wr, sc, pt, pl = hops.letterbox_geometry(375, 500, 640, 640)
     img = r.integers(0, 256, (hr, wr, 3), dtype=np.uint8)
     assert_exact(hops.letterbox(img, 640, 640, pt, pl), orc.letterbox(img, 640, 640, pt, pl), "letterbox")
+    # the batched form (frames of one camera, one launch) and its odd-size fallback: the same bits per image
+    imgs = r.integers(0, 256, (3, hr, wr, 3), dtype=np.uint8)
+    got = hops.letterbox_batch(imgs, 640, 640, pt, pl)
+    for b in range(3):
+        assert_exact(got[b], orc.letterbox(imgs[b], 640, 640, pt, pl), "letterbox batch image %d" % b)
+    hr2, wr2, _, pt2, pl2 = hops.letterbox_geometry(30, 50, 63, 63)
+    odd = r.integers(0, 256, (2, hr2, wr2, 3), dtype=np.uint8)
+    got = hops.letterbox_batch(odd, 63, 63, pt2, pl2)
+    for b in range(2):
+        assert_exact(got[b], orc.letterbox(odd[b], 63, 63, pt2, pl2), "letterbox batch, odd size, image %d" % b)
 
 
 @pytest.mark.parametrize("n,rows,nc,thr,agnostic,hot", [

@@ -14,13 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = os.path.join(ROOT, "tests", "_rank_child.py")
 
 
-@pytest.mark.parametrize("world,slots,graph", [(2, 3, 0), (3, 3, 1), (2, 1, 0)])
+@pytest.mark.parametrize("world,slots,graph", [(2, 3, 0), (3, 3, 1), (2, 1, 0), (8, 3, 0), (4, 4, 1)])
 def test_direct_gather_between_processes_is_bit_exact(gpu, tmp_path, world, slots, graph):
     """Every rank ends up with every rank's slab, bit for bit, for five consecutive steps with different inputs: overlapped
-    (3 slots: step s computes while step s-1's slabs travel), with hipGraph replay (one captured graph per output slot), and
-    unoverlapped (1 slot)."""
+    (3 slots: step s computes while step s-1's slabs travel), with hipGraph replay (one captured graph per output slot),
+    unoverlapped (1 slot), and at the node's real rank count (8 ranks, 7 peer copies per rank and step, on the one device: the
+    handle exchange, the shm barrier and the slot protocol at world = 8)."""
     from simpleinfer_amd import launch
-    code, out = launch.spawn_ranks([sys.executable, CHILD, "gather", str(tmp_path), str(slots), str(graph)], world, timeout=300)
+    code, out = launch.spawn_ranks([sys.executable, CHILD, "gather", str(tmp_path), str(slots), str(graph)], world, timeout=600)
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert code == 0 and lines, out
     res = json.loads(lines[-1])

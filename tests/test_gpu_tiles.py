@@ -13,8 +13,8 @@ from util import rng_uniform
 pytestmark = pytest.mark.gpu
 
 # variant ids of conv_igemm.hip (si_hip_conv2d_set_tile_variant)
-ALL_TILES = [4, 2, 0, 1, 5, 6, 10, 3, 11, 12, 13, 14, 15, 16, 17, 18, 19]
-SMALL_TILES = [11, 12, 13, 14, 15, 16, 17, 18, 19]
+ALL_TILES = [4, 2, 0, 1, 5, 6, 10, 3, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21]
+SMALL_TILES = [11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21]
 
 
 @pytest.fixture(scope="module")
@@ -98,6 +98,27 @@ def test_every_tile_same_bits_sibling_split_and_upsampled_source(hops, tile):
             base = cur
         for a, c in zip(base, cur):
             assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), "tile %d" % v
+
+
+def test_every_tile_same_bits_in_the_detect_epilogue(hops, tile):
+    """YOLOv5 Detect (sigmoid + grid / anchor decode + concat in the conv epilogue, reference src/layer/yolo_detect.cpp:223-266) on the
+    64x64 tile and on every 16x16-MFMA tile: the same bits, including maps smaller than a tile (rows spanning images)."""
+    na, ne, n = 3, 85, 3
+    feats, ws, bs, grids, anchors = [], [], [], [], []
+    for i, (h, c) in enumerate([(12, 64), (6, 128), (3, 256)]):
+        feats.append(rng_uniform(50 + i, (n, h, h, c), -1, 1))
+        ws.append(rng_uniform(60 + i, (na * ne, c, 1, 1), -0.3, 0.3))
+        bs.append(rng_uniform(70 + i, (na * ne,), -0.5, 0.5))
+        gy, gx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="ij")
+        grids.append(np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, h, h, 2)).copy())
+        anchors.append(np.broadcast_to(rng_uniform(80 + i, (1, na, 1, 1, 2), 5, 300), (1, na, h, h, 2)).copy())
+    base = None
+    for v in [4] + SMALL_TILES:
+        tile(v)
+        y = hops.yolo_detect(feats, ws, bs, grids, anchors, [8.0, 16.0, 32.0], na, fused=True)
+        if base is None:
+            base = y
+        assert np.array_equal(y.view(np.uint32), base.view(np.uint32)), "tile %d" % v
 
 
 def test_policy_follows_the_launch_size(hops):

@@ -20,7 +20,7 @@ def _spawn(mode, n, *extra, timeout=120):
     return code, (json.loads(line[-1]) if line else None)
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
 def test_node_group_barrier_and_allgather(native_libs, world):
     code, res = _spawn("group", world)
     assert code == 0 and res is not None
