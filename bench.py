@@ -21,12 +21,18 @@ of timed work have accumulated and `value` / `ms_per_step` are those of the MEDI
 min / max / first).
 
 One JSON line on stdout from rank 0.  Besides the contract's fields it carries
-  roofline     -- the dominant kernel (conv implicit-GEMM instantiation with the largest total time):
+  roofline     -- the dominant kernel (the conv kernel TEMPLATE with the largest total time, all its instantiations):
                   algorithmic direct-conv FLOPs per launch / average launch duration, measured live with HIP
                   events on the engine's stream in an instrumented pass right after the timed region
-                  (peak: 157.3 TFLOP/s fp32 MFMA); `traffic` from profiles/ when a PMC pass was recorded.
-  cpu_baseline -- the CPU oracle (restatement of SimpleInfer's Eigen/highway path, kind "port") timed on
-                  this box's host cores on a bounded sample, rank 0, N = 1 only.
+                  (peak: 157.3 TFLOP/s fp32 MFMA); `instantiations` lists every instantiation under the exact name
+                  rocprofv3 prints, with its launches, average duration, algorithmic bytes and the PMC `traffic`
+                  recorded for it under profiles/; a Winograd-dominated config also carries frac_executed_mfma.
+  cpu_baseline -- the CPU oracle (an unoptimised restatement of SimpleInfer's Eigen/highway path, kind "port") timed on
+                  this box's host cores on bounded samples (~20 s, run BEFORE the GPU leg), rank 0, N = 1 only.
+  host_io      -- the reference's host-tensor calling convention (Input borrows a host tensor, Extract returns host
+                  memory): PCIe-inclusive, never `value`.
+  app_pipeline -- test-yolo's flow end to end (u8 frames up, device letterbox, Forward, device NMS, boxes down), pipelined.
+  gather / step_bound -- N > 1: where a step's time went (host waits in the gather, per-peer copy rate).
 """
 import argparse
 import json
@@ -746,8 +752,12 @@ def main():
                     "ms_per_step_first": round(windows[0] / args.steps * 1e3, 3)},
         "forward_kernel_ms_per_step": round(fwd_ms_per_step, 3),
         "gather": gather_diag,
+        # what a step waited for: its own peer copies (the gather is the bound), the node barrier (the slowest rank: imbalance, or
+        # ranks sharing a device), or neither
         "step_bound": (None if gather_diag is None else
-                       ("gather" if gather_diag["gather_wait_ms_max_over_ranks"] > 0.1 * (dt / args.steps * 1e3) else "compute")),
+                       ("gather (waiting for the peer copies)" if gather_diag["gather_wait_copies_ms"] > 0.1 * (dt / args.steps * 1e3) else
+                        "slowest rank (waiting in the node barrier)" if gather_diag["gather_wait_barrier_ms"] > 0.1 * (dt / args.steps * 1e3) else
+                        "compute")),
         "gflop_per_image": round(flops_step / args.batch / 1e9, 3),
         "frac_of_mfma_ceiling": round(value / world / ceiling, 4),
         "roofline": roof,
