@@ -71,6 +71,13 @@ public:
     //   "fp16"            1/0  fp16 storage for internal activations and weights, fp16 MFMA with fp32 accumulation;
     //                          Input / Extract tensors stay fp32 (default 0: the reference's fp32 arithmetic)
     //   "batch"           N>0  serve batch N whatever batch the .param file was traced with (default 0: as in the file)
+    //   "host_slices"     G    host tensors in (Input) and out (Extract) -- the reference's calling convention: one synchronous
+    //                          Forward() pipelines G batch slices over an upload, a compute and a download stream; 1 = off,
+    //                          0 (default) = slices of 8 images from batch 16 on
+    //   "streams"         1/2  2: the batch runs as two half-batch lanes on two streams (default 1: no gain measured since the
+    //                          tile policy follows the launch size)
+    //   "detect_stream"   0/1/2  YOLOv5 Detect's finer levels on a second stream: 0 never, 1 (default) for levels with enough work,
+    //                          2 always
     //   "graph"           1/0  replay Forward() as a captured hipGraph (default 0)
     //   "outputs_to_host" 1/0  copy outputs to pinned host memory in Forward() (default 1);
     //                          with 0, Extract() returns device tensors
