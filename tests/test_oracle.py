@@ -327,3 +327,20 @@ def test_postprocess_oracle_matches_independent_numpy(orc, agnostic):
     ref = numpy_postprocess(pred[:, :300], -1.0, 0.45, agnostic)
     for b in range(2):
         assert_exact(outs[b], ref[b], "all rows, image %d" % b)
+
+
+@pytest.mark.parametrize("shape,oc,k,s,p,g", [((2, 21, 19, 64), 96, 3, 2, 1, 1), ((3, 13, 17, 128), 64, 1, 1, 0, 1), ((2, 10, 10, 40), 72, 1, 1, 0, 1),
+                                              ((2, 9, 11, 20), 24, 3, 1, 1, 1), ((2, 11, 11, 64), 64, 3, 1, 1, 2)])
+def test_device_order_fma_chain_is_the_convolution(orc, shape, oc, k, s, p, g):
+    """orc_conv2d_chain -- the DEVICE kernel's accumulation order as a scalar fmaf chain (not a reference algorithm; the GPU
+    tests hold every tile of the implicit-GEMM kernel to it bit for bit) -- is itself the convolution: within 2e-5 of the fp64
+    loop and within the reference test's own tolerance of its float loop (test_conv_2d.cpp:100-131)."""
+    from util import rng_uniform
+    x = rng_uniform(1, shape, -1, 1)
+    w = rng_uniform(2, (oc, shape[3] // g, k, k), -0.5, 0.5)
+    b = rng_uniform(3, (oc,), -0.5, 0.5)
+    chain = orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, path="chain")
+    naive = orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, path="naive")
+    assert np.abs(chain - naive).max() <= 2e-5 * np.abs(naive).max()
+    f32 = orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, path="naive", acc64=False)
+    assert np.abs(chain - f32).max() < 2e-4 * max(1.0, np.abs(f32).max() / 16)
