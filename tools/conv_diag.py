@@ -96,7 +96,7 @@ def main():
         launch()
         H.si_hip_device_sync()
         M, K = n * oh * ow, k * k * ci
-        tiles = 65536 if wino else min(((M + 63) // 64 + 7) // 8 * 8 * ((co + 63) // 64), 65536)
+        tiles = 65536   # (every stamp slot: the tile shape follows the launch size since round 3; empty slots are filtered below)
         raw = np.zeros(tiles * 8, np.uint64)
         rc = stamps_read(raw.ctypes.data_as(C.c_void_p), raw.size)
         assert rc == 0, rc
@@ -108,8 +108,10 @@ def main():
         clock = ((s[:, 5] - s[:, 1]) / ((rt1 - rt0) * 10.0)).mean()
         start = (rt0 - rt0.min()) / 100.0
         pro, fill, loop, epi = s[:, 2] - s[:, 1], s[:, 3] - s[:, 2], s[:, 4] - s[:, 3], s[:, 5] - s[:, 4]
-        nk = K // 32
-        mfma_cyc = nk * 16 * 64
+        # matrix-pipe cycles per wave of a workgroup: its share of the launch's FLOPs at 64 FLOP / clk / SIMD, four waves (any tile, any
+        # fp32 MFMA shape; a launch with more than 65536 workgroups is sampled by its first 65536)
+        n_wg = max(len(s), 1)
+        mfma_cyc = int(flops * min(1.0, 65536.0 / max(n_wg, 1)) / n_wg / 4 / 64) if n_wg < 65536 else 0
         if wino:   # per wave: 4 planes x (ic / 2) MFMAs of 64 cycles for 32 tiles x 32 channels
             mfma_cyc = 4 * (ci // 2) * 64
         hw = raw.reshape(tiles, 8)[:, 7]
