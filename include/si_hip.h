@@ -177,6 +177,10 @@ int si_hip_conv2d_set_tile_variant(int variant);
  * Conv3x3s1Winograd23TransformKernelPack4, winograd_helper.cpp:40-143).  `bias` must be 16-byte aligned; `out` /
  * `residual` rows that are not get scalar stores. */
 int si_hip_conv2d_wino23_eligible(const SiConv2dDesc* d);
+/* tuning / test hook: the kernel's work-unit form -- 32 tiles on v_mfma_f32_32x32x2_f32 or 16 tiles on v_mfma_f32_16x16x4_f32
+ * (half-size units for launches that do not fill the chip evenly; needs ic % 32 == 0) -- 16 / 32 force one for every later
+ * launch, 0 restores the policy.  The form never changes a result.  Returns the previous setting. */
+int si_hip_conv2d_wino23_set_form(int form);
 /* eligible AND measured faster than si_hip_conv2d_f32 on MI355X (currently: ic >= 32) */
 int si_hip_conv2d_wino23_preferred(const SiConv2dDesc* d);
 size_t si_hip_conv2d_wino23_weight_elems(const SiConv2dDesc* d);

@@ -29,6 +29,7 @@
 // flattened, so a block may span images; each tile row stages its own 4 input rows.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -87,14 +88,29 @@ __device__ __forceinline__ int wino_div(int n, int d, unsigned mg) {
 SI_STAMP_ARRAY(si_diag_stamps_wino);   // diagnostic build only (si_hip_internal.h)
 
 #define SI_WINO_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef SI_WINO16_WAVES   // waves per SIMD the 16-tile form is compiled for (experiments: 4 needs <= 128 registers and <= 40 KB of LDS)
+#define SI_WINO16_WAVES 3
+#endif
 
 // LOG_TBW: log2 of tiles per block row (the workgroup's 32 tiles form a TBH x TBW block).  OCG: 32-channel output groups per
 // workgroup (1 or 2): with two, every transformed input value feeds eight MFMAs instead of four and the patches are fetched
 // half as often, at the price of 128 accumulator registers (two waves per SIMD instead of three).
-template <int LOG_TBW, int OCG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 - OCG))) void conv_wino23_kernel(const WinoArgs a) {
+// MT: the MFMA tile.  32: v_mfma_f32_32x32x2_f32, a workgroup = 32 tiles x 32 * OCG output channels, 16-channel blocks of 8 steps
+// (2 channels each).  16 (round 3): v_mfma_f32_16x16x4_f32, a workgroup = 16 tiles x 32 output channels (two 16-wide halves),
+// 32-channel blocks of 8 steps (4 channels each) -- HALF-SIZE work units for launches whose 32-tile units do not fill the chip's
+// residency slots evenly or do not fill it at all (small batches).  Same transforms, same ascending channel order
+// in one fma chain per output, so the two forms produce the same bits (tests/test_gpu_ops.py).
+template <int LOG_TBW, int OCG, int MT = 32>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MT == 16 ? SI_WINO16_WAVES : 4 - OCG, MT == 16 ? SI_WINO16_WAVES : 4 - OCG))) void conv_wino23_kernel(const WinoArgs a) {
+    static_assert(MT == 32 || (MT == 16 && OCG == 1), "the 16x16 form has one 32-channel output group");
+    constexpr int TILES = MT;                // tiles per workgroup
+    constexpr int CBX = MT == 32 ? CB : 32;  // input channels per staged block
+    constexpr int LOG_CQ = MT == 32 ? 2 : 3; // log2 of the block's 4-channel vectors
+    constexpr int CQ = 1 << LOG_CQ;
+    constexpr int CPS = MT == 32 ? 2 : 4;    // channels per step (the MFMA's k)
+    constexpr int NH = MT == 32 ? 1 : 2;     // MFMA column tiles per 32 output channels
     constexpr int TBW = 1 << LOG_TBW;
-    constexpr int TBH = 32 / TBW;
+    constexpr int TBH = TILES / TBW;
     constexpr int PW = 2 * TBW + 2;          // staged pixels per tile row: 2 * TBW of its own and two of halo
     constexpr int PWP = PW;                  // even row pitch: every tile's four pixels start 8-byte aligned (ds_read_b64)
     constexpr int SLOTS = 4 * TBH;           // slot = r * TBH + tr  (r = plane row 0..3)
@@ -102,12 +118,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     // planes (4*PLANE apart = 8 banks apart), conflict free within a 32-lane group
     constexpr int PLANE = ((SLOTS * PWP + 5) / 8) * 8 + 2;
     static_assert(PLANE % 2 == 0, "8-byte aligned tile pixels");
-    constexpr int BUF = CB * PLANE;          // one staged channel block; two alternate, so a block costs ONE barrier
+    constexpr int BUF = CBX * PLANE;         // one staged channel block; two alternate, so a block costs ONE barrier
     constexpr int OCW = 32 * OCG;            // output channels per workgroup
-    constexpr int XCH = 4 * 2 * 32 * OCW;    // exchange: [plane row][output column][tile][oc]
-    constexpr int RING = OCG == 1 ? 4 : 2;   // filter values are requested RING steps (1024 MFMA cycles) before their step
+    constexpr int XCH = 4 * 2 * TILES * OCW; // exchange: [plane row][output column][tile][oc]
+    // filter values are requested RING steps before their step (32x32 form: 1024 MFMA cycles; the 16x16 form's two loads per step make
+    // a 4-deep ring 32 registers -- with 2 it fits three waves per SIMD without spilling)
+    constexpr int RING = (OCG == 1 && MT == 32) ? 4 : 2;
     constexpr int LDS_FLOATS = 2 * BUF > XCH ? 2 * BUF : XCH;
-    constexpr int NHALO = TBH * 2 * 4 * 4;   // halo loads: (tile row, pixel 2*TBW or 2*TBW+1, 4 channels, patch row)
+    constexpr int NHALO = TBH * 2 * CQ * 4;  // halo loads: (tile row, pixel 2*TBW or 2*TBW+1, 4 channels, patch row)
     constexpr int HR = (NHALO + 255) / 256;  // ... per thread
 
     __shared__ __attribute__((aligned(16))) float patch[LDS_FLOATS];
@@ -117,7 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int lane = tid & 63, l31 = lane & (MT - 1), lh = lane / MT;   // operand row (tile / oc) and k slot of the lane
     // block id -> (spatial block, oc block): the oc blocks of one spatial block share blockIdx % 8, i.e. one XCD and its
     // L2, because they all stage the same input patches (placement is a speed hint only)
     const int per_chunk = 8 * a.oc_blocks;
@@ -133,7 +151,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     const int oc0 = ocb * OCW;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
+    // (the 16x16 form reads the SECOND filter image, laid out for its lanes: see si_hip_conv2d_wino23_pack_weight_host)
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u) + (MT == 32 ? 0 : (size_t)16 * a.ic * a.oc), 0, a.u_bytes, 0x00020000);
 
     const unsigned row_pitch = (unsigned)(a.iw * a.in_ld * 4);
 
@@ -150,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
         for (int j = 0; j < 4; ++j) rows |= (ok && (unsigned)(y0 + j) < (unsigned)a.ih) ? (1u << j) : 0u;
         base = (unsigned)((img * a.ih + y0) * a.iw + x) * (unsigned)(a.in_ld * 4) + (unsigned)(cq * 16);
     };
-    const int c_cq = tid & 3, c_px = (tid >> 2) & (2 * TBW - 1), c_tr = tid >> (LOG_TBW + 3);
+    const int c_cq = tid & (CQ - 1), c_px = (tid >> LOG_CQ) & (2 * TBW - 1), c_tr = tid >> (LOG_TBW + 1 + LOG_CQ);
     unsigned c_base, c_rows;
     make_item(c_tr, c_px, c_cq, c_base, c_rows);
     c_base += row_pitch;                     // offset of patch row 1 (see fetch)
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
         const int hv = tid + 256 * i;
-        const int h_cq = (hv >> 2) & 3, h_px = 2 * TBW + ((hv >> 4) & 1), h_tr = (hv >> 5) & (TBH - 1);
+        const int h_cq = (hv >> 2) & (CQ - 1), h_px = 2 * TBW + ((hv >> (2 + LOG_CQ)) & 1), h_tr = (hv >> (3 + LOG_CQ)) & (TBH - 1);
         unsigned base, rows;
         make_item(h_tr, h_px, h_cq, base, rows);
         h_live[i] = hv < NHALO;
@@ -190,7 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
         const __amdgpu_buffer_rsrc_t rs = live ? rs_in : rs_none;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, c_off[j], (unsigned)(j == 0 ? 0 : j - 1) * row_pitch + (unsigned)(cb * CB * 4), 0);
+            dst[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, c_off[j], (unsigned)(j == 0 ? 0 : j - 1) * row_pitch + (unsigned)(cb * CBX * 4), 0);
     };
     // the row half of B^T d B (winograd_helper.cpp:188-239):  r=0: d0 - d2   r=1: d1 + d2   r=2: d2 - d1   r=3: d1 - d3,
     // computed where it is stored (rows r_lo..r_hi-1 of one item: 4 channels to 4 planes each)
@@ -208,7 +227,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     auto fetch_halo = [&](int cb, bool live) {
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
-            hpre[i] = __builtin_amdgcn_raw_buffer_load_b128(live ? rs_in : rs_none, h_off[i], (unsigned)(cb * CB * 4), 0);
+            hpre[i] = __builtin_amdgcn_raw_buffer_load_b128(live ? rs_in : rs_none, h_off[i], (unsigned)(cb * CBX * 4), 0);
         }
     };
     // lane j of a quad:  t_j = d[ja] +- d[jb]  with (ja, jb) = (0,2) (1,2) (2,1) (1,3): two quad permutes and one fma per value
@@ -246,19 +265,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     // block, 32-wide oc tile, step) the 64 lanes' float4s are 1 KB contiguous; element q of lane (o, h) is
     // U[4*row + q][cb*16 + 2*step + h][o], i.e. the B values of the step's four MFMAs.  One fully coalesced dwordx4 load per
     // output group and step, addressed by a scalar offset and one VGPR shared by all of them.
+    // 16x16 form: U3[plane row][cb (32 channels)][oc tile][step][oc half][lane][plane column], lane = 16 * (channel & 3) + oc % 16:
+    // again 1 KB of contiguous float4s per load instruction, two loads (the two 16-wide oc halves) per step
     const int noct = a.oc / 32;
-    const int ncb = a.ic / CB;
-    const unsigned u_lane = (unsigned)(l31 * 2 + lh) * 16u;
-    const unsigned u_row = (unsigned)(wave * ncb * noct + oc0 / 32) * 8192u;      // (row, cb 0, first oc tile, step 0)
-    const unsigned u_cb = (unsigned)noct * 8192u;
+    const int ncb = a.ic / CBX;
+    constexpr unsigned UBLK = 8192u * NH;    // bytes per (plane row, channel block, oc tile)
+    const unsigned u_lane = MT == 32 ? (unsigned)(l31 * 2 + lh) * 16u : (unsigned)lane * 16u;
+    const unsigned u_row = (unsigned)(wave * ncb * noct + oc0 / 32) * UBLK;      // (row, cb 0, first oc tile, step 0)
+    const unsigned u_cb = (unsigned)noct * UBLK;
 
-    f32x16 acc[OCG][4];
-    f32x4 ring[RING][OCG];
+    typedef typename std::conditional<MT == 32, f32x16, f32x4>::type acc_t;
+    constexpr int NG = OCG * NH;             // accumulator groups: 32-wide oc groups (MT 32) / 16-wide halves (MT 16)
+    acc_t acc[NG][4];
+    f32x4 ring[RING][NG];
     auto load_b = [&](int slot, int cb, int step) {
         if ((SI_WINO_ABLATE & 2) && (cb | step)) return;
 #pragma unroll
-        for (int g = 0; g < OCG; ++g)
-            ring[slot][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, u_lane, u_row + (unsigned)cb * u_cb + (unsigned)(g * 8 + step) * 1024u, 0));
+        for (int g = 0; g < NG; ++g)
+            ring[slot][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rs_u, u_lane, u_row + (unsigned)cb * u_cb + (MT == 32 ? (unsigned)(g * 8 + step) : (unsigned)(step * 2 + g)) * 1024u, 0));
     };
 
     // ---- prologue: block 0 staged, block 1 in flight, the filter values of the first RING steps requested
@@ -279,8 +304,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     float2 tq[2];
     float va[4], vb[4];
     auto read_t = [&](int o0, int o1, int s) {
-        tq[0] = *reinterpret_cast<const float2*>(patch + o0 + (2 * s) * PLANE);
-        tq[1] = *reinterpret_cast<const float2*>(patch + o1 + (2 * s) * PLANE);
+        tq[0] = *reinterpret_cast<const float2*>(patch + o0 + (CPS * s) * PLANE);
+        tq[1] = *reinterpret_cast<const float2*>(patch + o1 + (CPS * s) * PLANE);
     };
     auto col_transform = [&](float (&v)[4]) {   // the column half: V[r][0..3] from t0..t3
         const float t0 = tq[0].x, t1 = tq[0].y, t2 = tq[1].x, t3 = tq[1].y;
@@ -301,14 +326,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
         const int buf = cb & 1, nbuf = buf ^ 1;
         const int p0 = rd0 + buf * BUF, p1 = rd1 + buf * BUF;
         const int n0 = rd0 + nbuf * BUF, n1 = rd1 + nbuf * BUF;
-        const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        const acc_t zero = {};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float(&vc)[4] = (s & 1) ? vb : va;
             float(&vn)[4] = (s & 1) ? va : vb;
             const int slot = s % RING;
             auto mfma = [&](int g, int q) {
-                acc[g][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[q], ring[slot][g][q], (first && s == 0) ? zero : acc[g][q], 0, 0, 0);
+                if constexpr (MT == 32) {
+                    acc[g][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[q], ring[slot][g][q], (first && s == 0) ? zero : acc[g][q], 0, 0, 0);
+                } else {   // plane column q of both 16-wide oc halves
+#pragma unroll
+                    for (int hf = 0; hf < NH; ++hf)
+                        acc[hf][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[q], ring[slot][hf][q], (first && s == 0) ? zero : acc[hf][q], 0, 0, 0);
+                }
             };
             mfma(0, 0);
             SI_WINO_FENCE();
@@ -377,15 +408,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     __syncthreads();                          // every wave has read its last pixels: the patch buffers become the exchange
     float* xz = patch;
     {
-        float* mine = xz + (wave * 64 + 4 * lh) * OCW + l31;
+        float* mine = xz + (wave * 2 * TILES + 4 * lh) * OCW + l31;
 #pragma unroll
-        for (int g = 0; g < OCG; ++g)
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh
-                const int m = (e & 3) + 8 * (e >> 2);
-                mine[m * OCW + g * 32] = (acc[g][0][e] + acc[g][1][e]) + acc[g][2][e];
-                mine[(32 + m) * OCW + g * 32] = (acc[g][1][e] - acc[g][2][e]) - acc[g][3][e];
+            for (int e = 0; e < (MT == 32 ? 16 : 4); ++e) {
+                // C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh (32x32) / e + 4*lh (16x16); column = oc % MT
+                const int m = MT == 32 ? (e & 3) + 8 * (e >> 2) : e;
+                mine[m * OCW + g * MT] = (acc[g][0][e] + acc[g][1][e]) + acc[g][2][e];
+                mine[(TILES + m) * OCW + g * MT] = (acc[g][1][e] - acc[g][2][e]) - acc[g][3][e];
                 if ((e & 3) == 3) SI_WINO_FENCE();   // (keeps the accumulator reads from being hoisted into 64 * OCG live VGPRs)
             }
     }
@@ -395,11 +426,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4 - OCG, 4 
     auto finish = [&](auto act1, auto act2, auto has_res, auto vec) {
 #pragma clang fp contract(off)  // every instantiation must round alike (bit-exact batch sharding)
 #pragma unroll
-        for (int i4 = 0; i4 < 32 / TPI; ++i4) {
+        for (int i4 = 0; i4 < TILES / TPI; ++i4) {
             const int t = lane / QPT + TPI * i4;
             f32x4 zr[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) zr[r] = *reinterpret_cast<const f32x4*>(xz + ((r * 2 + jc) * 32 + t) * OCW + 4 * quad);
+            for (int r = 0; r < 4; ++r) zr[r] = *reinterpret_cast<const f32x4*>(xz + ((r * 2 + jc) * TILES + t) * OCW + 4 * quad);
             const f32x4 y = (i_out == 0) ? (zr[0] + zr[1]) + zr[2] : (zr[1] - zr[2]) - zr[3];
             const int tr = t >> LOG_TBW, tc = t & (TBW - 1);
             const int txg = col0 + tc;
@@ -467,10 +498,10 @@ SI_STAMP_ACCESSORS(si_diag_stamps_wino, si_hip_diag_stamps_read_wino, si_hip_dia
 namespace {
 #endif
 
-template <int LOG_TBW, int OCG>
+template <int LOG_TBW, int OCG, int MT = 32>
 int launch_wino(WinoArgs a, hipStream_t s) {
     constexpr int TBW = 1 << LOG_TBW;
-    constexpr int TBH = 32 / TBW;
+    constexpr int TBH = MT / TBW;
     a.col_blocks = (a.tw + TBW - 1) / TBW;
     a.oc_blocks = a.oc / (32 * OCG);
     const int row_blocks = (a.rows_total + TBH - 1) / TBH;
@@ -484,25 +515,25 @@ int launch_wino(WinoArgs a, hipStream_t s) {
     dim3 grid((unsigned)nblocks, 1, 1);
 #ifdef SI_DIAG_STAMPS   // residency experiments: extra dynamic LDS per workgroup
     static const int extra_lds = [] { const char* e = getenv("SI_WINO_EXTRA_LDS"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW, OCG>), grid, dim3(256), (size_t)extra_lds, s, a);
+    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW, OCG, MT>), grid, dim3(256), (size_t)extra_lds, s, a);
 #else
-    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW, OCG>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW, OCG, MT>), grid, dim3(256), 0, s, a);
 #endif
     return (int)hipGetLastError();
 }
 
 // fraction of tile slots that hold real tiles for a block shape
-inline double wino_cover(int tw, int rows_total, int tbw) {
-    const int tbh = 32 / tbw;
+inline double wino_cover(int tw, int rows_total, int tbw, int tiles = 32) {
+    const int tbh = tiles / tbw;
     const double cols = (double)((tw + tbw - 1) / tbw) * tbw, rows = (double)((rows_total + tbh - 1) / tbh) * tbh;
     return ((double)tw * rows_total) / (cols * rows);
 }
 
-inline int wino_pick_log_tbw(int tw, int rows_total) {
+inline int wino_pick_log_tbw(int tw, int rows_total, int tiles = 32) {
     int best = 3;
     double bc = -1.0;
     for (int l = 3; l >= 1; --l) {  // prefer wide blocks on ties (fewer staged halo columns)
-        const double c = wino_cover(tw, rows_total, 1 << l);
+        const double c = wino_cover(tw, rows_total, 1 << l, tiles);
         if (c > bc + 1e-9) {
             bc = c;
             best = l;
@@ -533,8 +564,12 @@ extern "C" int si_hip_conv2d_wino23_preferred(const SiConv2dDesc* d) {
     return si_hip_conv2d_wino23_eligible(d) && d->ic >= min_ic;
 }
 
+// the filter image U = G g G^T in the 32x32-MFMA kernel's operand order, followed -- when the channel count allows the 16x16-MFMA
+// form (ic a multiple of 32) -- by a second copy in that form's order: the form is chosen per launch (it follows the launch
+// size), the weights are packed once
+static bool wino_has_mt16(const SiConv2dDesc* d) { return d->ic % 32 == 0; }
 extern "C" size_t si_hip_conv2d_wino23_weight_elems(const SiConv2dDesc* d) {
-    return d ? (size_t)16 * d->ic * d->oc : 0;
+    return d ? (size_t)16 * d->ic * d->oc * (wino_has_mt16(d) ? 2 : 1) : 0;
 }
 
 // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], evaluated in the order of
@@ -569,8 +604,43 @@ extern "C" int si_hip_conv2d_wino23_pack_weight_host(const SiConv2dDesc* d, cons
             const int ncb = ic / 16, noct = oc / 32;
             for (int q = 0; q < 16; ++q)
                 u[((((((size_t)(q / 4) * ncb + cb) * noct + o / 32) * 8 + step) * 32 + o % 32) * 2 + h) * 4 + q % 4] = t[q];
+            if (wino_has_mt16(d)) {
+                // U3[plane row][cb (32 channels)][oc tile][step (4 channels)][oc half][lane = 16 * (channel & 3) + oc % 16][plane column]
+                float* u3 = u + (size_t)16 * ic * oc;
+                const int cb3 = c / 32, c3 = c % 32, step3 = c3 / 4, k3 = c3 % 4;
+                const int ncb3 = ic / 32, ot = o / 32, hf = (o % 32) / 16, o16 = o % 16;
+                for (int q = 0; q < 16; ++q)
+                    u3[(((((((size_t)(q / 4) * ncb3 + cb3) * noct + ot) * 8 + step3) * 2 + hf) * 64) + (k3 * 16 + o16)) * 4 + q % 4] = t[q];
+            }
         }
     return 0;
+}
+
+static std::atomic<int> g_wino_form{-1};   // -1: not yet read from the environment; 0 policy, 16 / 32 forced
+static int wino_forced_form() {
+    int v = g_wino_form.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("SI_WINO_MT");
+        v = e ? atoi(e) : 0;
+        if (v != 16 && v != 32) v = 0;
+        int expected = -1;
+        g_wino_form.compare_exchange_strong(expected, v);
+        v = g_wino_form.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+// tuning / test hook (like si_hip_conv2d_set_tile_variant): 16 / 32 force the work-unit form of every later launch, 0 restores
+// the policy; returns the previous setting.  The form never changes a result.
+extern "C" int si_hip_conv2d_wino23_set_form(int form) {
+    const int prev = wino_forced_form();
+    g_wino_form.store((form == 16 || form == 32) ? form : 0, std::memory_order_relaxed);
+    return prev;
+}
+
+// when the 16-tile form is expected to be faster (filled in from the sweep: tools/conv_bench.py --algo wino with SI_WINO_MT)
+static bool wino_use_mt16(const SiConv2dDesc* d, int tw, int rows_total) {
+    (void)d; (void)tw; (void)rows_total;
+    return false;
 }
 
 extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, const float* u, const float* bias,
@@ -582,8 +652,8 @@ extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, 
     if (d->in_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
     const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull;
     if (in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
-    const unsigned long long u_bytes = 16ull * d->ic * d->oc * 4ull;
-    if (u_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+    const unsigned long long u_bytes = 16ull * d->ic * d->oc * 4ull;   // (one image: the kernel's descriptor starts at the image it reads)
+    if (u_bytes * 2 >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
     if (d->has_bias && (reinterpret_cast<uintptr_t>(bias) & 15) != 0) return SI_E_UNSUPPORTED;
     if (d->oh != d->ih + 2 * d->pt - 2 || d->ow != d->iw + 2 * d->pl - 2) return SI_E_BADARG;
 
@@ -602,6 +672,15 @@ extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, 
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
 
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // Half-size work units (16 tiles on the 16x16x4 MFMA; same bits): SI_WINO_MT=16 / 32 forces either (development switch); the
+    // policy is wino_use_mt16
+    const int mt_force = wino_forced_form();
+    if (wino_has_mt16(d) && (mt_force == 16 || (mt_force == 0 && wino_use_mt16(d, a.tw, a.rows_total)))) {
+        const int l16 = wino_pick_log_tbw(a.tw, a.rows_total, 16);
+        if (l16 == 3) return launch_wino<3, 1, 16>(a, s);
+        if (l16 == 2) return launch_wino<2, 1, 16>(a, s);
+        return launch_wino<1, 1, 16>(a, s);
+    }
     const int l = wino_pick_log_tbw(a.tw, a.rows_total);
     // Two output groups per workgroup pay where the channel loop is long and the grid still covers the chip (MI355X, sustained:
     // 20x20x256 batch 32 0.0848 -> 0.0736 ms, 14x14x256 batch 64 0.0750 -> 0.0706; at 128 channels and below, or under

@@ -163,6 +163,33 @@ def test_winograd_fused_epilogue_and_strides(hops, orc):
         hops.conv2d_winograd(rng_uniform(75, (1, 8, 8, 12), -1, 1), rng_uniform(76, (32, 12, 3, 3)), None)  # ic % 16 != 0
 
 
+@pytest.mark.parametrize("n,h,w,ic,oc,pad", [(2, 40, 40, 64, 64, 1), (1, 80, 80, 32, 32, 1), (3, 20, 20, 128, 128, 1), (5, 10, 10, 256, 64, 1),
+                                             (2, 12, 12, 32, 96, 0), (4, 4, 4, 32, 64, 1), (1, 56, 56, 64, 64, 1), (2, 13, 17, 96, 32, 1),
+                                             (3, 7, 5, 32, 32, 1)])
+def test_winograd_half_size_units_same_bits(hops, gpu, n, h, w, ic, oc, pad):
+    """The kernel's 16-tile form on v_mfma_f32_16x16x4_f32 (half-size work units for launches that do not fill the chip evenly,
+    DESIGN.md 3g) against its 32-tile form on v_mfma_f32_32x32x2_f32: the same transforms and the same ascending channel order
+    in one fma chain per output, hence the SAME BITS -- every tile-block shape (2x8 / 4x4 / 8x2 tiles of 16), odd sizes, blocks
+    spanning images, ragged oc blocks, fused epilogues and strided tensors."""
+    from simpleinfer_amd import _native
+    H = _native.hip()
+    x = rng_uniform(n * 1000 + h, (n, h, w, ic), -1, 1)
+    wt = rng_uniform(n * 1000 + h + 1, (oc, ic, 3, 3), -0.5, 0.5)
+    b = rng_uniform(n * 1000 + h + 2, (oc,), -0.5, 0.5)
+    r = rng_uniform(n * 1000 + h + 3, (n, h + 2 * pad - 2, w + 2 * pad - 2, oc), -1, 1)
+    outs = {}
+    try:
+        for form in (32, 16):
+            H.si_hip_conv2d_wino23_set_form(form)
+            outs[form] = [hops.conv2d_winograd(x, wt, b, (pad, pad)),
+                          hops.conv2d_winograd(x, wt, b, (pad, pad), act1="silu", residual=r),
+                          hops.conv2d_winograd(x, wt, b, (pad, pad), residual=r, act2="relu", in_ld=ic + 16, out_ld=oc + 32, out_c_off=16)]
+    finally:
+        H.si_hip_conv2d_wino23_set_form(0)
+    for a, c, what in zip(outs[32], outs[16], ("plain", "silu + residual", "residual + relu, strided")):
+        assert_exact(c, a, "16-tile form vs 32-tile form: " + what)
+
+
 def test_winograd_64_channel_workgroups_and_unaligned_outputs():
     """The 64-output-channel form of the kernel (two accumulator groups per wave; picked by itself only for ic >= 256 on large
     grids) is forced onto every eligible shape of the two tests above in a child process (the switch is read once per process):
