@@ -369,16 +369,6 @@ def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
     max_det = 300
     wsb = H.si_hip_yolo_postprocess_workspace_bytes(n, rows, ne)
     ws, dets, cnt = hipops.DeviceBuffer(wsb), hipops.DeviceBuffer(n * max_det * 6 * 4), hipops.DeviceBuffer(n * 4)
-    # two prediction slabs (Engine::Output alternates between them): the filter / sort / NMS of batch k runs on its own stream
-    # beside the Forward() of batch k + 1
-    preds = [hipops.DeviceBuffer(n * rows * ne * 4), hipops.DeviceBuffer(n * rows * ne * 4)]
-    post_stream = C.c_void_p()
-    assert H.si_hip_stream_create(C.byref(post_stream)) == 0
-    ev_fwd = [C.c_void_p(), C.c_void_p()]
-    ev_post = [C.c_void_p(), C.c_void_p()]
-    for evs in (ev_fwd, ev_post):
-        for k in range(2):
-            H.si_hip_event_create(C.byref(evs[k]))
     hdets = [C.c_void_p(), C.c_void_p()]
     for k in range(2):
         assert H.si_hip_host_alloc(C.byref(hdets[k]), n * max_det * 6 * 4 + n * 4) == 0
@@ -391,6 +381,7 @@ def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
         for k in range(2):
             H.si_hip_event_create(C.byref(evs[k]))
     es = e.stream()
+    optr, _ = e.extract_ptr(oname)
 
     def upload(k):
         H.si_hip_stream_wait_event(copy_stream, ev_used[k])          # the letterbox of two batches ago has read this buffer
@@ -402,28 +393,21 @@ def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
         H.si_hip_letterbox_batch_u8_f32(dev_u8[k].ptr, n, img_bytes, hr, wr, dev_in[k].ptr, size, size, pt, pl, es)
         H.si_hip_event_record(ev_used[k], es)
         e.input_device(iname, dev_in[k].ptr)
-        e.bind_output(oname, preds[k].ptr)
-        H.si_hip_stream_wait_event(es, ev_post[k])            # the post-processing of two batches ago has read this slab
         e.forward_async()
-        H.si_hip_event_record(ev_fwd[k], es)
-        H.si_hip_stream_wait_event(post_stream, ev_fwd[k])
-        rc = H.si_hip_yolo_postprocess_f32(preds[k].ptr, n, rows, ne, thr, 0.45, 0, None, dets.ptr, cnt.ptr, max_det, ws.ptr, wsb, post_stream)
+        rc = H.si_hip_yolo_postprocess_f32(optr, n, rows, ne, thr, 0.45, 0, None, dets.ptr, cnt.ptr, max_det, ws.ptr, wsb, es)
         if rc != 0:
             raise RuntimeError("si_hip_yolo_postprocess_f32 rc=%d" % rc)
-        H.si_hip_memcpy_d2h(hdets[k], dets.ptr, n * max_det * 6 * 4, post_stream)
-        H.si_hip_memcpy_d2h(C.c_void_p(hdets[k].value + n * max_det * 6 * 4), cnt.ptr, n * 4, post_stream)
-        H.si_hip_event_record(ev_post[k], post_stream)
-        H.si_hip_event_record(ev_done[k], post_stream)
+        H.si_hip_memcpy_d2h(hdets[k], dets.ptr, n * max_det * 6 * 4, es)
+        H.si_hip_memcpy_d2h(C.c_void_p(hdets[k].value + n * max_det * 6 * 4), cnt.ptr, n * 4, es)
+        H.si_hip_event_record(ev_done[k], es)
 
     for k in range(2):
         H.si_hip_event_record(ev_used[k], es)
-        H.si_hip_event_record(ev_post[k], post_stream)
     # threshold where 3 % of the rows of this network's output pass
     upload(0)
     compute(0, 2.0)
     e.sync()
-    H.si_hip_stream_sync(post_stream)
-    pred = preds[0].to_numpy((n, rows, ne))
+    pred = hipops.DeviceBuffer.view(optr, n * rows * ne * 4).to_numpy((n, rows, ne))
     conf = pred[..., 4] * pred[..., 5:].max(axis=-1)
     thr = float(np.quantile(conf, 0.97))
     upload(1)
@@ -431,7 +415,6 @@ def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
         compute((it + 1) % 2, thr)
         upload(it % 2)
     e.sync()
-    H.si_hip_stream_sync(post_stream)
     steps = max(args.steps, 20)
     t0 = time.perf_counter()
     for it in range(steps):
@@ -441,27 +424,22 @@ def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
         if it > 0:
             H.si_hip_event_sync(ev_done[1 - k])   # the previous batch's boxes are on the host
     e.sync()
-    H.si_hip_stream_sync(post_stream)
     dt = time.perf_counter() - t0
-    e.bind_output(oname, None)
     kept = np.ctypeslib.as_array(C.cast(C.c_void_p(hdets[k].value + n * max_det * 6 * 4), C.POINTER(C.c_int32)), shape=(n,)).mean()
     for k in range(2):
         H.si_hip_host_free(pinned[k]); H.si_hip_host_free(hdets[k])
         dev_u8[k].free(); dev_in[k].free()
-    for evs in (ev_up, ev_used, ev_done, ev_fwd, ev_post):
+    for evs in (ev_up, ev_used, ev_done):
         for k in range(2):
             H.si_hip_event_destroy(evs[k])
-    for k in range(2):
-        preds[k].free()
     H.si_hip_stream_destroy(copy_stream)
-    H.si_hip_stream_destroy(post_stream)
     value = n * steps / dt
     return {"value": round(value, 2), "unit": "images/sec", "ms_per_batch": round(dt / steps * 1e3, 3),
             "ratio_to_device_resident": round(value / rate_resident, 4), "boxes_kept_per_image": round(float(kept), 1),
             "confidence_threshold": round(thr, 4), "bytes_up_per_image": img_bytes, "bytes_down_per_image": max_det * 24 + 4,
             "note": "test-yolo's flow (test_yolo.cpp:299-438) pipelined: u8 letterbox-target frames (480x640 -> %dx%d, padded to %dx%d on the "
-                    "device) uploaded double-buffered on a copy stream, device letterbox -> Forward into one of two prediction slabs -> device "
-                    "filter / sort / NMS on a third stream beside the next Forward, boxes downloaded; threshold at the 97th percentile of this random-init network's confidences (3 %% of rows pass, as with "
+                    "device) uploaded double-buffered on a copy stream, device letterbox -> Forward -> device filter / sort / NMS, boxes "
+                    "downloaded; threshold at the 97th percentile of this random-init network's confidences (3 %% of rows pass, as with "
                     "a trained detector); not `value`" % (hr, wr, size, size)}
 
 
