@@ -637,10 +637,29 @@ extern "C" int si_hip_conv2d_wino23_set_form(int form) {
     return prev;
 }
 
-// when the 16-tile form is expected to be faster (filled in from the sweep: tools/conv_bench.py --algo wino with SI_WINO_MT)
+// When the 16-tile form is expected to be faster: a round model fitted to profiles/r03_wino16_sweep.txt.  Workgroups run in
+// lock-step rounds over the residency slots (3 per CU; 2 for the 64-oc form, whose rounds are ~1.6x as long); a half-size unit
+// costs ~0.55 of a full one (prologue, fill and the exchange epilogue are per workgroup).  The 16-tile form wins where the 32-tile
+// grid sits just above a whole number of rounds (80x80x64 at batch 8: 800 workgroups for 768 slots) or leaves most of the chip
+// empty (20x20x256 at batch 8: 100 workgroups); with one 32-channel block (ic = 32) a unit is all overhead and it never does.
 static bool wino_use_mt16(const SiConv2dDesc* d, int tw, int rows_total) {
-    (void)d; (void)tw; (void)rows_total;
-    return false;
+    if (d->ic < 64) return false;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    auto spatial = [&](int tiles) {
+        const int tbw = 1 << wino_pick_log_tbw(tw, rows_total, tiles), tbh = tiles / tbw;
+        return (long long)((tw + tbw - 1) / tbw) * ((rows_total + tbh - 1) / tbh);
+    };
+    const long long s32 = spatial(32), s16 = spatial(16);
+    const bool two = d->oc % 64 == 0 && d->ic >= 256 && s32 * (d->oc / 64) >= 384;   // (the 32-tile form's own choice, below)
+    const long long w32 = s32 * (two ? d->oc / 64 : d->oc / 32), slots32 = (long long)cus * (two ? 2 : 3);
+    const double est32 = (double)((w32 + slots32 - 1) / slots32) * (two ? 1.6 : 1.0);
+    const long long w16 = s16 * (d->oc / 32), slots16 = (long long)cus * 3;
+    const double est16 = (double)((w16 + slots16 - 1) / slots16) * 0.55;
+    return est16 < 0.95 * est32;
 }
 
 extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, const float* u, const float* bias,
