@@ -79,6 +79,11 @@ def parse():
     return ap.parse_args()
 
 
+def workload_key(args, shape):
+    """what a recorded traffic table is keyed on: the launches of a kernel instantiation are those of one model at one batch"""
+    return "%s %dx%d %s batch %d" % (args.model, shape[1], shape[2], "fp16" if args.fp16 else "fp32", args.batch)
+
+
 def build_model(mg, name, batch, size):
     if name == "yolov5s":
         return mg.build_yolov5s(batch, size), (batch, size, size, 3)
@@ -169,17 +174,20 @@ def _template_of(kernel):
     return kernel.split("<", 1)[0]
 
 
-def _traffic_table(fp16):
-    tpath = os.path.join(ROOT, "profiles", "traffic_fp16.json" if fp16 else "traffic.json")
-    if not os.path.exists(tpath):
-        return {}, None
-    try:
-        table = json.load(open(tpath))
-    except Exception:
-        return {}, None
-    # PMC counters cannot be collected from inside this process: the figures are the ones tools/run_traffic.sh recorded
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes) for these instantiations, not a measurement of this run
-    return table, "profiles/%s (recorded at %s)" % (os.path.basename(tpath), table.get("_recorded_at", "an earlier round"))
+def _traffic_table(workload):
+    """The PMC traffic table recorded for THIS workload (model, size, precision, per-GPU batch), or nothing: bytes per launch of a
+    kernel instantiation mean something only for the launches they were measured on.  PMC counters cannot be collected from inside
+    this process: the figures are the ones tools/run_traffic.sh recorded (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes) -- not a measurement of this run -- and every table names the workload and the commit it was recorded at."""
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic*.json"))):
+        try:
+            table = json.load(open(tpath))
+        except Exception:
+            continue
+        if table.get("_workload") == workload:
+            return table, "profiles/%s (recorded at %s for %s)" % (os.path.basename(tpath), table.get("_recorded_at", "an earlier round"), workload)
+    return {}, None
 
 
 def _traffic_of(table, name):
@@ -199,7 +207,7 @@ def _traffic_of(table, name):
 WINOGRAD_MULT_REDUCTION = {"conv_wino23_kernel": 2.25, "conv_wino43_kernel": 4.0}   # direct multiplies per executed multiply
 
 
-def roofline_from_profile(passes, fp16=False):
+def roofline_from_profile(passes, fp16=False, workload=None):
     """passes: list of per-layer profile lists (same schedule).  The dominant KERNEL is the conv kernel template with the
     largest total time (all its instantiations: one source kernel whose tile / MFMA shape follows the launch size); it is
     priced as SUM of algorithmic work / SUM of launch durations, and every instantiation -- the names are exactly what
@@ -231,7 +239,7 @@ def roofline_from_profile(passes, fp16=False):
     flops_per_launch = a["flops"] / a["launches"]
     bytes_per_launch = a["bytes"] / a["launches"]
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-    table, traffic_source = _traffic_table(fp16)
+    table, traffic_source = _traffic_table(workload)
     rows, tsum, tn = [], 0.0, 0
     for k, v in sorted(inst.items(), key=lambda kv: -kv[1]["ms"]):
         if _template_of(k) != name:
@@ -697,7 +705,7 @@ def main():
                 e.bind_output(oname, None)
             passes = [e.profile() for _ in range(max(args.profile_passes, 1))]
             layers = passes[-1]
-            roof, agg = roofline_from_profile(passes, fp16=bool(args.fp16))
+            roof, agg = roofline_from_profile(passes, fp16=bool(args.fp16), workload=workload_key(args, shape))
             if args.layers:
                 for L in layers:
                     tf = L["flops"] / (L["ms"] * 1e-3) / 1e12 if L["ms"] > 0 else 0
@@ -742,6 +750,7 @@ def main():
                                                             args.batch * world,
                                                             (", every step's output slab all-gathered (%s), overlapped with the next step" % gather_text) if use_dist else ""),
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "workload_key": workload_key(args, shape),
                    "gather": gather_mode, "gather_note": gather_note, "engine_options": extra_opts, "lanes": lanes,
                    "hipgraph": bool(args.graph), "winograd_for_3x3s1": {0: "off", 1: "F(2,3)", 2: "F(4,3)"}.get(args.winograd, "F(2,3)")},
         "windows": {"count": len(windows), "steps_each": args.steps, "timed_s_total": round(total, 3),

@@ -328,7 +328,9 @@ int si_hip_f32_to_f16_host(const float* src, void* dst, size_t n);
 int si_hip_f16_to_f32_host(const void* src, float* dst, size_t n);
 /* 0: no fp16 kernel for this shape; 1: implicit GEMM on v_mfma_f32_32x32x16_f16 (needs ic/groups % 32 == 0);
  * 2: stem (ic <= 3; 6x6, 7x7 or 3x3 RGB kernels): fp32 input image, fp16 output, weights packed by
- *    si_hip_conv2d_stem_f16_pack_weight_host (csrc/hip/conv_stem_f16.hip) */
+ *    si_hip_conv2d_stem_f16_pack_weight_host (csrc/hip/conv_stem_f16.hip)
+ * 3: depthwise (groups == ic == oc, ic % 8 == 0): si_hip_conv2d_depthwise_f16
+ * (1 also covers ungrouped 1x1 convs with ic % 8 == 0: the K axis is zero-padded to whole 32-channel blocks) */
 int si_hip_conv2d_f16_supported(const SiConv2dDesc* d);
 size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d);
 /* OIHW fp32 -> [oc][K] fp16, K order (c/B, kh, kw, c%B), B = 64 when ic/groups % 64 == 0 else 32 */
@@ -337,6 +339,11 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
  * outputs) */
 int si_hip_conv2d_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
                       void* out, int out_is_f32, si_stream_t stream);
+/* depthwise convolution (groups == ic == oc, ic % 8 == 0) with fp16 activations (si_hip_conv2d_f16_supported == 3): w_packed is
+ * the FP32 depthwise image of si_hip_conv2d_pack_weight_host ([kh*kw][c]), bias fp32, fp32 tap sums, bias / activation / residual
+ * fused, outputs rounded to fp16 once */
+int si_hip_conv2d_depthwise_f16(const SiConv2dDesc* d, const void* in, const float* w_packed, const float* bias,
+                                const void* residual, void* out, si_stream_t stream);
 /* stem of the fp16 path: the reference's first Conv2d (src/layer/conv_2d.cpp:207-283 on a 3-channel image) with the
  * image read as fp32, rounded to fp16 on the way into LDS, contracted on v_mfma_f32_32x32x16_f16, bias / activation in
  * fp32, fp16 activations out.  Weights: OIHW fp32 -> [step][lane half][oc padded][8] fp16 B fragments. */
@@ -355,6 +362,10 @@ int si_hip_activation_f16(int act, float act_param, const void* in, size_t pixel
 /* same-shape add (op 0) / mul (op 2) */
 int si_hip_binary_same_f16(int op, const void* a, int a_ld, const void* b, int b_ld, void* out, int out_ld, size_t pixels,
                            int c, si_stream_t stream);
+/* out[b][p][c] = a[b][p][c] (op) s[b][c] (op: 0 add, 2 mul): the squeeze-excite scale -- BinaryOp whose second operand is
+ * broadcast over H, W -- with fp16 storage.  c and the strides multiples of 8, 16-byte aligned pointers. */
+int si_hip_binary_bcast_f16(int op, const void* a, int a_ld, const void* s, int s_ld, void* out, int out_ld, int n,
+                            size_t pixels_per_image, int c, si_stream_t stream);
 int si_hip_maxpool2d_f16(const SiPool2dDesc* d, const void* in, void* out, si_stream_t stream);
 /* SPPF pool chain: out1 = maxpool5(in), out2 = maxpool5(out1), out3 = maxpool5(out2), all 5x5 stride 1 pad 2 on [n,h,w,c]
  * maps -- three consecutive MaxPool2d::Forward calls of the reference (src/layer/max_pool_2d.cpp:77-121) in one launch

@@ -136,6 +136,7 @@ def hip():
         "si_hip_conv2d_f16_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_f16_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, i, vp]),
+        "si_hip_conv2d_depthwise_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_stem_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp]),
         "si_hip_conv2d_stem_f16_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_stem_f16_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
@@ -143,6 +144,7 @@ def hip():
         "si_hip_conv2d_yolo_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),
         "si_hip_activation_f16": (i, [i, f, vp, sz, i, i, vp, i, vp]),
         "si_hip_binary_same_f16": (i, [i, vp, i, vp, i, vp, i, sz, i, vp]),
+        "si_hip_binary_bcast_f16": (i, [i, vp, i, vp, i, vp, i, i, sz, i, vp]),
         "si_hip_maxpool2d_f16": (i, [C.POINTER(SiPool2dDesc), vp, vp, vp]),
         "si_hip_maxpool5_chain3_f32": (i, [vp, i, i, i, i, i, vp, i, vp, i, vp, i, vp]),
         "si_hip_maxpool5_chain3_f16": (i, [vp, i, i, i, i, i, vp, i, vp, i, vp, i, vp]),

@@ -33,6 +33,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // conv_stem_f16.hip: stem kernel of this path (fp32 image in, fp16 out)
 bool si_conv_stem_f16_ok(const SiConv2dDesc* d);
+// conv_depthwise_f16.hip: groups == ic == oc
+bool si_conv_depthwise_f16_ok(const SiConv2dDesc* d);
 
 namespace {
 
@@ -287,9 +289,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     auto load_tile = [&](u32x4 (&qa)[A_IT], u32x4 (&qb)[B_IT], int kt) {
         const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * BKH) * 2u;
         const int tapbit = ky * a.kw + kx;
+        // (a 1x1 conv whose channel count is a multiple of 8 but not of 32 has its K axis zero-padded to whole blocks in the weights:
+        // a vector that lies behind the last channel must read zeros, not the next pixel)
+        const bool cok = cb * BKH + kv * 8 < a.icg;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
-            const bool ok = (a_mask[i] >> tapbit) & 1ull;
+            const bool ok = ((a_mask[i] >> tapbit) & 1ull) && cok;
             qa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
         }
         const unsigned kb = (unsigned)kt * (BKH * 2);
@@ -400,12 +405,19 @@ struct SplitOutH {
 };
 
 // channel-block size of the K order (a property of the packed weights, so of the layer's static shape only)
-int f16_block(const SiConv2dDesc* d) { return ((d->ic / d->groups) % 64 == 0) ? 64 : 32; }
+// channels per tap in the packed weights: ic / groups, or -- ungrouped 1x1 convs with a channel count that is a multiple of 8 but
+// not of 32 (MobileNet's pointwise and squeeze-excite convs: 16 / 24 / 40 / 72 / 96 ...) -- that rounded up to x32 with zero weights
+int f16_icg_pad(const SiConv2dDesc* d) {
+    const int icg = d->ic / d->groups;
+    return icg % 32 == 0 ? icg : (icg + 31) / 32 * 32;
+}
+int f16_block(const SiConv2dDesc* d) { return (f16_icg_pad(d) % 64 == 0) ? 64 : 32; }
 
 bool f16_shape_ok(const SiConv2dDesc* d) {
     if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return false;
     const int icg = d->ic / d->groups;
-    return icg % 32 == 0 && d->kh * d->kw <= 64;
+    if (icg % 32 == 0) return d->kh * d->kw <= 64;
+    return d->kh * d->kw == 1 && d->groups == 1 && icg % 8 == 0 && icg >= 8;
 }
 
 // 0: 64x64, 1: 128x64, 2: 128x128 (SI_CONV_F16_VARIANT overrides, development only)
@@ -426,7 +438,7 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     if (d->in_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
     if ((long long)d->n * d->oh * d->ow > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 2ull;
-    const unsigned long long w_bytes = (unsigned long long)d->oc * d->kh * d->kw * (d->ic / d->groups) * 2ull;
+    const unsigned long long w_bytes = (unsigned long long)d->oc * d->kh * d->kw * f16_icg_pad(d) * 2ull;
     if (in_bytes >= 0xFFFFFF00ull || w_bytes >= 0x40000000ull) return SI_E_UNSUPPORTED;
 
     ConvArgsH a;
@@ -442,7 +454,7 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     a.icg = d->ic / d->groups;
     a.ocg = d->oc / d->groups;
     a.oc = d->oc;
-    a.Kp = d->kh * d->kw * a.icg;
+    a.Kp = d->kh * d->kw * f16_icg_pad(d);
     a.M = d->n * d->oh * d->ow;
     a.ohow = d->oh * d->ow;
     a.mg_ohow = a.ohow > 1 ? (unsigned)(0x100000000ull / (unsigned)a.ohow) : 0xFFFFFFFFu;
@@ -500,18 +512,19 @@ int si_hip_f16_to_f32_host(const void* src, float* dst, size_t n) {
 int si_hip_conv2d_f16_supported(const SiConv2dDesc* d) {
     if (!d) return 0;
     if (si_conv_stem_f16_ok(d)) return 2;  // stem: fp32 image in, fp16 out, weights from si_hip_conv2d_stem_f16_pack_weight_host
+    if (si_conv_depthwise_f16_ok(d)) return 3;  // depthwise: si_hip_conv2d_depthwise_f16, fp32 weights in the fp32 depthwise layout
     return f16_shape_ok(d) ? 1 : 0;
 }
 
 size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d) {
     if (!d || !f16_shape_ok(d)) return 0;
-    return (size_t)d->oc * d->kh * d->kw * (d->ic / d->groups);
+    return (size_t)d->oc * d->kh * d->kw * f16_icg_pad(d);
 }
 
 int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed) {
     if (!d || !w_oihw || !w_packed) return SI_E_BADARG;
     if (!f16_shape_ok(d)) return SI_E_UNSUPPORTED;
-    const int icg = d->ic / d->groups;
+    const int icg = d->ic / d->groups, icp = f16_icg_pad(d);
     const int ntaps = d->kh * d->kw;
     const int blk = f16_block(d);
     half_t* w = static_cast<half_t*>(w_packed);
@@ -519,10 +532,10 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
         for (int y = 0; y < d->kh; ++y)
             for (int x = 0; x < d->kw; ++x) {
                 const int tap = y * d->kw + x;
-                for (int c = 0; c < icg; ++c) {
-                    const float v = w_oihw[(((size_t)o * icg + c) * d->kh + y) * d->kw + x];
+                for (int c = 0; c < icp; ++c) {
+                    const float v = c < icg ? w_oihw[(((size_t)o * icg + c) * d->kh + y) * d->kw + x] : 0.0f;
                     const size_t k = ((size_t)(c / blk) * ntaps + tap) * blk + (c % blk);  // (c/blk, kh, kw, c%blk)
-                    w[(size_t)o * ntaps * icg + k] = (half_t)v;
+                    w[(size_t)o * ntaps * icp + k] = (half_t)v;
                 }
             }
     return 0;

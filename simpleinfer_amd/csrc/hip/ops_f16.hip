@@ -72,6 +72,23 @@ __global__ void binary_same_h_kernel(int op, const half_t* __restrict__ a, int a
     }
 }
 
+__global__ void binary_bcast_h_kernel(int op, const half_t* __restrict__ a, int a_ld, const half_t* __restrict__ sc, int s_ld,
+                                      half_t* __restrict__ out, int out_ld, int n, size_t ppi, int c) {
+    const size_t cv = (size_t)(c / 8);
+    const size_t total = (size_t)n * ppi * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cv;
+        const int ch = (int)(i - p * cv) * 8;
+        const size_t b = p / ppi;
+        const f16x8 x = *reinterpret_cast<const f16x8*>(a + p * a_ld + ch);
+        const f16x8 y = *reinterpret_cast<const f16x8*>(sc + b * s_ld + ch);
+        f16x8 r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = si_store_cast<half_t>((op == 0) ? (float)x[k] + (float)y[k] : (float)x[k] * (float)y[k]);
+        *reinterpret_cast<f16x8*>(out + p * out_ld + ch) = r;
+    }
+}
+
 // window max is exact in any precision: compare the fp16 values directly
 template <bool VEC>
 __global__ void maxpool_h_kernel(const SiPool2dDesc d, const half_t* __restrict__ in, half_t* __restrict__ out) {
@@ -205,6 +222,20 @@ int si_hip_binary_same_f16(int op, const void* a, int a_ld, const void* b, int b
         hipLaunchKernelGGL(binary_same_h_kernel<false>, dim3(si_grid_for(pixels * (size_t)c)), dim3(256), 0, s, op,
                            static_cast<const half_t*>(a), a_ld, static_cast<const half_t*>(b), b_ld, static_cast<half_t*>(out),
                            out_ld, pixels, c);
+    return (int)hipGetLastError();
+}
+
+// out[b][p][c] = a[b][p][c] (op) s[b][c]: the squeeze-excite scale (BinaryOp with broadcast factors H, W on the second operand,
+// reference src/layer/binary_op.cpp:52-94) with fp16 storage; computed in fp32, rounded once
+int si_hip_binary_bcast_f16(int op, const void* a, int a_ld, const void* s, int s_ld, void* out, int out_ld, int n,
+                            size_t pixels_per_image, int c, si_stream_t stream) {
+    if (!a || !s || !out || c <= 0 || n < 0 || a_ld < c || s_ld < c || out_ld < c) return SI_E_BADARG;
+    if (op != 0 && op != 2) return SI_E_UNSUPPORTED;
+    if (n == 0 || pixels_per_image == 0) return 0;
+    if (c % 8 != 0 || a_ld % 8 != 0 || s_ld % 8 != 0 || out_ld % 8 != 0 || !al16(a) || !al16(s) || !al16(out)) return SI_E_UNSUPPORTED;
+    hipLaunchKernelGGL(binary_bcast_h_kernel, dim3(si_grid_for((size_t)n * pixels_per_image * (size_t)(c / 8))), dim3(256), 0, (hipStream_t)stream, op,
+                       static_cast<const half_t*>(a), a_ld, static_cast<const half_t*>(s), s_ld, static_cast<half_t*>(out), out_ld, n,
+                       pixels_per_image, c);
     return (int)hipGetLastError();
 }
 

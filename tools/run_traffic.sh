@@ -44,6 +44,11 @@ for k, v in res.items():
                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950)"}
 import os
 final["_recorded_at"] = os.environ.get("SI_COMMIT", "unknown commit")
+# the workload these per-launch figures belong to (bench.py attaches them only to a run of the same workload)
+try:
+    final["_workload"] = json.loads(open(out + "/bench_FETCH_SIZE.json").read().strip().splitlines()[-1])["config"]["workload_key"]
+except Exception:
+    final["_workload"] = "unknown"
 json.dump(final, open(out + "/traffic.json", "w"), indent=1)
 for k, v in sorted(((k, v) for k, v in final.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
     print(k, v["hbm_bytes_per_launch"] / 1e6, "MB/launch", v["launches"])
