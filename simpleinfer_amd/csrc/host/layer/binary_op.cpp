@@ -55,9 +55,20 @@ Status BinaryOp::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
         for (int i = 0; i < 4; ++i)
             if (a[i] <= 0 || b[i] <= 0 || o[i] % a[i] != 0 || o[i] % b[i] != 0) return Status::kErrorShape;
         if (IsHalf(in[0]) || IsHalf(in[1]) || IsHalf(out[0])) {
-            // fp16 path: same-shape add / mul only (what residual blocks need)
-            if (!(IsHalf(in[0]) && IsHalf(in[1]) && IsHalf(out[0])) || a != o || b != o) return Status::kUnsupport;
+            // fp16 path: add / mul of same-shape tensors (residual blocks) or with one operand broadcast over H and W (the
+            // squeeze-excite scale [N,1,1,C] x [N,H,W,C])
+            if (!(IsHalf(in[0]) && IsHalf(in[1]) && IsHalf(out[0]))) return Status::kUnsupport;
             if (binary_op_type_ != BinaryOpType::kAdd && binary_op_type_ != BinaryOpType::kMul) return Status::kUnsupport;
+            auto per_image_vector = [&](const std::vector<int>& s) { return s[0] == o[0] && s[1] == 1 && s[2] == 1 && s[3] == o[3]; };
+            if (a == o && per_image_vector(b) && b != o)
+                return CheckHip(si_hip_binary_bcast_f16((int)binary_op_type_, in[0].RawData(), in[0].PixelStride(), in[1].RawData(), in[1].PixelStride(),
+                                                        out[0].RawData(), out[0].PixelStride(), o[0], (size_t)o[1] * o[2], o[3], Stream()),
+                                "BinaryOp (broadcast)");
+            if (b == o && per_image_vector(a) && a != o)   // add and mul commute
+                return CheckHip(si_hip_binary_bcast_f16((int)binary_op_type_, in[1].RawData(), in[1].PixelStride(), in[0].RawData(), in[0].PixelStride(),
+                                                        out[0].RawData(), out[0].PixelStride(), o[0], (size_t)o[1] * o[2], o[3], Stream()),
+                                "BinaryOp (broadcast)");
+            if (a != o || b != o) return Status::kUnsupport;
             return CheckHip(si_hip_binary_same_f16((int)binary_op_type_, in[0].RawData(), in[0].PixelStride(), in[1].RawData(),
                                                    in[1].PixelStride(), out[0].RawData(), out[0].PixelStride(),
                                                    (size_t)o[0] * o[1] * o[2], o[3], Stream()),
@@ -102,7 +113,14 @@ bool BinaryOp::HalfStorageOk(std::string& why) const {
         same = input_tensor_nodes_[0]->tensor.Shape() == o && input_tensor_nodes_[1]->tensor.Shape() == o;
     }
     if (all && addmul && same) return true;
-    why = "BinaryOp has an fp16 kernel for same-shape add / mul only (no broadcast, no scalar form, no sub / div / pow)";
+    if (all && addmul && !with_scalar_ && input_tensor_nodes_.size() == 2 && output_tensor_nodes_.size() == 1) {
+        // one operand a per-image channel vector [N,1,1,C] (squeeze-excite), channels a multiple of 8
+        const std::vector<int> a = input_tensor_nodes_[0]->tensor.ShapeAs(4), b = input_tensor_nodes_[1]->tensor.ShapeAs(4);
+        const std::vector<int> o = output_tensor_nodes_[0]->tensor.ShapeAs(4);
+        auto vec = [&](const std::vector<int>& s) { return s[0] == o[0] && s[1] == 1 && s[2] == 1 && s[3] == o[3]; };
+        if (o[3] % 8 == 0 && ((a == o && vec(b)) || (b == o && vec(a)))) return true;
+    }
+    why = "BinaryOp has fp16 kernels for add / mul of same-shape tensors or with a per-image channel vector only (no scalar form, no sub / div / pow)";
     return false;
 }
 

@@ -170,6 +170,10 @@ Status Conv2d::PrepareDevice(int mode) {
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
     d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
     if (mode == 1) return PrepareDeviceHalf(d);
+    if (mode == 3 && si_hip_conv2d_f16_supported(&d) != 3) {
+        LOG(ERROR) << "Conv2d: no fp16 depthwise kernel for " << in_channels_ << " channels (needs a multiple of 8)";
+        return Status::kUnsupport;
+    }   // (mode 3 then packs the fp32 depthwise image below, exactly as mode 0 does)
     if (mode == 2) {
         wino_tile_ = 0;
         use_winograd_ = false;
@@ -244,6 +248,7 @@ Status Conv2d::PrepareDeviceHalf(const SiConv2dDesc& d) {
 // converts its input first (in_half_)
 int Conv2d::PrecisionMode(const Tensor& input, const Tensor& output) const {
     if (!IsHalf(input) && !IsHalf(output)) return 0;
+    if (groups_ > 1 && groups_ == in_channels_ && in_channels_ == out_channels_ && IsHalf(input) && IsHalf(output)) return 3;   // depthwise, fp16 storage
     if (!IsHalf(input)) {
         SiConv2dDesc d;
         memset(&d, 0, sizeof(d));
@@ -322,6 +327,12 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
         return CheckHip(si_hip_conv2d_stem_f16(&d, input.Data<float>(), weight_dev_.As<void>(),
                                                use_bias_ ? bias_dev_.As<float>() : nullptr, output.RawData(), Stream()),
                         "conv2d stem (fp16 out)");
+    if (mode == 3) {
+        if (residual && !IsHalf(*residual)) return Status::kUnsupport;
+        return CheckHip(si_hip_conv2d_depthwise_f16(&d, input.RawData(), weight_dev_.As<float>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                    residual ? residual->RawData() : nullptr, output.RawData(), Stream()),
+                        "conv2d depthwise fp16");
+    }
     if (mode == 1) {
         if (residual && !IsHalf(*residual)) return Status::kUnsupport;
         Tensor xin;
@@ -438,6 +449,7 @@ const char* Conv2d::KernelName() const {
     const int mode = PrecisionMode(in, out);
     if (mode == 1) return "conv_igemm_f16_kernel<64, 64, 2, 2>";
     if (mode == 2) return "conv_stem_f16_kernel";
+    if (mode == 3) return "conv_depthwise_f16_kernel<2>";
     const int tile = WinogradTile(d);
     if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
     return si_hip_conv2d_kernel_name_form(&d, in.Data<float>(), up_node_ ? 1 : 0);
@@ -482,7 +494,7 @@ bool Conv2d::HalfStorageOk(std::string& why) const {
     d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
     if (si_hip_conv2d_f16_supported(&d) != 0) return true;
     why = "no fp16 conv kernel for " + std::to_string(in_channels_) + " -> " + std::to_string(out_channels_) + " channels, groups " +
-          std::to_string(groups_) + " (needs ic / groups % 32 == 0, or an RGB stem)";
+          std::to_string(groups_) + " (needs ic / groups % 32 == 0, an ungrouped 1x1 conv with ic % 8 == 0, a depthwise conv with ic % 8 == 0, or an RGB stem)";
     return false;
 }
 

@@ -61,7 +61,7 @@ Status Linear::PrepareDevice(bool half) {
     d.ic = in_features_; d.oc = out_features_; d.kh = d.kw = d.sh = d.sw = d.dh = d.dw = 1; d.groups = 1;
     if (half) {
         if (si_hip_conv2d_f16_supported(&d) != 1) {
-            LOG(ERROR) << "Linear: no fp16 kernel for in_features " << in_features_ << " (needs a multiple of 32)";
+            LOG(ERROR) << "Linear: no fp16 kernel for in_features " << in_features_ << " (needs a multiple of 8)";
             return Status::kUnsupport;
         }
         std::vector<uint16_t> packed(si_hip_conv2d_f16_weight_elems(&d));
@@ -110,9 +110,11 @@ double Linear::Flops() const {
 }
 
 bool Linear::HalfStorageOk(std::string& why) const {
-    if (!output_tensor_nodes_.empty() && IsHalf(output_tensor_nodes_[0]->tensor)) { why = "Linear writes fp32 only"; return false; }
-    if (!input_tensor_nodes_.empty() && IsHalf(input_tensor_nodes_[0]->tensor) && in_features_ % 32 != 0) {
-        why = "Linear's fp16 kernel needs in_features % 32 == 0";
+    const bool half_in = !input_tensor_nodes_.empty() && IsHalf(input_tensor_nodes_[0]->tensor);
+    const bool half_out = !output_tensor_nodes_.empty() && IsHalf(output_tensor_nodes_[0]->tensor);
+    if (half_out && !half_in) { why = "Linear writes fp16 only from fp16 features"; return false; }
+    if (half_in && in_features_ % 8 != 0) {
+        why = "Linear's fp16 kernel needs in_features % 8 == 0";
         return false;
     }
     return true;

@@ -502,8 +502,9 @@ def _f16(a) -> np.ndarray:
 
 
 def conv2d_f16(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1), groups=1, act1="none",
-               residual=None, act2="none", act_param=0.0, in_ld=None, out_ld=None, out_c_off=0, out_f32=False):
-    """si_hip_conv2d_f16, or si_hip_conv2d_stem_f16 when the shape is a stem (fp32 image in, fp16 out)."""
+               residual=None, act2="none", act_param=0.0, in_ld=None, out_ld=None, out_c_off=0, out_f32=False, in_fill=0.0):
+    """si_hip_conv2d_f16, si_hip_conv2d_stem_f16 when the shape is a stem (fp32 image in, fp16 out), or si_hip_conv2d_depthwise_f16.
+    in_fill: what lies between the pixels' channels of a strided (in_ld > ic) input."""
     H = _native.hip()
     w_oihw = _f32(w_oihw)
     n, ih, iw, ic = x.shape
@@ -534,11 +535,27 @@ def conv2d_f16(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1,
              "si_hip_conv2d_stem_f16")
         y = dy.to_numpy((n, oh, ow, out_ld), np.float16)
         return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
+    if kind == 3:   # depthwise: fp16 activations, the FP32 depthwise weight image
+        packed = np.zeros(H.si_hip_conv2d_weight_elems(C.byref(d)), np.float32)
+        _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack depthwise")
+        if out_f32:
+            raise HipError("the fp16 depthwise kernel writes fp16")
+        xh = _f16(x)
+        if in_ld != ic:
+            xw = np.zeros((n, ih, iw, in_ld), np.float16)
+            xw[..., :ic] = xh
+            xh = xw
+        dx, dw = DeviceBuffer.from_numpy(xh), DeviceBuffer.from_numpy(packed)
+        dr = DeviceBuffer.from_numpy(_f16(residual)) if residual is not None else None
+        _chk(H.si_hip_conv2d_depthwise_f16(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dr.ptr if dr else None,
+                                           dy.ptr + 2 * out_c_off, None), "si_hip_conv2d_depthwise_f16")
+        y = dy.to_numpy((n, oh, ow, out_ld), np.float16)
+        return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
     packed = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d)), np.float16)
     _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack f16")
     x = _f16(x)
     if in_ld != ic:
-        xw = np.zeros((n, ih, iw, in_ld), np.float16)
+        xw = np.full((n, ih, iw, in_ld), in_fill, np.float16)
         xw[..., :ic] = x
         x = xw
     dx, dw = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(packed)
@@ -604,6 +621,17 @@ def binary_same_f16(op, a, b):
     da, db, dy = DeviceBuffer.from_numpy(a), DeviceBuffer.from_numpy(b), DeviceBuffer(a.nbytes)
     _chk(H.si_hip_binary_same_f16({"add": 0, "mul": 2}[op], da.ptr, c, db.ptr, c, dy.ptr, c, pixels, c, None),
          "si_hip_binary_same_f16")
+    return dy.to_numpy(a.shape, np.float16)
+
+
+def binary_bcast_f16(op, a, s):
+    """si_hip_binary_bcast_f16: a [n][h][w][c] (op) s [n][c] broadcast over h, w (the squeeze-excite scale)."""
+    H = _native.hip()
+    a, s = _f16(a), _f16(s)
+    n, c = a.shape[0], a.shape[-1]
+    ppi = a.size // (n * c)
+    da, ds, dy = DeviceBuffer.from_numpy(a), DeviceBuffer.from_numpy(s), DeviceBuffer(a.nbytes)
+    _chk(H.si_hip_binary_bcast_f16({"add": 0, "mul": 2}[op], da.ptr, c, ds.ptr, c, dy.ptr, c, n, ppi, c, None), "si_hip_binary_bcast_f16")
     return dy.to_numpy(a.shape, np.float16)
 
 

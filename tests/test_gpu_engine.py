@@ -400,6 +400,26 @@ def test_fp16_graph_vs_fp32_oracle(si, orc, tmp_path, name):
     assert_exact(one[0], got[1], "fp16: an image's result does not depend on the batch")
 
 
+def test_fp16_mobilenetv3_vs_fp32_oracle(si, orc, tmp_path):
+    """MobileNetV3-Small with fp16 storage (round 3: depthwise convs on their own fp16 kernel, pointwise / squeeze-excite convs
+    with 16 / 24 / 40 / 72 / 96 ... channels through a zero-padded K axis, the squeeze-excite scale as a broadcast multiply,
+    Linear -> Hardswish -> Linear with an fp16 hidden vector): the logits against the fp32 oracle, every kernel family present,
+    batch invariance bit for bit."""
+    mg = si.modelgen
+    pp, bp = _save(tmp_path, mg.build_mobilenetv3_small(2, 96, num_classes=100), "mnv3h")
+    x = mg.synth_input((2, 96, 96, 3))
+    ref = orc.run_graph(pp, bp, {"0": x})
+    e, oname, got = _run(si, pp, bp, x, fp16=1)
+    assert got.dtype == np.float32
+    assert_parity(got, ref[oname], 5e-3, what="MobileNetV3-Small fp16 storage vs fp32 oracle")   # ~60 layers of fp16 roundings
+    kernels = {L["kernel"].split("<")[0] for L in e.profile()}
+    assert "conv_depthwise_f16_kernel" in kernels and "conv_igemm_f16_kernel" in kernels and "conv_stem_f16_kernel" in kernels, kernels
+    _, _, plain = _run(si, pp, bp, x, fp16=1, fuse=0, alias_cat=0)
+    assert_parity(plain, ref[oname], 5e-3, what="unfused")
+    e1, _, one = _run(si, *_save(tmp_path, mg.build_mobilenetv3_small(1, 96, num_classes=100), "mnv3h_b1"), x[1:2], fp16=1)
+    assert_exact(one[0], got[1], "fp16: an image's result does not depend on the batch")
+
+
 @pytest.mark.parametrize("tail", ["silu_unfused", "maxpool", "cat", "add", "upsample"])
 def test_fp16_graph_output_from_a_non_conv_layer(si, orc, tmp_path, tail):
     """Extract() stays fp32 when the last layer is not one that converts in its own epilogue: the engine appends a
@@ -471,9 +491,13 @@ def test_yolov5s_at_another_input_size(si, orc, tmp_path):
 
 def test_fp16_unsupported_graph_is_a_load_time_status(si, tmp_path):
     """An fp16 engine that has no kernel for some layer of a graph says so at LoadModel (kUnsupport, with the layer and the
-    reason in the log) -- not at the first Forward, and never by computing something else.  toy_yolo: channel counts that are
-    not multiples of 32; MobileNetV3: depthwise convs and the squeeze-excite broadcast multiply."""
-    for name, builder in (("toy16", si.modelgen.build_toy_yolo(1, 64)), ("mnv3", si.modelgen.build_mobilenetv3_small(1, 96, num_classes=10))):
+    reason in the log) -- not at the first Forward, and never by computing something else.  toy_yolo: 3x3 convs whose channel
+    counts are not multiples of 32; a graph with a UnaryOp (no fp16 kernel)."""
+    mg = si.modelgen
+    ub = mg.PnnxBuilder(0)
+    ux = ub.input((1, 3, 32, 32))
+    ub.output(ub.expression("sqrt(@0)", [mg._Conv(ub, ux, 32, 3, 2)]))
+    for name, builder in (("toy16", mg.build_toy_yolo(1, 64)), ("unary", ub)):
         pp, bp = _save(tmp_path, builder, name)
         e = si.Engine(fp16=1)
         with pytest.raises(si.StatusError) as ei:

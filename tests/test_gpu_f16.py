@@ -64,7 +64,53 @@ def test_conv_f16_fused_epilogue_strides_and_batch_invariance(hops, orc):
     full = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), act1="silu")
     assert_exact(hops.conv2d_f16(x[1:2], w, b, (1, 1), (1, 1), act1="silu")[0], full[1], "an image's result does not depend on the batch")
     with pytest.raises(hops.HipError):
-        hops.conv2d_f16(h(rng_uniform(5, (1, 8, 8, 24), -1, 1)), h(rng_uniform(6, (32, 24, 3, 3))), None)  # ic % 32 != 0
+        hops.conv2d_f16(h(rng_uniform(5, (1, 8, 8, 24), -1, 1)), h(rng_uniform(6, (32, 24, 3, 3))), None)  # 3x3 with ic % 32 != 0
+
+
+@pytest.mark.parametrize("ic,oc", [(16, 64), (24, 72), (40, 120), (72, 24), (96, 576), (8, 16), (144, 40)])
+def test_conv_f16_pointwise_padded_k(hops, orc, ic, oc):
+    """1x1 convs whose channel count is a multiple of 8 but not of 32 (MobileNet's pointwise and squeeze-excite convs): the weights'
+    K axis is zero-padded to whole 32-channel blocks and a vector behind the last channel reads zeros -- shown with NaNs between the
+    pixels' channels of a wider (concat-slice) input."""
+    x = h(rng_uniform(ic, (2, 9, 7, ic), -1, 1))
+    w = h(rng_uniform(ic + 1, (oc, ic, 1, 1), -0.5, 0.5))
+    b = rng_uniform(ic + 2, (oc,), -0.5, 0.5)
+    ref = orc.conv2d(x, w, b, path="naive")
+    assert_parity(hops.conv2d_f16(x, w, b).astype(np.float32), ref, F16_TOL, what="dense")
+    assert_parity(hops.conv2d_f16(x, w, b, out_f32=True), ref, 2e-5, what="fp32 out")
+    assert_parity(hops.conv2d_f16(x, w, b, act1="hardswish").astype(np.float32), orc.activation("hardswish", ref), F16_TOL, what="hardswish")
+    got = hops.conv2d_f16(x, w, b, in_ld=ic + 24, in_fill=np.nan)
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="strided input, NaN beyond the channels")
+
+
+@pytest.mark.parametrize("n,hw,c,k,s,p", [(2, 14, 16, 3, 1, 1), (2, 15, 72, 5, 2, 2), (3, 7, 96, 3, 2, 1), (1, 9, 240, 5, 1, 2), (2, 6, 8, 3, 1, 1)])
+def test_conv_f16_depthwise(hops, orc, n, hw, c, k, s, p):
+    """depthwise convolution with fp16 activations (fp32 weights / bias / tap sums): against the fp32 oracle on the same rounded
+    input, fused epilogues, strided tensors, batch invariance bit for bit."""
+    x = h(rng_uniform(c, (n, hw, hw, c), -1, 1))
+    w = rng_uniform(c + 1, (c, 1, k, k), -0.5, 0.5)
+    b = rng_uniform(c + 2, (c,), -0.5, 0.5)
+    ref = orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), c, path="naive")
+    got = hops.conv2d_f16(x, w, b, (s, s), (p, p), (1, 1), c)
+    assert got.dtype == np.float16
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="depthwise fp16")
+    assert_parity(hops.conv2d_f16(x, w, b, (s, s), (p, p), (1, 1), c, act1="hardswish").astype(np.float32), orc.activation("hardswish", ref), F16_TOL,
+                  what="hardswish")
+    r = h(rng_uniform(c + 3, ref.shape, -1, 1))
+    assert_parity(hops.conv2d_f16(x, w, b, (s, s), (p, p), (1, 1), c, residual=r, act2="relu").astype(np.float32), orc.activation("relu", ref + r), F16_TOL,
+                  what="residual + relu")
+    assert_parity(hops.conv2d_f16(x, w, b, (s, s), (p, p), (1, 1), c, in_ld=c + 8, out_ld=c + 16, out_c_off=8).astype(np.float32), ref, F16_TOL,
+                  what="strided tensors")
+    if n > 1:
+        assert_exact(hops.conv2d_f16(x[1:2], w, b, (s, s), (p, p), (1, 1), c)[0], got[1], "batch invariance")
+
+
+def test_binary_broadcast_f16(hops):
+    a = h(rng_uniform(1, (3, 5, 7, 72), -2, 2))
+    s = h(rng_uniform(2, (3, 72), 0, 1))
+    for op, fn in (("mul", np.multiply), ("add", np.add)):
+        want = fn(a, s[:, None, None, :]).astype(np.float16)
+        assert_exact(hops.binary_bcast_f16(op, a, s), want, "broadcast " + op)
 
 
 @pytest.mark.parametrize("hw,ic,oc,k,p,res", [(41, 32, 32, 3, 1, False), (41, 64, 64, 1, 0, False), (41, 32, 32, 3, 1, True),
