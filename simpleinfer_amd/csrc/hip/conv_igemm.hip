@@ -904,8 +904,8 @@ inline int round_up4(int v) { return (v + 3) & ~3; }
 // (6.7 ms vs 10.6 ms summed over the net).  Layers with <= 32 output channels use 128x32.
 //   id: 0 128x128x2  1 128x64x2  2 64x64x2  3 128x32x2  4 64x64x1  5 64x128x1  6 128x64x1  7 128x128x1
 //       8 64x128x2  10 128x32x1        (BM x BN x LDS stages; 32x32x2 MFMA)
-//       11 32x64x2  12 32x32x2  13 32x64x1  14 32x32x1  15 64x32x2  16 64x32x1  17 64x64x1  18 32x128x1  19 64x32x1 as 4x1 waves
-//       20 128x64x1  21 64x128x1     (16x16x4 MFMA, round 3)
+//       11 32x64x2  12 32x32x2  13 32x64x1  14 32x32x1  16 64x32x1  17 64x64x1  19 64x32x1 as 4x1 waves     (16x16x4 MFMA, round 3;
+//       15 / 18 / 20 / 21 -- 64x32x2, 32x128, 128x64, 64x128 -- were measured and removed)
 static constexpr int kConvVariants = 22;
 static int si_cu_count() {
     static const int cus = [] {
@@ -915,13 +915,16 @@ static int si_cu_count() {
     }();
     return cus;
 }
+// ids that were measured and removed again (15: 64x32 two-stage, 18: 32x128, 20: 128x64, 21: 64x128 on the 16x16x4 MFMA --
+// profiles/r03_tile_sweep.txt) and the unused 9 are not accepted
+static bool conv_variant_valid(int v) { return v >= 0 && v < kConvVariants && v != 9 && v != 15 && v != 18 && v != 20 && v != 21; }
 static std::atomic<int> g_forced_variant{-2};   // -2: not yet initialised from the environment, -1: policy
 static int conv_forced_variant() {
     int v = g_forced_variant.load(std::memory_order_relaxed);
     if (v == -2) {
         const char* e = getenv("SI_CONV_VARIANT");  // development override
         v = e ? atoi(e) : -1;
-        if (v < 0 || v >= kConvVariants || v == 9) v = -1;
+        if (!conv_variant_valid(v)) v = -1;
         int expected = -2;
         g_forced_variant.compare_exchange_strong(expected, v);
         v = g_forced_variant.load(std::memory_order_relaxed);
@@ -949,7 +952,7 @@ static int conv_variant(const SiConv2dDesc* d) {
             int v[7];
             if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) == 7)
                 for (int i = 0; i < 7; ++i)
-                    if (v[i] >= 0 && v[i] < kConvVariants && v[i] != 9) c[(size_t)i] = v[i];
+                    if (conv_variant_valid(v[i])) c[(size_t)i] = v[i];
         }
         return c;
     }();
@@ -1196,13 +1199,9 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
             case 12: return launch_fast<32, 32, 2, 2, 2, 16>(a, d->groups, fs);
             case 13: return launch_fast<32, 64, 2, 2, 1, 16>(a, d->groups, fs);
             case 14: return launch_fast<32, 32, 2, 2, 1, 16>(a, d->groups, fs);
-            case 15: return launch_fast<64, 32, 2, 2, 2, 16>(a, d->groups, fs);
             case 16: return launch_fast<64, 32, 2, 2, 1, 16>(a, d->groups, fs);
             case 17: return launch_fast<64, 64, 2, 2, 1, 16>(a, d->groups, fs);
-            case 18: return launch_fast<32, 128, 2, 2, 1, 16>(a, d->groups, fs);
             case 19: return launch_fast<64, 32, 4, 1, 1, 16>(a, d->groups, fs);
-            case 20: return launch_fast<128, 64, 2, 2, 1, 16>(a, d->groups, fs);
-            case 21: return launch_fast<64, 128, 2, 2, 1, 16>(a, d->groups, fs);
             default: return launch_fast<128, 32, 4, 1, 1>(a, d->groups, fs);
         }
     }
@@ -1249,7 +1248,7 @@ extern "C" int si_hip_conv2d_yolo_f32(const SiConv2dDesc* d, const float* in, co
 
 extern "C" int si_hip_conv2d_set_tile_variant(int variant) {
     const int prev = conv_forced_variant();
-    g_forced_variant.store((variant >= 0 && variant < kConvVariants && variant != 9) ? variant : -1, std::memory_order_relaxed);
+    g_forced_variant.store(conv_variant_valid(variant) ? variant : -1, std::memory_order_relaxed);
     return prev;
 }
 
