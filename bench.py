@@ -285,7 +285,7 @@ def roofline_from_profile(passes, fp16=False, workload=None):
     return roof, inst
 
 
-def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x):
+def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x, extra_opts=None):
     """Reported beside the headline, never part of `value`: (1) the PCIe-inclusive rate -- the same forward with the
     input handed over as a host buffer (re-uploaded on every Forward, as the reference's Input() contract requires)
     and the output slab copied back to host memory; (2) the device-side detection post-processing
@@ -293,7 +293,7 @@ def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x):
     import ctypes as C
     aux = {}
     steps = max(3, min(args.steps, 5))
-    e2 = si.Engine(device=dev, outputs_to_host=1, graph=args.graph, winograd=args.winograd, fp16=args.fp16)
+    e2 = si.Engine(device=dev, outputs_to_host=1, graph=args.graph, winograd=args.winograd, fp16=args.fp16, **(extra_opts or {}))
     e2.load_model(pp, bp)
     e2.input(e2.input_names()[0], x)
     for _ in range(3):   # the first Forward builds the sliced pipeline, the second pins the borrowed input buffer in place
@@ -716,7 +716,7 @@ def main():
 
         aux = {}
         if rank == 0 and world == 1 and not args.no_aux:
-            aux = aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x)
+            aux = aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x, extra_opts)
             if args.model == "yolov5s" and len(oshape) == 3 and not args.fp16:
                 aux["app_pipeline"] = app_pipeline(args, si, hipops, H, e, iname, oname, oshape, args.batch * args.steps / dt)
                 e.input_device(iname, dx.ptr)

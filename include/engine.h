@@ -73,7 +73,7 @@ public:
     //   "batch"           N>0  serve batch N whatever batch the .param file was traced with (default 0: as in the file)
     //   "host_slices"     G    host tensors in (Input) and out (Extract) -- the reference's calling convention: one synchronous
     //                          Forward() pipelines G batch slices over an upload, a compute and a download stream; 1 = off,
-    //                          0 (default) = slices of 8 images from batch 16 on
+    //                          0 (default) = slices of 8 images from batch 32 on, of 4 for batches 8 .. 31
     //   "streams"         1/2  2: the batch runs as two half-batch lanes on two streams (default 1: no gain measured since the
     //                          tile policy follows the launch size)
     //   "detect_stream"   0/1/2  YOLOv5 Detect's finer levels on a second stream: 0 never, 1 (default) for levels with enough work,

@@ -1019,10 +1019,13 @@ int EngineImpl::PlanSlices() const {
     }
     if (!user_outputs_.empty()) return 1;   // caller-owned device outputs: not the host contract
     if (opt_host_slices_ > 1) return batch % opt_host_slices_ == 0 ? opt_host_slices_ : 1;
-    // auto: slices of 8 images (MI355X, YOLOv5s: a batch-8 forward is still at 0.6 of the MFMA ceiling, and 8 images are 39 MB up /
-    // 69 MB down -- 0.7 / 1.3 ms of PCIe outside the overlap); at most 8 slices (one captured graph per slice under "graph")
-    if (batch < 16 || batch % 8 != 0) return 1;
-    int g = batch / 8;
+    // auto (MI355X, YOLOv5s 640x640, profiles/r03_host_slices.txt): slices of 8 images from batch 32 on (a batch-8 forward is still
+    // at 0.6 of the MFMA ceiling, and 8 images are 39 MB up / 69 MB down -- 0.7 / 1.3 ms of PCIe outside the overlap), slices of 4
+    // for batches 8 .. 31 (batch 8: 3.49 -> 2.95 ms per Forward with 2 slices; batch 16: 6.61 -> 4.95 with 4); at most 8 slices
+    // (one captured graph per slice under "graph")
+    const int per = batch >= 32 ? 8 : 4;
+    if (batch < 8 || batch % per != 0) return 1;
+    int g = batch / per;
     while (g > 8 && g % 2 == 0) g /= 2;
     return g <= 8 ? g : 1;
 }

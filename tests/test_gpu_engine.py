@@ -189,7 +189,7 @@ def test_two_half_batch_lanes_are_bit_identical_to_one_stream(si, tmp_path, name
 def test_host_tensor_pipeline_is_bit_identical(si, tmp_path, slices, graph):
     """The reference's calling convention -- Input() borrows a HOST tensor that is read at Forward() time, Extract() returns host
     memory (src/engine_impl.cpp:522-555) -- served as a pipeline of batch slices inside one synchronous Forward() (option
-    host_slices; 0 = auto: slices of 8 images from batch 16 on): upload of slice g, compute of slice g-1 and download of slice g-2
+    host_slices; 0 = auto: slices of 4 images here): upload of slice g, compute of slice g-1 and download of slice g-2
     overlap.  Same bits as the unsliced schedule, forward after forward, with the input buffer rewritten in place between
     forwards (it is pinned in place from the second forward on) and with a different buffer."""
     mg = si.modelgen
