@@ -106,3 +106,50 @@ def test_product_does_not_touch_the_oracle():
         if os.path.exists(lib):
             deps = subprocess.run(["ldd", lib], capture_output=True, text=True).stdout
             assert "oracle" not in deps
+
+
+def _desc(native, n, ih, iw, ic, oc, k, s, p, groups=1):
+    from simpleinfer_amd._native import SiConv2dDesc
+    oh, ow = (ih + 2 * p - k) // s + 1, (iw + 2 * p - k) // s + 1
+    return SiConv2dDesc(n, ih, iw, ic, ic, oh, ow, oc, oc, k, k, s, s, 1, 1, p, p, groups, 1, 0, 0, oc, 0, 0.0)
+
+
+def test_tile_policy_follows_the_launch_size_host_logic(native_libs):
+    """conv_variant() is host-side arithmetic (no GPU needed; without a device the CU count falls back to 256): the same layer
+    gets the 64x64 tile at batch 32, half tiles at batch 8 and 32x32 tiles at batch 1, all on the 16x16x4 MFMA; thin layers
+    (<= 32 output channels) get 64x32; the names are the full instantiation names rocprofv3 prints."""
+    hip, _ = native_libs
+    name = lambda d, form=0: hip.si_hip_conv2d_kernel_name_form(ctypes.byref(d), ctypes.c_void_p(4096), form).decode()
+    hip.si_hip_conv2d_set_tile_variant(-1)
+    assert name(_desc(hip, 32, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false, false, 16>"
+    assert name(_desc(hip, 8, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<32, 64, 2, 2, 1, false, false, false, false, 16>"
+    assert name(_desc(hip, 1, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<32, 32, 2, 2, 1, false, false, false, false, 16>"
+    assert name(_desc(hip, 32, 40, 40, 256, 256, 1, 1, 0)) == "conv_igemm_f32_fast_kernel<64, 32, 4, 1, 1, false, false, false, true, 16>"
+    assert name(_desc(hip, 32, 160, 160, 64, 32, 1, 1, 0)) == "conv_igemm_f32_fast_kernel<64, 32, 4, 1, 1, false, false, false, true, 16>"
+    assert name(_desc(hip, 32, 40, 40, 256, 256, 1, 1, 0), 1).endswith("false, true, false, false, 16>")      # dual-source form
+    assert name(_desc(hip, 32, 20, 20, 512, 255, 1, 1, 0), 2).endswith("false, false, true, false, 16>")      # Detect form
+    assert name(_desc(hip, 2, 10, 10, 40, 72, 1, 1, 0)).endswith("true, false, false, false, 16>")            # zero-padded K
+    # a forced variant overrides the policy; removed / unknown ids restore it
+    assert hip.si_hip_conv2d_set_tile_variant(4) == -1
+    assert name(_desc(hip, 1, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false, false, 32>"
+    assert hip.si_hip_conv2d_set_tile_variant(18) == 4
+    assert hip.si_hip_conv2d_set_tile_variant(-1) == -1
+
+
+def test_upcat_predicate_shares_the_dispatch_preconditions(native_libs):
+    """si_hip_conv2d_upcat_supported: what the engine asks before it drops an upsample launch (the fused form has no fallback at
+    Forward() time) -- shapes, 32-channel granularity and the 4 GiB limits of both tensors, without looking at any pointer."""
+    from simpleinfer_amd._native import SiConv2dUpsampledSource
+    hip, _ = native_libs
+
+    def ok(n, h, w, ic, oc, c0, c, scale=2, k=1):
+        d = _desc(hip, n, h, w, ic, oc, k, 1, 0 if k == 1 else 1)
+        up = SiConv2dUpsampledSource(None, h // scale, w // scale, c, c, c0, 0.5, 0.5)
+        return hip.si_hip_conv2d_upcat_supported(ctypes.byref(d), ctypes.byref(up))
+
+    assert ok(32, 40, 40, 512, 256, 0, 256) == 1            # YOLOv5s PAN: cat(up(20x20x256), 40x40x256) -> 1x1
+    assert ok(32, 80, 80, 256, 128, 128, 128) == 1          # upsampled range second
+    assert ok(32, 40, 40, 512, 256, 0, 250) == 0            # not whole 32-channel blocks
+    assert ok(32, 40, 40, 512, 256, 16, 256) == 0
+    assert ok(32, 40, 40, 512, 256, 0, 256, k=3) == 0       # not a pointwise conv
+    assert ok(2048, 160, 160, 512, 256, 0, 256) == 0        # concat buffer beyond 4 GiB: the unfused schedule must stay
