@@ -19,7 +19,7 @@ typedef struct SiEngine SiEngine;
 /* Engine::Engine / ~Engine */
 int si_engine_create(SiEngine** engine);
 int si_engine_destroy(SiEngine* engine);
-/* Engine::SetOption -- before load_model.  Keys: device, fuse, alias_cat, fuse_upsample, arena, winograd, fp16, batch, graph, outputs_to_host, streams, detect_stream
+/* Engine::SetOption -- before load_model.  Keys: device, fuse, alias_cat, fuse_upsample, arena, winograd, fp16, batch, graph, outputs_to_host, streams, host_slices, detect_stream
  * (include/engine.h documents the values) */
 int si_engine_set_option(SiEngine* engine, const char* key, int value);
 /* Engine::LoadModel / Release (reference src/engine_impl.cpp:16-75, :77-127) */
