@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--act", default="silu")
     ap.add_argument("--algo", default="direct", choices=["direct", "wino", "wino43"], help="wino: si_hip_conv2d_wino23_f32 on eligible shapes only")
     ap.add_argument("--shape", action="append", default=[], help="n,h,w,ci,co,k,s,p[,groups] (repeatable): custom shapes instead of a model")
+    ap.add_argument("--f16", action="store_true", help="the fp16 storage path (si_hip_conv2d_f16; SI_CONV_F16_VARIANT picks the tile); stems are skipped")
     args = ap.parse_args()
     H = _native.hip()
     b = mg.build_yolov5s(args.batch, args.size) if args.model == "yolov5s" else mg.build_resnet18(args.batch, 224)
@@ -73,6 +74,43 @@ def main():
             continue
         d = SiConv2dDesc(n, ih, iw, ci, ci, oh, ow, co, co, k[0], k[1], s[0], s[1], 1, 1, p[0], p[1], g, 1,
                          hipops.ACT[args.act], 0, co, 0, 0.0)
+        if args.f16:
+            if H.si_hip_conv2d_f16_supported(C.byref(d)) != 1:
+                continue
+            wn = H.si_hip_conv2d_f16_weight_elems(C.byref(d))
+            rng = np.random.default_rng(0)
+            w32 = ((rng.random((co, ci // g, k[0], k[1]), dtype=np.float32) - 0.5) * 0.1)
+            packed = np.zeros(wn, np.float16)
+            assert H.si_hip_conv2d_f16_pack_weight_host(C.byref(d), w32.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)) == 0
+            dx = hipops.DeviceBuffer.from_numpy(rng.random((n, ih, iw, ci), dtype=np.float32).astype(np.float16))
+            dw = hipops.DeviceBuffer.from_numpy(packed)
+            db = hipops.DeviceBuffer.from_numpy(rng.random(co, dtype=np.float32))
+            dy = hipops.DeviceBuffer(n * oh * ow * co * 2)
+
+            def fn16():
+                return H.si_hip_conv2d_f16(C.byref(d), dx.ptr, dw.ptr, db.ptr, None, dy.ptr, 0, None)
+            for _ in range(2):
+                assert fn16() == 0
+            H.si_hip_device_sync()
+            reps = args.reps
+            ms = C.c_float()
+            while True:
+                H.si_hip_event_record(ev0, None)
+                for _ in range(reps):
+                    fn16()
+                H.si_hip_event_record(ev1, None)
+                H.si_hip_event_sync(ev1)
+                H.si_hip_event_elapsed_ms(ev0, ev1, C.byref(ms))
+                if ms.value >= args.min_ms:
+                    break
+                reps = int(reps * max(2.0, 1.2 * args.min_ms / max(ms.value, 1e-3)))
+            ms = ms.value / reps
+            flops = 2.0 * n * oh * ow * co * k[0] * k[1] * (ci // g)
+            byts = 2.0 * (n * ih * iw * ci + n * oh * ow * co + wn)
+            rows.append((key, count, "f16 v%s" % os.environ.get("SI_CONV_F16_VARIANT", "policy"), ms, flops / ms / 1e9, byts / ms / 1e6, flops))
+            for buf in (dx, dw, db, dy):
+                buf.free()
+            continue
         wino = args.algo != "direct"
         fam = "wino23" if args.algo == "wino" else "wino43"
         if wino and not getattr(H, "si_hip_conv2d_%s_eligible" % fam)(C.byref(d)):
