@@ -557,10 +557,14 @@ constexpr unsigned OOB_B = 0x80000000u;  // weights are < 2 GB; + kt*128 cannot 
 // are bound by)
 // MT: the MFMA tile, 32 (v_mfma_f32_32x32x2_f32) or 16 (v_mfma_f32_16x16x4_f32: workgroup tiles of 32 rows for launches that
 // would otherwise leave most of the chip without a wave, i.e. small batches; same bits, see Mma / the K-tile loop)
-template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false, bool UPS = false, bool YOLO = false, bool PW = false, int MT = 32>
+// KU: K-tiles per barrier round.  2 = two K-tiles are staged side by side and consumed back to back between ONE pair of barriers
+// (NBUF = 1 only): the same MFMA sequence per output element, half the barrier / LDS-write / LDS-read round trips per K.  For
+// launches that leave a CU with one or two workgroups (small batches), where that round trip, not the matrix pipe, sets the pace.
+template <int BM, int BN, int WM, int WN, int NBUF, bool PADK = false, bool UPS = false, bool YOLO = false, bool PW = false, int MT = 32, int KU = 1>
 __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
+    static_assert(KU == 1 || ((KU == 2 || KU == 4) && NBUF == 1), "several K-tiles per barrier round: one-stage form only");
     static_assert(MT == 32 || MT == 16, "MFMA tile");
     static_assert(BM % 32 == 0 && BN % 32 == 0 && BM % (WM * MT) == 0 && BN % (WN * MT) == 0, "tile shape");
     constexpr int TM = BM / WM / MT;
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 
     // NBUF = 2: one barrier per K-tile.  NBUF = 1: half the LDS (more workgroups per CU), two barriers
     // per K-tile; the other resident workgroups cover them.
-    __shared__ __attribute__((aligned(16))) float lds[NBUF][(BM + BN) * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * KU][(BM + BN) * LDS_LD];
     SI_STAMP_DECL;
     SI_STAMP_RT(0);
     SI_STAMP(1);
@@ -665,11 +669,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         b_off[i] = o < a.ocg ? (unsigned)(o * a.Kp * 4 + kv * 16) : OOB_B;
     }
 
-    u32x4 pa[A_IT], pb[B_IT];
+    u32x4 pa_[KU][A_IT], pb_[KU][B_IT];
     // wave-uniform K walk
     int cb = 0, ky = 0, kx = 0;
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](u32x4 (&pa)[A_IT], u32x4 (&pb)[B_IT], int kt) {
         if (PW || UPS || YOLO) {
             const unsigned kb = (unsigned)kt * (BK * 4);   // the K-tile's 32 channels: the same 128 bytes further in both operands
             // UPS: K-tiles [up_cb0, up_cb1) come from the low-resolution tensor at the row's source pixel (wave-uniform choice)
@@ -714,7 +718,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](const u32x4 (&pa)[A_IT], const u32x4 (&pb)[B_IT], int buf) {
         float* As = lds[buf];
         float* Bs = lds[buf] + BM * LDS_LD;
 #pragma unroll
@@ -738,7 +742,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 
     const int nk = a.Kp / BK;  // icg_pad % 32 == 0
 
-    load_tile(0);
+    load_tile(pa_[0], pb_[0], 0);
+#pragma unroll
+    for (int u = 1; u < KU; ++u)
+        if (u < nk) load_tile(pa_[u], pb_[u], u);
     // this lane's bias values ride along with the first tile's loads
     float bias_pre[TN];
 #pragma unroll
@@ -747,16 +754,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
         bias_pre[u] = (a.bias && o < a.ocg) ? a.bias[g * a.ocg + o] : 0.0f;
     }
     SI_STAMP(2);
-    store_tile(0);
+    store_tile(pa_[0], pb_[0], 0);
+#pragma unroll
+    for (int u = 1; u < KU; ++u)
+        if (u < nk) store_tile(pa_[u], pb_[u], u);
     __syncthreads();
     SI_STAMP(3);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = NBUF == 2 ? (kt & 1) : 0;
-        if (kt + 1 < nk) load_tile(kt + 1);
-
-        const float* As = lds[cur] + (wm * TM * MT + lrow) * LDS_LD + lk * 4;
-        const float* Bs = lds[cur] + BM * LDS_LD + (wn * TN * MT + lrow) * LDS_LD + lk * 4;
+    // one K-tile from LDS stage `buf`
+    auto compute_tile = [&](int buf) {
+        const float* As = lds[buf] + (wm * TM * MT + lrow) * LDS_LD + lk * 4;
+        const float* Bs = lds[buf] + BM * LDS_LD + (wn * TN * MT + lrow) * LDS_LD + lk * 4;
         // CANONICAL K ORDER (every fp32 implicit-GEMM kernel of this file, so that they agree bit for bit): inside each 16-wide
         // block of a K-tile an output element accumulates k = j, 4+j, 8+j, 12+j for j = 0..3.  On the 16x16x4 MFMA that is one
         // 16-byte read per operand row (lane group g = lane >> 4 reads k = 4g..4g+3; MFMA j takes register j and chains the four
@@ -802,15 +810,38 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
                 __builtin_amdgcn_s_setprio(0);
             }
         }
+    };
 
-        if (NBUF == 2) {
-            if (kt + 1 < nk) store_tile(cur ^ 1);
-            __syncthreads();
-        } else {
-            __syncthreads();  // everyone is done reading tile kt
-            if (kt + 1 < nk) {
-                store_tile(0);
+    if constexpr (KU > 1) {
+        for (int kt = 0; kt < nk; kt += KU) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+                if (kt + KU + u < nk) load_tile(pa_[u], pb_[u], kt + KU + u);
+#pragma unroll
+            for (int u = 0; u < KU; ++u)
+                if (kt + u < nk) compute_tile(u);
+            if (kt + KU < nk) {
+                __syncthreads();  // everyone is done reading tiles kt .. kt+KU-1
+#pragma unroll
+                for (int u = 0; u < KU; ++u)
+                    if (kt + KU + u < nk) store_tile(pa_[u], pb_[u], u);
                 __syncthreads();
+            }
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = NBUF == 2 ? (kt & 1) : 0;
+            if (kt + 1 < nk) load_tile(pa_[0], pb_[0], kt + 1);
+            compute_tile(cur);
+            if (NBUF == 2) {
+                if (kt + 1 < nk) store_tile(pa_[0], pb_[0], cur ^ 1);
+                __syncthreads();
+            } else {
+                __syncthreads();  // everyone is done reading tile kt
+                if (kt + 1 < nk) {
+                    store_tile(pa_[0], pb_[0], 0);
+                    __syncthreads();
+                }
             }
         }
     }
@@ -834,7 +865,7 @@ SI_STAMP_ACCESSORS(si_diag_stamps, si_hip_diag_stamps_read, si_hip_diag_stamps_c
 namespace {
 #endif
 
-template <int BM, int BN, int WM, int WN, int NBUF, int MT = 32>
+template <int BM, int BN, int WM, int WN, int NBUF, int MT = 32, int KU = 1>
 int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
     ConvArgs b = a;
     b.m_tiles = (a.M + BM - 1) / BM;
@@ -848,7 +879,7 @@ int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
         // Detect: the default tile and the 16x16-MFMA ones
         if constexpr ((MT == 32 && NBUF == 1 && BM == 64 && BN == 64) || MT == 16) {
             if (a.icg % 32 != 0 || a.up) return SI_E_UNSUPPORTED;
-            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, true, false, MT>), grid, dim3(256), 0, s, b);
+            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, true, false, MT, KU>), grid, dim3(256), 0, s, b);
         } else {
             return SI_E_UNSUPPORTED;
         }
@@ -856,24 +887,24 @@ int launch_fast(const ConvArgs& a, int groups, hipStream_t s) {
         // dual-source pointwise conv (consumer of cat(upsample(x), skip))
         if constexpr (kFull) {
             if (a.icg % 32 != 0 || !a.pointwise) return SI_E_UNSUPPORTED;
-            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, true, false, false, MT>), grid, dim3(256), 0, s, b);
+            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, true, false, false, MT, KU>), grid, dim3(256), 0, s, b);
         } else {
             return SI_E_UNSUPPORTED;
         }
     } else if (a.icg % 32 != 0) {
         // zero-padded K (1x1 convs with a channel count that is not a multiple of 32)
         if constexpr (kFull)
-            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, true, false, false, false, MT>), grid, dim3(256), 0, s, b);
+            hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, true, false, false, false, MT, KU>), grid, dim3(256), 0, s, b);
         else
             return SI_E_UNSUPPORTED;
     } else {
         if constexpr (kFull) {
             if (a.pointwise) {
-                hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, false, true, MT>), grid, dim3(256), 0, s, b);
+                hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, false, true, MT, KU>), grid, dim3(256), 0, s, b);
                 return (int)hipGetLastError();
             }
         }
-        hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, false, false, MT>), grid, dim3(256), 0, s, b);
+        hipLaunchKernelGGL((conv_igemm_f32_fast_kernel<BM, BN, WM, WN, NBUF, false, false, false, false, MT, KU>), grid, dim3(256), 0, s, b);
     }
     return (int)hipGetLastError();
 }
@@ -906,7 +937,9 @@ inline int round_up4(int v) { return (v + 3) & ~3; }
 //       8 64x128x2  10 128x32x1        (BM x BN x LDS stages; 32x32x2 MFMA)
 //       11 32x64x2  12 32x32x2  13 32x64x1  14 32x32x1  16 64x32x1  17 64x64x1  19 64x32x1 as 4x1 waves     (16x16x4 MFMA, round 3;
 //       15 / 18 / 20 / 21 -- 64x32x2, 32x128, 128x64, 64x128 -- were measured and removed)
-static constexpr int kConvVariants = 22;
+//       22 32x32x1 with TWO K-tiles per barrier round (KU = 2; the same on 32x64 / 64x32 / 64x64 was measured and lost, four
+//          K-tiles per round gain another 0.4 % at batch 1: profiles/r03_ku2_sweep.txt)
+static constexpr int kConvVariants = 23;
 static int si_cu_count() {
     static const int cus = [] {
         int dev = 0, n = 0;
@@ -937,7 +970,8 @@ static int conv_forced_variant() {
 //     stride-2 layers run 3-6 % faster than on the 32x32x2 MFMA, the rest the same);
 //   * 1200 .. 4800: half tiles -- 64x32 (as four 16x32 waves) for pointwise layers, 32x64 for the others (2-6 % over 64x64);
 //   * below: 32x32 (a 20x20 layer at batch 32 has 800 64x64-tiles, at batch 4 a hundred: -14 % ... -40 %), except 3x3 layers
-//     with 600+ tiles, which still prefer 32x64;
+//     with 600+ tiles, which still prefer 32x64; with two K-tiles per barrier round for 3x3 layers under 450 tiles and pointwise
+//     layers under 64;
 //   * <= 32 output channels per group: 64x32 (four 16x32 waves: 32 consecutive channels per store, see epilogue_lean).
 // In the network (same-box interleaved A/B of whole policies, tools/ab_policy.sh, profiles/r03_ab_policy.txt): YOLOv5s batch 32
 // 7232-7308 img/s with the round-2 rule (64x64 / 128x32 on the 32x32x2 MFMA everywhere) -> 7513-7517 with this one.
@@ -945,13 +979,13 @@ static int conv_forced_variant() {
 static int conv_variant(const SiConv2dDesc* d) {
     const int forced = conv_forced_variant();
     if (forced >= 0) return forced;
-    // development: SI_CONV_POLICY="oc32,bigG,bigP,midG,midP,smallG,small" overrides the seven classes' variants (G: general, P: pointwise)
-    static const std::array<int, 7> cls = [] {
-        std::array<int, 7> c = {19, 17, 17, 13, 19, 13, 14};
+    // development: SI_CONV_POLICY="oc32,bigG,bigP,midG,midP,smallG,small[,tiny]" overrides the classes' variants (G: general, P: pointwise)
+    static const std::array<int, 8> cls = [] {
+        std::array<int, 8> c = {19, 17, 17, 13, 19, 13, 14, 22};
         if (const char* e = getenv("SI_CONV_POLICY")) {
-            int v[7];
-            if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) == 7)
-                for (int i = 0; i < 7; ++i)
+            int v[8] = {0, 0, 0, 0, 0, 0, 0, 22};
+            if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]) >= 7)
+                for (int i = 0; i < 8; ++i)
                     if (conv_variant_valid(v[i])) c[(size_t)i] = v[i];
         }
         return c;
@@ -966,12 +1000,16 @@ static int conv_variant(const SiConv2dDesc* d) {
     if (tiles64 * 256 >= 4800 * cus) return pointwise ? cls[2] : cls[1];
     if (tiles64 * 256 >= 1200 * cus) return pointwise ? cls[4] : cls[3];
     if (!pointwise && tiles64 * 256 >= 600 * cus) return cls[5];
+    // launches that leave most CUs with one workgroup or none (batch 1-4; the long-K 3x3 layers up to batch 8): the barrier /
+    // LDS round trip of a K-tile, not the matrix pipe, sets the pace -- two K-tiles per round trip (profiles/r03_ku2_sweep.txt:
+    // 3x3 s2 40x40x256->512 at batch 1 36.1 -> 24.8 us, the batch-1 sum over the implicit-GEMM shapes 336 -> 314 us)
+    if (pointwise ? tiles64 * 256 < 64 * cus : tiles64 * 256 < 450 * cus) return cls[7];
     return cls[6];
 }
 // the generic kernel (any channel count) has four tiles: 0 128x128, 1 128x64, 2 64x64, 3 128x32; a forced variant maps to the
 // nearest one, the policy is the round-1 rule (these layers are latency / HBM bound)
 static int conv_generic_tile(const SiConv2dDesc* d) {
-    static const int generic_of[kConvVariants] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 2};
+    static const int generic_of[kConvVariants] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 2, 2};
     const int forced = conv_forced_variant();
     if (forced >= 0) return generic_of[forced];
     return (d->oc / d->groups) <= 32 ? 3 : 2;
@@ -1202,6 +1240,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
             case 16: return launch_fast<64, 32, 2, 2, 1, 16>(a, d->groups, fs);
             case 17: return launch_fast<64, 64, 2, 2, 1, 16>(a, d->groups, fs);
             case 19: return launch_fast<64, 32, 4, 1, 1, 16>(a, d->groups, fs);
+            case 22: return launch_fast<32, 32, 2, 2, 1, 16, 2>(a, d->groups, fs);
             default: return launch_fast<128, 32, 4, 1, 1>(a, d->groups, fs);
         }
     }
@@ -1262,12 +1301,13 @@ extern "C" const char* si_hip_conv2d_kernel_name_form(const SiConv2dDesc* d, con
         {"conv_igemm_f32_kernel<128, 64, 2, 2, false>", "conv_igemm_f32_kernel<128, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<64, 64, 2, 2, false>", "conv_igemm_f32_kernel<64, 64, 2, 2, true>"},
         {"conv_igemm_f32_kernel<128, 32, 4, 1, false>", "conv_igemm_f32_kernel<128, 32, 4, 1, true>"}};
-    static const int tile_of[kConvVariants][6] = {{128, 128, 2, 2, 2, 32}, {128, 64, 2, 2, 2, 32}, {64, 64, 2, 2, 2, 32}, {128, 32, 4, 1, 2, 32},
-                                                  {64, 64, 2, 2, 1, 32},   {64, 128, 2, 2, 1, 32}, {128, 64, 2, 2, 1, 32}, {128, 128, 2, 2, 1, 32},
-                                                  {64, 128, 2, 2, 2, 32},  {128, 32, 4, 1, 1, 32}, {128, 32, 4, 1, 1, 32}, {32, 64, 2, 2, 2, 16},
-                                                  {32, 32, 2, 2, 2, 16},   {32, 64, 2, 2, 1, 16},  {32, 32, 2, 2, 1, 16},  {64, 32, 2, 2, 2, 16},
-                                                  {64, 32, 2, 2, 1, 16},   {64, 64, 2, 2, 1, 16},  {32, 128, 2, 2, 1, 16}, {64, 32, 4, 1, 1, 16},
-                                                  {128, 64, 2, 2, 1, 16},  {64, 128, 2, 2, 1, 16}};
+    // {BM, BN, WM, WN, NBUF, MT, KU}
+    static const int tile_of[kConvVariants][7] = {
+        {128, 128, 2, 2, 2, 32, 1}, {128, 64, 2, 2, 2, 32, 1}, {64, 64, 2, 2, 2, 32, 1},  {128, 32, 4, 1, 2, 32, 1}, {64, 64, 2, 2, 1, 32, 1},
+        {64, 128, 2, 2, 1, 32, 1},  {128, 64, 2, 2, 1, 32, 1}, {128, 128, 2, 2, 1, 32, 1}, {64, 128, 2, 2, 2, 32, 1}, {128, 32, 4, 1, 1, 32, 1},
+        {128, 32, 4, 1, 1, 32, 1},  {32, 64, 2, 2, 2, 16, 1},  {32, 32, 2, 2, 2, 16, 1},  {32, 64, 2, 2, 1, 16, 1},  {32, 32, 2, 2, 1, 16, 1},
+        {64, 32, 2, 2, 2, 16, 1},   {64, 32, 2, 2, 1, 16, 1},  {64, 64, 2, 2, 1, 16, 1},  {32, 128, 2, 2, 1, 16, 1}, {64, 32, 4, 1, 1, 16, 1},
+        {128, 64, 2, 2, 1, 16, 1},  {64, 128, 2, 2, 1, 16, 1}, {32, 32, 2, 2, 1, 16, 2}};
     // [variant][instantiation]: 0 general, 1 pointwise, 2 zero-padded K, 3 dual-source, 4 Detect
     static char fast_names[kConvVariants][5][112];
     static const bool named = [] {
@@ -1275,8 +1315,8 @@ extern "C" const char* si_hip_conv2d_kernel_name_form(const SiConv2dDesc* d, con
                                        "false, true, false, false", "false, false, true, false"};
         for (int v = 0; v < kConvVariants; ++v)
             for (int k = 0; k < 5; ++k)
-                snprintf(fast_names[v][k], sizeof(fast_names[v][k]), "conv_igemm_f32_fast_kernel<%d, %d, %d, %d, %d, %s, %d>", tile_of[v][0],
-                         tile_of[v][1], tile_of[v][2], tile_of[v][3], tile_of[v][4], flags[k], tile_of[v][5]);
+                snprintf(fast_names[v][k], sizeof(fast_names[v][k]), "conv_igemm_f32_fast_kernel<%d, %d, %d, %d, %d, %s, %d, %d>", tile_of[v][0],
+                         tile_of[v][1], tile_of[v][2], tile_of[v][3], tile_of[v][4], flags[k], tile_of[v][5], tile_of[v][6]);
         return true;
     }();
     (void)named;

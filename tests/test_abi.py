@@ -121,17 +121,20 @@ def test_tile_policy_follows_the_launch_size_host_logic(native_libs):
     hip, _ = native_libs
     name = lambda d, form=0: hip.si_hip_conv2d_kernel_name_form(ctypes.byref(d), ctypes.c_void_p(4096), form).decode()
     hip.si_hip_conv2d_set_tile_variant(-1)
-    assert name(_desc(hip, 32, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false, false, 16>"
-    assert name(_desc(hip, 8, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<32, 64, 2, 2, 1, false, false, false, false, 16>"
-    assert name(_desc(hip, 1, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<32, 32, 2, 2, 1, false, false, false, false, 16>"
-    assert name(_desc(hip, 32, 40, 40, 256, 256, 1, 1, 0)) == "conv_igemm_f32_fast_kernel<64, 32, 4, 1, 1, false, false, false, true, 16>"
-    assert name(_desc(hip, 32, 160, 160, 64, 32, 1, 1, 0)) == "conv_igemm_f32_fast_kernel<64, 32, 4, 1, 1, false, false, false, true, 16>"
-    assert name(_desc(hip, 32, 40, 40, 256, 256, 1, 1, 0), 1).endswith("false, true, false, false, 16>")      # dual-source form
-    assert name(_desc(hip, 32, 20, 20, 512, 255, 1, 1, 0), 2).endswith("false, false, true, false, 16>")      # Detect form
-    assert name(_desc(hip, 2, 10, 10, 40, 72, 1, 1, 0)).endswith("true, false, false, false, 16>")            # zero-padded K
+    assert name(_desc(hip, 32, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false, false, 16, 1>"
+    assert name(_desc(hip, 8, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<32, 64, 2, 2, 1, false, false, false, false, 16, 1>"
+    # (batch 1: 200 64x64-tiles for 256 CUs -- two K-tiles per barrier round; the last template argument)
+    assert name(_desc(hip, 1, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<32, 32, 2, 2, 1, false, false, false, false, 16, 2>"
+    assert name(_desc(hip, 4, 40, 40, 256, 256, 1, 1, 0)) == "conv_igemm_f32_fast_kernel<32, 32, 2, 2, 1, false, false, false, true, 16, 1>"
+    assert name(_desc(hip, 1, 20, 20, 512, 256, 1, 1, 0)) == "conv_igemm_f32_fast_kernel<32, 32, 2, 2, 1, false, false, false, true, 16, 2>"
+    assert name(_desc(hip, 32, 40, 40, 256, 256, 1, 1, 0)) == "conv_igemm_f32_fast_kernel<64, 32, 4, 1, 1, false, false, false, true, 16, 1>"
+    assert name(_desc(hip, 32, 160, 160, 64, 32, 1, 1, 0)) == "conv_igemm_f32_fast_kernel<64, 32, 4, 1, 1, false, false, false, true, 16, 1>"
+    assert name(_desc(hip, 32, 40, 40, 256, 256, 1, 1, 0), 1).endswith("false, true, false, false, 16, 1>")      # dual-source form
+    assert name(_desc(hip, 32, 20, 20, 512, 255, 1, 1, 0), 2).endswith("false, false, true, false, 16, 1>")      # Detect form
+    assert name(_desc(hip, 2, 10, 10, 40, 72, 1, 1, 0)).endswith("true, false, false, false, 16, 2>")            # zero-padded K
     # a forced variant overrides the policy; removed / unknown ids restore it
     assert hip.si_hip_conv2d_set_tile_variant(4) == -1
-    assert name(_desc(hip, 1, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false, false, 32>"
+    assert name(_desc(hip, 1, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false, false, 32, 1>"
     assert hip.si_hip_conv2d_set_tile_variant(18) == 4
     assert hip.si_hip_conv2d_set_tile_variant(-1) == -1
 

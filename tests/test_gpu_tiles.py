@@ -13,8 +13,8 @@ from util import rng_uniform
 pytestmark = pytest.mark.gpu
 
 # variant ids of conv_igemm.hip (si_hip_conv2d_set_tile_variant)
-ALL_TILES = [4, 2, 0, 1, 5, 6, 10, 3, 11, 12, 13, 14, 16, 17, 19]
-SMALL_TILES = [11, 12, 13, 14, 16, 17, 19]
+ALL_TILES = [4, 2, 0, 1, 5, 6, 10, 3, 11, 12, 13, 14, 16, 17, 19, 22]
+SMALL_TILES = [11, 12, 13, 14, 16, 17, 19, 22]
 
 
 @pytest.fixture(scope="module")
