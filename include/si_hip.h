@@ -158,7 +158,7 @@ const char* si_hip_conv2d_kernel_name(const SiConv2dDesc* d, const float* in);
 const char* si_hip_conv2d_kernel_name_form(const SiConv2dDesc* d, const float* in, int form);
 /* Tile policy of si_hip_conv2d_f32's implicit-GEMM kernels.  The default (variant < 0) picks the workgroup tile from the
  * launch size and the CU count (small batches run 32-row tiles on the 16x16x4 MFMA so that the chip is covered); a
- * variant id 0..15 (table in conv_igemm.hip) forces one tile for every later launch of this process -- tuning sweeps and
+ * variant id 0..22 (table in conv_igemm.hip; a few ids are retired) forces one tile for every later launch of this process -- tuning sweeps and
  * the tests that hold every tile to the same bits.  The tile never changes a result: all tiles accumulate an output
  * element as one fma chain in the same k order.  Returns the previous setting. */
 int si_hip_conv2d_set_tile_variant(int variant);
