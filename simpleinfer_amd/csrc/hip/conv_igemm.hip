@@ -367,6 +367,9 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, typename Mma<MT>::ac
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
+#ifndef SI_IGEMM_LDL16
+#define SI_IGEMM_LDL16 40   // development: 0 = the old pitch (36) for the 16x16x4 tiles too
+#endif
 
 SI_STAMP_ARRAY(si_diag_stamps);   // diagnostic build only (si_hip_internal.h)
 
@@ -574,7 +577,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 
     // NBUF = 2: one barrier per K-tile.  NBUF = 1: half the LDS (more workgroups per CU), two barriers
     // per K-tile; the other resident workgroups cover them.
-    __shared__ __attribute__((aligned(16))) float lds[NBUF * KU][(BM + BN) * LDS_LD];
+    // LDS row pitch: 36 floats put the 16 rows of a ds_read_b128 lane group of the 32x32x2 operand layout on 16 distinct 4-bank
+    // groups; the 16x16x4 layout (row = lane & 15, k group = lane >> 4) mixes two k groups in one lane group and needs 40 for the
+    // same (with 36 every such read took two LDS cycles per lane group: SQ_LDS_BANK_CONFLICT = a third of SQ_LDS_IDX_ACTIVE,
+    // profiles/r03_pmc_lds.txt)
+    constexpr int LDL = SI_IGEMM_LDL16 > 0 && MT == 16 ? SI_IGEMM_LDL16 : LDS_LD;
+    __shared__ __attribute__((aligned(16))) float lds[NBUF * KU][(BM + BN) * LDL];
     SI_STAMP_DECL;
     SI_STAMP_RT(0);
     SI_STAMP(1);
@@ -720,11 +728,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 
     auto store_tile = [&](const u32x4 (&pa)[A_IT], const u32x4 (&pb)[B_IT], int buf) {
         float* As = lds[buf];
-        float* Bs = lds[buf] + BM * LDS_LD;
+        float* Bs = lds[buf] + BM * LDL;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * LDS_LD + kv * 4) = pa[i];
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4*>(As + (r0 + 32 * i) * LDL + kv * 4) = pa[i];
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * LDS_LD + kv * 4) = pb[i];
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<u32x4*>(Bs + (r0 + 32 * i) * LDL + kv * 4) = pb[i];
     };
 
     const int wave = tid >> 6;
@@ -763,8 +771,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 
     // one K-tile from LDS stage `buf`
     auto compute_tile = [&](int buf) {
-        const float* As = lds[buf] + (wm * TM * MT + lrow) * LDS_LD + lk * 4;
-        const float* Bs = lds[buf] + BM * LDS_LD + (wn * TN * MT + lrow) * LDS_LD + lk * 4;
+        const float* As = lds[buf] + (wm * TM * MT + lrow) * LDL + lk * 4;
+        const float* Bs = lds[buf] + BM * LDL + (wn * TN * MT + lrow) * LDL + lk * 4;
         // CANONICAL K ORDER (every fp32 implicit-GEMM kernel of this file, so that they agree bit for bit): inside each 16-wide
         // block of a K-tile an output element accumulates k = j, 4+j, 8+j, 12+j for j = 0..3.  On the 16x16x4 MFMA that is one
         // 16-byte read per operand row (lane group g = lane >> 4 reads k = 4g..4g+3; MFMA j takes register j and chains the four
@@ -776,9 +784,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                    for (int t = 0; t < TM; ++t) fa[h][t] = *reinterpret_cast<const f32x4*>(As + t * 32 * LDS_LD + p * 16 + h * 8);
+                    for (int t = 0; t < TM; ++t) fa[h][t] = *reinterpret_cast<const f32x4*>(As + t * 32 * LDL + p * 16 + h * 8);
 #pragma unroll
-                    for (int u = 0; u < TN; ++u) fb[h][u] = *reinterpret_cast<const f32x4*>(Bs + u * 32 * LDS_LD + p * 16 + h * 8);
+                    for (int u = 0; u < TN; ++u) fb[h][u] = *reinterpret_cast<const f32x4*>(Bs + u * 32 * LDL + p * 16 + h * 8);
                 }
                 // raised priority around the MFMA cluster: +0.5-1.2 % on YOLOv5s (same-box A/B; per cdna_hip_programming.md T5 the
                 // effect is on how hipcc places the cluster relative to the LDS reads and barriers, not the s_setprio itself)
@@ -796,9 +804,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
             } else {
                 f32x4 fa[TM], fb[TN];
 #pragma unroll
-                for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f32x4*>(As + t * 16 * LDS_LD + p * 16);
+                for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f32x4*>(As + t * 16 * LDL + p * 16);
 #pragma unroll
-                for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f32x4*>(Bs + u * 16 * LDS_LD + p * 16);
+                for (int u = 0; u < TN; ++u) fb[u] = *reinterpret_cast<const f32x4*>(Bs + u * 16 * LDL + p * 16);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
