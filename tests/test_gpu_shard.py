@@ -53,7 +53,8 @@ def test_bench_line_single_gpu(gpu):
     assert p.returncode == 0 and r is not None, p.stderr[-3000:]
     assert len([ln for ln in p.stdout.splitlines() if ln.strip()]) == 1          # ONE line on stdout
     assert r["n_gpus"] == 1 and r["steps"] == 3 and r["scaling"] == "weak" and r["dtype"] == "f32" and r["unit"] == "images/sec"
-    assert r["value"] > 0 and abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-3
+    # (ms_per_step is printed to the microsecond: at this size a step is a few hundred of them)
+    assert r["value"] > 0 and abs(r["value"] - 4 * 3 / (r["ms_per_step"] * 3e-3)) / r["value"] < 1e-3 + 0.0006 / r["ms_per_step"]
     w = r["windows"]
     assert w["count"] >= 1 and w["ms_per_step_min"] <= w["ms_per_step_median"] <= w["ms_per_step_max"] and w["timed_s_total"] >= 0.2
     roof = r["roofline"]
