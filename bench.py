@@ -58,8 +58,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (images per Forward); weak scaling")
     ap.add_argument("--global-batch", type=int, default=0, help="total images per step over all GPUs (strong scaling): per-GPU batch = B / N")
-    ap.add_argument("--gather", default="auto", choices=["auto", "p2p", "rccl"],
-                    help="N > 1 output all-gather: p2p = direct IPC fan-out (include/si_shard.h), rccl = torch.distributed, auto = p2p with RCCL fallback")
+    ap.add_argument("--gather", default="auto", choices=["auto", "p2p", "rccl", "both", "torch"],
+                    help="N > 1 output all-gather, all behind the C-ABI of include/si_shard.h unless it says torch: p2p = direct IPC fan-out, "
+                         "rccl = ncclAllGather through si_rccl_* (librccl.so by dlopen, no torch), auto = p2p with a collective fallback to "
+                         "rccl, both = the timed region twice, p2p then rccl, in ONE run (`value` is p2p's, `gather_ab` carries both), "
+                         "torch = torch.distributed all_gather_into_tensor (the round-1 path, kept for A/B)")
     ap.add_argument("--min-time", type=float, default=10.0, help="repeat the K-step timed window until this many seconds are accumulated (BASELINE.md section 3: >= 10 s)")
     ap.add_argument("--max-windows", type=int, default=200)
     ap.add_argument("--size", type=int, default=640)
@@ -68,6 +71,8 @@ def parse():
     ap.add_argument("--winograd", type=int, default=1, help="3x3 s1 convs: 0 implicit GEMM everywhere, 1 fused Winograd F(2,3) where faster (default), 2 fused Winograd F(4,3) on those layers")
     ap.add_argument("--fp16", type=int, default=0, help="1: fp16 storage / fp16 MFMA path (BASELINE.json configs[3]); the headline metric is fp32 (default 0)")
     ap.add_argument("--no-aux", action="store_true", help="skip the host-I/O and post-processing side measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the bounded secondary configurations (fp16, ResNet18 b64, batch 8 / 4)")
+    ap.add_argument("--secondary-time", type=float, default=1.0, help="seconds of timed windows per secondary configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24, help="images in the batch-1 CPU baseline sample")
     ap.add_argument("--cpu-batch", type=int, default=16, help="batch of the batched CPU baseline samples (BASELINE.md section 3); the three CPU legs together are bounded to ~20 s")
@@ -217,21 +222,27 @@ def roofline_from_profile(passes, fp16=False, workload=None):
     fewer multiplies than it is credited with, so its line also carries frac_executed_mfma = frac / 2.25.
     fp16: every YOLOv5s layer is bound by memory, so the kernel is priced against HBM with its algorithmic bytes."""
     inst = {}
+    peak_tf = PEAK_F16_MFMA_TFLOPS if fp16 else PEAK_FP32_MFMA_TFLOPS
     for layers in passes:
         for L in layers:
             if not L["kernel"].startswith("conv_") or L["flops"] <= 0 or L["type"] == "models.yolo.Detect":
                 continue
-            a = inst.setdefault(L["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            a = inst.setdefault(L["kernel"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "t_flop": 0.0, "t_byte": 0.0, "t_bound": 0.0})
             a["ms"] += L["ms"]
             a["flops"] += L["flops"]
             a["bytes"] += L["bytes"]
             a["launches"] += 1
+            tf = L["flops"] / (peak_tf * 1e12)
+            tb = L["bytes"] / (PEAK_HBM_GBS * 1e9)
+            a["t_flop"] += tf
+            a["t_byte"] += tb
+            a["t_bound"] += max(tf, tb)
     if not inst:
         return None, inst
     tmpl = {}
     for k, v in inst.items():
-        t = tmpl.setdefault(_template_of(k), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-        for f in ("ms", "flops", "bytes", "launches"):
+        t = tmpl.setdefault(_template_of(k), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "t_flop": 0.0, "t_byte": 0.0, "t_bound": 0.0})
+        for f in ("ms", "flops", "bytes", "launches", "t_flop", "t_byte", "t_bound"):
             t[f] += v[f]
     name, a = max(tmpl.items(), key=lambda kv: kv[1]["ms"])
     npass = max(len(passes), 1)
@@ -252,19 +263,32 @@ def roofline_from_profile(passes, fp16=False, workload=None):
         row = {"kernel": k, "launches_per_step": v["launches"] // npass, "avg_launch_ms": round(ims, 4),
                "algorithmic_bytes": round(v["bytes"] / v["launches"]), "traffic": tr,
                "traffic_over_algorithmic": round(tr / (v["bytes"] / v["launches"]), 3) if tr else None}
+        row["gbs"] = round(v["bytes"] / v["launches"] / (ims * 1e-3) / 1e9, 1)
+        row["tflops"] = round(v["flops"] / v["launches"] / (ims * 1e-3) / 1e12, 2)
         if fp16:
-            row["gbs"] = round(v["bytes"] / v["launches"] / (ims * 1e-3) / 1e9, 1)
             row["frac"] = round(row["gbs"] / PEAK_HBM_GBS, 4)
         else:
-            row["tflops"] = round(v["flops"] / v["launches"] / (ims * 1e-3) / 1e12, 2)
             row["frac"] = round(row["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+        # which roofline this instantiation's launches sit under: the longer of the time its algorithmic FLOPs
+        # take at the matrix peak and the time its algorithmic bytes take at the HBM peak -- summed launch by launch, because
+        # one instantiation serves layers on both sides of the ridge -- and the fraction of THAT bound it reaches
+        row["bound"] = "mfma" if v["t_flop"] >= v["t_byte"] else "hbm"
+        row["frac_of_bound"] = round(v["t_bound"] / (v["ms"] * 1e-3), 4)
+        row["share_of_template_time"] = round(v["ms"] / a["ms"], 4)
         rows.append(row)
     # launch-weighted over the instantiations that have a recorded figure (None when none has)
     traffic = round(tsum / tn) if tn else None
     label = name + (" (all %d instantiations)" % len(rows) if len(rows) > 1 else "")
     if len(rows) == 1:
         label = rows[0]["kernel"]
-    common = {"kernel": label, "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+    common = {"kernel": label,
+              # the single largest instantiation by time (rows are sorted by it), named beside the family
+              "largest_instantiation": {"kernel": rows[0]["kernel"], "share_of_template_time": rows[0]["share_of_template_time"],
+                                        "bound": rows[0]["bound"], "frac_of_bound": rows[0]["frac_of_bound"],
+                                        "tflops": rows[0]["tflops"], "gbs": rows[0]["gbs"]},
+              # every launch against the roofline it sits under: sum of max(flop-time, byte-time) / sum of durations
+              "frac_bound_aware": round(a["t_bound"] / (a["ms"] * 1e-3), 4),
+              "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
               "algorithmic_bytes": round(bytes_per_launch), "launches_per_step": a["launches"] // npass,
               "avg_launch_ms": round(avg_ms, 4), "instantiations": rows}
     if fp16:
@@ -285,6 +309,60 @@ def roofline_from_profile(passes, fp16=False, workload=None):
     return roof, inst
 
 
+def secondary_measurements(args, si, hipops, H, mg, td, dev):
+    """BASELINE.json's other single-GPU configurations and the per-GPU batches of the headline metric's 4 / 8-GPU points, in the
+    driver's line: YOLOv5s fp16 batch 32 (configs[3]), ResNet18 224x224 fp32 batch 64 (configs[2]), YOLOv5s
+    fp32 batch 8 and batch 4 (batch 32 over 4 / 8 GPUs).  Each: device-resident input, >= --secondary-time seconds of 10-step
+    windows after a warm-up, median window.  `value` of the line stays the fp32 batch-32 headline; these are bounded (~6 s of
+    timing) side figures with the roofline each one sits under: fp32 nets against the conv-GEMM MFMA ceiling (direct-conv
+    FLOPs / 157.3 TF/s), the fp16 net against HBM (algorithmic bytes of its conv layers / 8 TB/s) as BASELINE.md prices it."""
+    out = {}
+    cases = [("yolov5s_fp16_b32", "yolov5s", 32, 640, 1), ("resnet18_fp32_b64", "resnet18", 64, 224, 0),
+             ("yolov5s_fp32_b8", "yolov5s", 8, 640, 0), ("yolov5s_fp32_b4", "yolov5s", 4, 640, 0)]
+    for key, model, batch, size, fp16 in cases:
+        try:
+            builder, shape = build_model(mg, model, batch, size)
+            pp, bp = os.path.join(td, key + ".param"), os.path.join(td, key + ".bin")
+            builder.save(pp, bp)
+            flops = mg.conv_flops(builder)
+            e = si.Engine(device=dev, outputs_to_host=0, graph=args.graph, winograd=args.winograd, fp16=fp16)
+            e.load_model(pp, bp)
+            dx = hipops.DeviceBuffer.from_numpy(mg.synth_input(shape, seed=1))
+            e.input_device(e.input_names()[0], dx.ptr)
+            for _ in range(3):
+                e.forward()
+            H.si_hip_device_sync()
+            steps, ws, total = 10, [], 0.0
+            while total < args.secondary_time:
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    e.forward()
+                H.si_hip_device_sync()
+                ws.append(time.perf_counter() - t0)
+                total += ws[-1]
+            ws.sort()
+            dt = ws[len(ws) // 2] / steps
+            rec = {"value": round(batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "windows": len(ws),
+                   "workload": "%s %dx%d %s batch %d" % (model, shape[1], shape[2], "fp16" if fp16 else "fp32", batch)}
+            if fp16:
+                layers = e.profile()
+                cbytes = sum(L["bytes"] for L in layers if L["kernel"].startswith("conv_"))
+                cms = sum(L["ms"] for L in layers if L["kernel"].startswith("conv_"))
+                rec.update({"bound": "hbm", "frac": round(cbytes / (cms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if cms > 0 else None,
+                            "frac_is": "algorithmic bytes of the conv launches / their event-timed durations / 8 TB/s",
+                            "frac_of_f16_mfma_ceiling": round(batch / dt / (PEAK_F16_MFMA_TFLOPS * 1e12 / (flops / batch)), 4),
+                            "kernels": sorted({L["kernel"].split("<")[0] for L in layers})})
+            else:
+                rec.update({"bound": "mfma", "frac": round(batch / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12 / (flops / batch)), 4),
+                            "frac_is": "images/s / (157.3 TF/s / direct-conv FLOPs per image)"})
+            out[key] = rec
+            e.release()
+            dx.free()
+        except Exception as ex:  # noqa: BLE001 -- a side figure must never cost the headline line
+            out[key] = {"error": str(ex)}
+    return out
+
+
 def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x, extra_opts=None):
     """Reported beside the headline, never part of `value`: (1) the PCIe-inclusive rate -- the same forward with the
     input handed over as a host buffer (re-uploaded on every Forward, as the reference's Input() contract requires)
@@ -293,7 +371,8 @@ def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x, extr
     import ctypes as C
     aux = {}
     steps = max(3, min(args.steps, 5))
-    e2 = si.Engine(device=dev, outputs_to_host=1, graph=args.graph, winograd=args.winograd, fp16=args.fp16, **(extra_opts or {}))
+    # pin_inputs: `x` stays alive and mapped until e2.release() below, which is what the opt-in asks of the caller
+    e2 = si.Engine(device=dev, outputs_to_host=1, graph=args.graph, winograd=args.winograd, fp16=args.fp16, pin_inputs=1, **(extra_opts or {}))
     e2.load_model(pp, bp)
     e2.input(e2.input_names()[0], x)
     for _ in range(3):   # the first Forward builds the sliced pipeline, the second pins the borrowed input buffer in place
@@ -309,7 +388,8 @@ def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x, extr
                       "note": "the reference's calling convention (bench/bench_yolo.cpp:20-28): Input() borrows a HOST tensor that is "
                               "uploaded on every Forward(), Extract() returns host memory (PCIe-inclusive: 4.9 MB up + 8.6 MB down per "
                               "image); one synchronous Forward() pipelines batch slices over an upload stream, a compute stream and a "
-                              "download stream (engine option host_slices); not `value`"}
+                              "download stream (engine option host_slices; the borrowed input buffer pinned in place: pin_inputs=1, opt-in); "
+                              "not `value`"}
     e2.release()
     if args.model == "yolov5s" and len(oshape) == 3:
         n, rows, ne = oshape
@@ -488,6 +568,8 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     # SI_BENCH_SHARE_DEVICE=1: ranks may share a device (exercises the multi-rank path, incl. the IPC gather, on a 1-GPU box)
     share = os.environ.get("SI_BENCH_SHARE_DEVICE") == "1"
+    if os.environ.get("SI_LAUNCH_PIN_VISIBLE") == "1":
+        local_world = 1   # every rank sees only its own GPU (simpleinfer_amd/launch.py)
     if local_world > ndev and not share:
         sys.exit("bench.py: need %d HIP devices for --gpus %d, found %d" % (local_world, world, ndev))
     dev = local_rank % ndev
@@ -507,18 +589,18 @@ def main():
     gather_note = None
     if use_dist:
         want = args.gather
-        if want in ("auto", "p2p"):
+        if want != "torch":
             try:
                 group = shard.NodeGroup(shard.default_group_name(), rank, world, timeout_s=120.0)
-                gather_mode = "p2p"
+                gather_mode = "rccl" if want == "rccl" else "p2p"
             except Exception as ex:  # every rank times out together when the rendezvous cannot form
-                if want == "p2p":
+                if want != "auto":
                     raise
                 gather_note = "node group unavailable (%s)" % ex
         if gather_mode is None:
-            if share and world > 1:
-                sys.exit("bench.py: RCCL cannot run two ranks on one device (SI_BENCH_SHARE_DEVICE needs --gather p2p)")
-            gather_mode = "rccl"
+            gather_mode = "torch"
+        if gather_mode in ("rccl", "torch") and share and world > 1:
+            sys.exit("bench.py: RCCL cannot run two ranks on one device (SI_BENCH_SHARE_DEVICE needs --gather p2p)")
 
     mg = si.modelgen
     with tempfile.TemporaryDirectory(prefix="si_bench_r%d_" % rank) as td:
@@ -548,14 +630,20 @@ def main():
         oshape = e.operand_shape(oname)
 
         sf = og = None
-        if gather_mode == "p2p":
+        if gather_mode in ("p2p", "rccl"):
             try:
-                sf = shard.ShardedForward(e, oname, group, dev, slots=4)   # collective: every rank succeeds or none does
+                # collective: every rank succeeds or none does.  auto: si_gather_create_mode(SI_GATHER_AUTO) itself falls back to
+                # RCCL on every rank when the direct path cannot be set up on one
+                sf = shard.ShardedForward(e, oname, group, dev, slots=4,
+                                          mode={"p2p": "direct", "rccl": "rccl"}[gather_mode] if args.gather != "auto" else "auto")
+                if sf.gather.mode == "rccl" and gather_mode == "p2p":
+                    gather_note = "direct gather could not be set up on every rank; RCCL through the C-ABI instead"
+                    gather_mode = "rccl"
             except shard.ShardError as ex:
-                if args.gather == "p2p":
+                if args.gather != "auto":
                     raise
-                gather_note = "direct gather unavailable (%s)" % ex
-                gather_mode = "rccl"
+                gather_note = "neither the direct nor the RCCL gather of include/si_shard.h could be set up (%s)" % ex
+                gather_mode = "torch"
                 if share and world > 1:
                     sys.exit("bench.py: RCCL cannot run two ranks on one device")
         def step():
@@ -620,12 +708,12 @@ def main():
             optr, _ = e.extract_ptr(oname)
             og = sd.OverlappedGather(sd.as_torch(optr, oshape, dev))
 
-        if gather_mode == "rccl":
+        if gather_mode == "torch":
             setup_rccl()
 
         # warm-up; with the direct gather in `auto` mode it doubles as the acceptance test of that path: every rank reports
         # whether its steps ran and its gathered buffer checks out, and unless ALL do, all fall back to RCCL together
-        if sf is not None and args.gather == "auto":
+        if sf is not None and args.gather == "auto" and sf.gather.mode == "direct":
             ok = 1
             try:
                 for _ in range(max(args.warmup, 2)):
@@ -652,10 +740,17 @@ def main():
                 except Exception:  # noqa: BLE001
                     pass
                 sf = None
-                gather_mode = "rccl"
                 if share and world > 1:
                     sys.exit("bench.py: RCCL cannot run two ranks on one device")
-                setup_rccl()
+                try:
+                    # (a fresh rendezvous: a timed-out barrier leaves the old group dead)
+                    group = shard.NodeGroup(shard.default_group_name() + "_rccl", rank, world, timeout_s=180.0)
+                    sf = shard.ShardedForward(e, oname, group, dev, slots=4, mode="rccl")
+                    gather_mode = "rccl"
+                except shard.ShardError as ex:
+                    gather_note += "; RCCL through the C-ABI failed too (%s)" % ex
+                    gather_mode = "torch"
+                    setup_rccl()
         for _ in range(args.warmup):
             step()
         fence()
@@ -663,40 +758,71 @@ def main():
             slab_checksums()
             fence()
 
-        if sf is not None:
-            sf.gather.stats(reset=True)
-        windows = []
-        fwd_ms = 0.0
-        total = 0.0
-        while True:
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-                fwd_ms += e.last_forward_ms()
+        def timed_region():
+            """K steps between two fences, repeated until --min-time of timed work has accumulated"""
+            if sf is not None:
+                sf.gather.stats(reset=True)
+            windows, fwd_ms, total = [], 0.0, 0.0
+            while True:
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                    fwd_ms += e.last_forward_ms()
+                fence()
+                dt = max_over_ranks(time.perf_counter() - t0) if use_dist else time.perf_counter() - t0
+                windows.append(dt)
+                total += dt
+                if total >= args.min_time or len(windows) >= args.max_windows:
+                    break
+            gather_diag = None
+            if sf is not None:
+                # where a step's time went: host waits inside si_gather_complete (0 = the fan-out hid behind the next step's
+                # compute) and the device time of the peer copies; every rank reports, rank 0 prints its own and the worst
+                gs = sf.gather.stats()
+                waits = group.allgather_f64(gs["gather_wait_ms"])
+                copies = group.allgather_f64(gs["peer_copy_ms"] or 0.0)
+                gather_diag = dict(gs)
+                gather_diag.update({"transport": sf.gather.mode,
+                                    "gather_wait_ms_max_over_ranks": round(float(waits.max()), 4),
+                                    "peer_copy_ms_max_over_ranks": round(float(copies.max()), 4),
+                                    "slab_mbytes": round(sf.gather.slab_bytes / 1e6, 2), "slots": sf.gather.slots,
+                                    "copy_engine": ("ncclAllGather, in place, on the gather's own stream (si_rccl_allgather)" if sf.gather.mode == "rccl" else
+                                                    "hipMemcpyDtoDAsync per peer on its own stream") +
+                                                   "; HSA_ENABLE_SDMA=%s (unset / 1: SDMA engines, 0: blit kernels that take CUs from the "
+                                                   "convs -- a rocprofv3 kernel trace shows them as __amd_rocclr_copyBuffer)" % os.environ.get("HSA_ENABLE_SDMA", "unset")})
+            return windows, fwd_ms, total, gather_diag
+
+        def median(ws):
+            w = sorted(ws)
+            return w[len(w) // 2] if len(w) % 2 else 0.5 * (w[len(w) // 2 - 1] + w[len(w) // 2])
+
+        windows, fwd_ms, total, gather_diag = timed_region()
+        gather_ab = None
+        if use_dist and args.gather == "both" and sf is not None:
+            # the same engine, the same run: the direct fan-out was timed above, now RCCL's all-gather through the C-ABI
+            slab_checksums()
             fence()
-            dt = max_over_ranks(time.perf_counter() - t0) if use_dist else time.perf_counter() - t0
-            windows.append(dt)
-            total += dt
-            if total >= args.min_time or len(windows) >= args.max_windows:
-                break
-        gather_diag = None
-        if sf is not None:
-            # where a step's time went: host waits inside si_gather_complete (0 = the fan-out hid behind the next step's
-            # compute) and the device time of the peer copies; every rank reports, rank 0 prints its own and the worst
-            gs = sf.gather.stats()
-            waits = group.allgather_f64(gs["gather_wait_ms"])
-            copies = group.allgather_f64(gs["peer_copy_ms"] or 0.0)
-            gather_diag = dict(gs)
-            gather_diag.update({"gather_wait_ms_max_over_ranks": round(float(waits.max()), 4),
-                                "peer_copy_ms_max_over_ranks": round(float(copies.max()), 4),
-                                "slab_mbytes": round(sf.gather.slab_bytes / 1e6, 2), "slots": sf.gather.slots,
-                                "copy_engine": "hipMemcpyDtoDAsync per peer on its own stream; HSA_ENABLE_SDMA=%s (unset / 1: SDMA engines, "
-                                               "0: blit kernels that take CUs from the convs -- a rocprofv3 kernel trace shows them as "
-                                               "__amd_rocclr_copyBuffer)" % os.environ.get("HSA_ENABLE_SDMA", "unset")})
-        if use_dist:
+            gather_ab = {"p2p": {"value": round(args.batch * world * args.steps / median(windows), 2),
+                                 "ms_per_step": round(median(windows) / args.steps * 1e3, 3), "gather": gather_diag}}
+            group.barrier()
+            sf.close()
+            try:
+                sf = shard.ShardedForward(e, oname, group, dev, slots=4, mode="rccl")
+                for _ in range(max(args.warmup, 2)):
+                    step()
+                fence()
+                slab_checksums()
+                fence()
+                w2, _, _, gd2 = timed_region()
+                gather_ab["rccl"] = {"value": round(args.batch * world * args.steps / median(w2), 2),
+                                     "ms_per_step": round(median(w2) / args.steps * 1e3, 3), "gather": gd2}
+            except shard.ShardError as ex:   # (collective: every rank fails the same way)
+                gather_ab["rccl"] = {"error": str(ex)}
+                sf = None
+        if use_dist and (sf is not None or og is not None):
             slab_checksums()
         wsorted = sorted(windows)
-        dt = wsorted[len(wsorted) // 2] if len(wsorted) % 2 else 0.5 * (wsorted[len(wsorted) // 2 - 1] + wsorted[len(wsorted) // 2])
+        dt = median(windows)
         fwd_ms_per_step = fwd_ms / (args.steps * len(windows))
 
         roof, agg, layers = None, {}, None
@@ -720,6 +846,9 @@ def main():
             if args.model == "yolov5s" and len(oshape) == 3 and not args.fp16:
                 aux["app_pipeline"] = app_pipeline(args, si, hipops, H, e, iname, oname, oshape, args.batch * args.steps / dt)
                 e.input_device(iname, dx.ptr)
+        secondary = None
+        if rank == 0 and world == 1 and not args.no_secondary and args.model == "yolov5s" and args.batch == 32 and args.size == 640 and not args.fp16:
+            secondary = secondary_measurements(args, si, hipops, H, mg, td, dev)
 
         if sf is not None:
             group.barrier()
@@ -738,7 +867,8 @@ def main():
     ceiling = (PEAK_F16_MFMA_TFLOPS if args.fp16 else PEAK_FP32_MFMA_TFLOPS) * 1e12 / (flops_step / args.batch)  # images/s/GPU at the MFMA peak
     strong = bool(args.global_batch)
     gather_text = {"p2p": "direct fan-out over IPC-shared HBM (include/si_shard.h), one device-to-device copy per peer",
-                   "rccl": "RCCL all_gather_into_tensor"}.get(gather_mode)
+                   "rccl": "RCCL ncclAllGather through the C-ABI (si_rccl_allgather, include/si_shard.h; no torch)",
+                   "torch": "RCCL through torch.distributed all_gather_into_tensor"}.get(gather_mode)
     out = {
         "metric": "images/sec %s %dx%d %s batch=%d per GPU, Engine::Forward()" % (
             {"yolov5s": "YOLOv5s", "resnet18": "ResNet18", "mobilenetv3": "MobileNetV3-Small"}[args.model], shape[1], shape[2], prec, args.batch),
@@ -761,6 +891,7 @@ def main():
                     "ms_per_step_first": round(windows[0] / args.steps * 1e3, 3)},
         "forward_kernel_ms_per_step": round(fwd_ms_per_step, 3),
         "gather": gather_diag,
+        "gather_ab": gather_ab,
         # what a step waited for: its own peer copies (the gather is the bound), the node barrier (the slowest rank: imbalance, or
         # ranks sharing a device), or neither
         "step_bound": (None if gather_diag is None else
@@ -776,6 +907,8 @@ def main():
     }
     out.update(cpu)
     out.update(aux)
+    if secondary is not None:
+        out["secondary"] = secondary
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)

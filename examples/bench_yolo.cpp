@@ -37,6 +37,7 @@ int main(int argc, char** argv) {
     for (int device_resident = 0; device_resident < 2; ++device_resident) {
         Engine engine;
         if (device_resident) engine.SetOption("outputs_to_host", 0);
+        else engine.SetOption("pin_inputs", 1);   // host_input below stays alive and mapped for the whole loop (include/engine.h)
         if (engine.LoadModel(argv[1], argv[2]) != Status::kSuccess) {
             fprintf(stderr, "LoadModel failed\n");
             return 1;

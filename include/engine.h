@@ -73,9 +73,17 @@ public:
     //   "batch"           N>0  serve batch N whatever batch the .param file was traced with (default 0: as in the file)
     //   "host_slices"     G    host tensors in (Input) and out (Extract) -- the reference's calling convention: one synchronous
     //                          Forward() pipelines G batch slices over an upload, a compute and a download stream; 1 = off,
-    //                          0 (default) = slices of 8 images from batch 32 on, of 4 for batches 8 .. 31
+    //                          0 (default) = slices of 8 images from batch 32 on, of 4 for batches 8 .. 31 (graphs of built-in
+    //                          layers only: the model is loaded a second time re-batched to N / G, which assumes per-image
+    //                          operators; a graph holding a RegisterLayer type is sliced only on an explicit G > 1).  If the
+    //                          pipeline cannot be set up the engine logs it and serves unsliced.
+    //   "pin_inputs"      1/0  host_slices only: a borrowed input buffer handed over for a second Forward() in a row is pinned IN
+    //                          PLACE (hipHostRegister) so its uploads run at link rate.  Default 0, opt-in: the registration
+    //                          outlives Forward(), so the caller must keep the buffer mapped -- not free or reallocate it --
+    //                          until the next Input() for that name or Release(), which unregister it; and must not hand the
+    //                          same buffer to a second engine meanwhile.  Without it the uploads are staged copies.
     //   "streams"         1/2  2: the batch runs as two half-batch lanes on two streams (default 1: no gain measured since the
-    //                          tile policy follows the launch size)
+    //                          tile policy follows the launch size); with 2 the lanes, not host_slices, serve host tensors
     //   "detect_stream"   0/1/2  YOLOv5 Detect's finer levels on a second stream: 0 never, 1 (default) for levels with enough work,
     //                          2 always
     //   "graph"           1/0  replay Forward() as a captured hipGraph (default 0)

@@ -2,7 +2,8 @@
 // SURVEY.md D9).  One process per GPU of one node; every rank loads the same model at its per-rank batch
 // (Engine::SetOption("batch", B / G)) and runs an independent Engine on its contiguous slab of the global batch;
 // the ONLY exchange is the all-gather of the output slabs [B/G, rows, 85] -> [B, rows, 85] (BASELINE.json
-// north_star), done here as a direct fan-out over IPC-shared HBM (include/si_shard.h): no ring, no torch, no RCCL.
+// north_star), done here as a direct fan-out over IPC-shared HBM or as RCCL's ncclAllGather through the C-ABI
+// (include/si_shard.h; librccl.so loaded with dlopen): no torch either way.
 //
 //   ShardedEngine sh;
 //   sh.Init("/job42", rank, world, &engine, engine.OutputNames()[0]);   // collective, after engine.LoadModel()
@@ -22,6 +23,10 @@ struct SiDirectGather;
 
 namespace SimpleInfer {
 
+// how the output slabs travel: the direct IPC fan-out, RCCL's all-gather, or direct with a collective fallback to RCCL when
+// the direct path cannot be set up on some rank (hipIpc / peer mapping refused)
+enum class GatherMode { kDirect = 0, kRccl = 1, kAuto = 2 };
+
 class ShardedEngine {
 public:
     ShardedEngine();
@@ -33,7 +38,8 @@ public:
     // rank.  `engine` must have a model loaded with device-resident outputs (SetOption("outputs_to_host", 0)); its
     // output operand `output_name` is re-bound into this object's gathered buffers (Engine::Output).
     Status Init(const std::string& group_name, int rank, int world, Engine* engine, const std::string& output_name,
-                int slots = 4, double timeout_s = 60.0);
+                int slots = 4, double timeout_s = 60.0, GatherMode gather = GatherMode::kAuto);
+    GatherMode Mode() const;   // kDirect or kRccl: what Init ended up with
     // engine->Forward() into this step's slot, start the fan-out of the slab to every peer (asynchronous), and complete
     // the PREVIOUS step's gather (wait for its copies + node barrier).
     Status Forward();

@@ -297,8 +297,8 @@ void si_letterbox_geometry(int height_origin, int width_origin, int height_new, 
                            int* width_resize, float* scale, int* padding_t, int* padding_l);
 /* The rest of PreProcess after cv::resize (test_yolo.cpp:220-259): BGR u8 [height_resize][width_resize][3] ->
  * reverse to RGB, pad to [height_new][width_new] with 114, cast to float, divide by 255; written to one image slot
- * `out` of the NHWC input tensor.  (The bilinear resize itself lives in the absent simpleocv submodule and stays
- * with the caller.) */
+ * `out` of the NHWC input tensor.  (The bilinear resize in front of it: si_hip_resize_bilinear_u8c3 /
+ * si_hip_resize_letterbox_batch_u8_f32 below.) */
 int si_hip_letterbox_u8_f32(const unsigned char* resized_bgr, int height_resize, int width_resize, float* out,
                             int height_new, int width_new, int padding_t, int padding_l, si_stream_t stream);
 /* ... for the n images of a batch that share one geometry (frames of one camera), image b at resized_bgr + b *
@@ -306,6 +306,18 @@ int si_hip_letterbox_u8_f32(const unsigned char* resized_bgr, int height_resize,
 int si_hip_letterbox_batch_u8_f32(const unsigned char* resized_bgr, int n, size_t image_stride_bytes, int height_resize,
                                   int width_resize, float* out, int height_new, int width_new, int padding_t,
                                   int padding_l, si_stream_t stream);
+/* The cv::resize of PreProcess (test_yolo.cpp:213-216) on the device (round 4).  cv::resize comes from the reference's simpleocv
+ * submodule, which is ABSENT from the checkout: this implements the published 8-bit INTER_LINEAR algorithm that library shares with
+ * OpenCV / ncnn (half-pixel centres, 11-bit fixed-point weights, 16-bit horizontal pass, + 2 >> 2 vertical pass) and is pinned to
+ * a numpy restatement of THAT (oracle/orc.py), not to the reference.  n images of src_h x src_w x 3 bytes at src + b *
+ * src_stride_bytes -> dst_h x dst_w x 3 at dst + b * dst_stride_bytes. */
+int si_hip_resize_bilinear_u8c3(const unsigned char* src, int n, size_t src_stride_bytes, int src_h, int src_w, unsigned char* dst,
+                                size_t dst_stride_bytes, int dst_h, int dst_w, si_stream_t stream);
+/* PreProcess whole for n camera frames that share one size: si_letterbox_geometry, the bilinear resize above (its output is never
+ * written), BGR -> RGB, pad(114), float, / 255 -- into slots 0..n-1 of the NHWC fp32 input tensor [n][height_new][width_new][3].
+ * Equals si_hip_resize_bilinear_u8c3 followed by si_hip_letterbox_batch_u8_f32, bit for bit. */
+int si_hip_resize_letterbox_batch_u8_f32(const unsigned char* frames_bgr, int n, size_t image_stride_bytes, int height_origin,
+                                         int width_origin, float* out, int height_new, int width_new, si_stream_t stream);
 /* Detection post-processing of test_yolo.cpp:337-428 on the device, for all images of a batch:
  *   confidence = pred[.,4] * max_k pred[.,5+k] (first maximum), kept when >= prob_threshold (:341-377);
  *   sorted by confidence, descending (:380; equal confidences are ordered by element index here, by an unstable
@@ -333,8 +345,17 @@ int si_hip_f16_to_f32_host(const void* src, float* dst, size_t n);
  * (1 also covers ungrouped 1x1 convs with ic % 8 == 0: the K axis is zero-padded to whole 32-channel blocks) */
 int si_hip_conv2d_f16_supported(const SiConv2dDesc* d);
 size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d);
-/* OIHW fp32 -> [oc][K] fp16, K order (c/B, kh, kw, c%B), B = 64 when ic/groups % 64 == 0 else 32 */
+/* OIHW fp32 -> two fp16 images of the same weights, one behind the other (si_hip_conv2d_f16_weight_elems counts both):
+ * [oc][K] rows, K order (c/B, kh, kw, c%B), B = 64 when ic/groups % 64 == 0 else 32; then the MFMA B-operand LANE ORDER
+ * [group][oc/32][K/16][lane 0..63][8] (lane l = channel l & 31, k = 8 (l >> 5) .. + 7 of the 16-deep step) that the kernels
+ * with weights fetched straight from L2 read with one coalesced 16-byte load per lane (round 4) */
 int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
+/* Tile variant of the fp16 implicit GEMM (tests, sweeps): 0-2 the one-stage kernel (64x64, 128x64, 128x128), 3-8 the kernels
+ * with lane-order weights (128x128, 128x64, 64x128, 64x64, 128x32, 256x64); -1 restores the launch-size policy.  Every variant
+ * produces the same bits.  Returns 0, or SI_E_BADARG for an unknown id. */
+int si_hip_conv2d_f16_set_tile_variant(int variant);
+/* the variant the policy (or the forced id) picks for this shape; -1 when the shape has no fp16 implicit-GEMM kernel */
+int si_hip_conv2d_f16_tile_variant(const SiConv2dDesc* d);
 /* as si_hip_conv2d_f32; in / residual / out fp16 (strides in elements), bias fp32; out_is_f32 != 0 stores fp32 (graph
  * outputs) */
 int si_hip_conv2d_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
@@ -351,6 +372,12 @@ size_t si_hip_conv2d_stem_f16_weight_elems(const SiConv2dDesc* d);
 int si_hip_conv2d_stem_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
 int si_hip_conv2d_stem_f16(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, void* out,
                            si_stream_t stream);
+/* si_hip_conv2d_upcat_f32 with fp16 storage (round 4): `up->src` points at HALF data (cast to the struct's pointer type), up->ld /
+ * up->c / up->c0 in elements; c0 and c multiples of the K block (64 when ic % 64 == 0, else 32), up->ld and in_ld multiples of 8.
+ * Same index rule, same bits as running si_hip_upsample_nearest on the half tensor, the concat copy and si_hip_conv2d_f16. */
+int si_hip_conv2d_upcat_f16(const SiConv2dDesc* d, const void* in, const SiConv2dUpsampledSource* up, const void* w_packed,
+                            const float* bias, void* out, int split_oc, void* out2, int out2_ld, si_stream_t stream);
+int si_hip_conv2d_upcat_f16_supported(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up);
 int si_hip_conv2d_split_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, void* out,
                             int split_oc, void* out2, int out2_ld, si_stream_t stream);
 /* fp16 features in, fp32 [n][rows_total][ne] detections out */

@@ -49,12 +49,14 @@ extern "C" {
 #define SI_SHARD_E_TIMEOUT (-103)  /* a peer did not arrive within the group's timeout */
 #define SI_SHARD_E_TOOBIG (-104)   /* more than SI_GROUP_MAX_BYTES per rank in si_group_allgather */
 #define SI_SHARD_E_PEER (-105)     /* another rank reported a failure in a collective setup step */
+#define SI_SHARD_E_RCCL (-106)     /* an RCCL call failed (the ncclResult_t is logged); librccl.so missing is SI_SHARD_E_SYS */
 
 #define SI_GROUP_MAX_BYTES 4096
 #define SI_GROUP_MAX_WORLD 64
 
 typedef struct SiNodeGroup SiNodeGroup;
 typedef struct SiDirectGather SiDirectGather;
+typedef struct SiRcclComm SiRcclComm;
 
 /* Every rank of the node calls this with the same `name` (a POSIX shm name: "/something", unique per job -- e.g.
  * derived from the launcher's pid and port) and `world`; rank 0 creates the segment, the others attach, and the
@@ -69,6 +71,19 @@ int si_group_allgather(SiNodeGroup* group, const void* mine, size_t bytes, void*
 
 /* Collective over the group.  `device`: this rank's HIP device.  Allocates slots x world x slab_bytes of HBM. */
 int si_gather_create(SiNodeGroup* group, int device, size_t slab_bytes, int slots, SiDirectGather** gather);
+/* The same object with the transport chosen (round 4; north_star: "RCCL all-gather of outputs over xGMI"):
+ *   SI_GATHER_DIRECT  the IPC fan-out above (si_gather_create)
+ *   SI_GATHER_RCCL    ncclAllGather (in place, on the gather's own stream behind the producer) into the same slot buffers; no IPC
+ *                     mapping, no peer access: what works wherever RCCL does
+ *   SI_GATHER_AUTO    direct; if its setup fails on ANY rank (hipIpc / peer mapping refused on the real node), every rank tears it
+ *                     down and all fall back to RCCL together
+ * push / complete / buffer / slab / stats / destroy are the same calls for every mode (for RCCL `complete` waits for this rank's
+ * collective of that slot; the collective itself orders the ranks, so there is no node barrier in it). */
+#define SI_GATHER_DIRECT 0
+#define SI_GATHER_RCCL 1
+#define SI_GATHER_AUTO 2
+int si_gather_create_mode(SiNodeGroup* group, int device, size_t slab_bytes, int slots, int mode, SiDirectGather** gather);
+int si_gather_mode(const SiDirectGather* gather); /* SI_GATHER_DIRECT or SI_GATHER_RCCL: what it ended up as */
 int si_gather_destroy(SiDirectGather* gather); /* collective */
 int si_gather_slots(const SiDirectGather* gather);
 size_t si_gather_slab_bytes(const SiDirectGather* gather);
@@ -82,8 +97,10 @@ int si_gather_complete(SiDirectGather* gather, int slot); /* collective */
  *   wait_copies_ms_total   host time si_gather_complete spent waiting for THIS rank's peer copies of the slot (0 when the
  *                          fan-out finished behind the next step's compute: the overlap worked)
  *   wait_barrier_ms_total  ... and then in the node barrier (waiting for the slowest rank)
- *   copy_ms_total / copies device time from "slab ready" to "landed in the peer", per peer copy: slab_bytes / that is the
- *                          achieved per-link rate when the copy stream was idle (xGMI: ~153 GB/s per link peak) */
+ *   copy_ms_total / copies device time of a peer copy itself (an event recorded on the copy stream right before it -> landed):
+ *                          slab_bytes / that is the achieved per-link rate (xGMI: ~153 GB/s per link peak)
+ *   landed_ms_total        device time from "slab ready" to "landed in the peer", summed over the same copies: the latency
+ *                          behind the producer, queueing behind earlier copies on that peer's stream included */
 typedef struct SiGatherStats {
     double wait_copies_ms_total;
     double wait_barrier_ms_total;
@@ -91,8 +108,20 @@ typedef struct SiGatherStats {
     double copy_ms_max;
     long long completes;
     long long copies;
+    double landed_ms_total;
 } SiGatherStats;
 int si_gather_stats(SiDirectGather* gather, SiGatherStats* out, int reset);
+
+/* ---- RCCL behind the C-ABI (SURVEY.md 8b `si_rccl_allgather`).  librccl.so is dlopen()ed at the first call (SI_RCCL_LIB names
+ * another file); nothing links against it, so the library loads -- and every other entry point works -- where RCCL is absent:
+ * these then return SI_SHARD_E_SYS.  No torch, no MPI: the ncclUniqueId travels through si_group_allgather. */
+int si_rccl_available(void); /* 1 when librccl.so can be loaded and has the five entry points used here */
+/* collective over the group: rank 0 draws the unique id, all ranks ncclCommInitRank on `device` */
+int si_rccl_init(SiNodeGroup* group, int device, SiRcclComm** comm);
+/* recv[r * bytes_per_rank ..] = rank r's send[0 .. bytes_per_rank), enqueued on `stream` (hipStream_t); in place when
+ * send == recv + rank * bytes_per_rank */
+int si_rccl_allgather(SiRcclComm* comm, const void* send, void* recv, size_t bytes_per_rank, si_stream_t stream);
+int si_rccl_destroy(SiRcclComm* comm);
 
 #ifdef __cplusplus
 }

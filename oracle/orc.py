@@ -236,6 +236,40 @@ def letterbox(resized_bgr, height_new, width_new, padding_t, padding_l):
     return out
 
 
+def resize_bilinear_u8c3(image, dst_h, dst_w):
+    """The cv::resize of PreProcess (test/test_yolo/test_yolo.cpp:213-216), 8-bit, 3 channels, INTER_LINEAR.  PARITY UNPINNED
+    against the reference: cv::resize lives in its simpleocv submodule, which is absent from /root/reference (empty 3rdparty
+    directory).  This restates the PUBLISHED fixed-point algorithm that library shares with OpenCV and ncnn (resize_bilinear_c3):
+    half-pixel centres, f = (d + 0.5) * (src / dst) - 0.5 in double rounded to float, s = floor(f) clamped (left: f = 0; right:
+    s = src - 2, f = 1), weights a = (short)(int)(w * 2048 + 0.5), horizontal pass (S[s] * a0 + S[s + 1] * a1) >> 4, vertical
+    pass (((b0 * r0) >> 16) + ((b1 * r1) >> 16) + 2) >> 2.  Plain numpy integer arithmetic; image u8 [h][w][3]."""
+    src = np.ascontiguousarray(image, dtype=np.uint8)
+    sh, sw = int(src.shape[0]), int(src.shape[1])
+
+    def axis(dst, n_src):
+        d = np.arange(dst, dtype=np.float64)
+        f = ((d + 0.5) * (np.float64(n_src) / np.float64(dst)) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        s[lo], f[lo] = 0, 0.0
+        hi = s >= n_src - 1
+        s[hi], f[hi] = n_src - 2, 1.0
+        if n_src == 1:
+            s[:], f[:] = 0, 0.0
+        a0 = ((np.float32(1.0) - f) * np.float32(2048.0) + np.float32(0.5)).astype(np.int64)
+        a1 = (f * np.float32(2048.0) + np.float32(0.5)).astype(np.int64)
+        return s, np.minimum(s + 1, n_src - 1) if n_src > 1 else s, a0, a1
+
+    x0, x1, ax0, ax1 = axis(dst_w, sw)
+    y0, y1, ay0, ay1 = axis(dst_h, sh)
+    S = src.astype(np.int64)
+    rows = (S[:, x0, :] * ax0[None, :, None] + S[:, x1, :] * ax1[None, :, None]) >> 4          # [sh][dst_w][3], fits 16 bits
+    r0, r1 = rows[y0], rows[y1]
+    out = (((ay0[:, None, None] * r0) >> 16) + ((ay1[:, None, None] * r1) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
 def yolo_postprocess(pred, prob_threshold=0.25, nms_threshold=0.45, agnostic=False, adjust=None, max_det=None):
     """test_yolo.cpp:337-428 per image; returns (list of [k][6] arrays, counts)."""
     pred = _f32(pred)

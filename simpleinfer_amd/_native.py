@@ -133,6 +133,10 @@ def hip():
         "si_hip_f32_to_f16_host": (i, [vp, vp, sz]),
         "si_hip_f16_to_f32_host": (i, [vp, vp, sz]),
         "si_hip_conv2d_f16_supported": (i, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_f16_set_tile_variant": (i, [i]),
+        "si_hip_conv2d_upcat_f16": (i, [C.POINTER(SiConv2dDesc), vp, C.POINTER(SiConv2dUpsampledSource), vp, vp, vp, i, vp, i, vp]),
+        "si_hip_conv2d_upcat_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dUpsampledSource)]),
+        "si_hip_conv2d_f16_tile_variant": (i, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_f16_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_f16_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, i, vp]),
@@ -154,6 +158,8 @@ def hip():
         "si_letterbox_geometry": (None, [i, i, i, i, ip, ip, C.POINTER(f), ip, ip]),
         "si_hip_letterbox_u8_f32": (i, [vp, i, i, vp, i, i, i, i, vp]),
         "si_hip_letterbox_batch_u8_f32": (i, [vp, i, sz, i, i, vp, i, i, i, i, vp]),
+        "si_hip_resize_bilinear_u8c3": (i, [vp, i, sz, i, i, vp, sz, i, i, vp]),
+        "si_hip_resize_letterbox_batch_u8_f32": (i, [vp, i, sz, i, i, vp, i, i, vp]),
         "si_hip_yolo_postprocess_workspace_bytes": (sz, [i, i, i]),
         "si_hip_yolo_postprocess_f32": (i, [vp, i, i, i, f, f, i, vp, vp, vp, i, vp, sz, vp]),
     }
@@ -169,7 +175,7 @@ def hip():
 class SiGatherStats(C.Structure):
     """include/si_shard.h"""
     _fields_ = [("wait_copies_ms_total", C.c_double), ("wait_barrier_ms_total", C.c_double), ("copy_ms_total", C.c_double),
-                ("copy_ms_max", C.c_double), ("completes", C.c_longlong), ("copies", C.c_longlong)]
+                ("copy_ms_max", C.c_double), ("completes", C.c_longlong), ("copies", C.c_longlong), ("landed_ms_total", C.c_double)]
 
 
 def host():
@@ -217,6 +223,12 @@ def host():
         "si_group_barrier": (i, [vp]),
         "si_group_allgather": (i, [vp, vp, sz, vp]),
         "si_gather_create": (i, [vp, i, sz, i, C.POINTER(vp)]),
+        "si_gather_create_mode": (i, [vp, i, sz, i, i, C.POINTER(vp)]),
+        "si_gather_mode": (i, [vp]),
+        "si_rccl_available": (i, []),
+        "si_rccl_init": (i, [vp, i, C.POINTER(vp)]),
+        "si_rccl_allgather": (i, [vp, vp, vp, sz, vp]),
+        "si_rccl_destroy": (i, [vp]),
         "si_gather_destroy": (i, [vp]),
         "si_gather_slots": (i, [vp]),
         "si_gather_slab_bytes": (sz, [vp]),

@@ -14,6 +14,7 @@
 // One ds_read_b128 per operand feeds one 32x32x16 MFMA (lane l holds k = 8*(l>>5) .. +7 of row l&31, A and W alike).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 
@@ -41,6 +42,8 @@ namespace {
 struct ConvArgsH {
     const half_t* in;
     const half_t* w;
+    const half_t* wl;           // the same weights in MFMA B-operand lane order (f16_lane_*; conv_igemm_f16_bd_kernel)
+    int wl_nb, wl_ks;           // its extents per group: 32-channel column blocks, 16-deep k-steps
     const float* bias;
     const half_t* res;
     void* out;                  // half, or float when ymode / out_f32
@@ -63,6 +66,12 @@ struct ConvArgsH {
     float ystride;
     const float* ygrid;
     const float* yanchor;
+    // dual-source input of a 1x1 conv that consumes cat(..., nn.Upsample(x), ...) (conv_igemm.hip ConvArgs::up): channel blocks
+    // [up_cb0, up_cb1) of the K axis are read from the LOW-RESOLUTION tensor `up` at the nearest-neighbour source pixel
+    const half_t* up;
+    int up_ih, up_iw, up_ld, up_cb0, up_cb1;
+    float up_inv_h, up_inv_w;
+    unsigned up_bytes;
 };
 
 // n / d for 0 <= n < 2^32 with mg = floor(2^32 / d) (0xFFFFFFFF for d = 1): the high product is the quotient or one less
@@ -214,7 +223,9 @@ constexpr unsigned OOB_B = 0x80000000u;
 // BKH: channels per K-tile = one tap of one BKH-channel block.  64 whenever the channel count allows: a row of the
 // tile is then a whole 128-byte line per load instruction (32: half lines) and a 1x1 conv over 64 channels needs a
 // single tile with all of its loads in flight at once.
-template <int BM, int BN, int WM, int WN, int BKH>
+// UPS: the dual-source pointwise form (ConvArgsH::up), its own instantiation so that the ordinary layers carry neither the extra
+// row offsets nor the per-K-tile source select
+template <int BM, int BN, int WM, int WN, int BKH, bool UPS = false>
 __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int LDH = BKH + 8;       // halves per LDS row (80 / 144 bytes: conflict-free ds_read_b128 phases)
@@ -247,13 +258,29 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<half_t*>(a.w + (size_t)g * a.ocg * a.Kp), 0, (unsigned)a.ocg * a.Kp * 2u, 0x00020000);
 
+    const __amdgpu_buffer_rsrc_t rs_up = UPS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.up), 0, a.up_bytes, 0x00020000) : rs_in;
     unsigned a_off[A_IT];
+    unsigned u_off[UPS ? A_IT : 1];   // UPS: byte offset of the row's source pixel in the low-resolution tensor
     unsigned long long a_mask[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + r0 + RPP * i;
         a_off[i] = 0;
         a_mask[i] = 0ull;
+        if (UPS) {
+            u_off[i] = OOB_A;
+            if (m < a.M) {
+                const int img = fast_div_h(m, a.ohow, a.mg_ohow);
+                const int rem = m - img * a.ohow;
+                const int oy = fast_div_h(rem, a.ow, a.mg_ow);
+                const int ox = rem - oy * a.ow;
+                // src/layer/upsample.cpp:85-92: src = clamp(int(float(dst) * (1 / scale)), 0, in - 1)
+                int sy = (int)((float)oy * a.up_inv_h), sx = (int)((float)ox * a.up_inv_w);
+                sy = max(0, min(a.up_ih - 1, sy));
+                sx = max(0, min(a.up_iw - 1, sx));
+                u_off[i] = (unsigned)((img * a.up_ih + sy) * a.up_iw + sx) * (unsigned)(a.up_ld * 2) + (unsigned)(kv * 16);
+            }
+        }
         if (m < a.M && a.pointwise) {
             a_off[i] = (unsigned)m * (unsigned)(a.in_ld * 2) + (unsigned)(kv * 16);
             a_mask[i] = 1ull;
@@ -292,10 +319,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
         // (a 1x1 conv whose channel count is a multiple of 8 but not of 32 has its K axis zero-padded to whole blocks in the weights:
         // a vector that lies behind the last channel must read zeros, not the next pixel)
         const bool cok = cb * BKH + kv * 8 < a.icg;
+        const bool from_up = UPS && cb >= a.up_cb0 && cb < a.up_cb1;   // wave-uniform: this K-tile's channels are upsampled ones
+        if (from_up) {
+            const unsigned du = (unsigned)(cb - a.up_cb0) * (unsigned)(BKH * 2);
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const bool ok = ((a_mask[i] >> tapbit) & 1ull) && cok;
-            qa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
+            for (int i = 0; i < A_IT; ++i)
+                qa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_up, u_off[i] == OOB_A ? OOB_A : u_off[i] + du, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const bool ok = ((a_mask[i] >> tapbit) & 1ull) && cok;
+                qa[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
+            }
         }
         const unsigned kb = (unsigned)kt * (BKH * 2);
 #pragma unroll
@@ -388,6 +423,226 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     }
 }
 
+// ---- B operand straight from L2 ("bd" kernels, round 4) ---------------------------------------------------------------------
+// The one-stage kernel above moves BOTH operands global -> registers -> ds_write_b128 -> barrier -> ds_read_b128 -> MFMA.  At
+// 32 cycles per v_mfma_f32_32x32x16_f16 that path, not the matrix pipe, sets the pace (rocprofv3 --pmc on the K = 2304 layers:
+// pipe 21 % busy, 61 % of the issue stalls are LDS issue, profiles/r03_f16_pipe_sweep.txt): a 32x32 wave tile needs two 1 KB
+// fragment reads per MFMA and the weight tile is written to and read back from LDS by every workgroup although its layout is
+// known at load time.  Here the weights are packed ONCE (si_hip_conv2d_f16_pack_weight_host) in the MFMA's B-operand LANE ORDER:
+// per (32-channel column block, 16-deep k-step) one contiguous 1 KB block, lane l holding W[col l & 31][k = 8 (l >> 5) .. + 7],
+// so a wave fetches a B fragment with ONE fully coalesced 16-byte-per-lane buffer load -- no ds_write, no ds_read, no barrier
+// dependency for B.  LDS carries the im2col A tile only (two stages, one barrier per K-tile), wave tiles are up to 64x64 (four
+// MFMAs per A read), and the fragments of K-tile t+1 are in flight in a second register slot while tile t is consumed.
+// Same k order and the same 16-wide MFMA steps as the one-stage kernel: an output element sees the same MFMA sequence, so the
+// two kernels agree bit for bit and the tile policy may follow the launch size (tests/test_gpu_f16.py).
+// SI_F16_ABL (diagnostic builds only, tools/f16_ablate.sh): bit 0 no A loads in the loop, 1 no B loads, 2 no LDS stores, 3 no
+// MFMAs (operands kept alive), 4 no barriers -- wrong results, timing only.  0 in the product build.
+#ifndef SI_F16_ABL
+#define SI_F16_ABL 0
+#endif
+template <int BM, int BN, int WM, int WN, int BKH, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_f16_bd_kernel(const ConvArgsH a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int LDH = BKH + 8;
+    constexpr int VPR = BKH / 8;
+    constexpr int RPP = 256 / VPR;
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int A_IT = (BM + RPP - 1) / RPP;   // (a 32-row tile has fewer rows than one pass of the 256 threads: the upper threads stage nothing)
+    constexpr int QS = BKH / 16;       // MFMA k-steps per K-tile
+    static_assert(TM >= 1 && TN >= 1 && A_IT >= 1, "tile too small");
+
+    __shared__ __attribute__((aligned(16))) half_t lds[2][BM * LDH];
+
+    const int g = blockIdx.y;
+    const int per_chunk = 8 * a.n_tiles;
+    const int chunk = blockIdx.x / per_chunk;
+    const int r = blockIdx.x - chunk * per_chunk;
+    const int m_tile = chunk * 8 + (r & 7);
+    const int n_tile = r >> 3;
+    if (m_tile >= a.m_tiles) return;
+    const int m0 = m_tile * BM;
+    const int n0 = n_tile * BN;
+
+    const int tid = threadIdx.x;
+    const int kv = tid % VPR;
+    const int r0 = tid / VPR;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(a.in + (size_t)g * a.icg), 0, a.in_bytes - (unsigned)g * a.icg * 2u, 0x00020000);
+    const unsigned wl_group_bytes = (unsigned)a.wl_nb * (unsigned)a.wl_ks * 1024u;
+    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(a.wl) + (size_t)g * (wl_group_bytes / 2u), 0, wl_group_bytes, 0x00020000);
+
+    unsigned a_off[A_IT];
+    unsigned long long a_mask[A_IT];
+    const bool stager = BM >= RPP || r0 < BM;   // this thread stages A rows at all
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + RPP * i;
+        a_off[i] = 0;
+        a_mask[i] = 0ull;
+        if (!stager) continue;
+        if (m < a.M && a.pointwise) {
+            a_off[i] = (unsigned)m * (unsigned)(a.in_ld * 2) + (unsigned)(kv * 16);
+            a_mask[i] = 1ull;
+        } else if (m < a.M) {
+            const int img = fast_div_h(m, a.ohow, a.mg_ohow);
+            const int rem = m - img * a.ohow;
+            const int oy = fast_div_h(rem, a.ow, a.mg_ow);
+            const int ox = rem - oy * a.ow;
+            const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
+            a_off[i] = (unsigned)((img * a.ih + y0) * a.iw + x0) * (unsigned)(a.in_ld * 2) + (unsigned)(kv * 16);
+            unsigned long long mk = 0ull;
+            for (int ky = 0; ky < a.kh; ++ky)
+                for (int kx = 0; kx < a.kw; ++kx) {
+                    const int y = y0 + ky * a.dh, x = x0 + kx * a.dw;
+                    if ((unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw) mk |= 1ull << (ky * a.kw + kx);
+                }
+            a_mask[i] = mk;
+        }
+    }
+    // this wave's column blocks in the lane-order image (a block behind the last one reads zeros)
+    unsigned b_off[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int nb = (n0 >> 5) + wn * TN + u;
+        b_off[u] = nb < a.wl_nb ? (unsigned)nb * (unsigned)a.wl_ks * 1024u + (unsigned)lane * 16u : OOB_B;
+    }
+
+    // The K loop is ONE basic block: every load is issued unconditionally and a K-tile behind the last one is an out-of-range
+    // offset (zeros, never consumed).  With branches around the prefetches hipcc parks the 64 accumulator registers in VGPRs
+    // across the block boundaries (128 v_accvgpr moves per K-tile) and waits for ALL outstanding loads before the first MFMA.
+    u32x4 ra[A_IT];
+    f16x8 rb[2][TN][QS];
+    const int nk = a.Kp / BKH;
+    int cb = 0, ky = 0, kx = 0;  // wave-uniform K walk of the A loads (ascending K-tiles)
+    auto load_a = [&](int kt) {
+        const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * BKH) * 2u;
+        const int tapbit = ky * a.kw + kx;
+        // (zero-padded K axis of a 1x1 conv: a vector behind the last channel reads zeros)
+        const bool cok = cb * BKH + kv * 8 < a.icg && kt < nk;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const bool ok = ((a_mask[i] >> tapbit) & 1ull) && cok;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
+        }
+        // branch-free walk: kx, then ky, then the channel block
+        ++kx;
+        const int wx = kx == a.kw ? 1 : 0;
+        kx = wx ? 0 : kx;
+        ky += wx;
+        const int wy = ky == a.kh ? 1 : 0;
+        ky = wy ? 0 : ky;
+        cb += wy;
+    };
+    auto store_a = [&](int stage) {
+        half_t* As = lds[stage];
+        if (BM < RPP && r0 >= BM) return;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4*>(As + (r0 + RPP * i) * LDH + kv * 8) = ra[i];
+    };
+    auto load_b = [&](f16x8 (&q)[TN][QS], int kt) {
+        // the K-tile's k-steps are consecutive 1 KB blocks: their offset rides in the load's scalar offset; a tile behind the
+        // last one is an out-of-range VECTOR offset (the scalar offset takes no part in the range check)
+        const bool live = kt < nk;
+        const unsigned kb = (unsigned)(live ? kt : 0) * (unsigned)(QS * 1024);
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const unsigned vo = live ? b_off[u] : OOB_B;
+#pragma unroll
+            for (int s = 0; s < QS; ++s)
+                q[u][s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wl, vo + (unsigned)(s * 1024), kb, 0));
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.0f;
+
+    load_a(0);
+    load_b(rb[0], 0);
+    float bias_pre[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) {
+        const int o = n0 + wn * TN * 32 + l31 + u * 32;
+        bias_pre[u] = (a.bias && o < a.ocg) ? a.bias[g * a.ocg + o] : 0.0f;
+    }
+    store_a(0);
+    load_a(1);
+    __syncthreads();
+
+    // one K-tile: B(kt+1) requested, A(kt+1) committed to the other stage and A(kt+2) requested, then the MFMAs of tile kt with
+    // the A fragments of step s+1 read while step s multiplies; one barrier
+    auto k_tile = [&](int kt, int cur, const f16x8 (&bcur)[TN][QS], f16x8 (&bnxt)[TN][QS]) {
+        if (!(SI_F16_ABL & 4)) store_a(cur ^ 1);
+        if (!(SI_F16_ABL & 2)) load_b(bnxt, kt + 1);
+        if (!(SI_F16_ABL & 1)) load_a(kt + 2);
+        // every request of this K-tile is issued before its first MFMA: left to itself the scheduler sinks the A loads (and their
+        // address arithmetic) two thirds into the MFMA sequence, a few hundred cycles before the wait that needs them
+        __builtin_amdgcn_sched_barrier(0);
+        const half_t* As = lds[cur] + (wm * TM * 32 + l31) * LDH + lh * 8;
+        f16x8 fa[2][TM];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) fa[0][t] = *reinterpret_cast<const f16x8*>(As + t * 32 * LDH);
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            if (s + 1 < QS) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[(s + 1) & 1][t] = *reinterpret_cast<const f16x8*>(As + t * 32 * LDH + (s + 1) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) {
+                    if (SI_F16_ABL & 8) asm volatile("" ::"v"(fa[s & 1][t]), "v"(bcur[u][s]));
+                    else acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][t], bcur[u][s], acc[t][u], 0, 0, 0);
+                }
+        }
+        if (!(SI_F16_ABL & 16)) __syncthreads();
+    };
+    for (int kp = 0; kp < (nk >> 1); ++kp) {
+        k_tile(2 * kp, 0, rb[0], rb[1]);
+        k_tile(2 * kp + 1, 1, rb[1], rb[0]);
+    }
+    if (nk & 1) k_tile(nk - 1, 0, rb[0], rb[1]);
+
+    const int mrow0 = m0 + wm * TM * 32 + 4 * lh, ocol0 = n0 + wn * TN * 32 + l31;
+    if (a.ymode) {
+        const int img = m0 / a.ohow;
+        if (m0 + BM <= a.M && m0 - img * a.ohow + BM <= a.ohow)
+            si_yolo_tile_one_image<TM, TN>(a, static_cast<float*>(a.out), acc, mrow0, ocol0, img);
+        else
+            epilogue_yolo_h<TM, TN>(a, acc, mrow0, ocol0);
+    } else if (a.out_f32) epilogue_plain<TM, TN, float>(a, acc, g, mrow0, ocol0);
+    else {
+        const bool interior = m0 + BM <= a.M;
+        if (a.act1 == SI_ACT_SILU && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_SILU, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_NONE, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        else if (a.act1 == SI_ACT_RELU && a.act2 == SI_ACT_NONE) epilogue_pick_h<TM, TN, SI_ACT_RELU, SI_ACT_NONE>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        else if (a.act1 == SI_ACT_NONE && a.act2 == SI_ACT_RELU) epilogue_pick_h<TM, TN, SI_ACT_NONE, SI_ACT_RELU>(a, acc, g, mrow0, ocol0, interior, bias_pre);
+        else epilogue_plain<TM, TN, half_t>(a, acc, g, mrow0, ocol0);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int BKH, int MINW = 1>
+int launch_bd(const ConvArgsH& a, int groups, hipStream_t s) {
+    ConvArgsH b = a;
+    b.m_tiles = (a.M + BM - 1) / BM;
+    b.n_tiles = (a.ocg + BN - 1) / BN;
+    const int chunks = (b.m_tiles + 7) / 8;
+    dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
+    hipLaunchKernelGGL((conv_igemm_f16_bd_kernel<BM, BN, WM, WN, BKH, MINW>), grid, dim3(256), 0, s, b);
+    return (int)hipGetLastError();
+}
+
 template <int BM, int BN, int WM, int WN, int BKH>
 int launch_h(const ConvArgsH& a, int groups, hipStream_t s) {
     ConvArgsH b = a;
@@ -395,7 +650,12 @@ int launch_h(const ConvArgsH& a, int groups, hipStream_t s) {
     b.n_tiles = (a.ocg + BN - 1) / BN;
     const int chunks = (b.m_tiles + 7) / 8;
     dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
-    hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, BKH>), grid, dim3(256), 0, s, b);
+    if (a.up) {
+        if constexpr (BM == 64 && BN == 64) hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, BKH, true>), grid, dim3(256), 0, s, b);
+        else return SI_E_UNSUPPORTED;
+    } else {
+        hipLaunchKernelGGL((conv_igemm_f16_kernel<BM, BN, WM, WN, BKH>), grid, dim3(256), 0, s, b);
+    }
     return (int)hipGetLastError();
 }
 
@@ -420,16 +680,81 @@ bool f16_shape_ok(const SiConv2dDesc* d) {
     return d->kh * d->kw == 1 && d->groups == 1 && icg % 8 == 0 && icg >= 8;
 }
 
-// 0: 64x64, 1: 128x64, 2: 128x128 (SI_CONV_F16_VARIANT overrides, development only)
+// extents of the lane-order weight image (per group): 32-channel column blocks x 16-deep k-steps x 1 KB
+int f16_lane_nb(const SiConv2dDesc* d) { return (d->oc / d->groups + 31) / 32; }
+int f16_lane_ks(const SiConv2dDesc* d) { return d->kh * d->kw * f16_icg_pad(d) / 16; }
+size_t f16_row_elems(const SiConv2dDesc* d) { return (size_t)d->oc * d->kh * d->kw * f16_icg_pad(d); }
+size_t f16_lane_elems(const SiConv2dDesc* d) { return (size_t)d->groups * f16_lane_nb(d) * f16_lane_ks(d) * 512; }
+
+// Tile variants.  One-stage kernel (both operands through LDS): 0: 64x64, 1: 128x64, 2: 128x128.  "bd" kernels (weights straight
+// from L2 in lane order, A through two LDS stages): 3: 128x128 (wave tiles 64x64), 4: 128x64 (64x32), 5: 64x128 (32x64), 6: 64x64
+// (32x32), 7: 128x32 as 4x1 waves (32x32), 8: 256x64 as 4x1 waves (64x64).  All variants produce the same bits (same k order, same
+// 16-deep MFMA steps).  si_hip_conv2d_f16_set_tile_variant / SI_CONV_F16_VARIANT force one (tests, sweeps); -1: the policy.
+constexpr int kF16Variants = 15;
+std::atomic<int> g_f16_forced{-2};
+int f16_forced_variant() {
+    int v = g_f16_forced.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char* e = getenv("SI_CONV_F16_VARIANT");
+        v = e ? atoi(e) : -1;
+        if (v < 0 || v >= kF16Variants) v = -1;
+        int expected = -2;
+        g_f16_forced.compare_exchange_strong(expected, v);
+        v = g_f16_forced.load(std::memory_order_relaxed);
+    }
+    return v;
+}
+int f16_cu_count() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    return cus;
+}
+// The policy (round 4; tools/f16_sweep.sh on MI355X, sustained, every YOLOv5s shape at batch 32, two boxes:
+// profiles/r04_f16_bd_sweep.txt).  Whatever is chosen the bits are the same (tests/test_gpu_f16.py), so it may look at M:
+//   * <= 32 output channels: 128x32 as four 32x32 waves with lane-order weights (160x160x32 3x3 61 -> 53 us, 1x1 22 -> 19);
+//   * 64 output channels, or a short K with few columns: the one-stage 64x64 kernel (these layers are HBM-bound; every
+//     lane-order tile measured slower);
+//   * K >= 512 and >= 128 columns (the 3x3 layers from 64 input channels on, the wide 1x1 layers), or K >= 256 with >= 256
+//     columns: 64x128 as four 64x32 waves side by side (A shared through LDS, every wave its own weight columns, 4 workgroups
+//     per CU) -- 20x20x256 3x3 35 -> 25 us, 80x80x128 -> 40x40x256 s2 60 -> 47; with >= 512 columns and enough 128-row tiles to
+//     cover the chip, 128x128 as four 128x32 waves (40x40x256 -> 20x20x512 s2 60 -> 45 us, 20x20x1024 -> 512 1x1 29 -> 23).
+// SI_CONV_F16_POLICY=0 restores "64x64 everywhere" (A/B runs).
 int f16_variant(const SiConv2dDesc* d) {
-    static const int forced = [] { const char* e = getenv("SI_CONV_F16_VARIANT"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 2) return forced;
-    return 0;
+    const int forced = f16_forced_variant();
+    if (forced >= 0) return forced;
+    static const bool policy_on = [] { const char* e = getenv("SI_CONV_F16_POLICY"); return !(e && atoi(e) == 0); }();
+    if (!policy_on) return 0;
+    const int ocg = d->oc / d->groups;
+    const long long K = (long long)d->kh * d->kw * f16_icg_pad(d);
+    const long long M = (long long)d->n * d->oh * d->ow;
+    if (ocg <= 32) return 7;
+    if (ocg < 128) return 0;
+    const bool wide = K >= 512 || (K >= 256 && ocg >= 256);
+    if (!wide) return 0;
+    const long long tiles128 = ((M + 127) / 128) * ((ocg + 127) / 128) * d->groups;
+    if (ocg >= 512 && tiles128 >= f16_cu_count()) return 9;
+    return 10;
+}
+
+// what si_hip_conv2d_upcat_f16 requires of a problem apart from the pointers' alignment (shape only): a plain pointwise conv,
+// whole K blocks on both sides of the seam, both tensors below 4 GiB
+bool f16_upcat_shape_ok(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up) {
+    if (!d || !up || d->groups != 1 || d->ic <= 0 || d->oc <= 0 || !f16_shape_ok(d)) return false;
+    const bool pointwise = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow;
+    if (!pointwise || d->has_residual || d->ic % 32 != 0) return false;
+    const int blk = f16_block(d);
+    if (up->c <= 0 || up->c % blk != 0 || up->c0 % blk != 0 || up->c0 + up->c > d->ic || up->ld % 8 != 0 || up->ih <= 0 || up->iw <= 0) return false;
+    if (d->in_ld % 8 != 0) return false;
+    const unsigned long long ub = (unsigned long long)d->n * up->ih * up->iw * up->ld * 2ull;
+    return ub < 0xFFFFFF00ull;
 }
 
 int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
                void* out, int out_f32, si_stream_t stream, const SiYoloLevel* yolo, const float* ygrid, const float* yanchor,
-               const SplitOutH* split) {
+               const SplitOutH* split, const SiConv2dUpsampledSource* up = nullptr) {
     if (!d || !in || !w_packed || !out) return SI_E_BADARG;
     if (d->n <= 0 || d->oh <= 0 || d->ow <= 0) return SI_E_BADARG;
     if (d->has_bias && !bias) return SI_E_BADARG;
@@ -438,12 +763,15 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     if (d->in_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
     if ((long long)d->n * d->oh * d->ow > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 2ull;
-    const unsigned long long w_bytes = (unsigned long long)d->oc * d->kh * d->kw * f16_icg_pad(d) * 2ull;
+    const unsigned long long w_bytes = (unsigned long long)(f16_row_elems(d) + f16_lane_elems(d)) * 2ull;
     if (in_bytes >= 0xFFFFFF00ull || w_bytes >= 0x40000000ull) return SI_E_UNSUPPORTED;
 
     ConvArgsH a;
     a.in = static_cast<const half_t*>(in);
     a.w = static_cast<const half_t*>(w_packed);
+    a.wl = a.w + f16_row_elems(d);   // the lane-order image sits behind the row-major one
+    a.wl_nb = f16_lane_nb(d);
+    a.wl_ks = f16_lane_ks(d);
     a.bias = d->has_bias ? bias : nullptr;
     a.res = d->has_residual ? static_cast<const half_t*>(residual) : nullptr;
     a.out = out;
@@ -466,6 +794,16 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     a.out_f32 = out_f32;
     a.out2 = nullptr; a.out2_ld = 0; a.split = 0;
     a.ymode = 0; a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.f; a.ygrid = a.yanchor = nullptr;
+    a.up = nullptr; a.up_ih = a.up_iw = a.up_ld = a.up_cb0 = a.up_cb1 = 0; a.up_inv_h = a.up_inv_w = 0.f; a.up_bytes = 0;
+    if (up) {
+        // channels [c0, c0 + c) of this 1x1 conv's input are nn.Upsample(nearest) of up->src: read them at the source
+        if (!up->src || yolo || !f16_upcat_shape_ok(d, up) || (reinterpret_cast<uintptr_t>(up->src) & 15) != 0) return SI_E_UNSUPPORTED;
+        const int blk = f16_block(d);
+        a.up = reinterpret_cast<const half_t*>(up->src);
+        a.up_ih = up->ih; a.up_iw = up->iw; a.up_ld = up->ld; a.up_cb0 = up->c0 / blk; a.up_cb1 = (up->c0 + up->c) / blk;
+        a.up_inv_h = up->inv_scale_h; a.up_inv_w = up->inv_scale_w;
+        a.up_bytes = (unsigned)((unsigned long long)d->n * up->ih * up->iw * up->ld * 2ull);
+    }
     if (split) {
         if (d->groups != 1 || out_f32 || split->split <= 0 || split->split >= d->oc || split->split % 32 != 0 || !split->out2)
             return SI_E_BADARG;
@@ -477,16 +815,41 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
         a.ystride = yolo->stride; a.ygrid = ygrid; a.yanchor = yanchor;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int v = up ? 0 : f16_variant(d);   // (the dual-source form lives in the one-stage 64x64 kernel)
     if (f16_block(d) == 64) {
-        switch (f16_variant(d)) {
+        switch (v) {
             case 1: return launch_h<128, 64, 2, 2, 64>(a, d->groups, s);
             case 2: return launch_h<128, 128, 2, 2, 64>(a, d->groups, s);
+            case 3: return launch_bd<128, 128, 2, 2, 64>(a, d->groups, s);
+            case 4: return launch_bd<128, 64, 2, 2, 64>(a, d->groups, s);
+            case 5: return launch_bd<64, 128, 2, 2, 64>(a, d->groups, s);
+            case 6: return launch_bd<64, 64, 2, 2, 64>(a, d->groups, s);
+            case 7: return launch_bd<128, 32, 4, 1, 64>(a, d->groups, s);
+            case 8: return launch_bd<256, 64, 4, 1, 64>(a, d->groups, s);
+            case 9: return launch_bd<128, 128, 1, 4, 64>(a, d->groups, s);
+            case 10: return launch_bd<64, 128, 1, 4, 64>(a, d->groups, s);
+            case 11: return launch_bd<128, 128, 1, 4, 64, 3>(a, d->groups, s);
+            case 12: return launch_bd<64, 256, 1, 4, 64>(a, d->groups, s);
+            case 13: return launch_bd<32, 128, 1, 4, 64>(a, d->groups, s);
+            case 14: return launch_bd<32, 256, 1, 4, 64>(a, d->groups, s);
             default: return launch_h<64, 64, 2, 2, 64>(a, d->groups, s);
         }
     }
-    switch (f16_variant(d)) {
+    switch (v) {
         case 1: return launch_h<128, 64, 2, 2, 32>(a, d->groups, s);
         case 2: return launch_h<128, 128, 2, 2, 32>(a, d->groups, s);
+        case 3: return launch_bd<128, 128, 2, 2, 32>(a, d->groups, s);
+        case 4: return launch_bd<128, 64, 2, 2, 32>(a, d->groups, s);
+        case 5: return launch_bd<64, 128, 2, 2, 32>(a, d->groups, s);
+        case 6: return launch_bd<64, 64, 2, 2, 32>(a, d->groups, s);
+        case 7: return launch_bd<128, 32, 4, 1, 32>(a, d->groups, s);
+        case 8: return launch_bd<256, 64, 4, 1, 32>(a, d->groups, s);
+        case 9: return launch_bd<128, 128, 1, 4, 32>(a, d->groups, s);
+        case 10: return launch_bd<64, 128, 1, 4, 32>(a, d->groups, s);
+        case 11: return launch_bd<128, 128, 1, 4, 32, 3>(a, d->groups, s);
+        case 12: return launch_bd<64, 256, 1, 4, 32>(a, d->groups, s);
+        case 13: return launch_bd<32, 128, 1, 4, 32>(a, d->groups, s);
+        case 14: return launch_bd<32, 256, 1, 4, 32>(a, d->groups, s);
         default: return launch_h<64, 64, 2, 2, 32>(a, d->groups, s);
     }
 }
@@ -518,7 +881,7 @@ int si_hip_conv2d_f16_supported(const SiConv2dDesc* d) {
 
 size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d) {
     if (!d || !f16_shape_ok(d)) return 0;
-    return (size_t)d->oc * d->kh * d->kw * f16_icg_pad(d);
+    return f16_row_elems(d) + f16_lane_elems(d);   // two images of the same weights: [oc][K] rows, then MFMA lane order
 }
 
 int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed) {
@@ -538,7 +901,32 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
                     w[(size_t)o * ntaps * icp + k] = (half_t)v;
                 }
             }
+    // second image, MFMA B-operand lane order (conv_igemm_f16_bd_kernel): per group [column block nb][k-step ks][lane][8 halves],
+    // lane l = W[o = nb*32 + (l & 31)][k = ks*16 + 8*(l >> 5) .. + 7] in the same K order; channels behind the last one are zeros
+    const int ocg = d->oc / d->groups, nb_n = f16_lane_nb(d), ks_n = f16_lane_ks(d);
+    const size_t Kp = (size_t)ntaps * icp;
+    half_t* wl = w + f16_row_elems(d);
+    for (int g = 0; g < d->groups; ++g)
+        for (int nb = 0; nb < nb_n; ++nb)
+            for (int ks = 0; ks < ks_n; ++ks)
+                for (int l = 0; l < 64; ++l) {
+                    const int o = nb * 32 + (l & 31);
+                    half_t* dst = wl + ((((size_t)g * nb_n + nb) * ks_n + ks) * 64 + l) * 8;
+                    for (int j = 0; j < 8; ++j)
+                        dst[j] = o < ocg ? w[((size_t)g * ocg + o) * Kp + (size_t)ks * 16 + 8 * (l >> 5) + j] : (half_t)0.0f;
+                }
     return 0;
+}
+
+int si_hip_conv2d_f16_set_tile_variant(int variant) {
+    if (variant >= kF16Variants) return SI_E_BADARG;
+    g_f16_forced.store(variant < 0 ? -1 : variant, std::memory_order_relaxed);
+    return 0;
+}
+
+int si_hip_conv2d_f16_tile_variant(const SiConv2dDesc* d) {
+    if (!d || !f16_shape_ok(d)) return -1;
+    return f16_variant(d);
 }
 
 int si_hip_conv2d_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
@@ -552,6 +940,18 @@ int si_hip_conv2d_split_f16(const SiConv2dDesc* d, const void* in, const void* w
     SplitOutH sp{static_cast<half_t*>(out2), out2_ld, split_oc};
     return dispatch_h(d, in, w_packed, bias, nullptr, out, 0, stream, nullptr, nullptr, nullptr, &sp);
 }
+
+int si_hip_conv2d_upcat_f16(const SiConv2dDesc* d, const void* in, const SiConv2dUpsampledSource* up, const void* w_packed,
+                            const float* bias, void* out, int split_oc, void* out2, int out2_ld, si_stream_t stream) {
+    if (!d || !up || d->has_residual) return SI_E_BADARG;
+    if (split_oc > 0) {
+        SplitOutH sp{static_cast<half_t*>(out2), out2_ld, split_oc};
+        return dispatch_h(d, in, w_packed, bias, nullptr, out, 0, stream, nullptr, nullptr, nullptr, &sp, up);
+    }
+    return dispatch_h(d, in, w_packed, bias, nullptr, out, 0, stream, nullptr, nullptr, nullptr, nullptr, up);
+}
+
+int si_hip_conv2d_upcat_f16_supported(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up) { return f16_upcat_shape_ok(d, up) ? 1 : 0; }
 
 int si_hip_conv2d_yolo_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias,
                            const SiYoloLevel* level, const float* grid_hwa2, const float* anchor_hwa2, float* detect_out,

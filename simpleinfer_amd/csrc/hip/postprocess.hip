@@ -52,6 +52,76 @@ __global__ void letterbox_batch_kernel(const unsigned char* __restrict__ src, si
     }
 }
 
+// ---- bilinear resize (the cv::resize of PreProcess, test_yolo.cpp:213-216) ------------------------------------------------
+// The reference calls cv::resize of its simpleocv submodule, whose source is ABSENT from this checkout (empty 3rdparty
+// directory), so this is pinned to the PUBLISHED algorithm that library and OpenCV share for 8-bit INTER_LINEAR -- not to the
+// reference: half-pixel centres, sx = floor((dx + 0.5) * (src / dst) - 0.5) clamped to the image (left edge: fx = 0; right edge:
+// sx = src - 2, fx = 1), 11-bit fixed-point coefficients a = round(f * 2048) (half away from zero), the horizontal pass kept
+// as (S[sx] * a0 + S[sx + 1] * a1) >> 4 in 16 bits, the vertical pass ((b0 * r0) >> 16) + ((b1 * r1) >> 16), + 2, >> 2.
+// oracle/orc.py restates it in numpy; the device must agree EXACTLY (tests/test_gpu_ops.py).
+struct ResizeAxis {
+    int s0;        // first source index
+    short a0, a1;  // 11-bit weights of s0 and s0 + 1
+};
+__device__ __forceinline__ ResizeAxis resize_axis(int d, double scale, int src) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.0f; }
+    if (s >= src - 1) { s = src - 2; f = 1.0f; }
+    if (src == 1) { s = 0; f = 0.0f; }
+    ResizeAxis r;
+    r.s0 = s;
+    r.a0 = (short)(int)((1.0f - f) * 2048.0f + 0.5f);
+    r.a1 = (short)(int)(f * 2048.0f + 0.5f);
+    return r;
+}
+__device__ __forceinline__ int resize_pixel(const unsigned char* __restrict__ src, int sw, int c, const ResizeAxis& ax, const ResizeAxis& ay, int sh) {
+    const int x1 = sw > 1 ? ax.s0 + 1 : ax.s0, y1 = sh > 1 ? ay.s0 + 1 : ay.s0;
+    const unsigned char* r0 = src + ((size_t)ay.s0 * sw) * 3 + c;
+    const unsigned char* r1 = src + ((size_t)y1 * sw) * 3 + c;
+    const int h0 = ((int)r0[ax.s0 * 3] * ax.a0 + (int)r0[x1 * 3] * ax.a1) >> 4;
+    const int h1 = ((int)r1[ax.s0 * 3] * ax.a0 + (int)r1[x1 * 3] * ax.a1) >> 4;
+    return ((((int)ay.a0 * (int)(short)h0) >> 16) + (((int)ay.a1 * (int)(short)h1) >> 16) + 2) >> 2;
+}
+
+// plain resize, u8 BGR (or any 3-channel) image -> u8, blockIdx.y = image
+__global__ void resize_bilinear_u8c3_kernel(const unsigned char* __restrict__ src, size_t src_stride, int sh, int sw,
+                                            unsigned char* __restrict__ dst, size_t dst_stride, int dh, int dw) {
+    const double scx = (double)sw / (double)dw, scy = (double)sh / (double)dh;
+    const unsigned char* s = src + (size_t)blockIdx.y * src_stride;
+    unsigned char* d = dst + (size_t)blockIdx.y * dst_stride;
+    const int total = dh * dw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / dw, x = i - y * dw;
+        const ResizeAxis ax = resize_axis(x, scx, sw), ay = resize_axis(y, scy, sh);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[(size_t)i * 3 + c] = (unsigned char)resize_pixel(s, sw, c, ax, ay, sh);
+    }
+}
+
+// resize + letterbox in one pass (PreProcess whole, test_yolo.cpp:194-259): camera frame [sh][sw][3] BGR u8 -> the aspect-
+// preserving [hr][wr] bilinear resize (never written) -> RGB, pad(114), float, / 255 into the [H][W][3] slot of the input tensor
+__global__ void resize_letterbox_batch_kernel(const unsigned char* __restrict__ src, size_t src_stride, int sh, int sw, int hr, int wr,
+                                              float* __restrict__ dst, int H, int W, int pt, int pl) {
+    const double scx = (double)sw / (double)wr, scy = (double)sh / (double)hr;
+    const unsigned char* s = src + (size_t)blockIdx.y * src_stride;
+    float* d = dst + (size_t)blockIdx.y * H * W * 3;
+    const int total = H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        const int ry = y - pt, rx = x - pl;
+        float v[3] = {114.0f, 114.0f, 114.0f};
+        if (ry >= 0 && ry < hr && rx >= 0 && rx < wr) {
+            const ResizeAxis ax = resize_axis(rx, scx, sw), ay = resize_axis(ry, scy, sh);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = (float)resize_pixel(s, sw, 2 - c, ax, ay, sh);   // bgr -> rgb
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[(size_t)i * 3 + c] = v[c] / 255.0f;
+    }
+}
+
 // ---- post-processing workspace ----------------------------------------------------------------
 // per image, cap = rows candidates, nbins = classes + 1 (bin = label + 1; label -1 = "no class"):
 //   count[n] | bin_count[n][nbins] | keep[n][cap]            (zeroed at the start of every call, one memset)
@@ -484,6 +554,33 @@ int si_hip_letterbox_batch_u8_f32(const unsigned char* resized_bgr, int n, size_
     const unsigned gx = si_grid_for((size_t)height_new * width_new * 3 / 4);
     hipLaunchKernelGGL(letterbox_batch_kernel, dim3(gx > 512 ? 512 : gx, n), dim3(256), 0, (hipStream_t)stream, resized_bgr, image_stride_bytes,
                        height_resize, width_resize, out, height_new, width_new, padding_t, padding_l);
+    return (int)hipGetLastError();
+}
+
+int si_hip_resize_bilinear_u8c3(const unsigned char* src, int n, size_t src_stride_bytes, int src_h, int src_w, unsigned char* dst,
+                                size_t dst_stride_bytes, int dst_h, int dst_w, si_stream_t stream) {
+    if (n < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0 || (n > 0 && (!src || !dst))) return SI_E_BADARG;
+    if ((long long)dst_h * dst_w > 0x7fffffffLL / 3 || (long long)src_h * src_w > 0x7fffffffLL / 3 || n > 65535) return SI_E_UNSUPPORTED;
+    if (n == 0) return 0;
+    const unsigned gx = si_grid_for((size_t)dst_h * dst_w);
+    hipLaunchKernelGGL(resize_bilinear_u8c3_kernel, dim3(gx > 1024 ? 1024 : gx, n), dim3(256), 0, (hipStream_t)stream, src, src_stride_bytes,
+                       src_h, src_w, dst, dst_stride_bytes, dst_h, dst_w);
+    return (int)hipGetLastError();
+}
+
+int si_hip_resize_letterbox_batch_u8_f32(const unsigned char* frames_bgr, int n, size_t image_stride_bytes, int height_origin,
+                                         int width_origin, float* out, int height_new, int width_new, si_stream_t stream) {
+    if (n < 0 || !out || height_new <= 0 || width_new <= 0 || height_origin <= 0 || width_origin <= 0 || (n > 0 && !frames_bgr)) return SI_E_BADARG;
+    if ((long long)height_new * width_new * 3 > 0x7fffffffLL || (long long)height_origin * width_origin > 0x7fffffffLL / 3 || n > 65535)
+        return SI_E_UNSUPPORTED;
+    if (n == 0) return 0;
+    int hr = 0, wr = 0, pt = 0, pl = 0;
+    float scale = 0.f;
+    si_letterbox_geometry(height_origin, width_origin, height_new, width_new, &hr, &wr, &scale, &pt, &pl);
+    if (hr <= 0 || wr <= 0) return SI_E_BADARG;
+    const unsigned gx = si_grid_for((size_t)height_new * width_new);
+    hipLaunchKernelGGL(resize_letterbox_batch_kernel, dim3(gx > 1024 ? 1024 : gx, n), dim3(256), 0, (hipStream_t)stream, frames_bgr,
+                       image_stride_bytes, height_origin, width_origin, hr, wr, out, height_new, width_new, pt, pl);
     return (int)hipGetLastError();
 }
 

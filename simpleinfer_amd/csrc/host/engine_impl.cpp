@@ -21,9 +21,6 @@ namespace SimpleInfer {
 
 namespace {
 
-// option "streams" = 0 (auto): two lanes from this batch on
-constexpr int kAutoLanesMinBatch = 1 << 30;
-
 // built-in operator types whose kernels honour a pixel stride on inputs and outputs
 bool HonoursPixelStride(const std::string& type) {
     static const std::set<std::string> ok = {
@@ -60,7 +57,9 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
-    else if (key == "streams") opt_streams_ = value;  // 2: two half-batch lanes on two streams, 1: one stream, 0 (default): auto
+    else if (key == "streams") opt_streams_ = value;  // 2: two half-batch lanes on two streams, 1 (default): one stream
+    else if (key == "_fail_slicer") debug_fail_slicer_ = value != 0;  // tests: the sliced pipeline's setup fails half way
+    else if (key == "pin_inputs") opt_pin_inputs_ = value != 0;  // host_slices: pin a borrowed input buffer in place (default 0, see engine.h)
     else if (key == "host_slices") opt_host_slices_ = value;  // host tensors in and out: G pipelined batch slices per Forward(), 1 off, 0 (default) auto
     else {
         LOG(ERROR) << "unknown engine option [" << key << "]";
@@ -153,6 +152,7 @@ Status EngineImpl::Release() {
     if (context_ && context_->stream()) si_hip_stream_sync(context_->stream());
     CHECK_STATUS(DestroyGraphCache());   // (a captured graph references the lanes' streams and buffers)
     CHECK_STATUS(DestroySlicer());
+    slicer_failed_ = false;
     UnpinInputs();
     CHECK_STATUS(DestroyLanes());
     CHECK_STATUS(DeallocateTensorMemory());
@@ -266,8 +266,10 @@ Status EngineImpl::DestroyTensorNodes() {
 }
 
 Status EngineImpl::CreateLayers() {
+    has_user_layers_ = false;
     for (pnnx::Operator* op : graph_->ops) {
         if ("pnnx.Input" == op->type || "pnnx.Output" == op->type) continue;
+        if (IsUserRegisteredLayer(op->type)) has_user_layers_ = true;
         if (layers_.count(op->name) > 0) {
             LOG(ERROR) << "layer [" << op->name << "] already exists";
             return Status::kFail;
@@ -380,20 +382,14 @@ Status EngineImpl::CreatePipeline() {
         CHECK_STATUS(FuseEpilogues(order));
         CHECK_STATUS(FuseSiblingConvs(order));
         CHECK_STATUS(FusePoolChains(order));
-        if (opt_fuse_upsample_ && opt_alias_cat_ && !opt_fp16_) CHECK_STATUS(FuseUpsampleIntoConvs(order));
+        if (opt_fuse_upsample_ && opt_alias_cat_) CHECK_STATUS(FuseUpsampleIntoConvs(order));   // (fp16 storage too since round 4)
     }
     if (opt_fp16_) {
         CHECK_STATUS(InsertOutputCasts(order));
-        // every layer is asked NOW whether it has a kernel for the storage types it ended up with: an fp16 engine that cannot run
-        // a graph says so at LoadModel, with the layer and the reason (not at the first Forward)
-        for (const Step& st : order) {
-            std::string why;
-            if (!st.layer->HalfStorageOk(why)) {
-                LOG(ERROR) << "fp16 storage: layer [" << st.op->name << "] (" << st.op->type << ") cannot run: " << why
-                           << "; load the model without the fp16 option";
-                return Status::kUnsupport;
-            }
-        }
+        // every layer is asked NOW whether it has a kernel for the storage types it ended up with.  One that has none (a 3x3 conv
+        // whose channel count is not a multiple of 32, UnaryOp ...) runs its fp32 kernel between two casts (round 4); only what
+        // even that cannot serve makes LoadModel fail -- at load, with the layer and the reason, never at the first Forward
+        CHECK_STATUS(InsertFp32Fallbacks(order));
     }
     plan_ = order;
     if (opt_alias_cat_) CHECK_STATUS(AliasConcats());
@@ -724,6 +720,81 @@ Status EngineImpl::InsertOutputCasts(std::vector<Step>& order) {
     return Status::kSuccess;
 }
 
+// fp16 storage, a layer without an fp16 kernel: its half operands get fp32 SHADOW tensors -- a cast step in front of the layer
+// for every half tensor it reads (inputs, a fused residual), one behind it for every half tensor it writes -- and the layer runs
+// the kernel it has.  What the reference computes in fp32 (src/layer/conv_2d.cpp:94-101 rejects anything else) is then computed
+// in fp32 here too; the neighbours keep their fp16 storage.
+Status EngineImpl::InsertFp32Fallbacks(std::vector<Step>& order) {
+    int serial = 0;
+    for (size_t i = 0; i < order.size(); ++i) {
+        Layer* layer = order[i].layer;
+        std::string why;
+        if (layer->HalfStorageOk(why)) continue;
+        const std::string lname = order[i].op->name;
+        auto refuse = [&](const std::string& more) {
+            LOG(ERROR) << "fp16 storage: layer [" << lname << "] (" << order[i].op->type << ") cannot run: " << why << more
+                       << "; load the model without the fp16 option";
+            return Status::kUnsupport;
+        };
+        auto shadow_of = [&](TensorNode* n, const char* tag) {
+            TensorNode* sh = new TensorNode;
+            sh->operand = n->operand;
+            sh->tensor = Tensor(DataType::kFloat32, n->tensor.Shape(), MemoryType::kDevice, false);
+            tensor_nodes_[(n->operand ? n->operand->name : lname) + "#" + tag + std::to_string(serial++)] = sh;
+            return sh;
+        };
+        std::vector<Step> before, after;
+        auto cast_step = [&](TensorNode* from, TensorNode* to, const char* suffix, std::vector<Step>& where) -> Status {
+            OutputCast* cast = new OutputCast(lname, (std::string(suffix) + std::to_string(serial++)).c_str());
+            layers_[cast->GetOp()->name] = cast;
+            cast->SetContext(context_);
+            cast->SetInputNodes({from});
+            cast->SetOutputNodes({to});
+            CHECK_STATUS(cast->Validate());
+            Step s;
+            s.layer = cast;
+            s.op = cast->GetOp();
+            where.push_back(s);
+            return Status::kSuccess;
+        };
+        std::map<TensorNode*, TensorNode*> in_shadow;
+        std::vector<TensorNode*> ins = layer->InputNodes(), outs = layer->OutputNodes(), extra;
+        layer->ExtraReads(extra);
+        for (TensorNode*& n : ins) {
+            if (n->tensor.GetDataType() != DataType::kFloat16) continue;
+            if (!in_shadow.count(n)) {
+                in_shadow[n] = shadow_of(n, "f32in");
+                CHECK_STATUS(cast_step(n, in_shadow[n], ".in_to_f32.", before));
+            }
+            n = in_shadow[n];
+        }
+        for (TensorNode* n : extra) {
+            if (n->tensor.GetDataType() != DataType::kFloat16) continue;
+            if (!in_shadow.count(n)) {
+                in_shadow[n] = shadow_of(n, "f32in");
+                CHECK_STATUS(cast_step(n, in_shadow[n], ".in_to_f32.", before));
+            }
+            if (!layer->ReplaceExtraRead(n, in_shadow[n])) return refuse(" (and its fused extra operand cannot be rebound to an fp32 copy)");
+        }
+        for (TensorNode*& n : outs) {
+            if (n->tensor.GetDataType() != DataType::kFloat16) continue;
+            TensorNode* sh = shadow_of(n, "f32out");
+            CHECK_STATUS(cast_step(sh, n, ".out_to_f16.", after));
+            n = sh;
+        }
+        layer->SetInputNodes(ins);
+        layer->SetOutputNodes(outs);
+        std::string still;
+        if (Status::kSuccess != layer->Validate() || !layer->HalfStorageOk(still)) return refuse(still.empty() ? "" : " / with fp32 operands: " + still);
+        LOG(INFO) << "fp16 storage: layer [" << lname << "] has no fp16 kernel (" << why << "): it runs in fp32 between " << before.size()
+                  << " + " << after.size() << " casts";
+        order.insert(order.begin() + i + 1, after.begin(), after.end());
+        order.insert(order.begin() + i, before.begin(), before.end());
+        i += before.size() + after.size();
+    }
+    return Status::kSuccess;
+}
+
 // torch.cat on the channel axis: every eligible input operand becomes a view into the concat output
 // (same pixel grid, pixel stride = total channels), so its producer writes in place and Cat::Forward
 // finds nothing left to copy.
@@ -845,20 +916,18 @@ Status EngineImpl::AllocateTensorMemory() {
             if (off + b.bytes > total) total = off + b.bytes;
             placed.push_back(bi);
         }
-        void* arena = nullptr;
-        SI_TRY_HIP(si_hip_malloc(&arena, total), "hipMalloc activation arena");
-        device_allocs_.push_back(arena);
         arena_bytes_ = total;
-        for (Buf& b : bufs) b.node->tensor.SetView(static_cast<char*>(arena) + b.offset, MemoryType::kDevice, 0);
+        arena_plan_.clear();
+        for (Buf& b : bufs) arena_plan_.push_back(ArenaSlot{b.node, b.offset});
+        arena_plan_bytes_ = total;
+        arena_pending_ = true;
         LOG(INFO) << "activation arena: " << total << " bytes for " << bufs.size() << " operands (" << unshared_bytes_ << " without sharing)";
     }
-    // 2. aliases point into their concat buffer
-    for (auto& kv : aliases_) {
-        Tensor& t = tensor_nodes_[kv.first]->tensor;
-        Tensor& parent = kv.second.parent->tensor;
-        t.SetView(static_cast<char*>(parent.RawData()) + (size_t)kv.second.channel_offset * ElementSize(parent.GetDataType()),
-                  MemoryType::kDevice, parent.Shape().back());
-    }
+    // An engine whose forwards may all be served by the sliced host pipeline (host outputs, slicing not switched off, not a lane)
+    // leaves the arena to the first forward that runs its OWN plan: the slicer has an arena of its own, and this one would be a
+    // second, never-touched allocation.  Everyone else allocates now, so LoadModel reports an arena that does not fit.
+    const bool defer = arena_pending_ && !is_lane_ && opt_outputs_to_host_ && opt_host_slices_ != 1 && lanes_.empty();
+    if (!defer) CHECK_STATUS(EnsureArena());
     // 3. pinned host mirrors for outputs
     if (opt_outputs_to_host_) {
         for (auto& kv : output_tensor_nodes_) {
@@ -870,7 +939,33 @@ Status EngineImpl::AllocateTensorMemory() {
     return Status::kSuccess;
 }
 
+// allocate the planned arena (once) and point the operands -- and the concat aliases, which hang off them -- into it
+Status EngineImpl::EnsureArena() {
+    if (arena_pending_) {
+        void* arena = nullptr;
+        SI_TRY_HIP(si_hip_malloc(&arena, arena_plan_bytes_), "hipMalloc activation arena");
+        device_allocs_.push_back(arena);
+        for (const ArenaSlot& b : arena_plan_) b.node->tensor.SetView(static_cast<char*>(arena) + b.offset, MemoryType::kDevice, 0);
+        arena_pending_ = false;
+    }
+    if (!aliases_bound_) {
+        for (auto& kv : aliases_) {
+            Tensor& t = tensor_nodes_[kv.first]->tensor;
+            Tensor& parent = kv.second.parent->tensor;
+            if (parent.RawData() == nullptr) continue;
+            t.SetView(static_cast<char*>(parent.RawData()) + (size_t)kv.second.channel_offset * ElementSize(parent.GetDataType()),
+                      MemoryType::kDevice, parent.Shape().back());
+        }
+        aliases_bound_ = true;
+    }
+    return Status::kSuccess;
+}
+
 Status EngineImpl::DeallocateTensorMemory() {
+    arena_plan_.clear();
+    arena_plan_bytes_ = 0;
+    arena_pending_ = false;
+    aliases_bound_ = false;
     for (void* p : device_allocs_) si_hip_free(p);
     device_allocs_.clear();
     input_buffers_.clear();
@@ -908,7 +1003,7 @@ bool EngineImpl::BatchSplittable(int& batch) const {
 
 Status EngineImpl::PlanLanes(int& lanes) {
     lanes = 1;
-    if (is_lane_ || opt_streams_ == 1) return Status::kSuccess;
+    if (is_lane_ || opt_streams_ < 2) return Status::kSuccess;
     int batch = 0;
     const bool ok = BatchSplittable(batch) && batch % 2 == 0;
     if (opt_streams_ >= 2) {
@@ -917,10 +1012,7 @@ Status EngineImpl::PlanLanes(int& lanes) {
             return Status::kUnsupport;
         }
         lanes = 2;
-        return Status::kSuccess;
     }
-    // auto: where the same-box A/B wins (profiles/r03_ab_streams.txt)
-    if (ok && batch >= kAutoLanesMinBatch) lanes = 2;
     return Status::kSuccess;
 }
 
@@ -1010,7 +1102,8 @@ Status EngineImpl::LaunchLanes() {
 // Forward is pinned in place (hipHostRegister) so its uploads run asynchronously at the link rate.  Bit-identical to the
 // unsliced schedule (per-image arithmetic; tests/test_gpu_engine.py::test_host_tensor_pipeline_*).
 int EngineImpl::PlanSlices() const {
-    if (is_lane_ || opt_host_slices_ == 1 || !opt_outputs_to_host_) return 1;
+    if (is_lane_ || opt_host_slices_ == 1 || !opt_outputs_to_host_ || slicer_failed_) return 1;
+    if (!lanes_.empty()) return 1;   // "streams" = 2 was asked for: the lanes serve the engine
     int batch = 0;
     if (!BatchSplittable(batch)) return 1;
     for (auto& kv : input_tensor_nodes_) {
@@ -1019,6 +1112,9 @@ int EngineImpl::PlanSlices() const {
     }
     if (!user_outputs_.empty()) return 1;   // caller-owned device outputs: not the host contract
     if (opt_host_slices_ > 1) return batch % opt_host_slices_ == 0 ? opt_host_slices_ : 1;
+    // auto re-batches the model to N / G: every built-in operator is per-image, a layer registered at run time
+    // (RegisterLayer) may not be -- such a graph is sliced only on an explicit host_slices > 1
+    if (has_user_layers_) return 1;
     // auto (MI355X, YOLOv5s 640x640, profiles/r03_host_slices.txt): slices of 8 images from batch 32 on (a batch-8 forward is still
     // at 0.6 of the MFMA ceiling, and 8 images are 39 MB up / 69 MB down -- 0.7 / 1.3 ms of PCIe outside the overlap), slices of 4
     // for batches 8 .. 31 (batch 8: 3.49 -> 2.95 ms per Forward with 2 slices; batch 16: 6.61 -> 4.95 with 4); at most 8 slices
@@ -1052,40 +1148,46 @@ void EngineImpl::UnpinInputs() {
     pinned_inputs_.clear();
 }
 
+// everything the sliced pipeline needs; slices_ is set LAST, so a failure half way leaves nothing that looks usable
+Status EngineImpl::SetupSlicer(int slices) {
+    CHECK_STATUS(DestroySlicer());
+    int batch = 0;
+    CHECK_BOOL(BatchSplittable(batch) && batch % slices == 0);
+    slicer_ = new EngineImpl;
+    slicer_->is_lane_ = true;
+    slicer_->opt_device_ = context_->device();
+    slicer_->opt_fuse_ = opt_fuse_;
+    slicer_->opt_alias_cat_ = opt_alias_cat_;
+    slicer_->opt_fuse_upsample_ = opt_fuse_upsample_;
+    slicer_->opt_arena_ = opt_arena_;
+    slicer_->opt_winograd_ = opt_winograd_;
+    slicer_->opt_detect_stream_ = opt_detect_stream_;
+    slicer_->opt_fp16_ = opt_fp16_;
+    slicer_->opt_graph_ = opt_graph_;          // one captured graph per slice (its I/O pointers key the cache) ...
+    slicer_->max_graphs_ = std::max<size_t>(max_graphs_, (size_t)slices);   // ... so the cache holds at least one per slice
+    slicer_->opt_outputs_to_host_ = false;
+    slicer_->opt_streams_ = 1;
+    slicer_->opt_batch_ = batch / slices;
+    CHECK_STATUS(slicer_->LoadModel(param_path_, bin_path_));
+    up_context_ = new Context;
+    CHECK_STATUS(up_context_->Init(context_->device()));
+    if (debug_fail_slicer_) return Status::kFail;
+    down_context_ = new Context;
+    CHECK_STATUS(down_context_->Init(context_->device()));
+    ev_up_.assign((size_t)slices, nullptr);
+    ev_done_.assign((size_t)slices, nullptr);
+    for (auto& e : ev_up_) SI_TRY_HIP(si_hip_event_create(&e), "event create");
+    for (auto& e : ev_done_) SI_TRY_HIP(si_hip_event_create(&e), "event create");
+    SI_TRY_HIP(si_hip_event_create(&ev_down_all_), "event create");
+    if (!ev_fork_) SI_TRY_HIP(si_hip_event_create(&ev_fork_), "event create");
+    slices_ = slices;
+    LOG(INFO) << "host_slices: " << slices << " pipelined slices of batch " << batch / slices;
+    return Status::kSuccess;
+}
+
 Status EngineImpl::ForwardSliced(int slices) {
     si_stream_t stream = context_->stream();
-    if (slicer_ == nullptr || slices_ != slices) {
-        CHECK_STATUS(DestroySlicer());
-        int batch = 0;
-        CHECK_BOOL(BatchSplittable(batch) && batch % slices == 0);
-        slicer_ = new EngineImpl;
-        slicer_->is_lane_ = true;
-        slicer_->opt_device_ = context_->device();
-        slicer_->opt_fuse_ = opt_fuse_;
-        slicer_->opt_alias_cat_ = opt_alias_cat_;
-        slicer_->opt_fuse_upsample_ = opt_fuse_upsample_;
-        slicer_->opt_arena_ = opt_arena_;
-        slicer_->opt_winograd_ = opt_winograd_;
-        slicer_->opt_detect_stream_ = opt_detect_stream_;
-        slicer_->opt_fp16_ = opt_fp16_;
-        slicer_->opt_graph_ = opt_graph_;          // one captured graph per slice (its I/O pointers key the cache)
-        slicer_->opt_outputs_to_host_ = false;
-        slicer_->opt_streams_ = 1;
-        slicer_->opt_batch_ = batch / slices;
-        CHECK_STATUS(slicer_->LoadModel(param_path_, bin_path_));
-        slices_ = slices;
-        up_context_ = new Context;
-        CHECK_STATUS(up_context_->Init(context_->device()));
-        down_context_ = new Context;
-        CHECK_STATUS(down_context_->Init(context_->device()));
-        ev_up_.assign((size_t)slices, nullptr);
-        ev_done_.assign((size_t)slices, nullptr);
-        for (auto& e : ev_up_) SI_TRY_HIP(si_hip_event_create(&e), "event create");
-        for (auto& e : ev_done_) SI_TRY_HIP(si_hip_event_create(&e), "event create");
-        SI_TRY_HIP(si_hip_event_create(&ev_down_all_), "event create");
-        if (!ev_fork_) SI_TRY_HIP(si_hip_event_create(&ev_fork_), "event create");
-        LOG(INFO) << "host_slices: " << slices << " pipelined slices of batch " << batch / slices;
-    }
+    CHECK_BOOL(slicer_ != nullptr && slices_ == slices);
     // the engine's device-side input staging and its own output buffers, whole batch; the slices are views
     for (auto& kv : input_tensor_nodes_) kv.second->tensor.SetView(input_buffers_[kv.first], MemoryType::kDevice, 0);
     CHECK_STATUS(BindOutputs());
@@ -1099,7 +1201,9 @@ Status EngineImpl::ForwardSliced(int slices) {
             p.ptr = host.RawData();
             p.bytes = host.ByteSize();
         }
-        if (++p.seen == 2 && !p.registered) {
+        // (opt-in, "pin_inputs": a registration outlives this call, so the caller has to keep the buffer mapped until the next
+        // Input() / Release -- freeing it after Forward(), which the reference's borrow allows, would leave a stale registration)
+        if (opt_pin_inputs_ && ++p.seen == 2 && !p.registered) {
             p.registered = si_hip_host_register(const_cast<void*>(p.ptr), p.bytes) == 0;   // (failure: the uploads stay staged copies)
             if (!p.registered) LOG(INFO) << "host_slices: could not pin the input buffer of [" << kv.first << "]; uploads stay staged";
         }
@@ -1292,7 +1396,16 @@ Status EngineImpl::ForwardAsync() {
     }
     si_hip_set_device(context_->device());
     si_stream_t stream = context_->stream();
-    if (const int slices = PlanSlices(); slices > 1) return ForwardSliced(slices);
+    if (const int slices = PlanSlices(); slices > 1) {
+        if (slicer_ != nullptr && slices_ == slices) return ForwardSliced(slices);
+        if (Status::kSuccess == SetupSlicer(slices)) return ForwardSliced(slices);
+        // (a second arena that does not fit, an operator the re-batch rule cannot serve ...): the unsliced schedule below worked
+        // before there was a pipeline and still does; remembered, so the setup is not retried on every Forward
+        LOG(ERROR) << "host_slices: could not set up " << slices << " pipelined slices; serving this engine unsliced";
+        DestroySlicer();
+        slicer_failed_ = true;
+    }
+    CHECK_STATUS(EnsureArena());
     CHECK_STATUS(UploadInputs());
     CHECK_STATUS(BindOutputs());
     if (!lanes_.empty()) CHECK_STATUS(BindLanes());
@@ -1317,8 +1430,7 @@ Status EngineImpl::ForwardAsync() {
             const int rc = si_hip_graph_end_capture(stream, &exec);
             CHECK_STATUS(ret);
             SI_TRY_HIP(rc, "end capture");
-            constexpr size_t kMaxGraphs = 8;
-            if (graph_cache_.size() >= kMaxGraphs) {
+            if (graph_cache_.size() >= max_graphs_) {
                 // the evicted exec may be the one a not-yet-synchronised ForwardAsync() launched: let the stream drain first
                 SI_TRY_HIP(si_hip_stream_sync(stream), "stream sync");
                 si_hip_graph_destroy(graph_cache_.back().second);
@@ -1366,6 +1478,7 @@ Status EngineImpl::Profile(std::vector<LayerProfile>& layers) {
     layers.clear();
     if (nullptr == context_ || (plan_.empty() && lanes_.empty())) return Status::kFail;
     si_stream_t stream = context_->stream();
+    CHECK_STATUS(EnsureArena());
     CHECK_STATUS(UploadInputs());
     CHECK_STATUS(BindOutputs());
     if (!lanes_.empty()) {

@@ -98,6 +98,7 @@ private:
     Status FusePoolChains(std::vector<Step>& order);
     Status FuseUpsampleIntoConvs(std::vector<Step>& order);
     Status InsertOutputCasts(std::vector<Step>& order);
+    Status InsertFp32Fallbacks(std::vector<Step>& order);
     Status AliasConcats();
     Status UploadInputs();
     Status BindOutputs();
@@ -115,7 +116,9 @@ private:
     bool BatchSplittable(int& batch) const;
     int PlanSlices() const;
     Status ForwardSliced(int slices);
+    Status SetupSlicer(int slices);
     Status DestroySlicer();
+    Status EnsureArena();
     void UnpinInputs();
 
 private:
@@ -131,8 +134,9 @@ private:
     int opt_batch_ = 0;          // > 0: serve this batch whatever batch the file was traced with
     int opt_detect_stream_ = 1;        // Detect's early levels on a second stream beside the layers that follow their inputs: 0 never, 1 for levels with enough work, 2 always
     bool opt_fp16_ = false;      // fp16 storage for internal activations and weights (BASELINE.json configs[3])
-    int opt_streams_ = 0;        // 2: two half-batch lanes on two streams; 1: one stream; 0 (default): 2 where it was measured faster
+    int opt_streams_ = 1;        // 2: two half-batch lanes on two streams; 1 (default): one stream
     int opt_host_slices_ = 0;    // host inputs + host outputs: G batch slices pipelined over PCIe inside one Forward(); 1: off; 0 (default): auto
+    bool opt_pin_inputs_ = false; // the sliced pipeline may hipHostRegister a borrowed input buffer in place (opt-in: the caller keeps it mapped until the next Input() / Release)
 
     Context* context_ = nullptr;
     Context* side_context_ = nullptr;        // second stream (option "detect_stream"); created with the first plan that uses it
@@ -157,7 +161,18 @@ private:
     // the sliced host pipeline: ONE child engine of batch N / slices_ that runs the slices one after the other, an upload and a
     // download stream beside it
     EngineImpl* slicer_ = nullptr;
-    int slices_ = 0;
+    int slices_ = 0;                         // set only once every resource of the pipeline exists
+    bool debug_fail_slicer_ = false;         // option "_fail_slicer" (tests)
+    bool slicer_failed_ = false;             // setting the pipeline up failed once: serve unsliced from then on
+    bool has_user_layers_ = false;           // a layer type registered at run time (RegisterLayer): nothing is known about its batch semantics
+    size_t max_graphs_ = 8;                  // captured hipGraphs kept (one per distinct set of I/O pointers)
+    // the activation arena is planned at LoadModel but allocated at the first forward that runs THIS engine's plan (an engine
+    // served by the sliced host pipeline never needs it)
+    struct ArenaSlot { TensorNode* node; size_t offset; };
+    std::vector<ArenaSlot> arena_plan_;
+    size_t arena_plan_bytes_ = 0;
+    bool arena_pending_ = false;
+    bool aliases_bound_ = false;
     Context* up_context_ = nullptr;
     Context* down_context_ = nullptr;
     std::vector<si_event_t> ev_up_, ev_done_;

@@ -59,6 +59,8 @@ public:
     // tensors a layer reads besides its bound input nodes (fusion hooks: a conv's residual, its upsampled source); the engine's
     // memory planner needs every reader of a buffer
     virtual void ExtraReads(std::vector<TensorNode*>& nodes) const { (void)nodes; }
+    // rebind one of the ExtraReads nodes (the engine's fp32 fallback hands a layer fp32 shadows of its half operands); false: cannot
+    virtual bool ReplaceExtraRead(TensorNode* from, TensorNode* to) { (void)from; (void)to; return false; }
     // the stream this layer's launches go to (its context's)
     si_stream_t LaunchStream() const { return Stream(); }
     // fp16 storage (Engine option "fp16"): can this layer run with the storage types its bound nodes now have?  Asked once, at

@@ -226,18 +226,20 @@ Status Conv2d::PrepareDeviceHalf(const SiConv2dDesc& d) {
                    << " (needs ic/groups % 32 == 0)";
         return Status::kUnsupport;
     }
-    std::vector<uint16_t> packed(si_hip_conv2d_f16_weight_elems(&d));
-    CHECK_STATUS(CheckHip(si_hip_conv2d_f16_pack_weight_host(&d, weight_.data(), packed.data()), "pack fp16 weight"));
+    // sibling fusion: ONE conv over the concatenated filters (OIHW: the sibling's rows follow this layer's), packed as a whole --
+    // the packed buffer holds two images (rows, then MFMA lane order, include/si_hip.h), so two packed buffers cannot be appended
+    SiConv2dDesc df = d;
+    std::vector<float> w_all = weight_;
     std::vector<float> bias_all = bias_;
     if (sibling_) {
-        SiConv2dDesc ds = d;
-        ds.oc = sibling_->out_channels_;
-        CHECK_BOOL(sibling_->weight_.size() == (size_t)ds.oc * in_channels_);
-        std::vector<uint16_t> packed2(si_hip_conv2d_f16_weight_elems(&ds));
-        CHECK_STATUS(CheckHip(si_hip_conv2d_f16_pack_weight_host(&ds, sibling_->weight_.data(), packed2.data()), "pack sibling weight"));
-        packed.insert(packed.end(), packed2.begin(), packed2.end());
+        CHECK_BOOL(sibling_->weight_.size() == (size_t)sibling_->out_channels_ * in_channels_);
+        df.oc = d.oc + sibling_->out_channels_;
+        w_all.insert(w_all.end(), sibling_->weight_.begin(), sibling_->weight_.end());
         if (use_bias_) bias_all.insert(bias_all.end(), sibling_->bias_.begin(), sibling_->bias_.end());
     }
+    std::vector<uint16_t> packed(si_hip_conv2d_f16_weight_elems(&df));
+    CHECK_BOOL(!packed.empty());
+    CHECK_STATUS(CheckHip(si_hip_conv2d_f16_pack_weight_host(&df, w_all.data(), packed.data()), "pack fp16 weight"));
     CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(uint16_t)), "upload weight"));
     if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_all.data(), bias_all.size() * sizeof(float)), "upload bias"));
     device_ready_ = true;
@@ -285,6 +287,14 @@ Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
         if (di.c != in_channels_ || d0.c != out_channels_ || d1.c != sibling_->out_channels_ || d0.pixels() != d1.pixels()) return Status::kErrorShape;
         SiConv2dDesc d = MakeDesc(in[0], out[0]);
         d.oc = out_channels_ + sibling_->out_channels_;
+        if (mode == 1 && up_node_) {
+            if (!IsHalf(in[0])) return Status::kUnsupport;
+            SiConv2dUpsampledSource up;
+            CHECK_STATUS(MakeUpsampledSource(up));
+            return CheckHip(si_hip_conv2d_upcat_f16(&d, in[0].RawData(), &up, weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                    out[0].RawData(), out_channels_, out[1].RawData(), out[1].PixelStride(), Stream()),
+                            "conv2d fp16 (fused siblings, upsampled source)");
+        }
         if (mode == 1) {
             Tensor xin;
             CHECK_STATUS(HalfInput(in[0], xin));
@@ -333,6 +343,14 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
                                                     residual ? residual->RawData() : nullptr, output.RawData(), Stream()),
                         "conv2d depthwise fp16");
     }
+    if (mode == 1 && up_node_) {
+        if (residual || !IsHalf(input) || !IsHalf(output)) return Status::kUnsupport;
+        SiConv2dUpsampledSource up;
+        CHECK_STATUS(MakeUpsampledSource(up));
+        return CheckHip(si_hip_conv2d_upcat_f16(&d, input.RawData(), &up, weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                output.RawData(), 0, nullptr, 0, Stream()),
+                        "conv2d fp16 (upsampled source)");
+    }
     if (mode == 1) {
         if (residual && !IsHalf(*residual)) return Status::kUnsupport;
         Tensor xin;
@@ -379,7 +397,10 @@ bool Conv2d::CanReadUpsampledFrom(const TensorNode* low, int c0, float scale_h, 
     Dims4 lo, di, dout;
     if (!low || input_tensor_nodes_.size() != 1 || output_tensor_nodes_.empty()) return false;
     if (!GetDims4(low->tensor, lo) || !GetDims4(input_tensor_nodes_[0]->tensor, di) || !GetDims4(output_tensor_nodes_[0]->tensor, dout)) return false;
-    if (IsHalf(low->tensor) || IsHalf(input_tensor_nodes_[0]->tensor) || !CanReadUpsampled(c0, lo.c) || scale_h <= 0.f || scale_w <= 0.f) return false;
+    const bool half = IsHalf(low->tensor);
+    // fp16 storage (round 4): both sources and the output half (a graph-output conv writes fp32 through the plain kernel only)
+    if (half != IsHalf(input_tensor_nodes_[0]->tensor) || (half && !IsHalf(output_tensor_nodes_[0]->tensor))) return false;
+    if (!CanReadUpsampled(c0, lo.c) || scale_h <= 0.f || scale_w <= 0.f) return false;
     SiConv2dDesc d = MakeDesc(input_tensor_nodes_[0]->tensor, output_tensor_nodes_[0]->tensor);
     d.in_ld = di.c;   // (the concat buffer is dense: the conv's input IS the concat output)
     if (sibling_) d.oc = out_channels_ + sibling_->out_channels_;
@@ -387,6 +408,11 @@ bool Conv2d::CanReadUpsampledFrom(const TensorNode* low, int c0, float scale_h, 
     memset(&up, 0, sizeof(up));
     up.ih = lo.h; up.iw = lo.w; up.c = lo.c; up.ld = lo.c; up.c0 = c0;
     up.inv_scale_h = 1.0f / scale_h; up.inv_scale_w = 1.0f / scale_w;
+    if (half) {
+        for (const TensorNode* o : output_tensor_nodes_)
+            if (!IsHalf(o->tensor)) return false;
+        return si_hip_conv2d_upcat_f16_supported(&d, &up) == 1;
+    }
     return si_hip_conv2d_upcat_supported(&d, &up) == 1;
 }
 
@@ -399,8 +425,8 @@ void Conv2d::SetUpsampledSource(TensorNode* low, int c0, float scale_h, float sc
 
 Status Conv2d::MakeUpsampledSource(SiConv2dUpsampledSource& up) const {
     Dims4 lo;
-    if (!up_node_ || !GetDims4(up_node_->tensor, lo) || IsHalf(up_node_->tensor)) return Status::kUnsupport;
-    up.src = up_node_->tensor.Data<float>();
+    if (!up_node_ || !GetDims4(up_node_->tensor, lo)) return Status::kUnsupport;
+    up.src = static_cast<const float*>(up_node_->tensor.RawData());   // (half data for si_hip_conv2d_upcat_f16: include/si_hip.h)
     up.ih = lo.h; up.iw = lo.w; up.c = lo.c; up.ld = up_node_->tensor.PixelStride();
     up.c0 = up_c0_;
     up.inv_scale_h = 1.0f / up_scale_h_;   // as si_hip_upsample_nearest_f32 forms it (reference upsample.cpp:85-92)

@@ -37,6 +37,10 @@ public:
         if (residual_node_) nodes.push_back(residual_node_);
         if (up_node_) nodes.push_back(up_node_);
     }
+    virtual bool ReplaceExtraRead(TensorNode* from, TensorNode* to) override {
+        if (from && from == residual_node_) { residual_node_ = to; return true; }
+        return false;   // (an upsampled source is only ever set on a conv that has a kernel for its storage types)
+    }
     int WinogradTile(const SiConv2dDesc& d) const;
     virtual double Flops() const override;
     virtual double Bytes() const override;

@@ -1,6 +1,7 @@
 #include "layer_registry.h"
 
 #include <map>
+#include <set>
 
 namespace SimpleInfer {
 
@@ -60,11 +61,19 @@ const LayerRegistryEntry* GetLayerRegistry(std::string type) {
     return it == t.end() ? nullptr : &it->second;
 }
 
+static std::set<std::string>& UserTypes() {
+    static std::set<std::string> types;
+    return types;
+}
+
 bool RegisterLayer(const std::string& type, LayerCreatorFunc creator, LayerDestroyerFunc destroyer) {
     if (!creator || !destroyer) return false;
     Table()[type] = LayerRegistryEntry{creator, destroyer};
+    UserTypes().insert(type);
     return true;
 }
+
+bool IsUserRegisteredLayer(const std::string& type) { return UserTypes().count(type) > 0; }
 
 std::vector<std::string> RegisteredLayerTypes() {
     std::vector<std::string> out;

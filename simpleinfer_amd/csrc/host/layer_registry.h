@@ -25,4 +25,9 @@ bool RegisterLayer(const std::string& type, LayerCreatorFunc creator, LayerDestr
 
 std::vector<std::string> RegisteredLayerTypes();
 
+// true for a type whose entry came from RegisterLayer (also one that replaced a built-in): the engine knows nothing about such
+// a layer beyond the Layer interface -- in particular not whether it is per-image -- and does not re-batch graphs that hold one
+// unless asked to (Engine option "host_slices" > 1, "batch")
+bool IsUserRegisteredLayer(const std::string& type);
+
 }  // namespace SimpleInfer

@@ -3,6 +3,7 @@
 // No reference counterpart (SimpleInfer is single-process); the partitioning it serves is SURVEY.md 8(e).
 #include "si_shard.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -178,6 +179,132 @@ int si_group_allgather(SiNodeGroup* g, const void* mine, size_t bytes, void* all
 
 }  // extern "C"
 
+// ---- RCCL behind the C-ABI -----------------------------------------------------------------------------------------------
+// librccl.so is loaded with dlopen at the first use: nothing links against it, and the five entry points are declared here with
+// the (stable, NCCL-compatible) C signatures of rccl.h -- ncclResult_t is an int, ncclComm_t an opaque pointer, ncclUniqueId 128
+// opaque bytes passed BY VALUE, ncclChar = 0.
+namespace {
+
+struct RcclUniqueId { char internal[128]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclUniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+
+RcclApi& rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        // SI_RCCL_LIB, when set, is the ONLY file tried (a test can name one that does not exist)
+        const char* forced = getenv("SI_RCCL_LIB");
+        const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        if (forced && forced[0]) {
+            a.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char* n : defaults) {
+                a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                if (a.lib) break;
+            }
+        }
+        if (!a.lib) return a;
+        a.GetUniqueId = reinterpret_cast<int (*)(RcclUniqueId*)>(dlsym(a.lib, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<int (*)(void**, int, RcclUniqueId, int)>(dlsym(a.lib, "ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(a.lib, "ncclCommDestroy"));
+        a.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, void*)>(dlsym(a.lib, "ncclAllGather"));
+        a.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(a.lib, "ncclGetErrorString"));
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
+
+int rccl_fail(const char* what, int res) {
+    LOG(ERROR) << what << ": RCCL error " << res << " (" << (rccl_api().GetErrorString ? rccl_api().GetErrorString(res) : "?") << ")";
+    return SI_SHARD_E_RCCL;
+}
+
+}  // namespace
+
+struct SiRcclComm {
+    void* comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
+
+extern "C" {
+
+int si_rccl_available(void) { return rccl_api().ok ? 1 : 0; }
+
+int si_rccl_init(SiNodeGroup* g, int device, SiRcclComm** out) {
+    if (!out) return SI_SHARD_E_BADARG;
+    *out = nullptr;
+    if (!g) return SI_SHARD_E_BADARG;
+    RcclApi& api = rccl_api();
+    // every rank learns whether every rank has the library before anybody enters a collective that the others would hang in
+    int32_t have = api.ok ? 1 : 0;
+    std::vector<int32_t> all((size_t)g->world);
+    int rc = si_group_allgather(g, &have, sizeof(have), all.data());
+    if (rc != 0) return rc;
+    for (int32_t v : all)
+        if (!v) {
+            if (!api.ok) LOG(ERROR) << "si_rccl_init: librccl.so could not be loaded (" << (dlerror() ? "dlopen failed" : "symbols missing") << "); SI_RCCL_LIB names another file";
+            return api.ok ? SI_SHARD_E_PEER : SI_SHARD_E_SYS;
+        }
+    RcclUniqueId id;
+    memset(&id, 0, sizeof(id));
+    int res = 0;
+    if (g->rank == 0) res = api.GetUniqueId(&id);
+    std::vector<RcclUniqueId> ids((size_t)g->world);
+    rc = si_group_allgather(g, &id, sizeof(id), ids.data());
+    if (rc != 0) return rc;
+    int mine = res != 0 ? rccl_fail("ncclGetUniqueId", res) : si_hip_set_device(device);
+    void* comm = nullptr;
+    if (mine == 0) {
+        res = api.CommInitRank(&comm, g->world, ids[0], g->rank);
+        if (res != 0) mine = rccl_fail("ncclCommInitRank", res);
+    }
+    // (ncclCommInitRank is itself collective: a rank that failed BEFORE it leaves the others waiting inside RCCL until its own
+    // timeout; what can be agreed on here is the outcome)
+    std::vector<int32_t> rcs((size_t)g->world);
+    const int32_t m32 = mine;
+    rc = si_group_allgather(g, &m32, sizeof(m32), rcs.data());
+    if (rc == 0 && mine == 0)
+        for (int32_t v : rcs) if (v != 0) rc = SI_SHARD_E_PEER;
+    if (mine != 0) rc = mine;
+    if (rc != 0) {
+        if (comm) api.CommDestroy(comm);
+        return rc;
+    }
+    SiRcclComm* c = new (std::nothrow) SiRcclComm;
+    if (!c) { api.CommDestroy(comm); return SI_SHARD_E_SYS; }
+    c->comm = comm; c->rank = g->rank; c->world = g->world; c->device = device;
+    *out = c;
+    return 0;
+}
+
+int si_rccl_allgather(SiRcclComm* c, const void* send, void* recv, size_t bytes_per_rank, si_stream_t stream) {
+    if (!c || !c->comm || !send || !recv) return SI_SHARD_E_BADARG;
+    const int res = rccl_api().AllGather(send, recv, bytes_per_rank, /*ncclChar*/ 0, c->comm, stream);
+    return res == 0 ? 0 : rccl_fail("ncclAllGather", res);
+}
+
+int si_rccl_destroy(SiRcclComm* c) {
+    if (!c) return 0;
+    int rc = 0;
+    if (c->comm) {
+        si_hip_set_device(c->device);
+        const int res = rccl_api().CommDestroy(c->comm);
+        if (res != 0) rc = rccl_fail("ncclCommDestroy", res);
+    }
+    delete c;
+    return rc;
+}
+
+}  // extern "C"
+
 // ---- direct all-gather -----------------------------------------------------------------------------------------------
 struct SiDirectGather {
     SiNodeGroup* group = nullptr;
@@ -188,8 +315,14 @@ struct SiDirectGather {
     std::vector<si_stream_t> stream;         // [rank] copy stream towards that peer
     std::vector<si_event_t> ready;           // [slot] producer finished writing the slab
     std::vector<std::vector<si_event_t>> sent;  // [slot][rank] my slab of that slot has landed in that peer
+    std::vector<std::vector<si_event_t>> start; // [slot][rank] recorded on the copy stream right before that copy (bandwidth = slab / (sent - start))
     std::vector<char> pushed;                // [slot] a push is outstanding
     SiGatherStats stats;                     // since the last reset
+    // SI_GATHER_RCCL: the same slot buffers, filled by an in-place ncclAllGather on `coll_stream` behind the producer; sent[slot][rank]
+    // of THIS rank is the event that collective records
+    int mode = SI_GATHER_DIRECT;
+    SiRcclComm* rccl = nullptr;
+    si_stream_t coll_stream = nullptr;
 };
 
 namespace {
@@ -216,8 +349,11 @@ int agree(SiNodeGroup* g, int rc) {
 void release(SiDirectGather* d) {
     for (auto& slots : d->peer) for (void* p : slots) if (p) si_hip_ipc_close_mem_handle(p);
     for (si_stream_t s : d->stream) if (s) si_hip_stream_destroy(s);
+    if (d->coll_stream) si_hip_stream_destroy(d->coll_stream);
+    if (d->rccl) si_rccl_destroy(d->rccl);
     for (si_event_t e : d->ready) if (e) si_hip_event_destroy(e);
     for (auto& evs : d->sent) for (si_event_t e : evs) if (e) si_hip_event_destroy(e);
+    for (auto& evs : d->start) for (si_event_t e : evs) if (e) si_hip_event_destroy(e);
     for (void* p : d->mine) if (p) si_hip_free(p);
     delete d;
 }
@@ -239,6 +375,7 @@ int si_gather_create(SiNodeGroup* g, int device, size_t slab_bytes, int slots, S
     d->stream.assign((size_t)world, nullptr);
     d->ready.assign((size_t)slots, nullptr);
     d->sent.assign((size_t)slots, std::vector<si_event_t>((size_t)world, nullptr));
+    d->start.assign((size_t)slots, std::vector<si_event_t>((size_t)world, nullptr));
     d->pushed.assign((size_t)slots, 0);
 
     Advert me;
@@ -277,6 +414,7 @@ int si_gather_create(SiNodeGroup* g, int device, size_t slab_bytes, int slots, S
         for (int s = 0; rc == 0 && s < slots; ++s) rc = si_hip_ipc_open_mem_handle(all[(size_t)p].handle[s], &d->peer[(size_t)p][(size_t)s]);
         if (rc == 0) rc = si_hip_stream_create(&d->stream[(size_t)p]);
         for (int s = 0; rc == 0 && s < slots; ++s) rc = si_hip_event_create(&d->sent[(size_t)s][(size_t)p]);
+        for (int s = 0; rc == 0 && s < slots; ++s) rc = si_hip_event_create(&d->start[(size_t)s][(size_t)p]);
     }
     rc = agree(g, rc);
     if (rc != 0) { LOG(ERROR) << "si_gather_create: opening the peers' buffers failed (" << rc << ")"; release(d); return rc; }
@@ -284,10 +422,57 @@ int si_gather_create(SiNodeGroup* g, int device, size_t slab_bytes, int slots, S
     return 0;
 }
 
+// the RCCL-backed form of the same object: own slot buffers, one communicator, one stream for the collectives
+static int gather_create_rccl(SiNodeGroup* g, int device, size_t slab_bytes, int slots, SiDirectGather** out) {
+    SiDirectGather* d = new (std::nothrow) SiDirectGather;
+    if (!d) return SI_SHARD_E_SYS;
+    d->group = g; d->device = device; d->slots = slots; d->slab = slab_bytes; d->mode = SI_GATHER_RCCL;
+    const int world = g->world, rank = g->rank;
+    d->mine.assign((size_t)slots, nullptr);
+    d->ready.assign((size_t)slots, nullptr);
+    d->sent.assign((size_t)slots, std::vector<si_event_t>((size_t)world, nullptr));
+    d->start.assign((size_t)slots, std::vector<si_event_t>((size_t)world, nullptr));
+    d->pushed.assign((size_t)slots, 0);
+    memset(&d->stats, 0, sizeof(d->stats));
+    int rc = si_hip_set_device(device);
+    for (int s = 0; rc == 0 && s < slots; ++s) {
+        rc = si_hip_malloc(&d->mine[(size_t)s], slab_bytes * (size_t)world);
+        if (rc == 0) rc = si_hip_memset_async(d->mine[(size_t)s], 0, slab_bytes * (size_t)world, nullptr);
+        if (rc == 0) rc = si_hip_event_create(&d->ready[(size_t)s]);
+        if (rc == 0) rc = si_hip_event_create(&d->sent[(size_t)s][(size_t)rank]);
+        if (rc == 0) rc = si_hip_event_create(&d->start[(size_t)s][(size_t)rank]);
+    }
+    if (rc == 0) rc = si_hip_stream_create(&d->coll_stream);
+    if (rc == 0) rc = si_hip_device_sync();
+    rc = agree(g, rc);
+    if (rc == 0) rc = si_rccl_init(g, device, &d->rccl);   // collective; agrees on its own outcome
+    if (rc != 0) { LOG(ERROR) << "si_gather_create_mode: RCCL gather setup failed on rank " << rank << " (" << rc << ")"; release(d); return rc; }
+    *out = d;
+    return 0;
+}
+
+int si_gather_create_mode(SiNodeGroup* g, int device, size_t slab_bytes, int slots, int mode, SiDirectGather** out) {
+    if (!out) return SI_SHARD_E_BADARG;
+    *out = nullptr;
+    if (!g || slab_bytes == 0 || slots < 1 || slots > 8) return SI_SHARD_E_BADARG;
+    if (mode == SI_GATHER_DIRECT) return si_gather_create(g, device, slab_bytes, slots, out);
+    if (mode == SI_GATHER_RCCL) return gather_create_rccl(g, device, slab_bytes, slots, out);
+    if (mode != SI_GATHER_AUTO) return SI_SHARD_E_BADARG;
+    // si_gather_create fails on every rank when it fails on one (its setup steps are agreed on), so the fallback is collective
+    const int rc = si_gather_create(g, device, slab_bytes, slots, out);
+    if (rc == 0) return 0;
+    if (rc == SI_SHARD_E_TIMEOUT) return rc;   // a dead group cannot agree on anything
+    LOG(INFO) << "si_gather_create_mode: the direct gather could not be set up (" << rc << "); falling back to RCCL on every rank";
+    return gather_create_rccl(g, device, slab_bytes, slots, out);
+}
+
+int si_gather_mode(const SiDirectGather* d) { return d ? d->mode : -1; }
+
 int si_gather_destroy(SiDirectGather* d) {
     if (!d) return 0;
     si_hip_set_device(d->device);
     for (si_stream_t s : d->stream) if (s) si_hip_stream_sync(s);
+    if (d->coll_stream) si_hip_stream_sync(d->coll_stream);
     // nobody frees a buffer a peer may still be copying into
     const int rc = si_group_barrier(d->group);
     SiNodeGroup* g = d->group;
@@ -308,8 +493,18 @@ void* si_gather_slab(SiDirectGather* d, int slot) {
 int si_gather_push(SiDirectGather* d, int slot, si_stream_t producer) {
     if (!d || slot < 0 || slot >= d->slots) return SI_SHARD_E_BADARG;
     const int world = d->group->world, rank = d->group->rank;
-    if (world == 1) return 0;
+    if (world == 1 && d->mode != SI_GATHER_RCCL) return 0;   // (a one-rank RCCL gather still runs its collective: tests)
     int rc = si_hip_event_record(d->ready[(size_t)slot], producer);
+    if (d->mode == SI_GATHER_RCCL) {
+        // in place: this rank's slab already sits at its offset of the slot buffer
+        unsigned char* buf = static_cast<unsigned char*>(d->mine[(size_t)slot]);
+        if (rc == 0) rc = si_hip_stream_wait_event(d->coll_stream, d->ready[(size_t)slot]);
+        if (rc == 0) rc = si_hip_event_record(d->start[(size_t)slot][(size_t)rank], d->coll_stream);
+        if (rc == 0) rc = si_rccl_allgather(d->rccl, buf + (size_t)rank * d->slab, buf, d->slab, d->coll_stream);
+        if (rc == 0) rc = si_hip_event_record(d->sent[(size_t)slot][(size_t)rank], d->coll_stream);
+        d->pushed[(size_t)slot] = 1;
+        return rc;
+    }
     const size_t off = (size_t)rank * d->slab;
     const unsigned char* src = static_cast<const unsigned char*>(d->mine[(size_t)slot]) + off;
     // one copy per peer, each on its own stream: point-to-point links, no ring; start at rank + 1 so that at any moment the
@@ -317,6 +512,7 @@ int si_gather_push(SiDirectGather* d, int slot, si_stream_t producer) {
     for (int i = 1; rc == 0 && i < world; ++i) {
         const int p = (rank + i) % world;
         rc = si_hip_stream_wait_event(d->stream[(size_t)p], d->ready[(size_t)slot]);
+        if (rc == 0) rc = si_hip_event_record(d->start[(size_t)slot][(size_t)p], d->stream[(size_t)p]);
         if (rc == 0) rc = si_hip_memcpy_d2d(static_cast<unsigned char*>(d->peer[(size_t)p][(size_t)slot]) + off, src, d->slab, d->stream[(size_t)p]);
         if (rc == 0) rc = si_hip_event_record(d->sent[(size_t)slot][(size_t)p], d->stream[(size_t)p]);
     }
@@ -334,18 +530,22 @@ int si_gather_complete(SiDirectGather* d, int slot) {
     if (d->pushed[(size_t)slot]) {
         for (si_event_t e : d->sent[(size_t)slot]) if (e && rc == 0) rc = si_hip_event_sync(e);
         d->pushed[(size_t)slot] = 0;
-        // how long each peer copy took behind the producer (ready -> landed); with an idle copy stream that is the copy itself
-        for (si_event_t e : d->sent[(size_t)slot]) {
-            float ms = 0.f;
-            if (e && rc == 0 && si_hip_event_elapsed_ms(d->ready[(size_t)slot], e, &ms) == 0 && ms > 0.f) {
+        // per peer copy: the copy itself (start event on the copy stream right before it -> landed: slab / that is the link
+        // rate) and the latency behind the producer (slab ready -> landed, which includes queueing behind earlier copies)
+        for (size_t p = 0; p < d->sent[(size_t)slot].size(); ++p) {
+            si_event_t e = d->sent[(size_t)slot][p];
+            float ms = 0.f, lat = 0.f;
+            if (e && rc == 0 && si_hip_event_elapsed_ms(d->start[(size_t)slot][p], e, &ms) == 0 && ms > 0.f) {
                 d->stats.copy_ms_total += ms;
                 d->stats.copies += 1;
                 if (ms > d->stats.copy_ms_max) d->stats.copy_ms_max = ms;
+                if (si_hip_event_elapsed_ms(d->ready[(size_t)slot], e, &lat) == 0 && lat > 0.f) d->stats.landed_ms_total += lat;
             }
         }
     }
     const double t1 = now_s();
-    const int b = si_group_barrier(d->group);
+    // (RCCL: the collective itself orders the ranks -- every rank's slab is in this buffer once THIS rank's collective is done)
+    const int b = d->mode == SI_GATHER_RCCL ? 0 : si_group_barrier(d->group);
     const double t2 = now_s();
     d->stats.completes += 1;
     d->stats.wait_copies_ms_total += (t1 - t0) * 1e3;

@@ -23,8 +23,10 @@ ShardedEngine::~ShardedEngine() { Release(); }
 int ShardedEngine::Rank() const { return group_ ? si_group_rank(group_) : 0; }
 int ShardedEngine::World() const { return group_ ? si_group_world(group_) : 1; }
 
+GatherMode ShardedEngine::Mode() const { return gather_ && si_gather_mode(gather_) == SI_GATHER_RCCL ? GatherMode::kRccl : GatherMode::kDirect; }
+
 Status ShardedEngine::Init(const std::string& group_name, int rank, int world, Engine* engine, const std::string& output_name,
-                           int slots, double timeout_s) {
+                           int slots, double timeout_s, GatherMode gather) {
     CHECK_BOOL(engine != nullptr && group_ == nullptr);
     Tensor out;
     CHECK_STATUS(engine->Extract(output_name, out));
@@ -34,9 +36,9 @@ Status ShardedEngine::Init(const std::string& group_name, int rank, int world, E
     }
     SI_TRY_SHARD(si_hip_get_device(&device_), "hipGetDevice");
     SI_TRY_SHARD(si_group_create(group_name.c_str(), rank, world, timeout_s, &group_), "si_group_create");
-    const int rc = si_gather_create(group_, device_, out.ByteSize(), slots, &gather_);
+    const int rc = si_gather_create_mode(group_, device_, out.ByteSize(), slots, (int)gather, &gather_);
     if (rc != 0) {
-        LOG(ERROR) << "si_gather_create failed with code " << rc;
+        LOG(ERROR) << "si_gather_create_mode failed with code " << rc;
         si_group_destroy(group_);
         group_ = nullptr;
         return Status::kFail;

@@ -69,8 +69,8 @@ class Engine:
         self._check("LoadModel", self._L.si_engine_load_model(self._h, param_path.encode(), bin_path.encode()))
 
     def release(self):
+        self._check("Release", self._L.si_engine_release(self._h))   # (first: Release is where a pinned buffer is let go)
         self._inputs.clear()
-        self._check("Release", self._L.si_engine_release(self._h))
 
     def input_names(self) -> List[str]:
         return [self._L.si_engine_input_name(self._h, i).decode() for i in range(self._L.si_engine_num_inputs(self._h))]
@@ -90,8 +90,10 @@ class Engine:
         a = np.ascontiguousarray(array, dtype=np.float32)
         if a.size != int(np.prod(shape)):
             raise StatusError("Input(%s): %s does not match %s" % (name, a.shape, shape), Status.kErrorShape)
-        self._inputs[name] = a
+        # hand the new buffer over BEFORE the previous array is dropped: Input() is where the engine lets go of the old one
+        # (with "pin_inputs" it is still registered with the driver until then)
         self._check("Input(%s)" % name, self._L.si_engine_input(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), 0))
+        self._inputs[name] = a
 
     def input_device(self, name: str, device_ptr: int):
         """Device-resident input: the engine reads the buffer in place (no H2D in forward)."""

@@ -164,6 +164,35 @@ def conv2d_upcat(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1=
     return dy.to_numpy((n, oh, ow, oc))
 
 
+def conv2d_upcat_f16(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1="none", split_oc=0):
+    """si_hip_conv2d_upcat_f16: conv2d_upcat with fp16 storage (half tensors in and out, fp32 bias)."""
+    H = _native.hip()
+    low, skip = np.asarray(low, np.float16), np.asarray(skip, np.float16)
+    w_oihw = _f32(w_oihw)
+    n, oh, ow, cs = skip.shape
+    _, lh, lw, cl = low.shape
+    ic, oc = cl + cs, w_oihw.shape[0]
+    d = SiConv2dDesc(n, oh, ow, ic, ic, oh, ow, oc, oc, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1 if bias is not None else 0, ACT[act1], 0, oc, 0, 0.0)
+    wp = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d)), np.float16)
+    _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p)), "pack f16")
+    cat = np.full((n, oh, ow, ic), np.nan, np.float16)   # the upsampled range is poison: nobody may read it
+    c0 = 0 if up_first else cs
+    cat[..., (cl if up_first else 0):(cl if up_first else 0) + cs] = skip
+    dcat, dlow, dw = DeviceBuffer.from_numpy(cat), DeviceBuffer.from_numpy(np.ascontiguousarray(low)), DeviceBuffer.from_numpy(wp)
+    db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
+    up = _native.SiConv2dUpsampledSource(dlow.ptr, lh, lw, cl, cl, c0, np.float32(1.0) / np.float32(scale[0]), np.float32(1.0) / np.float32(scale[1]))
+    if split_oc:
+        d.out_ld = split_oc
+        dy, dy2 = DeviceBuffer(n * oh * ow * split_oc * 2), DeviceBuffer(n * oh * ow * (oc - split_oc) * 2)
+        _chk(H.si_hip_conv2d_upcat_f16(C.byref(d), dcat.ptr, C.byref(up), dw.ptr, db.ptr if db else None, dy.ptr, split_oc, dy2.ptr,
+                                       oc - split_oc, None), "si_hip_conv2d_upcat_f16")
+        return dy.to_numpy((n, oh, ow, split_oc), np.float16), dy2.to_numpy((n, oh, ow, oc - split_oc), np.float16)
+    dy = DeviceBuffer(n * oh * ow * oc * 2)
+    _chk(H.si_hip_conv2d_upcat_f16(C.byref(d), dcat.ptr, C.byref(up), dw.ptr, db.ptr if db else None, dy.ptr, 0, None, 0, None),
+         "si_hip_conv2d_upcat_f16")
+    return dy.to_numpy((n, oh, ow, oc), np.float16)
+
+
 def conv2d_kernel_name(x_shape, w_shape, stride=(1, 1), padding=(0, 0), groups=1) -> str:
     """The kernel instantiation si_hip_conv2d_f32 picks for this shape with dense, 16-byte aligned tensors."""
     H = _native.hip()
@@ -464,6 +493,30 @@ def letterbox_batch(resized_bgr, height_new, width_new, padding_t, padding_l):
     dout = DeviceBuffer(max(n * height_new * width_new * 3 * 4, 16))
     _chk(H.si_hip_letterbox_batch_u8_f32(dsrc.ptr, n, hr * wr * 3, hr, wr, dout.ptr, height_new, width_new, padding_t, padding_l, None),
          "si_hip_letterbox_batch_u8_f32")
+    return dout.to_numpy((n, height_new, width_new, 3))
+
+
+def resize_bilinear_u8c3(images, dst_h, dst_w):
+    """si_hip_resize_bilinear_u8c3: u8 [n][h][w][3] -> u8 [n][dst_h][dst_w][3] (the cv::resize of PreProcess, test_yolo.cpp:213-216)."""
+    H = _native.hip()
+    src = np.ascontiguousarray(images, dtype=np.uint8)
+    n, h, w = int(src.shape[0]), int(src.shape[1]), int(src.shape[2])
+    dsrc = DeviceBuffer.from_numpy(src)
+    dout = DeviceBuffer(max(n * dst_h * dst_w * 3, 16))
+    _chk(H.si_hip_resize_bilinear_u8c3(dsrc.ptr, n, h * w * 3, h, w, dout.ptr, dst_h * dst_w * 3, dst_h, dst_w, None), "si_hip_resize_bilinear_u8c3")
+    return dout.to_numpy((n, dst_h, dst_w, 3), np.uint8)
+
+
+def resize_letterbox_batch(frames_bgr, height_new, width_new):
+    """si_hip_resize_letterbox_batch_u8_f32: camera frames u8 BGR [n][h][w][3] -> float RGB [n][height_new][width_new][3]
+    (aspect-preserving bilinear resize + pad(114) + / 255: PreProcess whole, test_yolo.cpp:194-259) in one launch."""
+    H = _native.hip()
+    src = np.ascontiguousarray(frames_bgr, dtype=np.uint8)
+    n, h, w = int(src.shape[0]), int(src.shape[1]), int(src.shape[2])
+    dsrc = DeviceBuffer.from_numpy(src)
+    dout = DeviceBuffer(max(n * height_new * width_new * 3 * 4, 16))
+    _chk(H.si_hip_resize_letterbox_batch_u8_f32(dsrc.ptr, n, h * w * 3, h, w, dout.ptr, height_new, width_new, None),
+         "si_hip_resize_letterbox_batch_u8_f32")
     return dout.to_numpy((n, height_new, width_new, 3))
 
 

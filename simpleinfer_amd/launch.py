@@ -34,6 +34,16 @@ def rank_env(rank: int, world: int, port: int, base: Optional[dict] = None) -> d
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SI_SPAWNED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL, hipIpc*)
+    # SI_LAUNCH_PIN_VISIBLE=1: every rank sees ONLY its own GPU (as container runtimes and some launchers arrange it), so every
+    # rank calls its GPU "device 0" and peers can only be named by PCI bus id (include/si_shard.h).  SI_LAUNCH_VISIBLE_LIST, a
+    # ';'-separated list of VAR=value with one entry per rank, gives the settings instead (tests: the same device hidden behind
+    # two different mechanisms, HIP_VISIBLE_DEVICES for one rank and ROCR_VISIBLE_DEVICES for the other).
+    if env.get("SI_LAUNCH_PIN_VISIBLE") == "1":
+        names = [v for v in env.get("SI_LAUNCH_VISIBLE_LIST", "").split(";") if "=" in v]
+        var, val = names[rank].split("=", 1) if rank < len(names) else ("HIP_VISIBLE_DEVICES", str(rank))
+        env[var] = val
+        env["LOCAL_RANK"] = "0"
+        env["LOCAL_WORLD_SIZE"] = "1"
     return env
 
 

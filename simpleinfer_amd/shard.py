@@ -1,6 +1,7 @@
-"""ctypes mirror of include/si_shard.h: the node-local rank group (POSIX shared memory rendezvous) and the direct
-output all-gather over IPC-shared HBM.  This is the torch-free multi-GPU path: ``bench.py --gpus N`` uses it by default
-and falls back to RCCL (``simpleinfer_amd.distributed``) only when the direct path cannot be set up.
+"""ctypes mirror of include/si_shard.h: the node-local rank group (POSIX shared memory rendezvous) and the output
+all-gather -- the direct fan-out over IPC-shared HBM, or RCCL's ncclAllGather through the C-ABI (si_rccl_*, librccl.so loaded
+with dlopen).  This is the torch-free multi-GPU path: ``bench.py --gpus N`` uses the direct form by default and falls back to
+RCCL collectively when the direct path cannot be set up (SI_GATHER_AUTO).
 
 Nothing here computes; the GPU is touched only by si_gather_* (hipMalloc / hipIpc* / device-to-device copies).
 """
@@ -69,16 +70,42 @@ class NodeGroup:
             pass
 
 
+GATHER_MODES = {"direct": 0, "rccl": 1, "auto": 2}
+
+
+def rccl_available() -> bool:
+    return bool(_native.host().si_rccl_available())
+
+
+class RcclComm:
+    """include/si_shard.h si_rccl_*: a communicator over the node group, the unique id exchanged through the group."""
+
+    def __init__(self, group: NodeGroup, device: int):
+        self._h = _native.host()
+        self._c = C.c_void_p()
+        _check(self._h.si_rccl_init(group._g, device, C.byref(self._c)), "si_rccl_init")
+
+    def allgather(self, send_ptr: int, recv_ptr: int, bytes_per_rank: int, stream: Optional[int] = None):
+        _check(self._h.si_rccl_allgather(self._c, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), bytes_per_rank, stream), "si_rccl_allgather")
+
+    def close(self):
+        if self._c:
+            c, self._c = self._c, C.c_void_p()
+            _check(self._h.si_rccl_destroy(c), "si_rccl_destroy")
+
+
 class DirectGather:
     """include/si_shard.h SiDirectGather: `slots` gathered buffers [world][slab_bytes] per rank; every step each rank
-    pushes its slab into the same slot of every peer with one device-to-device copy per peer."""
+    pushes its slab into the same slot of every peer with one device-to-device copy per peer (mode "direct"), or all ranks
+    run an in-place ncclAllGather into the slot (mode "rccl"); "auto" = direct, RCCL on every rank if that cannot be set up."""
 
-    def __init__(self, group: NodeGroup, device: int, slab_bytes: int, slots: int = 4):
+    def __init__(self, group: NodeGroup, device: int, slab_bytes: int, slots: int = 4, mode: str = "direct"):
         self._h = _native.host()
         self.group = group
         self._d = C.c_void_p()
-        _check(self._h.si_gather_create(group._g, device, slab_bytes, slots, C.byref(self._d)), "si_gather_create")
+        _check(self._h.si_gather_create_mode(group._g, device, slab_bytes, slots, GATHER_MODES[mode], C.byref(self._d)), "si_gather_create_mode")
         self.slots, self.slab_bytes = slots, slab_bytes
+        self.mode = "rccl" if self._h.si_gather_mode(self._d) == 1 else "direct"
 
     def slab_ptr(self, slot: int) -> int:
         return int(self._h.si_gather_slab(self._d, slot) or 0)
@@ -100,9 +127,12 @@ class DirectGather:
         n, c = max(int(st.completes), 1), int(st.copies)
         out = {"gather_wait_copies_ms": round(st.wait_copies_ms_total / n, 4), "gather_wait_barrier_ms": round(st.wait_barrier_ms_total / n, 4),
                "gather_wait_ms": round((st.wait_copies_ms_total + st.wait_barrier_ms_total) / n, 4), "completes": int(st.completes),
-               "peer_copies": c, "peer_copy_ms": None, "peer_copy_ms_max": None, "gather_gbps_per_peer": None}
+               "peer_copies": c, "peer_copy_ms": None, "peer_copy_ms_max": None, "gather_gbps_per_peer": None, "peer_landed_ms": None}
         if c:
+            # peer_copy_ms: the copy itself (start event on the copy stream -> landed), so slab / that IS the link rate;
+            # peer_landed_ms: slab ready -> landed, i.e. the same plus queueing behind earlier copies on that peer's stream
             out["peer_copy_ms"] = round(st.copy_ms_total / c, 4)
+            out["peer_landed_ms"] = round(st.landed_ms_total / c, 4)
             out["peer_copy_ms_max"] = round(st.copy_ms_max, 4)
             out["gather_gbps_per_peer"] = round(self.slab_bytes / (st.copy_ms_total / c * 1e-3) / 1e9, 2)
         return out
@@ -117,11 +147,11 @@ class ShardedForward:
     """The step of the sharded path (the Python twin of SimpleInfer::ShardedEngine, include/shard.h): Forward() into this
     step's slot, start the fan-out, complete the previous step's gather."""
 
-    def __init__(self, engine, output_name: str, group: NodeGroup, device: int, slots: int = 4):
+    def __init__(self, engine, output_name: str, group: NodeGroup, device: int, slots: int = 4, mode: str = "direct"):
         self.e, self.oname = engine, output_name
         shape = engine.operand_shape(output_name)
         self.local_shape = tuple(shape)
-        self.gather = DirectGather(group, device, int(np.prod(shape)) * 4, slots)
+        self.gather = DirectGather(group, device, int(np.prod(shape)) * 4, slots, mode)
         self.step = 0
         self.pending = -1
         self.completed = -1

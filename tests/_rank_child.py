@@ -82,7 +82,8 @@ def main():
         e = si.Engine(device=dev, outputs_to_host=0, graph=int(sys.argv[4]))
         e.load_model(pp, bp)
         oname = e.output_names()[0]
-        sf = shard.ShardedForward(e, oname, g, dev, slots=slots)
+        gmode = sys.argv[5] if len(sys.argv) > 5 else "direct"
+        sf = shard.ShardedForward(e, oname, g, dev, slots=slots, mode=gmode)
         ref = si.Engine(device=dev)                      # an independent engine computes every rank's slab for the check
         ref.load_model(pp, bp)
         ok = True
@@ -109,7 +110,7 @@ def main():
         oks = g.allgather_bytes(bytes([1 if ok else 0]))
         sf.close()
         if rank == 0:
-            print(json.dumps({"ok": [b[0] for b in oks], "shape": list(sf.gathered_shape())}))
+            print(json.dumps({"ok": [b[0] for b in oks], "shape": list(sf.gathered_shape()), "mode": sf.gather.mode}))
         g.close()
         return
     if mode == "slow_consumer":

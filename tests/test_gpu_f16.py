@@ -228,3 +228,110 @@ def test_pool_activation_binary_convert_f16(hops, orc):
     with np.errstate(over="ignore"):
         assert_exact(half, z.astype(np.float16), "fp32 -> fp16 is round-to-nearest-even (overflow to inf)")
     assert_exact(back, half.astype(np.float32), "fp16 -> fp32 is exact")
+
+
+# ---- tile variants of the fp16 implicit GEMM (round 4): the one-stage kernel (0-2) and the kernels that fetch the weights
+# straight from L2 in MFMA lane order (3-8) must agree BIT FOR BIT -- the same k order through the same 16-deep MFMA steps --
+# so that the tile policy may follow the launch size without touching the batch-invariance contract.
+F16_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14]
+
+
+@pytest.fixture()
+def tile16(gpu):
+    from simpleinfer_amd import _native
+    H = _native.hip()
+
+    def set_variant(v):
+        assert H.si_hip_conv2d_f16_set_tile_variant(int(v)) == 0
+    yield set_variant
+    H.si_hip_conv2d_f16_set_tile_variant(-1)
+
+
+F16_TILE_SHAPES = [
+    # shape NHWC, oc, k, s, p, d, groups
+    ((2, 21, 19, 64), 96, 3, 2, 1, 1, 1),     # 3x3 s2, ragged 32-wide column block, M not a multiple of any tile
+    ((1, 20, 20, 256), 160, 3, 2, 1, 1, 1),   # K = 2304: 36 K-tiles (even), ring of two
+    ((1, 11, 13, 192), 128, 3, 1, 1, 1, 1),   # K = 1728: 27 K-tiles (odd)
+    ((3, 13, 17, 128), 64, 1, 1, 0, 1, 1),    # pointwise, two K-tiles
+    ((2, 9, 9, 64), 32, 1, 1, 0, 1, 1),       # ONE K-tile, 32 output channels
+    ((2, 12, 12, 64), 255, 1, 1, 0, 1, 1),    # ragged oc (Detect's channel count)
+    ((2, 11, 11, 64), 64, 3, 1, 1, 1, 2),     # grouped, 32 channels per group (32-wide K blocks)
+    ((2, 10, 10, 40), 72, 1, 1, 0, 1, 1),     # zero-padded K
+    ((2, 12, 12, 32), 64, 3, 1, 2, 2, 1),     # 32-wide K blocks, dilation
+    ((1, 40, 40, 32), 32, 5, 1, 2, 1, 1),     # 25 taps
+]
+
+
+@pytest.mark.parametrize("shape,oc,k,s,p,d,g", F16_TILE_SHAPES)
+def test_every_f16_tile_variant_same_bits(hops, orc, tile16, shape, oc, k, s, p, d, g):
+    seed = (shape[1] * 131 + shape[3] * 7 + oc) % 100000
+    x = h(rng_uniform(seed, shape, -1, 1))
+    w = h(rng_uniform(seed + 1, (oc, shape[3] // g, k, k), -0.3, 0.3))
+    b = rng_uniform(seed + 2, (oc,), -0.5, 0.5)
+    tile16(0)
+    base32 = hops.conv2d_f16(x, w, b, (s, s), (p, p), (d, d), g, out_f32=True)
+    base16 = hops.conv2d_f16(x, w, b, (s, s), (p, p), (d, d), g, act1="silu")
+    ref = orc.conv2d(x, w, b, (s, s), (p, p), (d, d), g, path="naive")
+    assert_parity(base32, ref, 2e-5, what="one-stage kernel, fp32 out")
+    for v in F16_TILES[1:]:
+        tile16(v)
+        got32 = hops.conv2d_f16(x, w, b, (s, s), (p, p), (d, d), g, out_f32=True)
+        bad = int((got32.view(np.uint32) != base32.view(np.uint32)).sum())
+        assert bad == 0, "fp16 tile variant %d: %d of %d fp32 outputs differ from variant 0 (max abs %.3e)" % (
+            v, bad, base32.size, float(np.abs(got32 - base32).max()))
+        got16 = hops.conv2d_f16(x, w, b, (s, s), (p, p), (d, d), g, act1="silu")
+        assert_exact(got16, base16, "fp16 tile variant %d, silu epilogue" % v)
+
+
+def test_every_f16_tile_variant_same_bits_through_epilogues_split_and_detect(hops, tile16):
+    x = h(rng_uniform(11, (2, 15, 13, 64), -1, 1))
+    w = h(rng_uniform(12, (96, 64, 3, 3), -0.3, 0.3))
+    b = rng_uniform(13, (96,), -0.5, 0.5)
+    r = h(rng_uniform(14, (2, 15, 13, 96), -1, 1))
+    xs = h(rng_uniform(20, (2, 12, 12, 64), -1, 1))
+    wa, wb = h(rng_uniform(21, (32, 64, 1, 1), -0.3, 0.3)), h(rng_uniform(22, (64, 64, 1, 1), -0.3, 0.3))
+    ba, bb = rng_uniform(23, (32,), -0.5, 0.5), rng_uniform(24, (64,), -0.5, 0.5)
+    na, ne, n = 3, 85, 3
+    feats, ws, bs, grids, anchors = [], [], [], [], []
+    for i, (hh, c) in enumerate(((8, 64), (4, 128), (2, 256))):
+        feats.append(h(rng_uniform(50 + i, (n, hh, hh, c), -1, 1)))
+        ws.append(h(rng_uniform(60 + i, (na * ne, c, 1, 1), -0.3, 0.3)))
+        bs.append(rng_uniform(70 + i, (na * ne,), -0.5, 0.5))
+        gy, gx = np.meshgrid(np.arange(hh, dtype=np.float32), np.arange(hh, dtype=np.float32), indexing="ij")
+        grids.append(np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, hh, hh, 2)).copy())
+        anchors.append(np.broadcast_to(rng_uniform(80 + i, (1, na, 1, 1, 2), 5, 300), (1, na, hh, hh, 2)).copy())
+    outs = {}
+    for v in F16_TILES:
+        tile16(v)
+        outs[v] = (
+            hops.conv2d_f16(x, w, b, (1, 1), (1, 1), act1="silu", residual=r, out_ld=128, out_c_off=16),
+            hops.conv2d_f16(x, w, b, (1, 1), (1, 1), residual=r, act2="relu"),
+            hops.conv2d_f16(x, w, b, (1, 1), (1, 1), act1="hardswish"),
+        ) + tuple(hops.conv2d_split_f16(xs, wa, ba, wb, bb, act1="silu")) + (
+            hops.yolo_detect_f16(feats, ws, bs, grids, anchors, [8.0, 16.0, 32.0], na),)
+    for v in F16_TILES[1:]:
+        for i, (got, want) in enumerate(zip(outs[v], outs[0])):
+            assert_exact(got, want, "fp16 tile variant %d, output %d" % (v, i))
+
+
+@pytest.mark.parametrize("n,lh,lw,cl,cs,oc,scale,up_first", [
+    (2, 10, 10, 128, 128, 128, (2.0, 2.0), True),    # the YOLOv5 PAN form, 64-wide K blocks
+    (3, 5, 7, 64, 192, 96, (2.0, 2.0), False),       # upsampled tensor second, ragged column block
+    (1, 4, 6, 32, 64, 64, (3.0, 2.0), True),         # 96 channels: 32-wide K blocks; non-square scale
+])
+def test_conv_f16_reads_upsampled_source(hops, orc, n, lh, lw, cl, cs, oc, scale, up_first):
+    """si_hip_conv2d_upcat_f16 (round 4): the 1x1 conv behind cat(upsample(x), skip) reads x at the source pixel with the reference's
+    index rule (src/layer/upsample.cpp:85-92) -- BIT exact versus si_hip_conv2d_f16 on the materialised concat, also in the
+    sibling-split form."""
+    oh, ow = int(lh * scale[0]), int(lw * scale[1])
+    low, skip = h(rng_uniform(400, (n, lh, lw, cl), -1, 1)), h(rng_uniform(401, (n, oh, ow, cs), -1, 1))
+    w, b = h(rng_uniform(402, (oc, cl + cs, 1, 1), -0.3, 0.3)), rng_uniform(403, (oc,), -0.5, 0.5)
+    upo = orc.upsample_nearest(low, scale[0], scale[1], (oh, ow))
+    cat = np.concatenate([upo, skip] if up_first else [skip, upo], axis=-1)
+    got = hops.conv2d_upcat_f16(low, skip, w, b, scale, up_first, act1="silu")
+    assert got.dtype == np.float16
+    assert_exact(got, hops.conv2d_f16(cat, w, b, act1="silu"), "dual-source fp16 conv == conv over the materialised concat")
+    assert_parity(got.astype(np.float32), orc.activation("silu", orc.conv2d(cat, w, b)), F16_TOL, what="vs the oracle's upsample + cat + conv")
+    if oc >= 64:
+        ya, yb = hops.conv2d_upcat_f16(low, skip, w, b, scale, up_first, act1="silu", split_oc=32)
+        assert_exact(np.concatenate([ya, yb], -1), got, "sibling-split form")

@@ -481,6 +481,39 @@ def test_letterbox_exact(hops, orc):
         assert_exact(got[b], orc.letterbox(odd[b], 63, 63, pt2, pl2), "letterbox batch, odd size, image %d" % b)
 
 
+@pytest.mark.parametrize("sh,sw,dh,dw", [(720, 1280, 360, 640), (1080, 810, 640, 480), (375, 500, 480, 640), (33, 47, 64, 20), (1, 5, 3, 9), (7, 1, 2, 4)])
+def test_resize_bilinear_u8c3_exact(hops, orc, sh, sw, dh, dw):
+    """si_hip_resize_bilinear_u8c3 (round 4, the cv::resize of PreProcess, test_yolo.cpp:213-216): EXACT against the numpy
+    restatement of the published 8-bit INTER_LINEAR fixed-point algorithm (oracle/orc.py -- simpleocv's source is absent, so this is
+    not pinned to the reference), down- and up-scaling, one-pixel edges; and within 1 LSB of float bilinear interpolation with
+    half-pixel centres (torch.nn.functional.interpolate, align_corners=False) where torch is importable."""
+    r = np.random.Generator(np.random.Philox(sh * 7 + sw))
+    imgs = r.integers(0, 256, (2, sh, sw, 3), dtype=np.uint8)
+    got = hops.resize_bilinear_u8c3(imgs, dh, dw)
+    for b in range(2):
+        assert_exact(got[b], orc.resize_bilinear_u8c3(imgs[b], dh, dw), "resize image %d" % b)
+    try:
+        import torch
+    except Exception:  # noqa: BLE001
+        return
+    t = torch.from_numpy(imgs.astype(np.float32)).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False, antialias=False).permute(0, 2, 3, 1).numpy()
+    assert np.abs(got.astype(np.float32) - ref).max() <= 1.0 + 1e-3
+
+
+def test_resize_letterbox_fused_equals_the_two_steps(hops, orc):
+    """si_hip_resize_letterbox_batch_u8_f32: PreProcess whole (test_yolo.cpp:194-259) for a batch of camera frames in one launch
+    == resize, then letterbox, bit for bit -- a 720x1280 frame into the 640x640 input, a portrait frame, an upscaled thumbnail."""
+    r = np.random.Generator(np.random.Philox(77))
+    for (sh, sw, H, W) in ((720, 1280, 640, 640), (1080, 810, 640, 640), (90, 120, 160, 160), (31, 17, 63, 63)):
+        frames = r.integers(0, 256, (3, sh, sw, 3), dtype=np.uint8)
+        hr, wr, sc, pt, pl = hops.letterbox_geometry(sh, sw, H, W)
+        got = hops.resize_letterbox_batch(frames, H, W)
+        for b in range(3):
+            want = orc.letterbox(orc.resize_bilinear_u8c3(frames[b], hr, wr), H, W, pt, pl)
+            assert_exact(got[b], want, "fused resize + letterbox, %dx%d image %d" % (sh, sw, b))
+
+
 @pytest.mark.parametrize("n,rows,nc,thr,agnostic,hot", [
     (3, 25200, 80, 0.25, False, 0.03),     # the application's shape and thresholds
     (2, 25200, 80, 0.25, True, 0.03),

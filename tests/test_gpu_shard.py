@@ -29,6 +29,59 @@ def test_direct_gather_between_processes_is_bit_exact(gpu, tmp_path, world, slot
     assert res["shape"][0] == 2 * world
 
 
+def test_rccl_behind_the_c_abi_world_1_round_trip(gpu, tmp_path):
+    """include/si_shard.h si_rccl_*: librccl.so through dlopen, the unique id through the node group, ncclAllGather on a caller
+    stream -- no torch.  One rank is what a 1-GPU box can run (RCCL refuses two ranks on one device): the communicator comes up,
+    an out-of-place and an in-place all-gather move the bytes, and the RCCL-backed gather of ShardedForward (mode "rccl") serves
+    five steps bit-exactly; mode "auto" stays on the direct path where that works."""
+    import numpy as np
+    from simpleinfer_amd import hipops, launch, shard
+    assert shard.rccl_available()
+    g = shard.NodeGroup("/si_test_rccl_%d" % os.getpid(), 0, 1, 30.0)
+    comm = shard.RcclComm(g, 0)
+    src = np.arange(1 << 16, dtype=np.uint32)
+    a = hipops.DeviceBuffer.from_numpy(src)
+    b = hipops.DeviceBuffer(src.nbytes)
+    comm.allgather(a.ptr, b.ptr, src.nbytes)
+    from simpleinfer_amd import _native
+    _native.hip().si_hip_device_sync()
+    assert np.array_equal(b.to_numpy(src.shape, np.uint32), src)
+    comm.allgather(a.ptr, a.ptr, src.nbytes)            # in place (rank 0 of 1: send == recv)
+    _native.hip().si_hip_device_sync()
+    assert np.array_equal(a.to_numpy(src.shape, np.uint32), src)
+    comm.close(); g.close(); a.free(); b.free()
+    for gmode, want in (("rccl", "rccl"), ("auto", "direct")):
+        code, out = launch.spawn_ranks([sys.executable, CHILD, "gather", str(tmp_path), "3", "0", gmode], 1, timeout=600)
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        assert code == 0 and lines, out
+        res = json.loads(lines[-1])
+        assert res["ok"] == [1] and res["mode"] == want, res
+
+
+def test_peers_are_named_by_pci_bus_id_when_every_rank_has_its_own_visible_devices(gpu, tmp_path):
+    """Launchers and container runtimes hand every rank its own HIP_VISIBLE_DEVICES, so every rank calls its GPU "device 0" and
+    a device INDEX means nothing to a peer: si_gather_create advertises the PCI bus id instead and resolves a peer's GPU to the
+    local index of that bus id (or relies on the IPC mapping when the GPU is hidden).  On the 1-GPU box: two ranks that reach the
+    same GPU through DIFFERENT visibility settings (HIP_VISIBLE_DEVICES=0 for one, ROCR_VISIBLE_DEVICES=0 for the other) -- the
+    gather comes up by bus id and is bit-exact."""
+    from simpleinfer_amd import launch
+    env = {"SI_LAUNCH_PIN_VISIBLE": "1", "SI_LAUNCH_VISIBLE_LIST": "HIP_VISIBLE_DEVICES=0;ROCR_VISIBLE_DEVICES=0"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        code, out = launch.spawn_ranks([sys.executable, CHILD, "gather", str(tmp_path), "3", "0"], 2, timeout=600)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert code == 0 and lines, out
+    res = json.loads(lines[-1])
+    assert res["ok"] == [1, 1] and res["mode"] == "direct"
+
+
 def test_gathered_tensor_survives_the_next_step_with_default_slots(gpu, tmp_path):
     """include/si_shard.h slot lifetime: with the default 4 slots the gathered tensor handed out after Forward(s) is still
     step s-1's after Forward(s+1) -- a slow consumer on one rank while the others run ahead (3 ranks sharing the device)."""

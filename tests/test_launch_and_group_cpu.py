@@ -84,3 +84,35 @@ def test_bench_self_launches_and_fails_cleanly_without_devices(native_libs):
     assert "torch.distributed.run" not in p.stderr
     assert "HIP device" in p.stderr or "devices" in p.stderr, p.stderr[-2000:]
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_rccl_entry_points_fail_cleanly_without_the_library(native_libs, tmp_path):
+    """include/si_shard.h si_rccl_*: librccl.so is dlopen()ed on first use, nothing links against it.  With SI_RCCL_LIB naming a
+    file that does not exist every entry point reports SI_SHARD_E_SYS (-102) / "not available" instead of failing to load the
+    host library or crashing -- and the RCCL-backed gather refuses the same way on every rank."""
+    code = subprocess.run([sys.executable, "-c", """
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+from simpleinfer_amd import _native, shard
+H = _native.host()
+assert H.si_rccl_available() == 0
+g = shard.NodeGroup("/si_test_norccl_%%d" %% os.getpid(), 0, 1, 5.0)
+c = C.c_void_p()
+rc = H.si_rccl_init(g._g, 0, C.byref(c))
+assert rc == -102 and not c.value, rc
+d = C.c_void_p()
+rc = H.si_gather_create_mode(g._g, 0, 4096, 2, 1, C.byref(d))
+assert rc != 0 and not d.value, rc
+assert H.si_rccl_allgather(None, None, None, 0, None) == -101
+assert H.si_rccl_destroy(None) == 0
+print("ok")
+""" % ROOT], env=dict(os.environ, SI_RCCL_LIB=str(tmp_path / "no_such_librccl.so")), capture_output=True, text=True)
+    assert code.returncode == 0 and "ok" in code.stdout, code.stdout + code.stderr
+
+
+def test_gather_mode_argument_is_checked(native_libs):
+    import ctypes as C
+    _, host = native_libs
+    d = C.c_void_p()
+    assert host.si_gather_create_mode(None, 0, 4096, 2, 0, C.byref(d)) == -101
+    assert host.si_gather_mode(None) == -1

@@ -106,7 +106,7 @@ def main():
                 reps = int(reps * max(2.0, 1.2 * args.min_ms / max(ms.value, 1e-3)))
             ms = ms.value / reps
             flops = 2.0 * n * oh * ow * co * k[0] * k[1] * (ci // g)
-            byts = 2.0 * (n * ih * iw * ci + n * oh * ow * co + wn)
+            byts = 2.0 * (n * ih * iw * ci + n * oh * ow * co + co * (ci // g) * k[0] * k[1])   # (wn counts both packed weight images)
             rows.append((key, count, "f16 v%s" % os.environ.get("SI_CONV_F16_VARIANT", "policy"), ms, flops / ms / 1e9, byts / ms / 1e6, flops))
             for buf in (dx, dw, db, dy):
                 buf.free()
