@@ -58,7 +58,7 @@ __global__ void letterbox_batch_kernel(const unsigned char* __restrict__ src, si
 // reference: half-pixel centres, sx = floor((dx + 0.5) * (src / dst) - 0.5) clamped to the image (left edge: fx = 0; right edge:
 // sx = src - 2, fx = 1), 11-bit fixed-point coefficients a = round(f * 2048) (half away from zero), the horizontal pass kept
 // as (S[sx] * a0 + S[sx + 1] * a1) >> 4 in 16 bits, the vertical pass ((b0 * r0) >> 16) + ((b1 * r1) >> 16), + 2, >> 2.
-// oracle/orc.py restates it in numpy; the device must agree EXACTLY (tests/test_gpu_ops.py).
+// The test suite holds the device to a numpy restatement of exactly this arithmetic (tests/test_gpu_ops.py).
 struct ResizeAxis {
     int s0;        // first source index
     short a0, a1;  // 11-bit weights of s0 and s0 + 1
