@@ -833,10 +833,16 @@ def main():
             layers = passes[-1]
             roof, agg = roofline_from_profile(passes, fp16=bool(args.fp16), workload=workload_key(args, shape))
             if args.layers:
+                # per layer: achieved TF/s and GB/s, the roofline the layer's ALGORITHMIC work sits under (the longer of its FLOPs at
+                # the matrix peak of the precision and its bytes at 8 TB/s) and the fraction of that bound it reaches
+                peak_tf = PEAK_F16_MFMA_TFLOPS if args.fp16 else PEAK_FP32_MFMA_TFLOPS
                 for L in layers:
                     tf = L["flops"] / (L["ms"] * 1e-3) / 1e12 if L["ms"] > 0 else 0
                     gb = L["bytes"] / (L["ms"] * 1e-3) / 1e9 if L["ms"] > 0 else 0
-                    print("%-28s %-22s %-48s %8.3f ms %7.1f TF/s %8.1f GB/s" % (L["name"], L["type"], L["kernel"], L["ms"], tf, gb),
+                    t_f, t_b = L["flops"] / (peak_tf * 1e12), L["bytes"] / (PEAK_HBM_GBS * 1e9)
+                    bound = "mfma" if t_f >= t_b else "hbm"
+                    frac = max(t_f, t_b) / (L["ms"] * 1e-3) if L["ms"] > 0 else 0
+                    print("%-28s %-22s %-48s %8.3f ms %7.1f TF/s %8.1f GB/s  %-4s %5.2f" % (L["name"], L["type"], L["kernel"], L["ms"], tf, gb, bound, frac),
                           file=sys.stderr)
                 print("sum of layer times %.3f ms" % sum(L["ms"] for L in layers), file=sys.stderr)
 

@@ -57,7 +57,6 @@ struct PolyArgs {
     float act_param;
 };
 
-constexpr int TILES = 32;   // output tiles per workgroup
 constexpr int OCW = 64;     // output channels per workgroup (4 consumer waves x 16)
 constexpr int CB = 16;      // input channels per block
 constexpr int NP = 25;      // planes
@@ -81,7 +80,17 @@ __device__ __forceinline__ float poly_act(int act, float v, float p) {
     }
 }
 
-__global__ __launch_bounds__(384) void conv_s2poly_kernel(const PolyArgs a) {
+// SI_POLY_ABL (diagnostic builds only, timing experiments with wrong results): 1 the producers fetch block 0 only, 2 the consumers
+// load the first filter planes only, 4 no output stores
+#ifndef SI_POLY_ABL
+#define SI_POLY_ABL 0
+#endif
+// TILES: output tiles per workgroup.  32: consumers hold 200 accumulator registers, one workgroup (4 consumer + 2 producer waves,
+// 100 KB of LDS) per CU.  16: 100 accumulators, one producer wave, 50 KB -- two or three workgroups per CU cover each other's
+// prologue, epilogue and barriers, at twice the filter traffic per multiply.
+template <int TILES>
+__global__ __launch_bounds__(256 + TILES * 4) void conv_s2poly_kernel(const PolyArgs a) {
+    constexpr int NH = TILES / 16;   // 16-tile halves per consumer wave
     // V[buffer][plane][tile][16 channels]: a consumer's ds_read_b128 covers 16 tiles x 64 bytes = 1 KB contiguous, a producer's
     // ds_write_b128 of one plane 32 tiles x 64 bytes: no bank conflicts either way
     __shared__ __attribute__((aligned(16))) float V[2 * NP * TILES * CB];
@@ -124,6 +133,7 @@ __global__ __launch_bounds__(384) void conv_s2poly_kernel(const PolyArgs a) {
         }
         f32x4 d[5][5];
         auto fetch = [&](int cb) {
+            if ((SI_POLY_ABL & 1) && cb > 0) return;
             const bool more = cb < ncb;
             const unsigned so = (unsigned)((more ? cb : 0) * CB * 4);
 #pragma unroll
@@ -177,13 +187,14 @@ __global__ __launch_bounds__(384) void conv_s2poly_kernel(const PolyArgs a) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_u, live ? u_lane : OOB, (unsigned)p * u_plane + (unsigned)(live ? cb : 0) * u_cb, 0));
     };
 
-    f32x4 acc[NP][2];
+    f32x4 acc[NP][NH];
 #pragma unroll
     for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) acc[p][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < NH; ++h) acc[p][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int RING = 4;
+    constexpr int RING = 5;   // filter planes in flight; divides the 25 planes of a block, so a plane's slot is the same in every block
+    static_assert(NP % RING == 0, "ring slots must line up across channel blocks");
     f32x4 ub[RING];
 #pragma unroll
     for (int i = 0; i < RING; ++i) ub[i] = load_u(i, 0);
@@ -194,18 +205,26 @@ __global__ __launch_bounds__(384) void conv_s2poly_kernel(const PolyArgs a) {
     const float* va = V + r16 * CB + g4 * 4;
     for (int cb = 0; cb < ncb; ++cb) {
         const float* vb = va + (size_t)(cb & 1) * NP * TILES * CB;
+        // software pipeline, pinned with sched_barrier (one consumer wave per SIMD: nothing else hides an exposed wait): the A
+        // fragments of plane p + 1 and the filter plane p + RING are requested BEFORE the eight MFMAs of plane p are issued
+        f32x4 af[NH], nf[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) af[h] = *reinterpret_cast<const f32x4*>(vb + h * 16 * CB);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const f32x4 b = ub[p % RING];
-            // the filter plane RING steps ahead (this block's, or the first planes of the next block)
-            ub[p % RING] = p + RING < NP ? load_u(p + RING, cb) : load_u(p + RING - NP, cb + 1);
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(vb + p * TILES * CB);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(vb + p * TILES * CB + 16 * CB);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[p][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b[j], acc[p][0], 0, 0, 0);
-                acc[p][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b[j], acc[p][1], 0, 0, 0);
-            }
+            for (int h = 0; h < NH; ++h) nf[h] = p + 1 < NP ? *reinterpret_cast<const f32x4*>(vb + (p + 1) * TILES * CB + h * 16 * CB) : af[h];
+            // the filter plane RING steps ahead (this block's, or the first planes of the next block)
+            if (!(SI_POLY_ABL & 2)) ub[p % RING] = p + RING < NP ? load_u(p + RING, cb) : load_u(p + RING - NP, cb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) acc[p][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[h][j], b[j], acc[p][h], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) af[h] = nf[h];
         }
         __syncthreads();   // the producers have finished block cb + 1; everybody is done reading block cb
     }
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(384) void conv_s2poly_kernel(const PolyArgs a) {
     const int oc_l = oc0 + r16;
     const bool oc_ok = oc_l < a.oc;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float c0[5], c1[5];
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(384) void conv_s2poly_kernel(const PolyArgs a) {
                     float v = poly_act(a.act1, y[dy][dx] + bias_v, a.act_param);
                     if (a.res) v += a.res[pix * a.res_ld + oc_l];
                     v = poly_act(a.act2, v, a.act_param);
-                    a.out[pix * a.out_ld + oc_l] = v;
+                    if (!(SI_POLY_ABL & 4) || v == 12345.678f) a.out[pix * a.out_ld + oc_l] = v;
                 }
         }
 }
@@ -306,6 +325,11 @@ int si_hip_conv2d_s2poly_f32(const SiConv2dDesc* d, const float* in, const float
     const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull;
     const unsigned long long u_bytes = (unsigned long long)NP * d->ic * d->oc * 4ull;
     if (in_bytes >= 0xFFFFFF00ull || u_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+    // 32-tile workgroups where they still give every CU several rounds, 16-tile ones below that (SI_POLY_TILES forces one)
+    static const int forced = [] { const char* e = getenv("SI_POLY_TILES"); return e ? atoi(e) : 0; }();
+    const long long tiles_ll = (long long)d->n * ((d->oh + 1) / 2) * ((d->ow + 1) / 2);
+    const int TILES = forced == 16 || forced == 32 ? forced : 32;
+    (void)tiles_ll;
     PolyArgs a;
     a.in = in; a.u = u; a.bias = d->has_bias ? bias : nullptr; a.res = d->has_residual ? residual : nullptr; a.out = out;
     a.n = d->n; a.ih = d->ih; a.iw = d->iw; a.ic = d->ic; a.in_ld = d->in_ld;
@@ -323,7 +347,8 @@ int si_hip_conv2d_s2poly_f32(const SiConv2dDesc* d, const float* in, const float
     a.in_bytes = (unsigned)in_bytes; a.u_bytes = (unsigned)u_bytes;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
     const int chunks = (a.spatial_blocks + 7) / 8;
-    hipLaunchKernelGGL(conv_s2poly_kernel, dim3(chunks * 8 * a.oc_blocks), dim3(384), 0, static_cast<hipStream_t>(stream), a);
+    if (TILES == 16) hipLaunchKernelGGL(conv_s2poly_kernel<16>, dim3(chunks * 8 * a.oc_blocks), dim3(320), 0, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(conv_s2poly_kernel<32>, dim3(chunks * 8 * a.oc_blocks), dim3(384), 0, static_cast<hipStream_t>(stream), a);
     return (int)hipGetLastError();
 }
 

@@ -112,7 +112,7 @@ def main():
                 buf.free()
             continue
         wino = args.algo != "direct"
-        fam = {"wino": "wino23", "wino43": "wino43", "s2poly": "s2poly"}[args.algo]
+        fam = {"wino": "wino23", "wino43": "wino43", "s2poly": "s2poly"}.get(args.algo, "")
         if wino and not getattr(H, "si_hip_conv2d_%s_eligible" % fam)(C.byref(d)):
             continue
         wn = getattr(H, "si_hip_conv2d_%s_weight_elems" % fam)(C.byref(d)) if wino else H.si_hip_conv2d_weight_elems(C.byref(d))

@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/raw" -- python3 "$REPO/bench.py" --no-cpu-baseline --no-aux "$@" > "$OUT/bench.json" 2> "$OUT/stderr.txt" || true
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/raw" -- python3 "$REPO/bench.py" --no-cpu-baseline --no-aux --no-secondary "$@" > "$OUT/bench.json" 2> "$OUT/stderr.txt" || true
 cd "$REPO"
 find "$OUT/raw" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 find "$OUT/raw" -name "*kernel_trace.csv" -exec sh -c 'head -1 {} > '"$OUT"'/kernel_trace_head.csv' \;

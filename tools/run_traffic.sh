@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 REPO=$PWD
 for C in FETCH_SIZE WRITE_SIZE; do
   cd /tmp
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/raw_$C" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --min-time 0 --max-windows 1 --no-cpu-baseline --no-aux --profile-passes 1 "$@" > "$OUT/bench_$C.json" 2> "$OUT/stderr_$C.txt" || true
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/raw_$C" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --min-time 0 --max-windows 1 --no-cpu-baseline --no-aux --no-secondary --profile-passes 1 "$@" > "$OUT/bench_$C.json" 2> "$OUT/stderr_$C.txt" || true
   cd "$REPO"
   find "$OUT/raw_$C" -name "*counter_collection.csv" -exec cp {} "$OUT/counters_$C.csv" \;
   rm -rf "$OUT/raw_$C"
