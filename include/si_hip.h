@@ -363,9 +363,10 @@ size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d);
  * [group][oc/32][K/16][lane 0..63][8] (lane l = channel l & 31, k = 8 (l >> 5) .. + 7 of the 16-deep step) that the kernels
  * with weights fetched straight from L2 read with one coalesced 16-byte load per lane (round 4) */
 int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
-/* Tile variant of the fp16 implicit GEMM (tests, sweeps): 0-2 the one-stage kernel (64x64, 128x64, 128x128), 3-8 the kernels
- * with lane-order weights (128x128, 128x64, 64x128, 64x64, 128x32, 256x64); -1 restores the launch-size policy.  Every variant
- * produces the same bits.  Returns 0, or SI_E_BADARG for an unknown id. */
+/* Tile variant of the fp16 implicit GEMM (tests, sweeps): 0-2 the one-stage kernel (64x64, 128x64, 128x128); 3, 7, 9, 10, 11 the
+ * kernels with lane-order weights (128x128 as 2x2 waves, 128x32 as 4x1, 128x128 as 1x4, 64x128 as 1x4, 9 at three waves per SIMD);
+ * -1 restores the launch-size policy.  Every variant produces the same bits.  Returns 0, or SI_E_BADARG for an unknown or
+ * retired id (4, 5, 6, 8 and >= 12 were measured and removed, profiles/r04_f16_bd_sweep.txt). */
 int si_hip_conv2d_f16_set_tile_variant(int variant);
 /* the variant the policy (or the forced id) picks for this shape; -1 when the shape has no fp16 implicit-GEMM kernel */
 int si_hip_conv2d_f16_tile_variant(const SiConv2dDesc* d);

@@ -687,17 +687,21 @@ size_t f16_row_elems(const SiConv2dDesc* d) { return (size_t)d->oc * d->kh * d->
 size_t f16_lane_elems(const SiConv2dDesc* d) { return (size_t)d->groups * f16_lane_nb(d) * f16_lane_ks(d) * 512; }
 
 // Tile variants.  One-stage kernel (both operands through LDS): 0: 64x64, 1: 128x64, 2: 128x128.  "bd" kernels (weights straight
-// from L2 in lane order, A through two LDS stages): 3: 128x128 (wave tiles 64x64), 4: 128x64 (64x32), 5: 64x128 (32x64), 6: 64x64
-// (32x32), 7: 128x32 as 4x1 waves (32x32), 8: 256x64 as 4x1 waves (64x64).  All variants produce the same bits (same k order, same
-// 16-deep MFMA steps).  si_hip_conv2d_f16_set_tile_variant / SI_CONV_F16_VARIANT force one (tests, sweeps); -1: the policy.
-constexpr int kF16Variants = 15;
+// from L2 in lane order, A through two LDS stages): 3: 128x128 as 2x2 waves of 64x64 (the form the ablations of
+// profiles/r04_f16_ablation.txt were taken on), 7: 128x32 as 4x1 waves, 9: 128x128 as 1x4 waves of 128x32 (every wave its own weight
+// columns, A shared through LDS), 10: 64x128 as 1x4 waves of 64x32, 11: 9 compiled for three waves per SIMD.  Measured and retired
+// (profiles/r04_f16_bd_sweep.txt; the ids are not accepted): 4 128x64 2x2, 5 64x128 2x2, 6 64x64 2x2, 8 256x64 4x1, 12 64x256 1x4,
+// 13 32x128 1x4, 14 32x256 1x4.  All variants produce the same bits (same k order, same 16-deep MFMA steps).
+// si_hip_conv2d_f16_set_tile_variant / SI_CONV_F16_VARIANT force one (tests, sweeps); -1: the policy.
+constexpr int kF16Variants = 12;
+bool f16_variant_valid(int v) { return v >= 0 && v < kF16Variants && v != 4 && v != 5 && v != 6 && v != 8; }
 std::atomic<int> g_f16_forced{-2};
 int f16_forced_variant() {
     int v = g_f16_forced.load(std::memory_order_relaxed);
     if (v == -2) {
         const char* e = getenv("SI_CONV_F16_VARIANT");
         v = e ? atoi(e) : -1;
-        if (v < 0 || v >= kF16Variants) v = -1;
+        if (!f16_variant_valid(v)) v = -1;
         int expected = -2;
         g_f16_forced.compare_exchange_strong(expected, v);
         v = g_f16_forced.load(std::memory_order_relaxed);
@@ -821,17 +825,10 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
             case 1: return launch_h<128, 64, 2, 2, 64>(a, d->groups, s);
             case 2: return launch_h<128, 128, 2, 2, 64>(a, d->groups, s);
             case 3: return launch_bd<128, 128, 2, 2, 64>(a, d->groups, s);
-            case 4: return launch_bd<128, 64, 2, 2, 64>(a, d->groups, s);
-            case 5: return launch_bd<64, 128, 2, 2, 64>(a, d->groups, s);
-            case 6: return launch_bd<64, 64, 2, 2, 64>(a, d->groups, s);
             case 7: return launch_bd<128, 32, 4, 1, 64>(a, d->groups, s);
-            case 8: return launch_bd<256, 64, 4, 1, 64>(a, d->groups, s);
             case 9: return launch_bd<128, 128, 1, 4, 64>(a, d->groups, s);
             case 10: return launch_bd<64, 128, 1, 4, 64>(a, d->groups, s);
             case 11: return launch_bd<128, 128, 1, 4, 64, 3>(a, d->groups, s);
-            case 12: return launch_bd<64, 256, 1, 4, 64>(a, d->groups, s);
-            case 13: return launch_bd<32, 128, 1, 4, 64>(a, d->groups, s);
-            case 14: return launch_bd<32, 256, 1, 4, 64>(a, d->groups, s);
             default: return launch_h<64, 64, 2, 2, 64>(a, d->groups, s);
         }
     }
@@ -839,17 +836,10 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
         case 1: return launch_h<128, 64, 2, 2, 32>(a, d->groups, s);
         case 2: return launch_h<128, 128, 2, 2, 32>(a, d->groups, s);
         case 3: return launch_bd<128, 128, 2, 2, 32>(a, d->groups, s);
-        case 4: return launch_bd<128, 64, 2, 2, 32>(a, d->groups, s);
-        case 5: return launch_bd<64, 128, 2, 2, 32>(a, d->groups, s);
-        case 6: return launch_bd<64, 64, 2, 2, 32>(a, d->groups, s);
         case 7: return launch_bd<128, 32, 4, 1, 32>(a, d->groups, s);
-        case 8: return launch_bd<256, 64, 4, 1, 32>(a, d->groups, s);
         case 9: return launch_bd<128, 128, 1, 4, 32>(a, d->groups, s);
         case 10: return launch_bd<64, 128, 1, 4, 32>(a, d->groups, s);
         case 11: return launch_bd<128, 128, 1, 4, 32, 3>(a, d->groups, s);
-        case 12: return launch_bd<64, 256, 1, 4, 32>(a, d->groups, s);
-        case 13: return launch_bd<32, 128, 1, 4, 32>(a, d->groups, s);
-        case 14: return launch_bd<32, 256, 1, 4, 32>(a, d->groups, s);
         default: return launch_h<64, 64, 2, 2, 32>(a, d->groups, s);
     }
 }
@@ -919,7 +909,7 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
 }
 
 int si_hip_conv2d_f16_set_tile_variant(int variant) {
-    if (variant >= kF16Variants) return SI_E_BADARG;
+    if (variant >= 0 && !f16_variant_valid(variant)) return SI_E_BADARG;
     g_f16_forced.store(variant < 0 ? -1 : variant, std::memory_order_relaxed);
     return 0;
 }

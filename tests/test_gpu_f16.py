@@ -231,9 +231,9 @@ def test_pool_activation_binary_convert_f16(hops, orc):
 
 
 # ---- tile variants of the fp16 implicit GEMM (round 4): the one-stage kernel (0-2) and the kernels that fetch the weights
-# straight from L2 in MFMA lane order (3-8) must agree BIT FOR BIT -- the same k order through the same 16-deep MFMA steps --
+# straight from L2 in MFMA lane order (3, 7, 9, 10, 11; seven more were measured and retired) must agree BIT FOR BIT -- the same k order through the same 16-deep MFMA steps --
 # so that the tile policy may follow the launch size without touching the batch-invariance contract.
-F16_TILES = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14]
+F16_TILES = [0, 1, 2, 3, 7, 9, 10, 11]
 
 
 @pytest.fixture()
