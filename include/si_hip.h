@@ -370,6 +370,9 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
 int si_hip_conv2d_f16_set_tile_variant(int variant);
 /* the variant the policy (or the forced id) picks for this shape; -1 when the shape has no fp16 implicit-GEMM kernel */
 int si_hip_conv2d_f16_tile_variant(const SiConv2dDesc* d);
+/* name of the instantiation si_hip_conv2d_f16 (form 0) / si_hip_conv2d_upcat_f16 (form 1) launches for this problem, exactly as
+ * rocprofv3 prints it minus the namespace (as si_hip_conv2d_kernel_name_form for fp32); "" when there is no fp16 kernel */
+const char* si_hip_conv2d_f16_kernel_name(const SiConv2dDesc* d, int form);
 /* as si_hip_conv2d_f32; in / residual / out fp16 (strides in elements), bias fp32; out_is_f32 != 0 stores fp32 (graph
  * outputs) */
 int si_hip_conv2d_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,

@@ -141,6 +141,7 @@ def hip():
         "si_hip_conv2d_upcat_f16": (i, [C.POINTER(SiConv2dDesc), vp, C.POINTER(SiConv2dUpsampledSource), vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_upcat_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dUpsampledSource)]),
         "si_hip_conv2d_f16_tile_variant": (i, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_f16_kernel_name": (C.c_char_p, [C.POINTER(SiConv2dDesc), i]),
         "si_hip_conv2d_f16_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_f16_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, i, vp]),

@@ -919,6 +919,26 @@ int si_hip_conv2d_f16_tile_variant(const SiConv2dDesc* d) {
     return f16_variant(d);
 }
 
+const char* si_hip_conv2d_f16_kernel_name(const SiConv2dDesc* d, int form) {
+    // the instantiation dispatch_h launches for this problem, exactly as rocprofv3 prints it (minus the namespace); form 1: the
+    // dual-source (upsampled) form, which lives in the one-stage 64x64 kernel
+    if (!d || !f16_shape_ok(d)) return "";
+    const int v = form == 1 ? 0 : f16_variant(d);
+    const bool b64 = f16_block(d) == 64;
+    switch (v) {
+        case 1: return b64 ? "conv_igemm_f16_kernel<128, 64, 2, 2, 64, false>" : "conv_igemm_f16_kernel<128, 64, 2, 2, 32, false>";
+        case 2: return b64 ? "conv_igemm_f16_kernel<128, 128, 2, 2, 64, false>" : "conv_igemm_f16_kernel<128, 128, 2, 2, 32, false>";
+        case 3: return b64 ? "conv_igemm_f16_bd_kernel<128, 128, 2, 2, 64, 1>" : "conv_igemm_f16_bd_kernel<128, 128, 2, 2, 32, 1>";
+        case 7: return b64 ? "conv_igemm_f16_bd_kernel<128, 32, 4, 1, 64, 1>" : "conv_igemm_f16_bd_kernel<128, 32, 4, 1, 32, 1>";
+        case 9: return b64 ? "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 64, 1>" : "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 32, 1>";
+        case 10: return b64 ? "conv_igemm_f16_bd_kernel<64, 128, 1, 4, 64, 1>" : "conv_igemm_f16_bd_kernel<64, 128, 1, 4, 32, 1>";
+        case 11: return b64 ? "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 64, 3>" : "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 32, 3>";
+        default:
+            if (form == 1) return b64 ? "conv_igemm_f16_kernel<64, 64, 2, 2, 64, true>" : "conv_igemm_f16_kernel<64, 64, 2, 2, 32, true>";
+            return b64 ? "conv_igemm_f16_kernel<64, 64, 2, 2, 64, false>" : "conv_igemm_f16_kernel<64, 64, 2, 2, 32, false>";
+    }
+}
+
 int si_hip_conv2d_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
                       void* out, int out_is_f32, si_stream_t stream) {
     return dispatch_h(d, in, w_packed, bias, residual, out, out_is_f32 ? 1 : 0, stream, nullptr, nullptr, nullptr, nullptr);

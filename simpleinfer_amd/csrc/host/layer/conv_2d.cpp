@@ -473,7 +473,10 @@ const char* Conv2d::KernelName() const {
     SiConv2dDesc d = MakeDesc(in, out);
     if (sibling_) d.oc += sibling_->out_channels_;
     const int mode = PrecisionMode(in, out);
-    if (mode == 1) return "conv_igemm_f16_kernel<64, 64, 2, 2>";
+    if (mode == 1) {
+        const char* name = si_hip_conv2d_f16_kernel_name(&d, up_node_ ? 1 : 0);   // the tile follows the launch size (round 4)
+        return name && name[0] ? name : "conv_igemm_f16_kernel";
+    }
     if (mode == 2) return "conv_stem_f16_kernel";
     if (mode == 3) return "conv_depthwise_f16_kernel<2>";
     const int tile = WinogradTile(d);
