@@ -432,17 +432,20 @@ def aux_measurements(args, si, hipops, H, e, oname, oshape, pp, bp, dev, x, extr
 
 def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
     """The application around Forward() in the reference's test-yolo (test/test_yolo/test_yolo.cpp:299-438) as a pipelined
-    stream of batches, every stage on the device except the resize the reference leaves to cv::resize: per batch the host holds
-    u8 BGR images already resized to the letterbox target; they are uploaded (u8: 39 MB per 32 images instead of 157 MB of fp32)
-    on a copy stream into one of TWO device buffers while the previous batch computes; on the engine's stream: letterbox (pad /
-    BGR->RGB / cast / divide by 255, :220-259) into the engine's input, Forward(), confidence filter + sort + per-class NMS
+    stream of batches, EVERY stage on the device (round 4: cv::resize too): per batch the host holds 720 x 1280 u8 BGR camera
+    frames; they are uploaded (u8: 88 MB per 32 images) on a copy stream into one of TWO device buffers while the previous batch
+    computes; on the engine's stream: bilinear resize + letterbox (pad / BGR->RGB / cast / divide by 255, :194-259) in one launch
+    into the engine's input, Forward(), confidence filter + sort + per-class NMS
     (:337-428), and the boxes (7 KB per image) come back.  Reported: images/sec end to end and its ratio to the device-resident
     Forward() rate of the same run.  Random-init weights put every row near confidence 0.25, so the confidence threshold is set
     where 3 % of the rows pass (~750 candidates per image, what a trained detector yields), and says so."""
     import ctypes as C
     n, size = args.batch, args.size
     rows, ne = oshape[1], oshape[2]
-    hr, wr, scale, pt, pl = hipops.letterbox_geometry(480, 640, size, size)   # 4:3 camera frames
+    # round 4: the host holds CAMERA frames (720 x 1280 BGR u8, 2.8 MB each) and the whole of PreProcess -- cv::resize included --
+    # runs on the device (si_hip_resize_letterbox_batch_u8_f32: bilinear resize + letterbox in one launch)
+    cam_h, cam_w = 720, 1280
+    hr, wr = cam_h, cam_w
     img_bytes = hr * wr * 3
     rng = np.random.default_rng(5)
     frames = rng.integers(0, 256, (2, n, hr, wr, 3), dtype=np.uint8)
@@ -478,7 +481,9 @@ def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
 
     def compute(k, thr):
         H.si_hip_stream_wait_event(es, ev_up[k])
-        H.si_hip_letterbox_batch_u8_f32(dev_u8[k].ptr, n, img_bytes, hr, wr, dev_in[k].ptr, size, size, pt, pl, es)
+        rc = H.si_hip_resize_letterbox_batch_u8_f32(dev_u8[k].ptr, n, img_bytes, cam_h, cam_w, dev_in[k].ptr, size, size, es)
+        if rc != 0:
+            raise RuntimeError("si_hip_resize_letterbox_batch_u8_f32 rc=%d" % rc)
         H.si_hip_event_record(ev_used[k], es)
         e.input_device(iname, dev_in[k].ptr)
         e.forward_async()
@@ -525,10 +530,10 @@ def app_pipeline(args, si, hipops, H, e, iname, oname, oshape, rate_resident):
     return {"value": round(value, 2), "unit": "images/sec", "ms_per_batch": round(dt / steps * 1e3, 3),
             "ratio_to_device_resident": round(value / rate_resident, 4), "boxes_kept_per_image": round(float(kept), 1),
             "confidence_threshold": round(thr, 4), "bytes_up_per_image": img_bytes, "bytes_down_per_image": max_det * 24 + 4,
-            "note": "test-yolo's flow (test_yolo.cpp:299-438) pipelined: u8 letterbox-target frames (480x640 -> %dx%d, padded to %dx%d on the "
-                    "device) uploaded double-buffered on a copy stream, device letterbox -> Forward -> device filter / sort / NMS, boxes "
-                    "downloaded; threshold at the 97th percentile of this random-init network's confidences (3 %% of rows pass, as with "
-                    "a trained detector); not `value`" % (hr, wr, size, size)}
+            "note": "test-yolo's flow (test_yolo.cpp:299-438) pipelined, every stage on the device: %dx%d u8 BGR camera frames uploaded "
+                    "double-buffered on a copy stream, bilinear resize + letterbox to %dx%d in one launch (PreProcess incl. cv::resize) -> "
+                    "Forward -> device filter / sort / NMS, boxes downloaded; threshold at the 97th percentile of this random-init "
+                    "network's confidences (3 %% of rows pass, as with a trained detector); not `value`" % (cam_h, cam_w, size, size)}
 
 
 def self_launch(args):
