@@ -401,6 +401,12 @@ int si_hip_conv2d_split_f16(const SiConv2dDesc* d, const void* in, const void* w
 int si_hip_conv2d_yolo_f16(const SiConv2dDesc* d, const void* in, const void* w_packed, const float* bias,
                            const SiYoloLevel* level, const float* grid_hwa2, const float* anchor_hwa2, float* detect_out,
                            si_stream_t stream);
+/* Round 4: a Detect level over 128 / 256 / 512 channels runs as a tile shape of its own (64 consecutive pixels x all na*ne columns
+ * per workgroup, decoded rows staged through LDS and written as one contiguous run; conv_igemm_f16.hip detect_f16_tile_kernel) --
+ * same bits as the generic tiles.  set_tile(0) forces the generic tiles (tests, A/B runs; SI_DETECT_F16_TILE=0 does the same at
+ * start-up); _tile() tells which form si_hip_conv2d_yolo_f16 launches for this problem (1: the Detect tile). */
+int si_hip_conv2d_yolo_f16_set_tile(int on);
+int si_hip_conv2d_yolo_f16_tile(const SiConv2dDesc* d, const SiYoloLevel* level);
 int si_hip_activation_f16(int act, float act_param, const void* in, size_t pixels, int c, int in_ld, void* out, int out_ld,
                           si_stream_t stream);
 /* same-shape add (op 0) / mul (op 2) */

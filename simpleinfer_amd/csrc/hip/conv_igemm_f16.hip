@@ -659,6 +659,201 @@ int launch_h(const ConvArgsH& a, int groups, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// ---- YOLOv5 Detect level as ONE tile shape of its own (round 4) ------------------------------------------------------------------
+// A Detect level is a 1x1 conv to na*ne = 255 columns whose decoded fp32 result is 17 x its fp16 input: the launch is a WRITE stream
+// (batch 32, 80x80x128: 26 MB in, 209 MB out).  Through the 64x64 tiles above it ran as 12 800 workgroups of two K-tiles each, every
+// one a load -> LDS -> barrier -> MFMA -> decode chain ending in 256-byte dword stores at a 1020-byte row pitch: 113 us = 1.85 TB/s.
+// Here a workgroup owns 64 CONSECUTIVE PIXELS of one image and ALL columns: in the [H][W][A] row order of the output
+// (src/layer/yolo_detect.cpp:223-266 writes the same bytes) those are one contiguous run of 64 * 255 floats.  The whole A tile
+// (64 pixels x K) is requested at once, the weights come from the lane-order image (L2 -> registers, four waves x 64 columns), and
+// the decoded values are staged through LDS in two 32-pixel halves and leave as 16-byte-per-lane stores down the run.
+// Same k order and the same 16-deep MFMA steps as the other fp16 kernels, the same decode expressions: the same bits
+// (tests/test_gpu_f16.py).  NCH = K / 128.
+// SI_DET_ABL (diagnostic builds only, tools/detect_ablate.sh): bit 0 no sigmoid (bias add only), 1 no global stores, 2 no A loads,
+// 3 no MFMA loop, 4 no staging writes -- wrong results, timing only.  0 in the product build.
+#ifndef SI_DET_ABL
+#define SI_DET_ABL 0
+#endif
+#ifndef SI_DET_RING
+#define SI_DET_RING 4
+#endif
+#ifndef SI_DET_MINW
+#define SI_DET_MINW 3
+#endif
+template <int NCH>
+__global__ __launch_bounds__(256, NCH <= 2 ? SI_DET_MINW : 2) void detect_f16_tile_kernel(const ConvArgsH a) {
+    constexpr int K = NCH * 128;
+    constexpr int LDH = K + 8;            // halves per LDS row: (2K + 16) mod 128 = 16, the conflict-free pitch of the kernels above
+    constexpr int VPR = K / 8;            // 16-byte vectors per row
+    constexpr int A_IT = 64 * VPR / 256;  // vectors per thread
+    constexpr int KS = K / 16;            // MFMA k-steps
+    constexpr int RING = SI_DET_RING;     // weight fragments in flight, in k-steps (K = 128: all of them, requested with the A tile)
+    extern __shared__ __attribute__((aligned(16))) unsigned char det_smem[];
+    half_t* const As = reinterpret_cast<half_t*>(det_smem);
+    float* const stage = reinterpret_cast<float*>(det_smem);   // 32 pixels x 255 floats, over the A tile once the MFMAs are done
+
+    const int tiles_per_img = (a.ohow + 63) >> 6;
+    const int img = blockIdx.x / tiles_per_img;
+    const int pix0 = (blockIdx.x - img * tiles_per_img) * 64;
+    const int valid = min(64, a.ohow - pix0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.in), 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(a.wl), 0, (unsigned)a.wl_nb * (unsigned)a.wl_ks * 1024u, 0x00020000);
+
+    u32x4 ra[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / VPR, kv = idx - row * VPR;
+        const unsigned off = (unsigned)(img * a.ohow + pix0 + row) * (unsigned)(a.in_ld * 2) + (unsigned)(kv * 16);
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (row < valid && !(SI_DET_ABL & 4)) ? off : OOB_A, 0, 0);
+    }
+    unsigned b_off[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int nb = wave * 2 + u;
+        b_off[u] = nb < a.wl_nb ? (unsigned)nb * (unsigned)a.wl_ks * 1024u + (unsigned)lane * 16u : OOB_B;
+    }
+    f16x8 rb[RING][2];
+#pragma unroll
+    for (int s = 0; s < RING; ++s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            rb[s][u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wl, b_off[u], (unsigned)(s * 1024), 0));
+    float bv[2];
+    int col[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        col[u] = wave * 64 + u * 32 + l31;
+        bv[u] = (a.bias && col[u] < a.ocg) ? a.bias[col[u]] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx / VPR, kv = idx - row * VPR;
+        *reinterpret_cast<u32x4*>(As + row * LDH + kv * 8) = ra[i];
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.0f;
+    const half_t* const Ar = As + l31 * LDH + lh * 8;
+    f16x8 fa[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) fa[0][t] = *reinterpret_cast<const f16x8*>(Ar + t * 32 * LDH);
+#pragma unroll
+    for (int s = 0; s < ((SI_DET_ABL & 8) ? 0 : KS); ++s) {
+        if (s + 1 < KS) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fa[(s + 1) & 1][t] = *reinterpret_cast<const f16x8*>(Ar + t * 32 * LDH + (s + 1) * 16);
+        }
+        f16x8 bc[2] = {rb[s % RING][0], rb[s % RING][1]};
+        if (s + RING < KS) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                rb[s % RING][u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wl, b_off[u], (unsigned)((s + RING) * 1024), 0));
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][t], bc[u], acc[t][u], 0, 0, 0);
+    }
+
+    // decode (si_yolo_tile_one_image's expressions) -> LDS -> the contiguous run, 32 pixels at a time
+    const int per_pix = a.yna * a.yne;
+    float* const orun = static_cast<float*>(a.out) + ((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix0 * per_pix;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        __syncthreads();   // t = 0: every wave is done reading A; t = 1: the first half has left the stage
+        const int rows = min(32, valid - 32 * t);
+        if (rows > 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool live = col[u] < a.ocg;
+                const int oo = live ? col[u] : 0;
+                const int anc = oo / a.yne;
+                const int e_ = oo - anc * a.yne;
+                const bool is_xy = e_ < 2, is_box = e_ < 4;
+                const float* const ap = (is_xy ? a.ygrid + e_ : a.yanchor + (is_box ? e_ - 2 : 0)) + anc * 2 + (size_t)(pix0 + 32 * t) * a.yna * 2;
+                float auxv[16];   // (all sixteen requested before the first is used: si_yolo_tile_one_image)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) auxv[e] = 0.0f;
+                if (is_box) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int dm = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        auxv[e] = ap[(dm < rows ? dm : 0) * a.yna * 2];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dm = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float sg = (SI_DET_ABL & 1) ? acc[t][u][e] + bv[u] : __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[t][u][e] + bv[u])));
+                    const float aux = auxv[e];
+                    const float t2 = sg * 2.0f;
+                    const float xy = (t2 + aux) * a.ystride;
+                    const float wh = t2 * t2 * aux;
+                    const float v = is_xy ? xy : (is_box ? wh : sg);
+                    if (SI_DET_ABL & 16) asm volatile("" ::"v"(v));
+                    else if (live) stage[dm * per_pix + oo] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (rows > 0 && !(SI_DET_ABL & 2)) {
+            float* const dst = orun + (size_t)(32 * t) * per_pix;
+            const int nfl = rows * per_pix;
+            if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                const int n4 = nfl >> 2;
+                for (int i = tid; i < n4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(stage)[i];
+                const int done = n4 << 2;
+                if (tid < nfl - done) dst[done + tid] = stage[done + tid];
+            } else {
+                for (int i = tid; i < nfl; i += 256) dst[i] = stage[i];
+            }
+        }
+    }
+}
+
+// -1: on when the shape allows (default), 0: off (the generic tiles above), SI_DETECT_F16_TILE / si_hip_conv2d_yolo_f16_set_tile
+std::atomic<int> g_detect_tile{-2};
+bool detect_tile_on() {
+    int v = g_detect_tile.load(std::memory_order_relaxed);
+    if (v == -2) {
+        const char* e = getenv("SI_DETECT_F16_TILE");
+        v = (e && atoi(e) == 0) ? 0 : 1;
+        int expected = -2;
+        g_detect_tile.compare_exchange_strong(expected, v);
+        v = g_detect_tile.load(std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+// shape half of the eligibility: a plain pointwise conv over 128 / 256 / 512 channels to at most 256 columns, rows of at most
+// 32 x 255 floats per stage half
+bool detect_tile_shape_ok(const SiConv2dDesc* d, const SiYoloLevel* y) {
+    const bool pointwise = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow;
+    return pointwise && d->groups == 1 && (d->ic == 128 || d->ic == 256 || d->ic == 512) && d->oc <= 256 && y->na * y->ne == d->oc && !d->has_residual;
+}
+template <int NCH>
+int launch_detect_tile(const ConvArgsH& a, int n, hipStream_t s) {
+    constexpr int K = NCH * 128;
+    const size_t a_bytes = (size_t)64 * (K + 8) * 2, st_bytes = (size_t)32 * a.ocg * 4;
+    const size_t smem = a_bytes > st_bytes ? a_bytes : st_bytes;
+    static const int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&detect_f16_tile_kernel<NCH>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (K + 8) * 2 > 32 * 256 * 4 ? 64 * (K + 8) * 2 : 32 * 256 * 4);
+    if (attr_rc != 0) return attr_rc;
+    const int tiles = ((a.ohow + 63) >> 6) * n;
+    hipLaunchKernelGGL((detect_f16_tile_kernel<NCH>), dim3(tiles), dim3(256), smem, s, a);
+    return (int)hipGetLastError();
+}
+
 struct SplitOutH {
     half_t* out2;
     int out2_ld, split;
@@ -819,6 +1014,13 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
         a.ystride = yolo->stride; a.ygrid = ygrid; a.yanchor = yanchor;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (yolo && detect_tile_on() && detect_tile_shape_ok(d, yolo)) {
+        switch (d->ic) {
+            case 128: return launch_detect_tile<1>(a, d->n, s);
+            case 256: return launch_detect_tile<2>(a, d->n, s);
+            default: return launch_detect_tile<4>(a, d->n, s);
+        }
+    }
     const int v = up ? 0 : f16_variant(d);   // (the dual-source form lives in the one-stage 64x64 kernel)
     if (f16_block(d) == 64) {
         switch (v) {
@@ -968,6 +1170,16 @@ int si_hip_conv2d_yolo_f16(const SiConv2dDesc* d, const void* in, const void* w_
                            si_stream_t stream) {
     if (!level || !grid_hwa2 || !anchor_hwa2 || level->ne < 4 || level->na <= 0) return SI_E_BADARG;
     return dispatch_h(d, in, w_packed, bias, nullptr, detect_out, 0, stream, level, grid_hwa2, anchor_hwa2, nullptr);
+}
+
+int si_hip_conv2d_yolo_f16_set_tile(int on) {
+    g_detect_tile.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
+int si_hip_conv2d_yolo_f16_tile(const SiConv2dDesc* d, const SiYoloLevel* level) {
+    if (!d || !level) return 0;
+    return (detect_tile_on() && f16_shape_ok(d) && detect_tile_shape_ok(d, level)) ? 1 : 0;
 }
 
 }  // extern "C"

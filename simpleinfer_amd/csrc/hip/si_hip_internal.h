@@ -106,12 +106,21 @@ __device__ __forceinline__ void si_yolo_tile_one_image(const Args& a, float* out
             const int pix0 = mrow0 + t * MT - img * a.ohow;
             float* const op = out + ((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix0 * per_pix + oo;
             const float* const ap = auxp + (size_t)pix0 * a.yna * 2;
+            // the box lanes' grid / anchor values, ALL requested before the first one is used: with the load inside the element
+            // loop hipcc waits for each one in turn (16 L2 round trips per 32x32 block on the waves that own a box column)
+            constexpr int NE = MT == 32 ? 16 : 4;
+            float auxv[NE];
 #pragma unroll
-            for (int e = 0; e < (MT == 32 ? 16 : 4); ++e) {
+            for (int e = 0; e < NE; ++e) auxv[e] = 0.0f;
+            if (is_box) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) auxv[e] = ap[(MT == 32 ? (e & 3) + 8 * (e >> 2) : e) * a.yna * 2];
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
                 const int dm = MT == 32 ? (e & 3) + 8 * (e >> 2) : e;
                 const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[t][u][e] + bv)));
-                float aux = 0.0f;
-                if (is_box) aux = ap[dm * a.yna * 2];
+                const float aux = auxv[e];
                 const float t2 = sg * 2.0f;
                 const float xy = (t2 + aux) * a.ystride;
                 const float wh = t2 * t2 * aux;

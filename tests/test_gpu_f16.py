@@ -314,6 +314,43 @@ def test_every_f16_tile_variant_same_bits_through_epilogues_split_and_detect(hop
             assert_exact(got, want, "fp16 tile variant %d, output %d" % (v, i))
 
 
+@pytest.mark.parametrize("n,levels", [
+    (3, ((20, 128), (10, 256), (5, 512))),     # 400 / 100 / 25 pixels per image: whole tiles, a 16-pixel tail, a tile of 25
+    (2, ((9, 256), (3, 128), (1, 512))),       # 91 rows x 3: image bases only 4-byte aligned -> the dword form of the run
+    (1, ((16, 512), (8, 128), (4, 256))),
+])
+def test_detect_tile_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, levels):
+    """Round 4: a Detect level over 128 / 256 / 512 channels runs as detect_f16_tile_kernel (64 consecutive pixels x all 255 columns
+    per workgroup, decoded rows staged through LDS, one contiguous run out).  Same MFMA sequence per element and the same decode
+    expressions as the generic tiles, so the two forms agree BIT for bit; and the oracle's bar holds (src/layer/yolo_detect.cpp:223-266)."""
+    from simpleinfer_amd import _native
+    H = _native.hip()
+    na, ne = 3, 85
+    feats, ws, bs, grids, anchors = [], [], [], [], []
+    for i, (hh, c) in enumerate(levels):
+        feats.append(h(rng_uniform(150 + i, (n, hh, hh, c), -1, 1)))
+        ws.append(h(rng_uniform(160 + i, (na * ne, c, 1, 1), -0.3, 0.3)))
+        bs.append(rng_uniform(170 + i, (na * ne,), -0.5, 0.5))
+        gy, gx = np.meshgrid(np.arange(hh, dtype=np.float32), np.arange(hh, dtype=np.float32), indexing="ij")
+        grids.append(np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, hh, hh, 2)).copy())
+        anchors.append(np.broadcast_to(rng_uniform(180 + i, (1, na, 1, 1, 2), 5, 300), (1, na, hh, hh, 2)).copy())
+    strides = [8.0, 16.0, 32.0]
+    import ctypes as C
+    d = _native.SiConv2dDesc(n, 20, 20, 128, 128, 20, 20, na * ne, na * ne, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, na * ne, 0, 0.0)
+    lv = _native.SiYoloLevel(na, ne, 1200, 0, 8.0)
+    try:
+        assert H.si_hip_conv2d_yolo_f16_set_tile(0) == 0
+        assert H.si_hip_conv2d_yolo_f16_tile(C.byref(d), C.byref(lv)) == 0
+        base = hops.yolo_detect_f16(feats, ws, bs, grids, anchors, strides, na)
+        assert H.si_hip_conv2d_yolo_f16_set_tile(1) == 0
+        assert H.si_hip_conv2d_yolo_f16_tile(C.byref(d), C.byref(lv)) == 1
+        got = hops.yolo_detect_f16(feats, ws, bs, grids, anchors, strides, na)
+    finally:
+        H.si_hip_conv2d_yolo_f16_set_tile(1)
+    assert_exact(got, base, "Detect tile kernel vs generic tiles")
+    assert_detect_parity(got, orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na), 1e-4, 1e-4, what="Detect tile kernel")
+
+
 @pytest.mark.parametrize("n,lh,lw,cl,cs,oc,scale,up_first", [
     (2, 10, 10, 128, 128, 128, (2.0, 2.0), True),    # the YOLOv5 PAN form, 64-wide K blocks
     (3, 5, 7, 64, 192, 96, (2.0, 2.0), False),       # upsampled tensor second, ragged column block
