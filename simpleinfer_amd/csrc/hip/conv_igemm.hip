@@ -183,6 +183,17 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, typename Mma<MT
                 const int mb = rbase + t * 16;
                 float* const op = obase + (size_t)mb * old;
                 const float* const rp = HAS_RES ? a.res + (size_t)mb * a.res_ld + oc_abs : nullptr;
+                // the block's residual values, ALL requested before its first store: a load behind a store that may alias it is
+                // not moved up by the compiler, and on gfx9 vmcnt counts the stores too, so "load, wait, add, store" per element
+                // is a full memory round trip per element.  (A row behind M re-reads row M - 1: always a valid address.)
+                float rx[4], ry[4];
+                if (HAS_RES) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        rx[e] = rp[((INTERIOR || mb + e < a.M) ? e : a.M - 1 - mb) * a.res_ld];
+                        ry[e] = rp[((INTERIOR || mb + 4 + e < a.M) ? 4 + e : a.M - 1 - mb) * a.res_ld];
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float vl = act_fn<ACT1>(acc[t][u][e] + bv_l, a.act_param);
@@ -193,11 +204,11 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, typename Mma<MT
                     float x = vl, y = vr;
                     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
                     if (live && (INTERIOR || mb + e < a.M)) {
-                        if (HAS_RES) x += rp[e * a.res_ld];
+                        if (HAS_RES) x += rx[e];
                         op[e * old] = act_fn<ACT2>(x, a.act_param);
                     }
                     if (live && (INTERIOR || mb + 4 + e < a.M)) {
-                        if (HAS_RES) y += rp[(4 + e) * a.res_ld];
+                        if (HAS_RES) y += ry[e];
                         op[(4 + e) * old] = act_fn<ACT2>(y, a.act_param);
                     }
                 }
@@ -235,12 +246,20 @@ __device__ __forceinline__ void epilogue_lean(const ConvArgs& a, typename Mma<MT
                     if (INTERIOR || mb + c0 + 1 < a.M) op[(c0 + 1) * old] = o[1];
                 }
             } else {
+            float rv[NE];   // (all of the block's residual values before its first store, see above)
+            if (HAS_RES) {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const int c = Mma<MT>::row(e);
+                    rv[e] = rp[((INTERIOR || mb + c < a.M) ? c : a.M - 1 - mb) * a.res_ld];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
                 const int c = Mma<MT>::row(e);  // row of the C/D map (plus 4 * (lane >> 5) or 4 * (lane >> 4), already in mrow0)
                 if (INTERIOR || mb + c < a.M) {
                     float v = act_fn<ACT1>(acc[t][u][e] + bv, a.act_param);
-                    if (HAS_RES) v += rp[c * a.res_ld];
+                    if (HAS_RES) v += rv[e];
                     op[c * old] = act_fn<ACT2>(v, a.act_param);
                 }
             }

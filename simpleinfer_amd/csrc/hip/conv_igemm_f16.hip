@@ -149,12 +149,24 @@ __device__ __forceinline__ void epilogue_lean_h(const ConvArgsH& a, f32x16 (&acc
             const int mb = mrow0 + t * 32;
             half_t* const op = obase + (size_t)mb * old;
             const half_t* const rp = HAS_RES ? a.res + (size_t)mb * a.res_ld + oc_abs : nullptr;
+            // the block's residual values, ALL requested before its first store: a load behind a store that may alias it is not
+            // moved up by the compiler, and on gfx9 vmcnt counts the stores too, so "load, wait, add, store" per element was a
+            // full memory round trip per element (64 in series per wave on the 64x32 wave tiles of the C3 bottleneck convs).
+            // (A row behind M re-reads row M - 1: always a valid address.)
+            half_t rv[16];
+            if (HAS_RES) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = (e & 3) + 8 * (e >> 2);
+                    rv[e] = rp[((INTERIOR || mb + c < a.M) ? c : a.M - 1 - mb) * a.res_ld];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int c = (e & 3) + 8 * (e >> 2);
                 if (INTERIOR || mb + c < a.M) {
                     float v = act_c<ACT1>(acc[t][u][e] + bv, a.act_param);
-                    if (HAS_RES) v += (float)rp[c * a.res_ld];
+                    if (HAS_RES) v += (float)rv[e];
                     op[c * old] = si_store_cast<half_t>(act_c<ACT2>(v, a.act_param));
                 }
             }
