@@ -406,6 +406,11 @@ int si_hip_conv2d_yolo_f16(const SiConv2dDesc* d, const void* in, const void* w_
  * same bits as the generic tiles.  set_tile(0) forces the generic tiles (tests, A/B runs; SI_DETECT_F16_TILE=0 does the same at
  * start-up); _tile() tells which form si_hip_conv2d_yolo_f16 launches for this problem (1: the Detect tile). */
 int si_hip_conv2d_yolo_f16_set_tile(int on);
+/* Round 4: a 3x3 stride-2 pad-1 conv over 32 input channels to 32 / 64 output channels (YOLOv5's second conv) runs as a persistent
+ * spatial-tile kernel (conv_igemm_f16.hip conv_s2c32_f16_kernel: the input patch of the next tile in flight while this one is
+ * computed, weights resident in registers) -- same bits as the generic tiles.  set_s2c32(0) forces the generic tiles (tests, A/B
+ * runs; SI_CONV_F16_S2C32=0 does the same at start-up). */
+int si_hip_conv2d_f16_set_s2c32(int on);
 int si_hip_conv2d_yolo_f16_tile(const SiConv2dDesc* d, const SiYoloLevel* level);
 int si_hip_activation_f16(int act, float act_param, const void* in, size_t pixels, int c, int in_ld, void* out, int out_ld,
                           si_stream_t stream);

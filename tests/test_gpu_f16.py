@@ -314,6 +314,36 @@ def test_every_f16_tile_variant_same_bits_through_epilogues_split_and_detect(hop
             assert_exact(got, want, "fp16 tile variant %d, output %d" % (v, i))
 
 
+@pytest.mark.parametrize("n,ih,iw,oc,act", [
+    (2, 64, 64, 64, "silu"),       # whole 4 x 16 tiles
+    (3, 38, 50, 64, "silu"),       # ragged tiles both ways (19 x 25 outputs), odd-sized borders
+    (1, 7, 9, 32, "relu"),         # one partial tile, a single 32-channel column block
+    (5, 16, 32, 64, "none"),
+])
+def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, act):
+    """Round 4: a 3x3 stride-2 pad-1 conv over 32 channels (YOLOv5's second conv) runs as the persistent spatial-tile kernel
+    conv_s2c32_f16_kernel.  Same k order, same MFMA steps, same epilogue expressions as the generic tiles: BIT identical; and the
+    fp16 bar against the oracle (src/layer/conv_2d.cpp:207-283) holds."""
+    from simpleinfer_amd import _native
+    H = _native.hip()
+    x = h(rng_uniform(700, (n, ih, iw, 32), -1, 1))
+    w = h(rng_uniform(701, (oc, 32, 3, 3), -0.3, 0.3))
+    b = rng_uniform(702, (oc,), -0.5, 0.5)
+    kw = {} if act == "none" else {"act1": act}
+    try:
+        assert H.si_hip_conv2d_f16_set_s2c32(0) == 0
+        base = hops.conv2d_f16(x, w, b, (2, 2), (1, 1), **kw)
+        assert H.si_hip_conv2d_f16_set_s2c32(1) == 0
+        got = hops.conv2d_f16(x, w, b, (2, 2), (1, 1), **kw)
+        wide = hops.conv2d_f16(x, w, b, (2, 2), (1, 1), out_ld=oc + 32, out_c_off=16, **kw)   # into a slice of a wider tensor
+    finally:
+        H.si_hip_conv2d_f16_set_s2c32(1)
+    assert_exact(got, base, "s2c32 kernel vs generic tiles")
+    assert_exact(wide, base, "s2c32 kernel, strided output")
+    ref = orc.conv2d(x, w, b, (2, 2), (1, 1), path="naive")
+    assert_parity(got.astype(np.float32), ref if act == "none" else orc.activation(act, ref), F16_TOL, what="s2c32 kernel")
+
+
 @pytest.mark.parametrize("n,levels", [
     (3, ((20, 128), (10, 256), (5, 512))),     # 400 / 100 / 25 pixels per image: whole tiles, a 16-pixel tail, a tile of 25
     (2, ((9, 256), (3, 128), (1, 512))),       # 91 rows x 3: image bases only 4-byte aligned -> the dword form of the run

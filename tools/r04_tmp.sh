@@ -1,12 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
-timeout 1200 python -m pytest tests/test_gpu_f16.py tests/test_gpu_tiles.py tests/test_gpu_ops.py -x -q -k "conv or tile or residual or f16" 2>&1 | tail -3
-ab() { for r in 1 2; do for lib in build_variants/libsi_hip_head.so simpleinfer_amd/libsi_hip.so; do
-SI_HIP_LIB=$lib python bench.py "$@" --no-cpu-baseline --no-aux --no-secondary --min-time 3 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$* $lib', d['value'], d['ms_per_step'])"
-done; done; }
-ab --fp16 1
-ab --fp16 1 --model resnet18 --batch 64 --size 224
-ab --model resnet18 --batch 64 --size 224
-ab --fp16 1 --model mobilenetv3 --batch 64 --size 224
-ab
+for v in 0 1 0 1; do SI_CONV_F16_S2C32=$v python tools/conv_bench.py --f16 --min-ms 50 --shape 32,320,320,32,64,3,2,1 2>&1 | grep -E "k3s2"; done
+for r in 1 2; do for p in 0 1; do
+SI_CONV_F16_S2C32=$p python bench.py --fp16 1 --no-cpu-baseline --no-aux --no-secondary --min-time 3 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('fp16 s2c32=$p', d['value'], d['ms_per_step'])"
+done; done
