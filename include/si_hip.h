@@ -411,6 +411,14 @@ int si_hip_conv2d_yolo_f16_set_tile(int on);
  * computed, weights resident in registers) -- same bits as the generic tiles.  set_s2c32(0) forces the generic tiles (tests, A/B
  * runs; SI_CONV_F16_S2C32=0 does the same at start-up). */
 int si_hip_conv2d_f16_set_s2c32(int on);
+/* Round 4: YOLOv5's first two convs in one persistent kernel (conv_stem_s2c32_f16.hip): `stem` = 6x6 s2 p2, 3 -> 32, SiLU on the
+ * dense fp32 image (src/layer/conv_2d.cpp:207-283), `conv` = 3x3 s2 p1, 32 -> 32 / 64, SiLU; the 32-channel intermediate is computed
+ * tile by tile into LDS and never written.  Weights: si_hip_conv2d_stem_f16_pack_weight_host(stem) and
+ * si_hip_conv2d_f16_pack_weight_host(conv).  Same bits as si_hip_conv2d_stem_f16 followed by si_hip_conv2d_f16. */
+int si_hip_conv2d_stem_s2c32_f16_supported(const SiConv2dDesc* stem, const SiConv2dDesc* conv);
+int si_hip_conv2d_stem_s2c32_f16(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const float* in, const void* stem_w_packed,
+                                 const float* stem_bias, const void* conv_w_packed, const float* conv_bias, void* out,
+                                 si_stream_t stream);
 int si_hip_conv2d_yolo_f16_tile(const SiConv2dDesc* d, const SiYoloLevel* level);
 int si_hip_activation_f16(int act, float act_param, const void* in, size_t pixels, int c, int in_ld, void* out, int out_ld,
                           si_stream_t stream);

@@ -17,6 +17,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "si_hip.h"
 #include "si_hip_internal.h"
@@ -452,7 +453,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
 #ifndef SI_F16_ABL
 #define SI_F16_ABL 0
 #endif
-template <int BM, int BN, int WM, int WN, int BKH, int MINW = 1>
+// NA / NB: register slots of the A / B prefetch rings.  A tile kt + 1 + NA and B tile kt + NB - 1 are requested while tile kt
+// multiplies (NA = 1, NB = 2: one K-tile ahead each, the form of the sweeps); deeper rings keep more bytes in flight per wave, which
+// is what a launch of one or two workgroups per CU is short of (bytes in flight per CU / memory latency = its load rate).
+template <int BM, int BN, int WM, int WN, int BKH, int MINW = 1, int NA = 1, int NB = 2>
 __global__ __launch_bounds__(256, MINW) void conv_igemm_f16_bd_kernel(const ConvArgsH a) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int LDH = BKH + 8;
@@ -528,11 +532,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f16_bd_kernel(const Conv
     // The K loop is ONE basic block: every load is issued unconditionally and a K-tile behind the last one is an out-of-range
     // offset (zeros, never consumed).  With branches around the prefetches hipcc parks the 64 accumulator registers in VGPRs
     // across the block boundaries (128 v_accvgpr moves per K-tile) and waits for ALL outstanding loads before the first MFMA.
-    u32x4 ra[A_IT];
-    f16x8 rb[2][TN][QS];
+    u32x4 ra[NA][A_IT];
+    f16x8 rb[NB][TN][QS];
     const int nk = a.Kp / BKH;
     int cb = 0, ky = 0, kx = 0;  // wave-uniform K walk of the A loads (ascending K-tiles)
-    auto load_a = [&](int kt) {
+    auto load_a = [&](u32x4 (&ra)[A_IT], int kt) {
         const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * BKH) * 2u;
         const int tapbit = ky * a.kw + kx;
         // (zero-padded K axis of a 1x1 conv: a vector behind the last channel reads zeros)
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f16_bd_kernel(const Conv
         ky = wy ? 0 : ky;
         cb += wy;
     };
-    auto store_a = [&](int stage) {
+    auto store_a = [&](const u32x4 (&ra)[A_IT], int stage) {
         half_t* As = lds[stage];
         if (BM < RPP && r0 >= BM) return;
 #pragma unroll
@@ -579,24 +583,31 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f16_bd_kernel(const Conv
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.0f;
 
-    load_a(0);
-    load_b(rb[0], 0);
+    load_a(ra[0], 0);
+#pragma unroll
+    for (int j = 0; j + 1 < NB; ++j) load_b(rb[j], j);
     float bias_pre[TN];
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
         const int o = n0 + wn * TN * 32 + l31 + u * 32;
         bias_pre[u] = (a.bias && o < a.ocg) ? a.bias[g * a.ocg + o] : 0.0f;
     }
-    store_a(0);
-    load_a(1);
+    store_a(ra[0], 0);
+#pragma unroll
+    for (int j = 1; j <= NA; ++j) load_a(ra[j % NA], j);   // (ascending: the K walk inside load_a is sequential)
     __syncthreads();
 
     // one K-tile: B(kt+1) requested, A(kt+1) committed to the other stage and A(kt+2) requested, then the MFMAs of tile kt with
     // the A fragments of step s+1 read while step s multiplies; one barrier
-    auto k_tile = [&](int kt, int cur, const f16x8 (&bcur)[TN][QS], f16x8 (&bnxt)[TN][QS]) {
-        if (!(SI_F16_ABL & 4)) store_a(cur ^ 1);
-        if (!(SI_F16_ABL & 2)) load_b(bnxt, kt + 1);
-        if (!(SI_F16_ABL & 1)) load_a(kt + 2);
+    // PH: kt modulo the unroll factor (a compile-time constant, so every ring slot is a fixed register set)
+    auto k_tile = [&](int kt, auto ph) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr int cur = PH & 1;
+        constexpr int sa = (PH + 1) % NA;            // slot of A tile kt + 1: committed to LDS now, then refilled with tile kt + 1 + NA
+        const f16x8 (&bcur)[TN][QS] = rb[PH % NB];
+        if (!(SI_F16_ABL & 4)) store_a(ra[sa], cur ^ 1);
+        if (!(SI_F16_ABL & 2)) load_b(rb[(PH + NB - 1) % NB], kt + NB - 1);
+        if (!(SI_F16_ABL & 1)) load_a(ra[sa], kt + 1 + NA);
         // every request of this K-tile is issued before its first MFMA: left to itself the scheduler sinks the A loads (and their
         // address arithmetic) two thirds into the MFMA sequence, a few hundred cycles before the wait that needs them
         __builtin_amdgcn_sched_barrier(0);
@@ -620,11 +631,34 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f16_bd_kernel(const Conv
         }
         if (!(SI_F16_ABL & 16)) __syncthreads();
     };
-    for (int kp = 0; kp < (nk >> 1); ++kp) {
-        k_tile(2 * kp, 0, rb[0], rb[1]);
-        k_tile(2 * kp + 1, 1, rb[1], rb[0]);
+    constexpr int UN = (NA == 3 || NB == 3) ? 6 : ((NA == 4 || NB == 4) ? 4 : 2);   // lcm(2, NA, NB) for the depths instantiated
+    static_assert(UN % 2 == 0 && UN % NA == 0 && UN % NB == 0, "unroll factor");
+    const int nfull = nk / UN;
+    for (int kq = 0; kq < nfull; ++kq) {
+        const int k0 = kq * UN;
+        k_tile(k0, std::integral_constant<int, 0>{});
+        k_tile(k0 + 1, std::integral_constant<int, 1>{});
+        if constexpr (UN > 2) {
+            k_tile(k0 + 2, std::integral_constant<int, 2>{});
+            k_tile(k0 + 3, std::integral_constant<int, 3>{});
+        }
+        if constexpr (UN > 4) {
+            k_tile(k0 + 4, std::integral_constant<int, 4>{});
+            k_tile(k0 + 5, std::integral_constant<int, 5>{});
+        }
     }
-    if (nk & 1) k_tile(nk - 1, 0, rb[0], rb[1]);
+    {
+        const int k0 = nfull * UN, rem = nk - k0;
+        if (rem > 0) k_tile(k0, std::integral_constant<int, 0>{});
+        if constexpr (UN > 2) {
+            if (rem > 1) k_tile(k0 + 1, std::integral_constant<int, 1>{});
+            if (rem > 2) k_tile(k0 + 2, std::integral_constant<int, 2>{});
+        }
+        if constexpr (UN > 4) {
+            if (rem > 3) k_tile(k0 + 3, std::integral_constant<int, 3>{});
+            if (rem > 4) k_tile(k0 + 4, std::integral_constant<int, 4>{});
+        }
+    }
 
     const int mrow0 = m0 + wm * TM * 32 + 4 * lh, ocol0 = n0 + wn * TN * 32 + l31;
     if (a.ymode) {
@@ -644,14 +678,14 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f16_bd_kernel(const Conv
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BKH, int MINW = 1>
+template <int BM, int BN, int WM, int WN, int BKH, int MINW = 1, int NA = 1, int NB = 2>
 int launch_bd(const ConvArgsH& a, int groups, hipStream_t s) {
     ConvArgsH b = a;
     b.m_tiles = (a.M + BM - 1) / BM;
     b.n_tiles = (a.ocg + BN - 1) / BN;
     const int chunks = (b.m_tiles + 7) / 8;
     dim3 grid(chunks * 8 * b.n_tiles, groups, 1);
-    hipLaunchKernelGGL((conv_igemm_f16_bd_kernel<BM, BN, WM, WN, BKH, MINW>), grid, dim3(256), 0, s, b);
+    hipLaunchKernelGGL((conv_igemm_f16_bd_kernel<BM, BN, WM, WN, BKH, MINW, NA, NB>), grid, dim3(256), 0, s, b);
     return (int)hipGetLastError();
 }
 
@@ -1044,6 +1078,9 @@ size_t f16_lane_elems(const SiConv2dDesc* d) { return (size_t)d->groups * f16_la
 // (profiles/r04_f16_bd_sweep.txt; the ids are not accepted): 4 128x64 2x2, 5 64x128 2x2, 6 64x64 2x2, 8 256x64 4x1, 12 64x256 1x4,
 // 13 32x128 1x4, 14 32x256 1x4.  All variants produce the same bits (same k order, same 16-deep MFMA steps).
 // si_hip_conv2d_f16_set_tile_variant / SI_CONV_F16_VARIANT force one (tests, sweeps); -1: the policy.
+// Also measured and retired (round 4, late; profiles/r04_f16_deep_rings.txt): 10 / 9 / 7 with deeper prefetch rings (NA 2 or 4 register
+// slots for A, NB 4 for B -- the kernel template still takes the depths): never faster, 3-60 % slower; what these launches wait for is not
+// bytes in flight.
 constexpr int kF16Variants = 12;
 bool f16_variant_valid(int v) { return v >= 0 && v < kF16Variants && v != 4 && v != 5 && v != 6 && v != 8; }
 std::atomic<int> g_f16_forced{-2};
@@ -1289,11 +1326,11 @@ const char* si_hip_conv2d_f16_kernel_name(const SiConv2dDesc* d, int form) {
     switch (v) {
         case 1: return b64 ? "conv_igemm_f16_kernel<128, 64, 2, 2, 64, false>" : "conv_igemm_f16_kernel<128, 64, 2, 2, 32, false>";
         case 2: return b64 ? "conv_igemm_f16_kernel<128, 128, 2, 2, 64, false>" : "conv_igemm_f16_kernel<128, 128, 2, 2, 32, false>";
-        case 3: return b64 ? "conv_igemm_f16_bd_kernel<128, 128, 2, 2, 64, 1>" : "conv_igemm_f16_bd_kernel<128, 128, 2, 2, 32, 1>";
-        case 7: return b64 ? "conv_igemm_f16_bd_kernel<128, 32, 4, 1, 64, 1>" : "conv_igemm_f16_bd_kernel<128, 32, 4, 1, 32, 1>";
-        case 9: return b64 ? "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 64, 1>" : "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 32, 1>";
-        case 10: return b64 ? "conv_igemm_f16_bd_kernel<64, 128, 1, 4, 64, 1>" : "conv_igemm_f16_bd_kernel<64, 128, 1, 4, 32, 1>";
-        case 11: return b64 ? "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 64, 3>" : "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 32, 3>";
+        case 3: return b64 ? "conv_igemm_f16_bd_kernel<128, 128, 2, 2, 64, 1, 1, 2>" : "conv_igemm_f16_bd_kernel<128, 128, 2, 2, 32, 1, 1, 2>";
+        case 7: return b64 ? "conv_igemm_f16_bd_kernel<128, 32, 4, 1, 64, 1, 1, 2>" : "conv_igemm_f16_bd_kernel<128, 32, 4, 1, 32, 1, 1, 2>";
+        case 9: return b64 ? "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 64, 1, 1, 2>" : "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 32, 1, 1, 2>";
+        case 10: return b64 ? "conv_igemm_f16_bd_kernel<64, 128, 1, 4, 64, 1, 1, 2>" : "conv_igemm_f16_bd_kernel<64, 128, 1, 4, 32, 1, 1, 2>";
+        case 11: return b64 ? "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 64, 3, 1, 2>" : "conv_igemm_f16_bd_kernel<128, 128, 1, 4, 32, 3, 1, 2>";
         default:
             if (form == 1) return b64 ? "conv_igemm_f16_kernel<64, 64, 2, 2, 64, true>" : "conv_igemm_f16_kernel<64, 64, 2, 2, 32, true>";
             return b64 ? "conv_igemm_f16_kernel<64, 64, 2, 2, 64, false>" : "conv_igemm_f16_kernel<64, 64, 2, 2, 32, false>";

@@ -1,0 +1,287 @@
+// conv_stem_s2c32_f16.hip -- YOLOv5's first two convolutions in ONE persistent kernel (fp16 storage path, round 4).
+//
+// conv_0 (6x6 s2 p2, 3 -> 32, SiLU; reference src/layer/conv_2d.cpp:207-283 on the 3-channel image) writes 210 MB of fp16
+// activations at batch 32 that conv_1 (3x3 s2 p1, 32 -> 64, SiLU) reads straight back: 118 + 70 us for 157 MB in and 105 MB out.
+// Here a workgroup owns 4 x 16 pixels of conv_1's OUTPUT per item and never lets the intermediate leave the CU:
+//   stage 0  the 22 x 70-pixel window of the fp32 image under the tile is requested one item ahead (global -> registers) and
+//            committed to LDS as fp16 -- conv_stem_f16.hip's row staging;
+//   phase A  the 9 x 33 stem pixels conv_1's tile needs are computed with conv_stem_f16.hip's contraction (kernel rows cut into
+//            groups of 8 values, two groups per v_mfma_f32_32x32x16_f16, B fragments in LDS; ten 32-pixel blocks: one per patch
+//            row plus one for the 33rd column), bias + SiLU, rounded to fp16 and written into conv_s2c32_f16_kernel's patch image
+//            (odd / even column planes, 80-byte pixels); stem pixels outside the stem's output are conv_1's zero padding;
+//   phase B  conv_s2c32_f16_kernel's nine taps from the patch, weights resident in registers, bias + SiLU, fp16 out.
+// The stem is recomputed on the one-pixel seam between tiles (9 x 33 for 8 x 32: 1.16x).  Same MFMA steps in the same order and
+// the same epilogue expressions as the two kernels it replaces, the same fp16 rounding of the intermediate: the same bits
+// (tests/test_gpu_f16.py::test_stem_s2c32_fused_same_bits).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+
+#include "si_hip.h"
+#include "si_hip_internal.h"
+
+#pragma clang fp contract(off)
+
+typedef _Float16 half_t;
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct FusedArgs {
+    const float* in;      // [n][ih][iw][3] fp32
+    const half_t* ws;     // stem B fragments [9 steps][lane half][32][8] (si_hip_conv2d_stem_f16_pack_weight_host)
+    const float* bs;      // stem bias or null
+    const half_t* wl;     // conv_1 weights in MFMA lane order: [oc / 32][18 k-steps][64 lanes][8]
+    const float* bc;      // conv_1 bias or null
+    half_t* out;
+    int ih, iw, soh, sow; // image, stem output
+    int oh, ow, oc, out_ld, nb;
+    int tiles_x, tiles_y, items;
+    unsigned in_bytes;
+};
+
+__device__ __forceinline__ float silu_f(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
+// SiLU of (x0 + b, x1 + b) on the packed fp32 instructions (conv_igemm.hip epilogue_lean: each component is rounded exactly like the
+// scalar form -- __expf(-t) is v_exp_f32(t * -log2(e)) -- so the bits are silu_f's), then fp16 bit patterns
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void silu2_bits(float x0, float x1, float b, unsigned& h0, unsigned& h1) {
+    const f32x2 v = f32x2{x0, x1} + f32x2{b, b};
+    const f32x2 x = v * f32x2{-1.44269504088896340736f, -1.44269504088896340736f};
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])} + f32x2{1.0f, 1.0f};
+    const f32x2 o = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    h0 = __builtin_bit_cast(unsigned short, si_store_cast<half_t>(o[0]));
+    h1 = __builtin_bit_cast(unsigned short, si_store_cast<half_t>(o[1]));
+}
+
+constexpr unsigned OOB = 0xFFFFFF00u;
+constexpr int PITCH = 80, ROWP = 2688, EOFF = 17 * PITCH;     // patch image, bytes (conv_s2c32_f16_kernel)
+constexpr int PR = 9;
+constexpr int RL = 216;                                       // halves per staged image row: 70 pixels x 3 + the last group's over-read
+constexpr int IR = 22;                                        // image rows under a tile
+constexpr int VPRW = RL / 4;                                  // 16-byte fp32 vectors per staged row (54)
+constexpr int NVEC = IR * VPRW, N_IT = (NVEC + 255) / 256;
+constexpr int PATCH_BYTES = PR * ROWP, STAGE_BYTES = IR * RL * 2, WS_BYTES = 9 * 2 * 32 * 8 * 2;
+
+#ifndef SI_FUSED_MINW
+#define SI_FUSED_MINW 2
+#endif
+__global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel(const FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char patch[PATCH_BYTES];
+    __shared__ __attribute__((aligned(16))) half_t stage[IR * RL];
+    __shared__ __attribute__((aligned(16))) half_t wsl[9 * 2 * 32 * 8];
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+    const int row_floats = a.iw * 3;
+
+    // staging vectors of this thread: vector v of staged row r is image floats [192 tx - 12 + 4 v, + 4) of image row 16 ty - 4 + r
+    int v_r[N_IT], v_v[N_IT];
+#pragma unroll
+    for (int i = 0; i < N_IT; ++i) {
+        const int c = tid + 256 * i;
+        v_r[i] = c < NVEC ? c / VPRW : -1;
+        v_v[i] = c - (c / VPRW) * VPRW;
+    }
+    f32x4 pre[N_IT];
+    auto prefetch = [&](int item) {
+        const int tx = item % a.tiles_x, t2 = item / a.tiles_x;
+        const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
+        const int iy0 = 16 * ty - 4, e0 = 192 * tx - 12;
+#pragma unroll
+        for (int i = 0; i < N_IT; ++i) {
+            const int y = iy0 + v_r[i], e = e0 + 4 * v_v[i];
+            const bool ok = v_r[i] >= 0 && (unsigned)y < (unsigned)a.ih && e >= 0 && e + 3 < row_floats;
+            const unsigned off = ((unsigned)((img * a.ih + y) * row_floats + e)) * 4u;
+            pre[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? off : OOB, 0, 0));
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < N_IT; ++i)
+            if (v_r[i] >= 0) {
+                f16x4 h;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) h[t] = (half_t)pre[i][t];
+                *reinterpret_cast<f16x4*>(stage + v_r[i] * RL + 4 * v_v[i]) = h;
+            }
+    };
+
+    int item = blockIdx.x;
+    if (item >= a.items) return;
+    prefetch(item);
+    for (int i = tid; i < 9 * 2 * 32; i += 256) *reinterpret_cast<f16x8*>(wsl + i * 8) = *reinterpret_cast<const f16x8*>(a.ws + (size_t)i * 8);
+    // conv_1: this wave's column block of the weights, 18 k-steps (tap-major, two 16-channel halves per tap), resident in registers
+    const int wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wl), 0, (unsigned)a.nb * 18u * 1024u, 0x00020000);
+    f16x8 wf[18];
+    {
+        const unsigned vo = wn < a.nb ? (unsigned)wn * 18u * 1024u + (unsigned)lane * 16u : 0x80000000u;
+#pragma unroll
+        for (int s = 0; s < 18; ++s) wf[s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wl, vo, (unsigned)(s * 1024), 0));
+    }
+    const float bsv = a.bs ? a.bs[l31] : 0.0f;
+    const int o = wn * 32 + l31;
+    const float bcv = (a.bc && o < a.oc) ? a.bc[o] : 0.0f;
+    const half_t* const wfrag = wsl + (lh * 32 + l31) * 8;
+    const uint32_t* const stage_w = reinterpret_cast<const uint32_t*>(stage);
+    const int a_base = (2 * (2 * wm + (l31 >> 4))) * ROWP + (l31 & 15) * PITCH + lh * 16;
+
+    for (; item < a.items; item += gridDim.x) {
+        const int tx = item % a.tiles_x, t2 = item / a.tiles_x;
+        const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
+        commit();          // (waits for this item's window; the stores of the previous item are younger than those loads)
+        __syncthreads();   // the window is staged; every wave is done with the previous item's patch
+        const int next = item + gridDim.x;
+        if (next < a.items) prefetch(next);
+
+        // ---- phase A: stem pixels of the patch.  Block b < 9: patch row b, columns 0..31; block 9: column 32 of rows 0..8.
+        // Everything about an element's place is either uniform (the row, its validity) or a per-lane base plus a compile-time
+        // offset (column r = (e & 3) + 8 (e >> 2) + 4 lh: its plane is the parity of the compile-time part).
+        const int sx_l = 32 * tx - 1 + 4 * lh;                               // stem column of this lane's row r = 4 lh
+        unsigned char* const prow_l = patch + (2 * lh) * PITCH + l31 * 2;     // ... and its place in a patch row
+        for (int b = wave; b < 10; b += 4) {
+            const int pi = b < 9 ? b : min(l31, 8), pj = b < 9 ? l31 : 32;
+            const int base_h = (2 * pi) * RL + 6 * pj;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                // group 2s for the low lanes, 2s + 1 for the high ones (conv_stem_f16.hip): kernel row G / 3, values 8 (G % 3) ..
+                const int G0 = 2 * s, G1 = 2 * s + 1;
+                const int off0 = (G0 / 3) * RL + 8 * (G0 % 3), off1 = (G1 / 3) * RL + 8 * (G1 % 3);
+                const int h0 = base_h + (lh ? off1 : off0);
+                const uint32_t* p = stage_w + (h0 >> 1);
+                u32x4 fa;
+                fa[0] = p[0]; fa[1] = p[1]; fa[2] = p[2]; fa[3] = p[3];
+                const f16x8 fb = *reinterpret_cast<const f16x8*>(wfrag + s * (2 * 32 * 8));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), fb, acc, 0, 0, 0);
+            }
+            // C/D map: col = lane & 31 (stem channel), row = (e & 3) + 8 (e >> 2) + 4 lh (block pixel)
+            if (b < 9) {
+                const bool row_ok = (unsigned)(8 * ty - 1 + b) < (unsigned)a.soh;   // uniform
+                unsigned char* const pr = prow_l + b * ROWP;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int c = (e & 3) + 8 * (e >> 2);                        // compile-time part of the column (c, c + 1)
+                    unsigned h0, h1;
+                    silu2_bits(acc[e], acc[e + 1], bsv, h0, h1);
+                    // (masks, not branches: a pixel outside the stem's output is conv_1's zero padding)
+                    h0 &= (row_ok && (unsigned)(sx_l + c) < (unsigned)a.sow) ? 0xFFFFu : 0u;
+                    h1 &= (row_ok && (unsigned)(sx_l + c + 1) < (unsigned)a.sow) ? 0xFFFFu : 0u;
+                    *reinterpret_cast<unsigned short*>(pr + ((c & 1) ? EOFF : 0) + (c >> 1) * PITCH) = (unsigned short)h0;
+                    *reinterpret_cast<unsigned short*>(pr + (((c + 1) & 1) ? EOFF : 0) + ((c + 1) >> 1) * PITCH) = (unsigned short)h1;
+                }
+            } else {
+                const bool col_ok = (unsigned)(32 * tx + 31) < (unsigned)a.sow;  // uniform
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    unsigned h0, h1;
+                    silu2_bits(acc[e], acc[e + 1], bsv, h0, h1);
+                    h0 &= (col_ok && (unsigned)(8 * ty - 1 + r) < (unsigned)a.soh) ? 0xFFFFu : 0u;
+                    h1 &= (col_ok && (unsigned)(8 * ty + r) < (unsigned)a.soh) ? 0xFFFFu : 0u;
+                    if (r < PR) *reinterpret_cast<unsigned short*>(patch + r * ROWP + 16 * PITCH + l31 * 2) = (unsigned short)h0;
+                    if (r + 1 < PR) *reinterpret_cast<unsigned short*>(patch + (r + 1) * ROWP + 16 * PITCH + l31 * 2) = (unsigned short)h1;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: conv_1 from the patch (conv_s2c32_f16_kernel)
+        {
+            const unsigned char* const P = patch + a_base;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
+                const int off = ky * ROWP + (kx == 1 ? EOFF : (kx == 2 ? PITCH : 0)) + (s & 1) * 32;
+                const f16x8 fa = *reinterpret_cast<const f16x8*>(P + off);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, wf[s], acc, 0, 0, 0);
+            }
+            const int oy0 = ty * 4 + 2 * wm, ox0 = tx * 16;
+            half_t* const ob = a.out + o;
+            if (o < a.oc) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;   // rows r, r + 1: the same output row (r & 15 is even)
+                    const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+                    unsigned h0, h1;
+                    silu2_bits(acc[e], acc[e + 1], bcv, h0, h1);
+                    unsigned short* const op = reinterpret_cast<unsigned short*>(ob + (size_t)((img * a.oh + oy) * a.ow + ox) * a.out_ld);
+                    if (oy < a.oh && ox < a.ow) op[0] = (unsigned short)h0;
+                    if (oy < a.oh && ox + 1 < a.ow) op[a.out_ld] = (unsigned short)h1;
+                }
+            }
+        }
+    }
+}
+
+bool stem_ok(const SiConv2dDesc* d) {
+    return d->groups == 1 && d->ic == 3 && d->in_ld == 3 && d->oc == 32 && d->kh == 6 && d->kw == 6 && d->sh == 2 && d->sw == 2 &&
+           d->dh == 1 && d->dw == 1 && d->pt == 2 && d->pl == 2 && !d->has_residual && d->act1 == SI_ACT_SILU && d->act2 == SI_ACT_NONE &&
+           d->iw % 4 == 0 && d->oh == (d->ih + 4 - 6) / 2 + 1 && d->ow == (d->iw + 4 - 6) / 2 + 1 && d->oh > 0 && d->ow > 0;
+}
+bool conv_ok(const SiConv2dDesc* d) {
+    return d->groups == 1 && d->ic == 32 && (d->oc == 32 || d->oc == 64) && d->kh == 3 && d->kw == 3 && d->sh == 2 && d->sw == 2 &&
+           d->dh == 1 && d->dw == 1 && d->pt == 1 && d->pl == 1 && !d->has_residual && d->act1 == SI_ACT_SILU && d->act2 == SI_ACT_NONE &&
+           d->oh == (d->ih + 2 - 3) / 2 + 1 && d->ow == (d->iw + 2 - 3) / 2 + 1 && d->oh > 0 && d->ow > 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int si_hip_conv2d_stem_s2c32_f16_supported(const SiConv2dDesc* stem, const SiConv2dDesc* conv) {
+    if (!stem || !conv) return 0;
+    return (stem_ok(stem) && conv_ok(conv) && stem->n == conv->n && stem->oh == conv->ih && stem->ow == conv->iw) ? 1 : 0;
+}
+
+int si_hip_conv2d_stem_s2c32_f16(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const float* in, const void* stem_w_packed,
+                                 const float* stem_bias, const void* conv_w_packed, const float* conv_bias, void* out,
+                                 si_stream_t stream) {
+    if (!stem || !conv || !in || !stem_w_packed || !conv_w_packed || !out) return SI_E_BADARG;
+    if (stem->has_bias && !stem_bias) return SI_E_BADARG;
+    if (conv->has_bias && !conv_bias) return SI_E_BADARG;
+    if (!si_hip_conv2d_stem_s2c32_f16_supported(stem, conv)) return SI_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(conv_w_packed) & 15) != 0 ||
+        (reinterpret_cast<uintptr_t>(stem_w_packed) & 15) != 0)
+        return SI_E_UNSUPPORTED;
+    const unsigned long long in_bytes = (unsigned long long)stem->n * stem->ih * stem->iw * 3ull * 4ull;
+    if (in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+    FusedArgs a;
+    a.in = in;
+    a.ws = static_cast<const half_t*>(stem_w_packed);
+    a.bs = stem->has_bias ? stem_bias : nullptr;
+    // the lane-order image sits behind the row-major one in si_hip_conv2d_f16_pack_weight_host's buffer ([oc][9 * 32] rows first)
+    a.wl = static_cast<const half_t*>(conv_w_packed) + (size_t)conv->oc * 9 * 32;
+    a.bc = conv->has_bias ? conv_bias : nullptr;
+    a.out = static_cast<half_t*>(out);
+    a.ih = stem->ih; a.iw = stem->iw; a.soh = stem->oh; a.sow = stem->ow;
+    a.oh = conv->oh; a.ow = conv->ow; a.oc = conv->oc; a.out_ld = conv->out_ld; a.nb = conv->oc / 32;
+    a.tiles_x = (conv->ow + 15) / 16; a.tiles_y = (conv->oh + 3) / 4;
+    const long long items = (long long)conv->n * a.tiles_x * a.tiles_y;
+    if (items > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    a.items = (int)items;
+    a.in_bytes = (unsigned)in_bytes;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    const int per_cu = si_resident_blocks(conv_stem_s2c32_f16_kernel, 256, 0);
+    long long grid = (long long)cus * per_cu;
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL(conv_stem_s2c32_f16_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

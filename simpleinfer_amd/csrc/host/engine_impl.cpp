@@ -54,6 +54,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "fp16") opt_fp16_ = value != 0;
     else if (key == "batch") opt_batch_ = value;  // > 0: re-batch the graph at load (the file bakes its batch into every shape)
     else if (key == "arena") opt_arena_ = value != 0;  // 1 (default): intermediates share one arena by lifetime; 0: one hipMalloc each
+    else if (key == "fuse_stem") opt_fuse_stem_ = value != 0;  // fp16: RGB stem conv + the 3x3 s2 conv behind it in one launch (default 1)
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
@@ -383,6 +384,7 @@ Status EngineImpl::CreatePipeline() {
         CHECK_STATUS(FuseSiblingConvs(order));
         CHECK_STATUS(FusePoolChains(order));
         if (opt_fuse_upsample_ && opt_alias_cat_) CHECK_STATUS(FuseUpsampleIntoConvs(order));   // (fp16 storage too since round 4)
+        if (opt_fp16_ && opt_fuse_stem_) CHECK_STATUS(FuseStemPairs(order));
     }
     if (opt_fp16_) {
         CHECK_STATUS(InsertOutputCasts(order));
@@ -670,6 +672,36 @@ Status EngineImpl::FuseUpsampleIntoConvs(std::vector<Step>& order) {
         }
         if (!ok || readers.empty()) continue;
         for (Conv2d* r : readers) r->SetUpsampledSource(up->InputNodes()[0], c0, up->scale_factor_h_, up->scale_factor_w_);
+        removed[i] = true;
+        fused_ops_.insert(order[i].op->name);
+    }
+    std::vector<Step> out;
+    for (size_t i = 0; i < order.size(); ++i)
+        if (!removed[i]) out.push_back(order[i]);
+    order.swap(out);
+    return Status::kSuccess;
+}
+
+// fp16 storage (round 4): the RGB stem conv (fp32 image in, 32 half channels out) whose ONLY reader is a 3x3 stride-2 conv over those
+// 32 channels -- YOLOv5's conv_0 -> conv_1 -- becomes one launch at the second conv's slot (si_hip_conv2d_stem_s2c32_f16): the
+// intermediate (210 MB at batch 32) is computed tile by tile in LDS and never written.  The stem's step leaves the order, its
+// operand is never allocated; the kernel is asked NOW, with the bound shapes, whether it takes the pair.
+Status EngineImpl::FuseStemPairs(std::vector<Step>& order) {
+    std::map<const pnnx::Operator*, size_t> index;
+    for (size_t i = 0; i < order.size(); ++i) index[order[i].op] = i;
+    std::vector<bool> removed(order.size(), false);
+    for (size_t i = 0; i < order.size(); ++i) {
+        Conv2d* stem = dynamic_cast<Conv2d*>(order[i].layer);
+        if (!stem || order[i].op->type != "nn.Conv2d" || stem->InputNodes().size() != 1 || stem->OutputNodes().size() != 1) continue;
+        const pnnx::Operand* img = stem->InputNodes()[0]->operand;
+        const pnnx::Operand* mid = stem->OutputNodes()[0]->operand;
+        if (!img || !mid || !input_tensor_nodes_.count(img->name) || output_tensor_nodes_.count(mid->name) || mid->consumers.size() != 1) continue;
+        const pnnx::Operator* c = mid->consumers[0];
+        if (!c || c->type != "nn.Conv2d" || !index.count(c) || sibling_ops_.count(c->name)) continue;
+        Conv2d* conv = dynamic_cast<Conv2d*>(order[index[c]].layer);
+        if (!conv || !conv->CanFuseStemProducer(*stem)) continue;
+        conv->SetStemProducer(stem);
+        dead_operands_.insert(mid->name);
         removed[i] = true;
         fused_ops_.insert(order[i].op->name);
     }
@@ -1026,6 +1058,7 @@ Status EngineImpl::LoadLanes(int lanes) {
         lane->opt_fuse_ = opt_fuse_;
         lane->opt_alias_cat_ = opt_alias_cat_;
         lane->opt_fuse_upsample_ = opt_fuse_upsample_;
+        lane->opt_fuse_stem_ = opt_fuse_stem_;
         lane->opt_arena_ = opt_arena_;
         lane->opt_winograd_ = opt_winograd_;
         lane->opt_detect_stream_ = opt_detect_stream_;
@@ -1159,6 +1192,7 @@ Status EngineImpl::SetupSlicer(int slices) {
     slicer_->opt_fuse_ = opt_fuse_;
     slicer_->opt_alias_cat_ = opt_alias_cat_;
     slicer_->opt_fuse_upsample_ = opt_fuse_upsample_;
+    slicer_->opt_fuse_stem_ = opt_fuse_stem_;
     slicer_->opt_arena_ = opt_arena_;
     slicer_->opt_winograd_ = opt_winograd_;
     slicer_->opt_detect_stream_ = opt_detect_stream_;

@@ -97,6 +97,7 @@ private:
     Status FuseSiblingConvs(std::vector<Step>& order);
     Status FusePoolChains(std::vector<Step>& order);
     Status FuseUpsampleIntoConvs(std::vector<Step>& order);
+    Status FuseStemPairs(std::vector<Step>& order);
     Status InsertOutputCasts(std::vector<Step>& order);
     Status InsertFp32Fallbacks(std::vector<Step>& order);
     Status AliasConcats();
@@ -127,6 +128,7 @@ private:
     bool opt_fuse_ = true;
     bool opt_alias_cat_ = true;
     bool opt_fuse_upsample_ = true;
+    bool opt_fuse_stem_ = true;
     bool opt_arena_ = true;      // intermediate operands share one HBM arena by lifetime (0: one allocation per operand, as the reference)
     bool opt_graph_ = false;
     bool opt_outputs_to_host_ = true;

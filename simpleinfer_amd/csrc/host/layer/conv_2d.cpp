@@ -111,6 +111,28 @@ bool Conv2d::CanFuseSibling(const Conv2d& o) const {
            act_param_ == o.act_param_ && use_bias_ == o.use_bias_ && out_channels_ % 32 == 0 && in_channels_ % 32 == 0;
 }
 
+bool Conv2d::CanFuseStemProducer(const Conv2d& stem) const {
+    if (residual_node_ || sibling_ || up_node_ || stem_producer_ || stem.residual_node_ || stem.sibling_ || stem.up_node_) return false;
+    if (input_tensor_nodes_.size() != 1 || output_tensor_nodes_.size() != 1 || stem.input_tensor_nodes_.size() != 1 ||
+        stem.output_tensor_nodes_.size() != 1 || stem.output_tensor_nodes_[0] != input_tensor_nodes_[0])
+        return false;
+    const Tensor& img = stem.input_tensor_nodes_[0]->tensor;
+    const Tensor& mid = input_tensor_nodes_[0]->tensor;
+    const Tensor& out = output_tensor_nodes_[0]->tensor;
+    if (IsHalf(img) || !IsHalf(mid) || !IsHalf(out)) return false;
+    if (img.Shape().size() != 4 || mid.Shape().size() != 4 || out.Shape().size() != 4) return false;
+    SiConv2dDesc d0 = stem.MakeDesc(img, mid), d1 = MakeDesc(mid, out);
+    d0.in_ld = d0.ic; d0.out_ld = d0.oc; d1.in_ld = d1.ic;   // (dense views: the image as handed over, the intermediate nowhere)
+    return si_hip_conv2d_stem_s2c32_f16_supported(&d0, &d1) == 1;
+}
+
+void Conv2d::SetStemProducer(Conv2d* stem) {
+    stem_producer_ = stem;
+    stem_mid_ = input_tensor_nodes_.empty() ? nullptr : input_tensor_nodes_[0];
+    if (stem) SetInputNodes(stem->InputNodes());
+    device_ready_ = false;
+}
+
 void Conv2d::SetSibling(Conv2d* other) {
     sibling_ = other;
     device_ready_ = false;
@@ -320,6 +342,19 @@ Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
 }
 
 Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& output) {
+    if (stem_producer_) {
+        // the stem conv and this one in one launch: `input` is the fp32 image
+        if (residual || !stem_mid_ || IsHalf(input) || !IsHalf(output)) return Status::kUnsupport;
+        CHECK_STATUS(PrepareDevice(1));
+        CHECK_STATUS(stem_producer_->PrepareDevice(2));
+        SiConv2dDesc d0 = stem_producer_->MakeDesc(input, stem_mid_->tensor), d1 = MakeDesc(stem_mid_->tensor, output);
+        d0.out_ld = d0.oc; d1.in_ld = d1.ic;
+        return CheckHip(si_hip_conv2d_stem_s2c32_f16(&d0, &d1, input.Data<float>(), stem_producer_->weight_dev_.As<void>(),
+                                                     stem_producer_->use_bias_ ? stem_producer_->bias_dev_.As<float>() : nullptr,
+                                                     weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr, output.RawData(),
+                                                     Stream()),
+                        "conv2d stem + 3x3 s2 (fp16, one launch)");
+    }
     const int mode = PrecisionMode(input, output);
     CHECK_STATUS(PrepareDevice(mode));
     Dims4 in, out;
@@ -470,6 +505,7 @@ const char* Conv2d::KernelName() const {
     const Tensor& in = input_tensor_nodes_[0]->tensor;
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
+    if (stem_producer_) return "conv_stem_s2c32_f16_kernel";
     SiConv2dDesc d = MakeDesc(in, out);
     if (sibling_) d.oc += sibling_->out_channels_;
     const int mode = PrecisionMode(in, out);
@@ -502,13 +538,17 @@ double Conv2d::Flops() const {
     if (output_tensor_nodes_.empty() || groups_ <= 0) return 0.0;
     double elems = 0.0;
     for (auto* n : output_tensor_nodes_) elems += (double)n->tensor.NumElements();
-    return 2.0 * elems * kernel_h_ * kernel_w_ * (in_channels_ / groups_);
+    double f = 2.0 * elems * kernel_h_ * kernel_w_ * (in_channels_ / groups_);
+    if (stem_producer_ && stem_mid_)   // the fused-away stem's own multiplies (its recomputed seam not counted)
+        f += 2.0 * (double)stem_mid_->tensor.NumElements() * stem_producer_->kernel_h_ * stem_producer_->kernel_w_ * stem_producer_->in_channels_;
+    return f;
 }
 
 double Conv2d::Bytes() const {
     double b = Layer::Bytes() + (double)weight_.size() * sizeof(float);
     if (sibling_) b += (double)sibling_->weight_.size() * sizeof(float);
     if (residual_node_) b += (double)residual_node_->tensor.ByteSize();
+    if (stem_producer_) b += (double)stem_producer_->weight_.size() * sizeof(float);
     return b;
 }
 
@@ -517,6 +557,7 @@ bool Conv2d::HalfStorageOk(std::string& why) const {
     const Tensor& in = input_tensor_nodes_[0]->tensor;
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (!IsHalf(in) && !IsHalf(out)) return true;
+    if (stem_producer_) return true;   // (asked of the kernel when the pair was fused: CanFuseStemProducer)
     SiConv2dDesc d;
     memset(&d, 0, sizeof(d));
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;

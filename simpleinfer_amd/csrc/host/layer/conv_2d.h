@@ -66,6 +66,13 @@ public:
     void SetUpsampledSource(TensorNode* low, int c0, float scale_h, float scale_w);
     TensorNode* UpsampledSource() const { return up_node_; }
 
+    // engine fusion hook (fp16 storage, round 4): `stem` is the RGB stem conv whose only reader is this 3x3 stride-2 conv over 32
+    // channels (YOLOv5's first two layers); this layer then reads the fp32 IMAGE and computes both in one launch
+    // (si_hip_conv2d_stem_s2c32_f16), the 32-channel intermediate never leaves the CU.  Same bits as the two launches.
+    bool CanFuseStemProducer(const Conv2d& stem) const;
+    void SetStemProducer(Conv2d* stem);
+    Conv2d* StemProducer() const { return stem_producer_; }
+
     Status PrepareDevice(int mode = 0);
     Status PrepareDeviceHalf(const SiConv2dDesc& d);
     int PrecisionMode(const Tensor& input, const Tensor& output) const;
@@ -109,6 +116,8 @@ public:
     TensorNode* residual_node_ = nullptr;
     Conv2d* sibling_ = nullptr;
     TensorNode* up_node_ = nullptr;   // see SetUpsampledSource
+    Conv2d* stem_producer_ = nullptr; // see SetStemProducer
+    TensorNode* stem_mid_ = nullptr;  // the fused-away intermediate (shape only: it is never allocated)
     int up_c0_ = 0;
     float up_scale_h_ = 1.0f, up_scale_w_ = 1.0f;
 

@@ -732,6 +732,34 @@ def convert_roundtrip_f16(x):
     return half, dy.to_numpy(x.shape)
 
 
+def conv_stem_s2c32_f16(x, w0, b0, w1, b1):
+    """si_hip_conv2d_stem_s2c32_f16: YOLOv5's first two convs (6x6 s2 p2 3 -> 32 SiLU, 3x3 s2 p1 32 -> oc SiLU) in one launch.
+    x fp32 [n][h][w][3]; returns fp16 [n][oh][ow][oc]."""
+    H = _native.hip()
+    x, w0, w1 = _f32(x), _f32(w0), _f32(w1)
+    n, ih, iw, _ = x.shape
+    sh_, sw_ = conv_out_hw(ih, iw, (6, 6), (2, 2), (2, 2), (1, 1))
+    oh, ow = conv_out_hw(sh_, sw_, (3, 3), (2, 2), (1, 1), (1, 1))
+    oc = w1.shape[0]
+    d0 = SiConv2dDesc(n, ih, iw, 3, 3, sh_, sw_, 32, 32, 6, 6, 2, 2, 1, 1, 2, 2, 1, 1 if b0 is not None else 0, ACT["silu"], 0, 32, 0, 0.0)
+    d1 = SiConv2dDesc(n, sh_, sw_, 32, 32, oh, ow, oc, oc, 3, 3, 2, 2, 1, 1, 1, 1, 1, 1 if b1 is not None else 0, ACT["silu"], 0, oc, 0, 0.0)
+    if not H.si_hip_conv2d_stem_s2c32_f16_supported(C.byref(d0), C.byref(d1)):
+        raise HipError("si_hip_conv2d_stem_s2c32_f16: unsupported shape")
+    p0 = np.zeros(H.si_hip_conv2d_stem_f16_weight_elems(C.byref(d0)), np.float16)
+    _chk(H.si_hip_conv2d_stem_f16_pack_weight_host(C.byref(d0), w0.ctypes.data_as(C.c_void_p), p0.ctypes.data_as(C.c_void_p)), "pack stem f16")
+    p1 = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d1)), np.float16)
+    _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d1), w1.ctypes.data_as(C.c_void_p), p1.ctypes.data_as(C.c_void_p)), "pack f16")
+    dx, dp0, dp1 = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(p0), DeviceBuffer.from_numpy(p1)
+    db0 = DeviceBuffer.from_numpy(_f32(b0)) if b0 is not None else None
+    db1 = DeviceBuffer.from_numpy(_f32(b1)) if b1 is not None else None
+    dy = DeviceBuffer(n * oh * ow * oc * 2)
+    dy.fill(0)
+    _chk(H.si_hip_conv2d_stem_s2c32_f16(C.byref(d0), C.byref(d1), dx.ptr, dp0.ptr, db0.ptr if db0 else None, dp1.ptr,
+                                        db1.ptr if db1 else None, dy.ptr, None), "si_hip_conv2d_stem_s2c32_f16")
+    sync()
+    return dy.to_numpy((n, oh, ow, oc), np.float16)
+
+
 def yolo_detect_f16(feats, weights, biases, grids, anchor_grids, strides, na=3):
     """si_hip_conv2d_yolo_f16 per level: fp16 features, fp32 [n][rows_total][ne] detections."""
     H = _native.hip()

@@ -148,6 +148,29 @@ def test_upsample_read_at_the_source_with_fp16_storage(si, tmp_path):
     assert not any("upsample" in L["kernel"] for L in e1.profile())
 
 
+def test_stem_pair_in_one_launch_with_fp16_storage(si, tmp_path):
+    """Round 4 (FuseStemPairs, si_hip_conv2d_stem_s2c32_f16): with fp16 storage YOLOv5's conv_0 (RGB stem) and conv_1 (3x3 s2 over its 32
+    channels) are ONE launch; the 32-channel intermediate is never allocated or written.  Not a bit of difference against the schedule
+    that runs them separately, at two batches and with a ragged tile grid; the fp32 schedule is untouched."""
+    for n, size, tag in ((2, 160, "sp"), (3, 96, "sp3")):
+        pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(n, size), tag)
+        x = si.modelgen.synth_input((n, size, size, 3))
+        e1, oname, fused = _run(si, pp, bp, x, fp16=1)
+        e0, _, plain = _run(si, pp, bp, x, fp16=1, fuse_stem=0)
+        assert_exact(fused, plain, "fp16: stem pair in one launch vs two")
+        s1, s0 = e1.schedule(), e0.schedule()
+        assert len(s0["run"]) == len(s1["run"]) + 1 and "conv_0" in s1["fused"] and "conv_0" not in s1["run"] and "conv_0" in s0["run"]
+        k1 = [L["kernel"] for L in e1.profile()]
+        assert k1.count("conv_stem_s2c32_f16_kernel") == 1 and "conv_stem_f16_kernel" not in k1, k1
+        assert "conv_stem_f16_kernel" in [L["kernel"] for L in e0.profile()]
+        for _ in range(3):
+            e1.forward()
+            assert_exact(e1.extract(oname), plain, "repeated forwards")
+    e32 = si.Engine()
+    e32.load_model(pp, bp)
+    assert "conv_0" in e32.schedule()["run"]
+
+
 @pytest.mark.parametrize("graph", [0, 1])
 def test_detect_levels_on_a_second_stream_are_bit_identical(si, tmp_path, graph):
     """Option detect_stream (on by default): the two finer Detect levels launch on a second stream right after the step that completes their

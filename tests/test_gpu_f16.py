@@ -344,6 +344,29 @@ def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, 
     assert_parity(got.astype(np.float32), ref if act == "none" else orc.activation(act, ref), F16_TOL, what="s2c32 kernel")
 
 
+@pytest.mark.parametrize("n,ih,iw,oc", [
+    (2, 128, 128, 64),     # whole tiles (32 x 32 outputs)
+    (3, 76, 100, 64),      # ragged tiles both ways (19 x 25 outputs)
+    (1, 20, 24, 32),       # one partial tile, a single 32-channel column block
+    (5, 64, 192, 64),
+])
+def test_stem_s2c32_fused_same_bits(hops, orc, gpu, n, ih, iw, oc):
+    """Round 4: YOLOv5's first two convs in one persistent kernel (si_hip_conv2d_stem_s2c32_f16): the 32-channel intermediate is
+    computed tile by tile into LDS and never written.  Same MFMA steps, same epilogues, same fp16 rounding of the intermediate as
+    si_hip_conv2d_stem_f16 followed by si_hip_conv2d_f16: BIT identical; and the fp16 bar against the oracle's two convs holds
+    (src/layer/conv_2d.cpp:207-283)."""
+    x = rng_uniform(800, (n, ih, iw, 3), 0, 1)
+    w0, b0 = rng_uniform(801, (32, 3, 6, 6), -0.3, 0.3), rng_uniform(802, (32,), -0.5, 0.5)
+    w1, b1 = h(rng_uniform(803, (oc, 32, 3, 3), -0.3, 0.3)), rng_uniform(804, (oc,), -0.5, 0.5)
+    mid = hops.conv2d_f16(x, w0, b0, (2, 2), (2, 2), act1="silu")
+    want = hops.conv2d_f16(mid, w1, b1, (2, 2), (1, 1), act1="silu")
+    got = hops.conv_stem_s2c32_f16(x, w0, b0, w1, b1)
+    assert_exact(got, want, "fused stem + conv vs the two launches")
+    ref0 = orc.activation("silu", orc.conv2d(x, h(w0), b0, (2, 2), (2, 2), path="naive"))
+    ref = orc.activation("silu", orc.conv2d(ref0, w1, b1, (2, 2), (1, 1), path="naive"))
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="fused stem + conv")
+
+
 @pytest.mark.parametrize("n,levels", [
     (3, ((20, 128), (10, 256), (5, 512))),     # 400 / 100 / 25 pixels per image: whole tiles, a 16-pixel tail, a tile of 25
     (2, ((9, 256), (3, 128), (1, 512))),       # 91 rows x 3: image bases only 4-byte aligned -> the dword form of the run
