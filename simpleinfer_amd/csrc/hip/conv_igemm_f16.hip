@@ -900,25 +900,29 @@ int launch_detect_tile(const ConvArgsH& a, int n, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
-// ---- 3x3 stride-2 conv over ONE 32-channel block as a persistent spatial-tile kernel (round 4, late) --------------------------------
-// YOLOv5s conv_1 (320x320x32 -> 160x160x64 at batch 32: 210 MB in, 105 MB out) ran 102-147 us through EVERY tile shape above
-// (profiles/r04_f16_bd_sweep.txt) -- not a pipe: 12 800 workgroups of nine K-tiles, each K-tile a load -> LDS -> barrier round trip.
-// Here a workgroup is persistent and owns 4 x 16 output pixels x 64 channels per item: the 9 x 33-pixel input patch of item i + 1 is
+// ---- 3x3 conv over ONE 32-channel block as a persistent spatial-tile kernel (round 4, late) ---------------------------------------
+// YOLOv5s conv_1 (320x320x32 -> 160x160x64, stride 2, at batch 32: 210 MB in, 105 MB out) ran 102-147 us through EVERY tile shape
+// above (profiles/r04_f16_bd_sweep.txt) -- not a pipe: 12 800 workgroups of nine K-tiles, each K-tile a load -> LDS -> barrier round
+// trip.  Here a workgroup is persistent and owns TR x 16 output pixels x 32 NBW channels per item: the input patch of item i + 1 is
 // requested (global -> registers) before item i is computed and committed to the OTHER LDS buffer after it, so a memory round trip
-// is paid once per workgroup, not nine times per tile; all nine taps read their A fragments from the patch at shifted addresses
-// (1.16x the tile's own input instead of 2.25x); the wave's 18 weight fragments (lane-order image) stay in registers for the
-// workgroup's lifetime.  LDS image: per patch row the ODD input columns (x = 2 ox0 - 1 + 2j, 17 pixels) then the EVEN ones (16), so
-// that the 16 output columns a fragment read spans are CONSECUTIVE pixels of a plane; pixel pitch 80 B, row pitch 2688 B: every
-// ds_read_b128 lane group lands on 16 distinct 16-byte slots (searched over the lane groups of MI355X_MICROARCH.md section LDS).
+// is paid once per workgroup, not nine times per tile; all nine taps read their A fragments from the patch at shifted addresses;
+// the wave's 18 weight fragments (lane-order image) stay in registers for the workgroup's lifetime.  Waves: 4 / NBW pixel blocks
+// (two output rows of 16 each) x NBW 32-channel column blocks.  LDS image, 80-byte pixels: stride 2 -- per patch row the ODD input
+// columns (x = 2 ox0 - 1 + 2j, 17 pixels) then the EVEN ones (16), so that the 16 output columns a fragment read spans are
+// CONSECUTIVE pixels of a plane, row pitch 2688 B; stride 1 -- 18 pixels, row pitch 1536 B: every ds_read_b128 lane group lands on
+// 16 distinct 16-byte slots (searched over the lane groups of MI355X_MICROARCH.md section LDS).  Optional residual (the C3
+// bottleneck's shortcut), all of a block's values requested before the matrix loop.
 // Same k order (tap-major, 16-deep steps) and the same epilogue expressions as the tiles above: the same bits.
-template <int ACT1>
-__global__ __launch_bounds__(256, 3) void conv_s2c32_f16_kernel(const ConvArgsH a, int tiles_x, int tiles_y, int items) {
-    constexpr int PITCH = 80, ROWP = 2688, EOFF = 17 * PITCH;   // bytes
-    constexpr int PR = 9, PW = 33, NCH = PR * PW * 4, N_IT = (NCH + 255) / 256;
+template <int STRIDE, int NBW, int ACT1, bool HAS_RES>
+__global__ __launch_bounds__(256, 3) void conv_c32_patch_f16_kernel(const ConvArgsH a, int tiles_x, int tiles_y, int items) {
+    static_assert((STRIDE == 1 || STRIDE == 2) && (NBW == 1 || NBW == 2), "instantiated forms");
+    constexpr int PITCH = 80, ROWP = STRIDE == 2 ? 2688 : 1536, EOFF = 17 * PITCH;   // bytes
+    constexpr int TR = 2 * (4 / NBW);                                                 // output rows per item
+    constexpr int PR = STRIDE * (TR - 1) + 3, PW = STRIDE * 15 + 3, NCH = PR * PW * 4, N_IT = (NCH + 255) / 256;
     __shared__ __attribute__((aligned(16))) unsigned char patch[2][PR * ROWP];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NBW, wn = wave - wm * NBW;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.in), 0, a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<half_t*>(a.wl), 0, (unsigned)a.wl_nb * (unsigned)a.wl_ks * 1024u, 0x00020000);
@@ -930,13 +934,14 @@ __global__ __launch_bounds__(256, 3) void conv_s2c32_f16_kernel(const ConvArgsH 
         const int c = tid + 256 * i;
         const int ch = c & 3, px = (c >> 2) % PW, pr = (c >> 2) / PW;
         c_pr[i] = pr; c_px[i] = px; c_ch[i] = ch;
-        l_off[i] = c < NCH ? pr * ROWP + ((px & 1) ? EOFF + (px >> 1) * PITCH : (px >> 1) * PITCH) + ch * 16 : -1;
+        const int pxo = STRIDE == 2 ? ((px & 1) ? EOFF + (px >> 1) * PITCH : (px >> 1) * PITCH) : px * PITCH;
+        l_off[i] = c < NCH ? pr * ROWP + pxo + ch * 16 : -1;
     }
     u32x4 rp[N_IT];
     auto prefetch = [&](int item) {
         const int tx = item % tiles_x, t2 = item / tiles_x;
         const int ty = t2 % tiles_y, img = t2 / tiles_y;
-        const int y0 = ty * 8 - 1, x0 = tx * 32 - 1;
+        const int y0 = ty * (TR * STRIDE) - 1, x0 = tx * (16 * STRIDE) - 1;
 #pragma unroll
         for (int i = 0; i < N_IT; ++i) {
             const int gy = y0 + c_pr[i], gx = x0 + c_px[i];
@@ -966,12 +971,27 @@ __global__ __launch_bounds__(256, 3) void conv_s2c32_f16_kernel(const ConvArgsH 
     commit(0);
     __syncthreads();
 
-    // A fragment base: block row = output pixel (2 wm + (l31 >> 4), l31 & 15) of the tile -> patch row 2 * that, plane pixel l31 & 15
-    const int a_base = (2 * (2 * wm + (l31 >> 4))) * ROWP + (l31 & 15) * PITCH + lh * 16;
+    // A fragment base: block row = output pixel (2 wm + (l31 >> 4), l31 & 15) of the tile -> patch row STRIDE * that; patch pixel
+    // STRIDE * (l31 & 15) (+ kx), which for stride 2 is pixel l31 & 15 of a plane
+    const int a_base = (STRIDE * (2 * wm + (l31 >> 4))) * ROWP + (l31 & 15) * PITCH + lh * 16;
     int cur = 0;
     for (; item < items; item += gridDim.x) {
         const int next = item + gridDim.x;
         if (next < items) prefetch(next);
+        const int tx = item % tiles_x, t2 = item / tiles_x;
+        const int ty = t2 % tiles_y, img = t2 / tiles_y;
+        const int oy0 = ty * TR + 2 * wm, ox0 = tx * 16;
+        // residual values of this lane's 16 pixels, requested before the matrix loop (a pixel outside the tensor re-reads element 0)
+        half_t rv[HAS_RES ? 16 : 1];
+        if (HAS_RES) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+                const bool in = oy < a.oh && ox < a.ow && o < a.ocg;
+                rv[e] = a.res[in ? (size_t)((img * a.oh + oy) * a.ow + ox) * a.res_ld + o : (size_t)0];
+            }
+        }
         const unsigned char* const P = patch[cur] + a_base;
         f32x16 acc;
 #pragma unroll
@@ -979,23 +999,21 @@ __global__ __launch_bounds__(256, 3) void conv_s2c32_f16_kernel(const ConvArgsH 
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
             const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
-            const int off = ky * ROWP + (kx == 1 ? EOFF : (kx == 2 ? PITCH : 0)) + (s & 1) * 32;
+            const int off = ky * ROWP + (STRIDE == 2 ? (kx == 1 ? EOFF : (kx == 2 ? PITCH : 0)) : kx * PITCH) + (s & 1) * 32;
             const f16x8 fa = *reinterpret_cast<const f16x8*>(P + off);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, wf[s], acc, 0, 0, 0);
         }
         // epilogue (epilogue_lean_h's expressions): C/D map col = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 lh (tile pixel)
         {
-            const int tx = item % tiles_x, t2 = item / tiles_x;
-            const int ty = t2 % tiles_y, img = t2 / tiles_y;
-            const int oy0 = ty * 4 + 2 * wm, ox0 = tx * 16;
             half_t* const ob = static_cast<half_t*>(a.out) + o;
             if (o < a.ocg) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
                     const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
-                    if (oy < a.oh && ox < a.ow)
-                        ob[(size_t)((img * a.oh + oy) * a.ow + ox) * a.out_ld] = si_store_cast<half_t>(act_c<ACT1>(acc[e] + bv, a.act_param));
+                    float v = act_c<ACT1>(acc[e] + bv, a.act_param);
+                    if (HAS_RES) v += (float)rv[e];
+                    if (oy < a.oh && ox < a.ow) ob[(size_t)((img * a.oh + oy) * a.ow + ox) * a.out_ld] = si_store_cast<half_t>(v);
                 }
             }
         }
@@ -1023,13 +1041,15 @@ bool s2c32_on() {
     return v != 0;
 }
 bool s2c32_shape_ok(const SiConv2dDesc* d) {
-    return d->groups == 1 && d->ic == 32 && (d->oc == 32 || d->oc == 64) && d->kh == 3 && d->kw == 3 && d->sh == 2 && d->sw == 2 &&
-           d->dh == 1 && d->dw == 1 && d->pt == 1 && d->pl == 1 && !d->has_residual && d->act2 == SI_ACT_NONE &&
-           (d->act1 == SI_ACT_SILU || d->act1 == SI_ACT_NONE || d->act1 == SI_ACT_RELU) &&
-           d->oh == (d->ih + 2 - 3) / 2 + 1 && d->ow == (d->iw + 2 - 3) / 2 + 1;
+    return d->groups == 1 && d->ic == 32 && (d->oc == 32 || d->oc == 64) && d->kh == 3 && d->kw == 3 && d->sh == d->sw &&
+           (d->sh == 1 || d->sh == 2) && d->dh == 1 && d->dw == 1 && d->pt == 1 && d->pl == 1 && d->act2 == SI_ACT_NONE &&
+           (d->act1 == SI_ACT_SILU || d->act1 == SI_ACT_NONE) && (!d->has_residual || d->res_ld % 2 == 0) &&
+           d->oh == (d->ih + 2 - 3) / d->sh + 1 && d->ow == (d->iw + 2 - 3) / d->sw + 1;
 }
-int launch_s2c32(const ConvArgsH& a, const SiConv2dDesc* d, hipStream_t s) {
-    const int tiles_x = (d->ow + 15) / 16, tiles_y = (d->oh + 3) / 4;
+template <int STRIDE, int NBW>
+int launch_c32_patch(const ConvArgsH& a, const SiConv2dDesc* d, hipStream_t s) {
+    constexpr int TR = 2 * (4 / NBW);
+    const int tiles_x = (d->ow + 15) / 16, tiles_y = (d->oh + TR - 1) / TR;
     const long long items = (long long)d->n * tiles_x * tiles_y;
     if (items > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     auto go = [&](auto kern) {
@@ -1039,9 +1059,13 @@ int launch_s2c32(const ConvArgsH& a, const SiConv2dDesc* d, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, a, tiles_x, tiles_y, (int)items);
         return (int)hipGetLastError();
     };
-    if (d->act1 == SI_ACT_SILU) return go(conv_s2c32_f16_kernel<SI_ACT_SILU>);
-    if (d->act1 == SI_ACT_RELU) return go(conv_s2c32_f16_kernel<SI_ACT_RELU>);
-    return go(conv_s2c32_f16_kernel<SI_ACT_NONE>);
+    const bool silu = d->act1 == SI_ACT_SILU;
+    if (d->has_residual) return silu ? go(conv_c32_patch_f16_kernel<STRIDE, NBW, SI_ACT_SILU, true>) : go(conv_c32_patch_f16_kernel<STRIDE, NBW, SI_ACT_NONE, true>);
+    return silu ? go(conv_c32_patch_f16_kernel<STRIDE, NBW, SI_ACT_SILU, false>) : go(conv_c32_patch_f16_kernel<STRIDE, NBW, SI_ACT_NONE, false>);
+}
+int launch_s2c32(const ConvArgsH& a, const SiConv2dDesc* d, hipStream_t s) {
+    if (d->sh == 2) return d->oc == 64 ? launch_c32_patch<2, 2>(a, d, s) : launch_c32_patch<2, 1>(a, d, s);
+    return d->oc == 64 ? launch_c32_patch<1, 2>(a, d, s) : launch_c32_patch<1, 1>(a, d, s);
 }
 
 struct SplitOutH {
@@ -1214,7 +1238,9 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
             default: return launch_detect_tile<4>(a, d->n, s);
         }
     }
-    if (!up && !yolo && !split && !out_f32 && s2c32_on() && f16_forced_variant() < 0 && s2c32_shape_ok(d)) return launch_s2c32(a, d, s);
+    if (!up && !yolo && !split && !out_f32 && s2c32_on() && f16_forced_variant() < 0 && s2c32_shape_ok(d) &&
+        (!d->has_residual || (reinterpret_cast<uintptr_t>(residual) & 1) == 0))
+        return launch_s2c32(a, d, s);
     const int v = up ? 0 : f16_variant(d);   // (the dual-source form lives in the one-stage 64x64 kernel)
     if (f16_block(d) == 64) {
         switch (v) {
@@ -1320,7 +1346,14 @@ const char* si_hip_conv2d_f16_kernel_name(const SiConv2dDesc* d, int form) {
     // dual-source (upsampled) form, which lives in the one-stage 64x64 kernel
     if (!d || !f16_shape_ok(d)) return "";
     if (form == 0 && s2c32_on() && f16_forced_variant() < 0 && s2c32_shape_ok(d))
-        return d->act1 == SI_ACT_SILU ? "conv_s2c32_f16_kernel<2>" : (d->act1 == SI_ACT_RELU ? "conv_s2c32_f16_kernel<1>" : "conv_s2c32_f16_kernel<0>");
+    {
+        static const char* const names[16] = {
+            "conv_c32_patch_f16_kernel<1, 1, 0, false>", "conv_c32_patch_f16_kernel<1, 1, 0, true>", "conv_c32_patch_f16_kernel<1, 1, 2, false>", "conv_c32_patch_f16_kernel<1, 1, 2, true>",
+            "conv_c32_patch_f16_kernel<1, 2, 0, false>", "conv_c32_patch_f16_kernel<1, 2, 0, true>", "conv_c32_patch_f16_kernel<1, 2, 2, false>", "conv_c32_patch_f16_kernel<1, 2, 2, true>",
+            "conv_c32_patch_f16_kernel<2, 1, 0, false>", "conv_c32_patch_f16_kernel<2, 1, 0, true>", "conv_c32_patch_f16_kernel<2, 1, 2, false>", "conv_c32_patch_f16_kernel<2, 1, 2, true>",
+            "conv_c32_patch_f16_kernel<2, 2, 0, false>", "conv_c32_patch_f16_kernel<2, 2, 0, true>", "conv_c32_patch_f16_kernel<2, 2, 2, false>", "conv_c32_patch_f16_kernel<2, 2, 2, true>"};
+        return names[(d->sh - 1) * 8 + (d->oc == 64 ? 4 : 0) + (d->act1 == SI_ACT_SILU ? 2 : 0) + (d->has_residual ? 1 : 0)];
+    }
     const int v = form == 1 ? 0 : f16_variant(d);
     const bool b64 = f16_block(d) == 64;
     switch (v) {

@@ -314,13 +314,17 @@ def test_every_f16_tile_variant_same_bits_through_epilogues_split_and_detect(hop
             assert_exact(got, want, "fp16 tile variant %d, output %d" % (v, i))
 
 
-@pytest.mark.parametrize("n,ih,iw,oc,act", [
-    (2, 64, 64, 64, "silu"),       # whole 4 x 16 tiles
-    (3, 38, 50, 64, "silu"),       # ragged tiles both ways (19 x 25 outputs), odd-sized borders
-    (1, 7, 9, 32, "relu"),         # one partial tile, a single 32-channel column block
-    (5, 16, 32, 64, "none"),
+@pytest.mark.parametrize("n,ih,iw,oc,act,stride,res", [
+    (2, 64, 64, 64, "silu", 2, False),       # whole 4 x 16 tiles
+    (3, 38, 50, 64, "silu", 2, False),       # ragged tiles both ways (19 x 25 outputs), odd-sized borders
+    (1, 7, 9, 32, "none", 2, False),         # one partial tile, a single 32-channel column block (8-row tiles)
+    (5, 16, 32, 64, "none", 2, True),
+    (2, 32, 32, 32, "silu", 1, True),        # stride 1: the C3 bottleneck's 3x3 with its shortcut (YOLOv5s conv_4)
+    (3, 19, 25, 32, "silu", 1, True),        # ragged
+    (1, 8, 16, 64, "silu", 1, False),
+    (2, 21, 40, 64, "none", 1, True),
 ])
-def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, act):
+def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, act, stride, res):
     """Round 4: a 3x3 stride-2 pad-1 conv over 32 channels (YOLOv5's second conv) runs as the persistent spatial-tile kernel
     conv_s2c32_f16_kernel.  Same k order, same MFMA steps, same epilogue expressions as the generic tiles: BIT identical; and the
     fp16 bar against the oracle (src/layer/conv_2d.cpp:207-283) holds."""
@@ -330,18 +334,25 @@ def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, 
     w = h(rng_uniform(701, (oc, 32, 3, 3), -0.3, 0.3))
     b = rng_uniform(702, (oc,), -0.5, 0.5)
     kw = {} if act == "none" else {"act1": act}
+    st = (stride, stride)
+    oh, ow = (ih + 2 - 3) // stride + 1, (iw + 2 - 3) // stride + 1
+    if res:
+        kw["residual"] = h(rng_uniform(703, (n, oh, ow, oc), -1, 1))
     try:
         assert H.si_hip_conv2d_f16_set_s2c32(0) == 0
-        base = hops.conv2d_f16(x, w, b, (2, 2), (1, 1), **kw)
+        base = hops.conv2d_f16(x, w, b, st, (1, 1), **kw)
         assert H.si_hip_conv2d_f16_set_s2c32(1) == 0
-        got = hops.conv2d_f16(x, w, b, (2, 2), (1, 1), **kw)
-        wide = hops.conv2d_f16(x, w, b, (2, 2), (1, 1), out_ld=oc + 32, out_c_off=16, **kw)   # into a slice of a wider tensor
+        got = hops.conv2d_f16(x, w, b, st, (1, 1), **kw)
+        wide = hops.conv2d_f16(x, w, b, st, (1, 1), out_ld=oc + 32, out_c_off=16, **kw)   # into a slice of a wider tensor
     finally:
         H.si_hip_conv2d_f16_set_s2c32(1)
-    assert_exact(got, base, "s2c32 kernel vs generic tiles")
-    assert_exact(wide, base, "s2c32 kernel, strided output")
-    ref = orc.conv2d(x, w, b, (2, 2), (1, 1), path="naive")
-    assert_parity(got.astype(np.float32), ref if act == "none" else orc.activation(act, ref), F16_TOL, what="s2c32 kernel")
+    assert_exact(got, base, "c32 patch kernel vs generic tiles")
+    assert_exact(wide, base, "c32 patch kernel, strided output")
+    ref = orc.conv2d(x, w, b, st, (1, 1), path="naive")
+    ref = ref if act == "none" else orc.activation(act, ref)
+    if res:
+        ref = ref + kw["residual"].astype(np.float32)
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="c32 patch kernel")
 
 
 @pytest.mark.parametrize("n,ih,iw,oc", [
