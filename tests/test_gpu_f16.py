@@ -323,6 +323,11 @@ def test_every_f16_tile_variant_same_bits_through_epilogues_split_and_detect(hop
     (3, 19, 25, 32, "silu", 1, True),        # ragged
     (1, 8, 16, 64, "silu", 1, False),
     (2, 21, 40, 64, "none", 1, True),
+    (2, 20, 32, 64, "silu", -1, True),       # stride -1: 64 INPUT channels, stride 1 (the 80x80 C3 bottleneck convs; whole tiles only)
+    (3, 12, 16, 64, "silu", -1, False),
+    (2, 16, 48, 64, "relu", -1, False),      # ResNet's basic block: ReLU, then (second conv) shortcut + ReLU
+    (2, 16, 48, 64, "res+relu", -1, True),
+    (2, 14, 18, 32, "res+relu", 1, True),    # ... ragged, on the 32-channel form
 ])
 def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, act, stride, res):
     """Round 4: a 3x3 stride-2 pad-1 conv over 32 channels (YOLOv5's second conv) runs as the persistent spatial-tile kernel
@@ -330,10 +335,12 @@ def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, 
     fp16 bar against the oracle (src/layer/conv_2d.cpp:207-283) holds."""
     from simpleinfer_amd import _native
     H = _native.hip()
-    x = h(rng_uniform(700, (n, ih, iw, 32), -1, 1))
-    w = h(rng_uniform(701, (oc, 32, 3, 3), -0.3, 0.3))
+    ic = 64 if stride < 0 else 32
+    stride = abs(stride)
+    x = h(rng_uniform(700, (n, ih, iw, ic), -1, 1))
+    w = h(rng_uniform(701, (oc, ic, 3, 3), -0.3, 0.3))
     b = rng_uniform(702, (oc,), -0.5, 0.5)
-    kw = {} if act == "none" else {"act1": act}
+    kw = {} if act == "none" else ({"act2": "relu"} if act == "res+relu" else {"act1": act})
     st = (stride, stride)
     oh, ow = (ih + 2 - 3) // stride + 1, (iw + 2 - 3) // stride + 1
     if res:
@@ -349,9 +356,11 @@ def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, 
     assert_exact(got, base, "c32 patch kernel vs generic tiles")
     assert_exact(wide, base, "c32 patch kernel, strided output")
     ref = orc.conv2d(x, w, b, st, (1, 1), path="naive")
-    ref = ref if act == "none" else orc.activation(act, ref)
+    ref = ref if act in ("none", "res+relu") else orc.activation(act, ref)
     if res:
         ref = ref + kw["residual"].astype(np.float32)
+    if act == "res+relu":
+        ref = orc.activation("relu", ref)
     assert_parity(got.astype(np.float32), ref, F16_TOL, what="c32 patch kernel")
 
 
