@@ -917,8 +917,8 @@ int launch_detect_tile(const ConvArgsH& a, int n, hipStream_t s) {
 // (144 registers: two workgroups per CU).
 template <int STRIDE, int NBW, int ACT1, bool HAS_RES, int CB = 32>
 __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_c32_patch_f16_kernel(const ConvArgsH a, int tiles_x, int tiles_y, int items) {
-    static_assert((STRIDE == 1 || STRIDE == 2) && (NBW == 1 || NBW == 2) && (CB == 32 || (CB == 64 && STRIDE == 1)), "instantiated forms");
-    constexpr int PITCH = CB * 2 + 16, ROWP = CB == 64 ? 2816 : (STRIDE == 2 ? 2688 : 1536), EOFF = 17 * PITCH;   // bytes
+    static_assert((STRIDE == 1 || STRIDE == 2) && (NBW == 1 || NBW == 2 || NBW == 4) && (CB == 32 || CB == 64), "instantiated forms");
+    constexpr int PITCH = CB * 2 + 16, ROWP = CB == 64 ? (STRIDE == 2 ? 4864 : 2816) : (STRIDE == 2 ? 2688 : 1536), EOFF = 17 * PITCH;   // bytes
     constexpr int TR = 2 * (4 / NBW);                                                 // output rows per item
     constexpr int CH8 = CB / 8, QS = CB / 16, KS = 9 * QS;                            // 16-byte chunks per pixel, k-steps per tap, in all
     constexpr int PR = STRIDE * (TR - 1) + 3, PW = STRIDE * 15 + 3, NCH = PR * PW * CH8, N_IT = (NCH + 255) / 256;
@@ -1050,7 +1050,9 @@ bool s2c32_shape_ok(const SiConv2dDesc* d) {
     // (64 input channels: only whole 4 x 16 tiles -- ResNet18's 56 x 56 maps, 3.5 tiles wide, measured 2.7 % slower than the generic
     // tiles over the network; the 80 x 80 maps of YOLOv5s 1.4x faster per layer)
     const bool c64 = d->ic == 64 && d->oc == 64 && d->sh == 1 && d->ow % 16 == 0 && d->oh % 4 == 0;
-    return d->groups == 1 && ((d->ic == 32 && (d->oc == 32 || d->oc == 64)) || c64) && d->kh == 3 && d->kw == 3 && d->sh == d->sw &&
+    // 64 -> 128 channels at stride 2 (YOLOv5s conv_7): four column-block waves over one 2 x 16-pixel block
+    const bool c64s2 = d->ic == 64 && d->oc == 128 && d->sh == 2 && d->ow % 16 == 0 && d->oh % 2 == 0;
+    return d->groups == 1 && ((d->ic == 32 && (d->oc == 32 || d->oc == 64)) || c64 || c64s2) && d->kh == 3 && d->kw == 3 && d->sh == d->sw &&
            (d->sh == 1 || d->sh == 2) && d->dh == 1 && d->dw == 1 && d->pt == 1 && d->pl == 1 &&
            (!d->has_residual || d->res_ld % 2 == 0) &&
            d->oh == (d->ih + 2 - 3) / d->sh + 1 && d->ow == (d->iw + 2 - 3) / d->sw + 1;
@@ -1073,7 +1075,7 @@ int launch_c32_patch(const ConvArgsH& a, const SiConv2dDesc* d, hipStream_t s) {
     return silu ? go(conv_c32_patch_f16_kernel<STRIDE, NBW, SI_ACT_SILU, false, CB>) : go(conv_c32_patch_f16_kernel<STRIDE, NBW, SI_ACT_NONE, false, CB>);
 }
 int launch_s2c32(const ConvArgsH& a, const SiConv2dDesc* d, hipStream_t s) {
-    if (d->ic == 64) return launch_c32_patch<1, 2, 64>(a, d, s);
+    if (d->ic == 64) return d->sh == 2 ? launch_c32_patch<2, 4, 64>(a, d, s) : launch_c32_patch<1, 2, 64>(a, d, s);
     if (d->sh == 2) return d->oc == 64 ? launch_c32_patch<2, 2>(a, d, s) : launch_c32_patch<2, 1>(a, d, s);
     return d->oc == 64 ? launch_c32_patch<1, 2>(a, d, s) : launch_c32_patch<1, 1>(a, d, s);
 }
@@ -1365,7 +1367,9 @@ const char* si_hip_conv2d_f16_kernel_name(const SiConv2dDesc* d, int form) {
         static const char* const names64[4] = {"conv_c32_patch_f16_kernel<1, 2, 0, false, 64>", "conv_c32_patch_f16_kernel<1, 2, 0, true, 64>",
                                                "conv_c32_patch_f16_kernel<1, 2, 2, false, 64>", "conv_c32_patch_f16_kernel<1, 2, 2, true, 64>"};
         const bool silu = d->act1 == SI_ACT_SILU && d->act2 == SI_ACT_NONE;
-        if (d->ic == 64) return names64[(silu ? 2 : 0) + (d->has_residual ? 1 : 0)];
+        static const char* const names64s2[4] = {"conv_c32_patch_f16_kernel<2, 4, 0, false, 64>", "conv_c32_patch_f16_kernel<2, 4, 0, true, 64>",
+                                                 "conv_c32_patch_f16_kernel<2, 4, 2, false, 64>", "conv_c32_patch_f16_kernel<2, 4, 2, true, 64>"};
+        if (d->ic == 64) return (d->sh == 2 ? names64s2 : names64)[(silu ? 2 : 0) + (d->has_residual ? 1 : 0)];
         return names[(d->sh - 1) * 8 + (d->oc == 64 ? 4 : 0) + (silu ? 2 : 0) + (d->has_residual ? 1 : 0)];
     }
     const int v = form == 1 ? 0 : f16_variant(d);

@@ -128,7 +128,17 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
     const float bsv = a.bs ? a.bs[l31] : 0.0f;
     const int o = wn * 32 + l31;
     const float bcv = (a.bc && o < a.oc) ? a.bc[o] : 0.0f;
+    // the stem's B fragments of this lane, resident too (SI_FUSED_WS_REGS=0: re-read from LDS per MFMA, as conv_stem_f16.hip does)
+#ifndef SI_FUSED_WS_REGS
+#define SI_FUSED_WS_REGS 1
+#endif
     const half_t* const wfrag = wsl + (lh * 32 + l31) * 8;
+    f16x8 wsf[9];
+    if (SI_FUSED_WS_REGS) {
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 9; ++s) wsf[s] = *reinterpret_cast<const f16x8*>(wfrag + s * (2 * 32 * 8));
+    }
     const uint32_t* const stage_w = reinterpret_cast<const uint32_t*>(stage);
     const int a_base = (2 * (2 * wm + (l31 >> 4))) * ROWP + (l31 & 15) * PITCH + lh * 16;
 
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
                 const uint32_t* p = stage_w + (h0 >> 1);
                 u32x4 fa;
                 fa[0] = p[0]; fa[1] = p[1]; fa[2] = p[2]; fa[3] = p[3];
-                const f16x8 fb = *reinterpret_cast<const f16x8*>(wfrag + s * (2 * 32 * 8));
+                const f16x8 fb = SI_FUSED_WS_REGS ? wsf[s] : *reinterpret_cast<const f16x8*>(wfrag + s * (2 * 32 * 8));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), fb, acc, 0, 0, 0);
             }
             // C/D map: col = lane & 31 (stem channel), row = (e & 3) + 8 (e >> 2) + 4 lh (block pixel)

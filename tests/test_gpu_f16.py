@@ -328,6 +328,8 @@ def test_every_f16_tile_variant_same_bits_through_epilogues_split_and_detect(hop
     (2, 16, 48, 64, "relu", -1, False),      # ResNet's basic block: ReLU, then (second conv) shortcut + ReLU
     (2, 16, 48, 64, "res+relu", -1, True),
     (2, 14, 18, 32, "res+relu", 1, True),    # ... ragged, on the 32-channel form
+    (2, 16, 64, 128, "silu", -2, False),     # stride -2: 64 input channels, stride 2, 128 outputs (YOLOv5s conv_7)
+    (3, 12, 32, 128, "none", -2, True),
 ])
 def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, act, stride, res):
     """Round 4: a 3x3 stride-2 pad-1 conv over 32 channels (YOLOv5's second conv) runs as the persistent spatial-tile kernel
@@ -336,7 +338,7 @@ def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, 
     from simpleinfer_amd import _native
     H = _native.hip()
     ic = 64 if stride < 0 else 32
-    stride = abs(stride)
+    stride = 2 if stride == -2 else abs(stride)
     x = h(rng_uniform(700, (n, ih, iw, ic), -1, 1))
     w = h(rng_uniform(701, (oc, ic, 3, 3), -0.3, 0.3))
     b = rng_uniform(702, (oc,), -0.5, 0.5)
