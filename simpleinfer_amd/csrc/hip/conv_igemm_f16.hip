@@ -999,12 +999,26 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_c32_patch_f16_kern
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        // A fragments in groups of three, the next group requested before this one multiplies: left one by one hipcc keeps a single
+        // read ahead of a chain of dependent MFMAs -- an LDS round trip per 32-cycle MFMA
+        auto frag = [&](int s) {
             const int tap = s / QS, ky = tap / 3, kx = tap - 3 * ky;
             const int off = ky * ROWP + (STRIDE == 2 ? (kx == 1 ? EOFF : (kx == 2 ? PITCH : 0)) : kx * PITCH) + (s % QS) * 32;
-            const f16x8 fa = *reinterpret_cast<const f16x8*>(P + off);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, wf[s], acc, 0, 0, 0);
+            return *reinterpret_cast<const f16x8*>(P + off);
+        };
+        constexpr int NG = KS / 3;
+        f16x8 fg[2][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fg[0][i] = frag(i);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) fg[(g + 1) & 1][i] = frag(3 * (g + 1) + i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fg[g & 1][i], wf[3 * g + i], acc, 0, 0, 0);
         }
         // epilogue (epilogue_lean_h's expressions): C/D map col = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 lh (tile pixel)
         {

@@ -46,6 +46,11 @@ struct FusedArgs {
     unsigned in_bytes;
 };
 
+// SI_FUSED_ABL (diagnostic builds only, tools/stem_fused_ablate.sh): bit 0 no SiLU (bias add only), 1 no stem MFMAs, 2 no phase B,
+// 3 no global stores, 4 no image prefetch after the first item -- wrong results, timing only.  0 in the product build.
+#ifndef SI_FUSED_ABL
+#define SI_FUSED_ABL 0
+#endif
 __device__ __forceinline__ float silu_f(float t) { return t * __builtin_amdgcn_rcpf(1.0f + __expf(-t)); }
 // SiLU of (x0 + b, x1 + b) on the packed fp32 instructions (conv_igemm.hip epilogue_lean: each component is rounded exactly like the
 // scalar form -- __expf(-t) is v_exp_f32(t * -log2(e)) -- so the bits are silu_f's), then fp16 bit patterns
@@ -54,7 +59,7 @@ __device__ __forceinline__ void silu2_bits(float x0, float x1, float b, unsigned
     const f32x2 v = f32x2{x0, x1} + f32x2{b, b};
     const f32x2 x = v * f32x2{-1.44269504088896340736f, -1.44269504088896340736f};
     const f32x2 d = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])} + f32x2{1.0f, 1.0f};
-    const f32x2 o = v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2 o = (SI_FUSED_ABL & 1) ? v : v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
     h0 = __builtin_bit_cast(unsigned short, si_store_cast<half_t>(o[0]));
     h1 = __builtin_bit_cast(unsigned short, si_store_cast<half_t>(o[1]));
 }
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
         commit();          // (waits for this item's window; the stores of the previous item are younger than those loads)
         __syncthreads();   // the window is staged; every wave is done with the previous item's patch
         const int next = item + gridDim.x;
-        if (next < a.items) prefetch(next);
+        if (next < a.items && !(SI_FUSED_ABL & 16)) prefetch(next);
 
         // ---- phase A: stem pixels of the patch.  Block b < 9: patch row b, columns 0..31; block 9: column 32 of rows 0..8.
         // Everything about an element's place is either uniform (the row, its validity) or a per-lane base plus a compile-time
@@ -161,6 +166,9 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+            // all nine A fragments of the block are requested before its first MFMA (left interleaved, hipcc keeps ONE step of
+            // reads ahead of a chain of dependent MFMAs: an LDS round trip per step, ~1200 cycles per block for 288 of matrix work)
+            u32x4 fa[9];
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
                 // group 2s for the low lanes, 2s + 1 for the high ones (conv_stem_f16.hip): kernel row G / 3, values 8 (G % 3) ..
@@ -168,10 +176,13 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
                 const int off0 = (G0 / 3) * RL + 8 * (G0 % 3), off1 = (G1 / 3) * RL + 8 * (G1 % 3);
                 const int h0 = base_h + (lh ? off1 : off0);
                 const uint32_t* p = stage_w + (h0 >> 1);
-                u32x4 fa;
-                fa[0] = p[0]; fa[1] = p[1]; fa[2] = p[2]; fa[3] = p[3];
+                fa[s][0] = p[0]; fa[s][1] = p[1]; fa[s][2] = p[2]; fa[s][3] = p[3];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < ((SI_FUSED_ABL & 2) ? 0 : 9); ++s) {
                 const f16x8 fb = SI_FUSED_WS_REGS ? wsf[s] : *reinterpret_cast<const f16x8*>(wfrag + s * (2 * 32 * 8));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa), fb, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s]), fb, acc, 0, 0, 0);
             }
             // C/D map: col = lane & 31 (stem channel), row = (e & 3) + 8 (e >> 2) + 4 lh (block pixel)
             if (b < 9) {
@@ -205,17 +216,29 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
         __syncthreads();
 
         // ---- phase B: conv_1 from the patch (conv_s2c32_f16_kernel)
-        {
+        if (!(SI_FUSED_ABL & 4)) {
             const unsigned char* const P = patch + a_base;
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 18; ++s) {
+            // A fragments in groups of three, the next group requested before this one multiplies (see phase A)
+            auto frag = [&](int s) {
                 const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
                 const int off = ky * ROWP + (kx == 1 ? EOFF : (kx == 2 ? PITCH : 0)) + (s & 1) * 32;
-                const f16x8 fa = *reinterpret_cast<const f16x8*>(P + off);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, wf[s], acc, 0, 0, 0);
+                return *reinterpret_cast<const f16x8*>(P + off);
+            };
+            f16x8 fb[2][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fb[0][i] = frag(i);
+#pragma unroll
+            for (int g = 0; g < 6; ++g) {
+                if (g + 1 < 6) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) fb[(g + 1) & 1][i] = frag(3 * (g + 1) + i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], wf[3 * g + i], acc, 0, 0, 0);
             }
             const int oy0 = ty * 4 + 2 * wm, ox0 = tx * 16;
             half_t* const ob = a.out + o;
@@ -227,6 +250,7 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
                     unsigned h0, h1;
                     silu2_bits(acc[e], acc[e + 1], bcv, h0, h1);
                     unsigned short* const op = reinterpret_cast<unsigned short*>(ob + (size_t)((img * a.oh + oy) * a.ow + ox) * a.out_ld);
+                    if (SI_FUSED_ABL & 8) { asm volatile("" ::"v"(h0), "v"(h1)); continue; }
                     if (oy < a.oh && ox < a.ow) op[0] = (unsigned short)h0;
                     if (oy < a.oh && ox + 1 < a.ow) op[a.out_ld] = (unsigned short)h1;
                 }
