@@ -32,6 +32,7 @@ typedef _Float16 half_t;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // conv_stem_f16.hip: stem kernel of this path (fp32 image in, fp16 out)
 bool si_conv_stem_f16_ok(const SiConv2dDesc* d);
@@ -972,7 +973,11 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_c32_patch_f16_kern
     const int o = wn * 32 + l31;
     const float bv = (a.bias && o < a.ocg) ? a.bias[o] : 0.0f;
     commit(0);
-    __syncthreads();
+    // the weights (and the bias) have LANDED before the loop: otherwise every MFMA of the item loop carries a vmcnt(N) wait for "its"
+    // weight register -- N counting down to 0 over the 18 / 36 steps -- and, the counter being in order, the last ones wait for the
+    // next item's patch loads and this item's output stores as well: a memory round trip per item (seen in the ISA)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    si_lds_barrier();
 
     // A fragment base: block row = output pixel (2 wm + (l31 >> 4), l31 & 15) of the tile -> patch row STRIDE * that; patch pixel
     // STRIDE * (l31 & 15) (+ kx), which for stride 2 is pixel l31 & 15 of a plane
@@ -1039,7 +1044,7 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_c32_patch_f16_kern
         }
         if (next < items) {
             commit(cur ^ 1);
-            __syncthreads();
+            si_lds_barrier();
             cur ^= 1;
         }
     }
@@ -1267,6 +1272,7 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     if (!up && !yolo && !split && !out_f32 && s2c32_on() && f16_forced_variant() < 0 && s2c32_shape_ok(d) &&
         (!d->has_residual || (reinterpret_cast<uintptr_t>(residual) & 1) == 0))
         return launch_s2c32(a, d, s);
+
     const int v = up ? 0 : f16_variant(d);   // (the dual-source form lives in the one-stage 64x64 kernel)
     if (f16_block(d) == 64) {
         switch (v) {

@@ -146,12 +146,15 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
     }
     const uint32_t* const stage_w = reinterpret_cast<const uint32_t*>(stage);
     const int a_base = (2 * (2 * wm + (l31 >> 4))) * ROWP + (l31 & 15) * PITCH + lh * 16;
+    // conv_1's weights and the biases have LANDED before the loop: otherwise every MFMA of phase B carries a vmcnt(N) wait for "its"
+    // weight register, N counting down to 0, i.e. for the next item's window loads and this item's output stores as well
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
     for (; item < a.items; item += gridDim.x) {
         const int tx = item % a.tiles_x, t2 = item / a.tiles_x;
         const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
         commit();          // (waits for this item's window; the stores of the previous item are younger than those loads)
-        __syncthreads();   // the window is staged; every wave is done with the previous item's patch
+        si_lds_barrier();   // the window is staged; every wave is done with the previous item's patch
         const int next = item + gridDim.x;
         if (next < a.items && !(SI_FUSED_ABL & 16)) prefetch(next);
 
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
                 }
             }
         }
-        __syncthreads();
+        si_lds_barrier();
 
         // ---- phase B: conv_1 from the patch (conv_s2c32_f16_kernel)
         if (!(SI_FUSED_ABL & 4)) {
