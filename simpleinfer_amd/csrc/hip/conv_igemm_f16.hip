@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_c32_patch_f16_kern
     // weight register -- N counting down to 0 over the 18 / 36 steps -- and, the counter being in order, the last ones wait for the
     // next item's patch loads and this item's output stores as well: a memory round trip per item (seen in the ISA)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    si_lds_barrier();
+    __syncthreads();
 
     // A fragment base: block row = output pixel (2 wm + (l31 >> 4), l31 & 15) of the tile -> patch row STRIDE * that; patch pixel
     // STRIDE * (l31 & 15) (+ kx), which for stride 2 is pixel l31 & 15 of a plane
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_c32_patch_f16_kern
         }
         if (next < items) {
             commit(cur ^ 1);
-            si_lds_barrier();
+            __syncthreads();
             cur ^= 1;
         }
     }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
         const int tx = item % a.tiles_x, t2 = item / a.tiles_x;
         const int ty = t2 % a.tiles_y, img = t2 / a.tiles_y;
         commit();          // (waits for this item's window; the stores of the previous item are younger than those loads)
-        si_lds_barrier();   // the window is staged; every wave is done with the previous item's patch
+        __syncthreads();   // the window is staged; every wave is done with the previous item's patch
         const int next = item + gridDim.x;
         if (next < a.items && !(SI_FUSED_ABL & 16)) prefetch(next);
 
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
                 }
             }
         }
-        si_lds_barrier();
+        __syncthreads();
 
         // ---- phase B: conv_1 from the patch (conv_s2c32_f16_kernel)
         if (!(SI_FUSED_ABL & 4)) {

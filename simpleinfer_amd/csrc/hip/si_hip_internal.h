@@ -57,14 +57,6 @@ static inline hipError_t si_allow_dynamic_lds(Kern kern, size_t lds) {
 // fp32 -> storage type. For _Float16 the empty asm keeps the value opaque so the compiler cannot fold the multiply / add
 // that produced it into v_fma_mix{lo,hi}_f16 for some unrolled elements and not others: the fused form rounds once, the
 // separate form twice, and an image's result would then depend on which accumulator slot (= batch position) it used.
-// Workgroup barrier for kernels whose waves talk through LDS ONLY: this wave's LDS operations are complete (lgkmcnt(0)), then
-// s_barrier.  __syncthreads() is a workgroup-scope fence as well and waits for EVERY outstanding vector-memory operation of the
-// wave (vmcnt(0): on gfx9 that counter holds the stores too) -- a persistent kernel that keeps the next item's loads in flight across
-// the barrier, or has just issued an item's output stores, would wait a full memory round trip at each one.
-__device__ __forceinline__ void si_lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 template <typename T>
 __device__ __forceinline__ T si_store_cast(float v) {
     if constexpr (sizeof(T) == 2) asm("" : "+v"(v));
