@@ -411,6 +411,11 @@ int si_hip_conv2d_yolo_f16_set_tile(int on);
  * computed, weights resident in registers) -- same bits as the generic tiles.  set_s2c32(0) forces the generic tiles (tests, A/B
  * runs; SI_CONV_F16_S2C32=0 does the same at start-up). */
 int si_hip_conv2d_f16_set_s2c32(int on);
+/* Round 5: 3x3 stride-1 pad-1 layers over 128 / 256 input channels (output channels a multiple of 128) as one-shot row slabs
+ * (conv_slab_f16.hip: a workgroup stages the input rows of its output rows once for every channel block, crosses one barrier and
+ * runs the whole K loop from LDS with the weights streamed from L2 in lane order); same bits as the generic tiles.  0 restores the
+ * generic tiles (SI_CONV_F16_SLAB=0 at start-up). */
+int si_hip_conv2d_f16_set_slab(int on);
 /* Round 4: YOLOv5's first two convs in one persistent kernel (conv_stem_s2c32_f16.hip): `stem` = 6x6 s2 p2, 3 -> 32, SiLU on the
  * dense fp32 image (src/layer/conv_2d.cpp:207-283), `conv` = 3x3 s2 p1, 32 -> 32 / 64, SiLU; the 32-channel intermediate is computed
  * tile by tile into LDS and never written.  Weights: si_hip_conv2d_stem_f16_pack_weight_host(stem) and

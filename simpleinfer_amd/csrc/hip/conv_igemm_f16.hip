@@ -38,6 +38,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 bool si_conv_stem_f16_ok(const SiConv2dDesc* d);
 // conv_depthwise_f16.hip: groups == ic == oc
 bool si_conv_depthwise_f16_ok(const SiConv2dDesc* d);
+// conv_slab_f16.hip: 3x3 stride-1 layers over 128 / 256 channels as one-shot row slabs (round 5)
+bool si_conv_slab_f16_ok(const SiConv2dDesc* d);
+const char* si_conv_slab_f16_name(const SiConv2dDesc* d);
+int si_conv_slab_f16_launch(const SiConv2dDesc* d, const void* in, const void* wl, int wl_nb, int wl_ks, const float* bias,
+                            const void* residual, void* out, hipStream_t s);
 
 namespace {
 
@@ -1272,6 +1277,9 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     if (!up && !yolo && !split && !out_f32 && s2c32_on() && f16_forced_variant() < 0 && s2c32_shape_ok(d) &&
         (!d->has_residual || (reinterpret_cast<uintptr_t>(residual) & 1) == 0))
         return launch_s2c32(a, d, s);
+    if (!up && !yolo && !split && !out_f32 && f16_forced_variant() < 0 && si_conv_slab_f16_ok(d) && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+        (!d->has_bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (!d->has_residual || (reinterpret_cast<uintptr_t>(residual) & 7) == 0))
+        return si_conv_slab_f16_launch(d, in, a.wl, a.wl_nb, a.wl_ks, bias, residual, out, s);
 
     const int v = up ? 0 : f16_variant(d);   // (the dual-source form lives in the one-stage 64x64 kernel)
     if (f16_block(d) == 64) {
@@ -1392,6 +1400,7 @@ const char* si_hip_conv2d_f16_kernel_name(const SiConv2dDesc* d, int form) {
         if (d->ic == 64) return (d->sh == 2 ? names64s2 : names64)[(silu ? 2 : 0) + (d->has_residual ? 1 : 0)];
         return names[(d->sh - 1) * 8 + (d->oc == 64 ? 4 : 0) + (silu ? 2 : 0) + (d->has_residual ? 1 : 0)];
     }
+    if (form == 0 && f16_forced_variant() < 0 && si_conv_slab_f16_ok(d)) return si_conv_slab_f16_name(d);
     const int v = form == 1 ? 0 : f16_variant(d);
     const bool b64 = f16_block(d) == 64;
     switch (v) {

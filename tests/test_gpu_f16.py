@@ -366,6 +366,53 @@ def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, 
     assert_parity(got.astype(np.float32), ref, F16_TOL, what="c32 patch kernel")
 
 
+@pytest.mark.parametrize("n,hh,ww,ic,oc,act,res", [
+    (2, 40, 40, 128, 128, "silu", False),     # YOLOv5s' 40x40 bottleneck conv: 5-row slabs, TM = 7
+    (3, 20, 20, 256, 256, "silu", True),      # ... 20x20 with the shortcut: two output-channel groups per slab, TM = 4
+    (2, 13, 17, 128, 256, "none", True),      # ragged: the last slab of an image is short, the last 32-pixel block part empty
+    (1, 7, 9, 256, 128, "relu", False),       # one slab per image
+    (5, 28, 28, 128, 128, "res+relu", True),  # ResNet's basic block form
+    (2, 3, 50, 128, 128, "silu", False),      # wide and flat
+    (4, 14, 14, 256, 256, "relu", True),
+    (2, 10, 10, 256, 128, "hardswish", False),  # not one of the kernel's activation pairs: the generic tiles serve it
+])
+def test_slab_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, hh, ww, ic, oc, act, res):
+    """Round 5: 3x3 stride-1 pad-1 convs over 128 / 256 channels run as one-shot row slabs (conv_slab_f16.hip): the input rows of
+    a slab staged once for all channel blocks, one barrier, the whole K loop from LDS with streamed lane-order weights.  Same k order,
+    same MFMA steps, same epilogue expressions as the generic tiles: BIT identical, at any batch position, into strided tensors; and
+    the fp16 bar against the oracle (src/layer/conv_2d.cpp:207-283) holds."""
+    from simpleinfer_amd import _native
+    H = _native.hip()
+    x = h(rng_uniform(900, (n, hh, ww, ic), -1, 1))
+    w = h(rng_uniform(901, (oc, ic, 3, 3), -0.1, 0.1))
+    b = rng_uniform(902, (oc,), -0.5, 0.5)
+    kw = {} if act == "none" else ({"act2": "relu"} if act == "res+relu" else {"act1": act})
+    if res:
+        kw["residual"] = h(rng_uniform(903, (n, hh, ww, oc), -1, 1))
+    try:
+        assert H.si_hip_conv2d_f16_set_slab(0) == 0
+        base = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), **kw)
+        assert H.si_hip_conv2d_f16_set_slab(1) == 0
+        got = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), **kw)
+        wide = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), out_ld=oc + 32, out_c_off=16, **kw)   # into a slice of a wider tensor
+        kw1 = dict(kw)
+        if res:
+            kw1["residual"] = kw["residual"][n - 1:]
+        last = hops.conv2d_f16(x[n - 1:], w, b, (1, 1), (1, 1), **kw1)                          # the last image alone: another grid
+    finally:
+        H.si_hip_conv2d_f16_set_slab(1)
+    assert_exact(got, base, "slab kernel vs generic tiles")
+    assert_exact(wide, base, "slab kernel, strided output")
+    assert_exact(last, got[n - 1:], "slab kernel, batch position")
+    ref = orc.conv2d(x, w, b, (1, 1), (1, 1), path="naive")
+    ref = ref if act in ("none", "res+relu") else orc.activation(act, ref)
+    if res:
+        ref = ref + kw["residual"].astype(np.float32)
+    if act == "res+relu":
+        ref = orc.activation("relu", ref)
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="slab kernel")
+
+
 @pytest.mark.parametrize("n,ih,iw,oc", [
     (2, 128, 128, 64),     # whole tiles (32 x 32 outputs)
     (3, 76, 100, 64),      # ragged tiles both ways (19 x 25 outputs)

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--act", default="silu")
     ap.add_argument("--algo", default="direct", choices=["direct", "wino", "wino43", "s2poly"], help="wino: si_hip_conv2d_wino23_f32 on eligible shapes only")
     ap.add_argument("--shape", action="append", default=[], help="n,h,w,ci,co,k,s,p[,groups] (repeatable): custom shapes instead of a model")
+    ap.add_argument("--graph", type=int, default=0, help="(--f16) time a replayed hipGraph of this many launches instead of host-issued launches")
     ap.add_argument("--f16", action="store_true", help="the fp16 storage path (si_hip_conv2d_f16; SI_CONV_F16_VARIANT picks the tile); stems are skipped")
     args = ap.parse_args()
     H = _native.hip()
@@ -87,24 +88,48 @@ def main():
             db = hipops.DeviceBuffer.from_numpy(rng.random(co, dtype=np.float32))
             dy = hipops.DeviceBuffer(n * oh * ow * co * 2)
 
-            def fn16():
-                return H.si_hip_conv2d_f16(C.byref(d), dx.ptr, dw.ptr, db.ptr, None, dy.ptr, 0, None)
+            def fn16(stream=None):
+                return H.si_hip_conv2d_f16(C.byref(d), dx.ptr, dw.ptr, db.ptr, None, dy.ptr, 0, stream)
             for _ in range(2):
                 assert fn16() == 0
             H.si_hip_device_sync()
             reps = args.reps
             ms = C.c_float()
-            while True:
-                H.si_hip_event_record(ev0, None)
-                for _ in range(reps):
-                    fn16()
-                H.si_hip_event_record(ev1, None)
-                H.si_hip_event_sync(ev1)
-                H.si_hip_event_elapsed_ms(ev0, ev1, C.byref(ms))
-                if ms.value >= args.min_ms:
-                    break
-                reps = int(reps * max(2.0, 1.2 * args.min_ms / max(ms.value, 1e-3)))
-            ms = ms.value / reps
+            if args.graph:
+                # a launch through ctypes costs the host 10-17 us: a kernel shorter than that is timed as a replayed hipGraph of
+                # `--graph` launches (round 5: the slab kernels' 17.0 us "back to back" was the host)
+                st, gx = C.c_void_p(), C.c_void_p()
+                assert H.si_hip_stream_create(C.byref(st)) == 0
+                assert H.si_hip_graph_begin_capture(st) == 0
+                for _ in range(args.graph):
+                    assert fn16(st) == 0
+                assert H.si_hip_graph_end_capture(st, C.byref(gx)) == 0
+                reps = 2
+                while True:
+                    H.si_hip_event_record(ev0, st)
+                    for _ in range(reps):
+                        H.si_hip_graph_launch(gx, st)
+                    H.si_hip_event_record(ev1, st)
+                    H.si_hip_event_sync(ev1)
+                    H.si_hip_event_elapsed_ms(ev0, ev1, C.byref(ms))
+                    if ms.value >= args.min_ms:
+                        break
+                    reps = int(reps * max(2.0, 1.2 * args.min_ms / max(ms.value, 1e-3)))
+                ms = ms.value / (reps * args.graph)
+                H.si_hip_graph_destroy(gx)
+                H.si_hip_stream_destroy(st)
+            else:
+                while True:
+                    H.si_hip_event_record(ev0, None)
+                    for _ in range(reps):
+                        fn16()
+                    H.si_hip_event_record(ev1, None)
+                    H.si_hip_event_sync(ev1)
+                    H.si_hip_event_elapsed_ms(ev0, ev1, C.byref(ms))
+                    if ms.value >= args.min_ms:
+                        break
+                    reps = int(reps * max(2.0, 1.2 * args.min_ms / max(ms.value, 1e-3)))
+                ms = ms.value / reps
             flops = 2.0 * n * oh * ow * co * k[0] * k[1] * (ci // g)
             byts = 2.0 * (n * ih * iw * ci + n * oh * ow * co + co * (ci // g) * k[0] * k[1])   # (wn counts both packed weight images)
             rows.append((key, count, "f16 v%s" % os.environ.get("SI_CONV_F16_VARIANT", "policy"), ms, flops / ms / 1e9, byts / ms / 1e6, flops))
