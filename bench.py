@@ -344,8 +344,15 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
             dt = ws[len(ws) // 2] / steps
             rec = {"value": round(batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "windows": len(ws),
                    "workload": "%s %dx%d %s batch %d" % (model, shape[1], shape[2], "fp16" if fp16 else "fp32", batch)}
+            # every entry carries its dominant kernel the way the headline does: template, largest instantiation with
+            # the roofline IT sits under, PMC traffic when a table was recorded for this workload; a Winograd kernel is credited with
+            # direct-conv FLOPs, so wherever such a figure appears its executed-work twin stands beside it
+            layers = e.profile()
+            roof, _ = roofline_from_profile([layers], fp16=bool(fp16), workload=rec["workload"])
+            convs = [L for L in layers if L["kernel"].startswith("conv_") and L["flops"] > 0]
+            executed = sum(L["flops"] / WINOGRAD_MULT_REDUCTION.get(_template_of(L["kernel"]), 1.0) for L in convs)
+            credited = sum(L["flops"] for L in convs)
             if fp16:
-                layers = e.profile()
                 cbytes = sum(L["bytes"] for L in layers if L["kernel"].startswith("conv_"))
                 cms = sum(L["ms"] for L in layers if L["kernel"].startswith("conv_"))
                 rec.update({"bound": "hbm", "frac": round(cbytes / (cms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if cms > 0 else None,
@@ -353,8 +360,24 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
                             "frac_of_f16_mfma_ceiling": round(batch / dt / (PEAK_F16_MFMA_TFLOPS * 1e12 / (flops / batch)), 4),
                             "kernels": sorted({L["kernel"].split("<")[0] for L in layers})})
             else:
-                rec.update({"bound": "mfma", "frac": round(batch / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12 / (flops / batch)), 4),
-                            "frac_is": "images/s / (157.3 TF/s / direct-conv FLOPs per image)"})
+                frac = batch / dt / (PEAK_FP32_MFMA_TFLOPS * 1e12 / (flops / batch))
+                rec.update({"bound": "mfma", "frac": round(frac, 4),
+                            "frac_is": "images/s / (157.3 TF/s / direct-conv FLOPs per image): DIRECT-CONV CREDIT -- Winograd layers execute "
+                                       "2.25x fewer multiplies than they are credited with, so this can exceed 1",
+                            "frac_executed_mfma": round(frac * executed / credited, 4) if credited > 0 else None,
+                            "frac_executed_mfma_is": "the same with every Winograd F(2,3) layer counted at the multiplies it executes (direct / 2.25): "
+                                                     "the matrix pipe's real share"})
+            if roof:
+                dom = {"kernel": roof["kernel"], "launches_per_step": roof["launches_per_step"], "avg_launch_ms": roof["avg_launch_ms"],
+                       "bound": roof["bound"], "frac": roof["frac"], "frac_bound_aware": roof["frac_bound_aware"],
+                       "largest_instantiation": roof["largest_instantiation"], "traffic": roof["traffic"],
+                       "algorithmic_bytes": roof["algorithmic_bytes"], "traffic_source": roof["traffic_source"]}
+                if roof.get("traffic"):
+                    dom["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes"], 3)
+                if "frac_executed_mfma" in roof:
+                    dom["frac_is"] = "direct-conv credit"
+                    dom["frac_executed_mfma"] = roof["frac_executed_mfma"]
+                rec["dominant_kernel"] = dom
             out[key] = rec
             e.release()
             dx.free()

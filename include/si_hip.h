@@ -163,19 +163,6 @@ const char* si_hip_conv2d_kernel_name_form(const SiConv2dDesc* d, const float* i
  * element as one fma chain in the same k order.  Returns the previous setting. */
 int si_hip_conv2d_set_tile_variant(int variant);
 
-/* ---- 3x3 stride-2 (pad 1) convolutions by polyphase minimal filtering (round 4, csrc/hip/conv_s2poly.hip) -----------------
- * One fused kernel for the reference's stride-2 "downsample" convs (Conv2d::ForwardIm2Col, src/layer/conv_2d.cpp:207-283): the
- * odd input phase of each dimension meets a 2-tap filter, F(2,2) computes its two outputs with 3 products instead of 4, so a
- * 2x2 output tile costs 25 multiplies per (ic, oc) instead of 36; transforms with coefficients 0 / +-1 in registers and LDS, 25
- * plane GEMMs on v_mfma_f32_16x16x4_f32, nothing transformed in HBM.  Eligibility (shape only): 3x3, stride 2, pad 1, dilation 1,
- * groups 1, ic % 16 == 0, oc % 16 == 0.  The filter is transformed once (U = G g G^t, 25 * ic * oc floats in the kernel's MFMA
- * lane order).  Same descriptor / epilogue convention as si_hip_conv2d_f32 (bias, act1, residual, act2). */
-int si_hip_conv2d_s2poly_eligible(const SiConv2dDesc* d);
-size_t si_hip_conv2d_s2poly_weight_elems(const SiConv2dDesc* d);
-int si_hip_conv2d_s2poly_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, float* u);
-int si_hip_conv2d_s2poly_f32(const SiConv2dDesc* d, const float* in, const float* u, const float* bias, const float* residual,
-                             float* out, si_stream_t stream);
-
 /* ---- Winograd F(2x2,3x3) for 3x3 stride-1 convolutions --------------------------------------------------------
  * One fused kernel replacing the reference's four-pass Conv2d::ForwardWinograd23 (src/layer/conv_2d.cpp:382-487):
  * Conv3x3s1Winograd23TransformInput (src/layer/simd/winograd_helper.cpp:413-580), the 16 GemmPack4F32 calls

@@ -105,10 +105,6 @@ def hip():
         "si_hip_conv2d_wino23_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino23_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_wino23_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
-        "si_hip_conv2d_s2poly_eligible": (i, [C.POINTER(SiConv2dDesc)]),
-        "si_hip_conv2d_s2poly_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
-        "si_hip_conv2d_s2poly_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
-        "si_hip_conv2d_s2poly_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_wino43_eligible": (i, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino43_preferred": (i, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino43_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),

@@ -239,37 +239,6 @@ def conv2d_winograd(x, w_oihw, bias=None, padding=(1, 1), act1="none", residual=
     return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
 
 
-def conv2d_s2poly(x, w_oihw, bias=None, act1="none", residual=None, act2="none", in_ld=None, out_ld=None, out_c_off=0):
-    """si_hip_conv2d_s2poly_f32: 3x3 stride-2 pad-1 conv by polyphase minimal filtering (25 instead of 36 multiplies per 2x2
-    output tile); raises HipError for ineligible shapes."""
-    H = _native.hip()
-    x, w_oihw = _f32(x), _f32(w_oihw)
-    n, ih, iw, ic = x.shape
-    oc = w_oihw.shape[0]
-    oh, ow = (ih + 2 - 3) // 2 + 1, (iw + 2 - 3) // 2 + 1
-    in_ld = in_ld or ic
-    out_ld = out_ld or oc
-    d = SiConv2dDesc(n, ih, iw, ic, in_ld, oh, ow, oc, out_ld, 3, 3, 2, 2, 1, 1, 1, 1, 1,
-                     1 if bias is not None else 0, ACT[act1], 1 if residual is not None else 0, oc, ACT[act2], 0.0)
-    if not H.si_hip_conv2d_s2poly_eligible(C.byref(d)):
-        raise HipError("shape not eligible for the polyphase stride-2 kernel")
-    u = np.zeros(H.si_hip_conv2d_s2poly_weight_elems(C.byref(d)), np.float32)
-    _chk(H.si_hip_conv2d_s2poly_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p)), "s2poly pack")
-    if in_ld != ic:
-        xw = np.zeros((n, ih, iw, in_ld), np.float32)
-        xw[..., :ic] = x
-        x = xw
-    dx, du = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(u)
-    db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
-    dr = DeviceBuffer.from_numpy(_f32(residual)) if residual is not None else None
-    dy = DeviceBuffer(n * oh * ow * out_ld * 4)
-    dy.fill(0)
-    _chk(H.si_hip_conv2d_s2poly_f32(C.byref(d), dx.ptr, du.ptr, db.ptr if db else None, dr.ptr if dr else None, dy.ptr + 4 * out_c_off, None),
-         "si_hip_conv2d_s2poly_f32")
-    y = dy.to_numpy((n, oh, ow, out_ld))
-    return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
-
-
 def conv2d_split(x, w_a, b_a, w_b, b_b, act1="none", out2_ld=None, out2_c_off=0):
     """si_hip_conv2d_split_f32: two 1x1 convs on the same input in one launch; returns (y_a, y_b)."""
     H = _native.hip()

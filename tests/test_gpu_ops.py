@@ -680,38 +680,3 @@ def test_conv_general_groups(hops, orc, n, hw, ic, oc, k, s, p, g):
     assert_parity(hops.conv2d(x, w, b, (s, s), (p, p), (1, 1), g), orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, path="auto"), what="vs the reference path")
     name = hops.conv2d_kernel_name(x.shape, w.shape, (s, s), (p, p), g)
     assert ("fast" in name) == (g != 6), name
-
-
-# ---- 3x3 stride-2 convolution by polyphase minimal filtering (round 4, csrc/hip/conv_s2poly.hip) ----
-@pytest.mark.parametrize("n,ih,iw,ic,oc,act,res", [
-    (2, 16, 16, 16, 64, "none", False),
-    (3, 21, 19, 32, 48, "silu", False),      # odd sizes (clipped tiles, padding on all four sides), oc not a multiple of 64
-    (1, 40, 40, 64, 128, "silu", True),      # several channel blocks, two output blocks, fused residual
-    (5, 9, 33, 48, 16, "relu", False),       # tiles spanning images, a single 16-channel output group
-    (2, 80, 80, 128, 64, "silu", False),     # a YOLOv5s layer shape (narrower)
-])
-def test_conv_s2poly_vs_oracle(hops, orc, n, ih, iw, ic, oc, act, res):
-    """si_hip_conv2d_s2poly_f32 against the reference's arithmetic restated (Conv2d::ForwardIm2Col, src/layer/conv_2d.cpp:207-283,
-    oracle path "auto") within the parity bar, against the fp64 convolution at the bar the Winograd tests use, and bit for bit
-    batch-invariant (an image alone == the image in the batch)."""
-    x = rng_uniform(ih * 3 + ic, (n, ih, iw, ic), -1, 1)
-    w = rng_uniform(ih * 3 + ic + 1, (oc, ic, 3, 3), -0.3, 0.3)
-    b = rng_uniform(ih * 3 + ic + 2, (oc,), -0.5, 0.5)
-    oh, ow = (ih - 1) // 2 + 1, (iw - 1) // 2 + 1
-    r = rng_uniform(ih * 3 + ic + 3, (n, oh, ow, oc), -1, 1) if res else None
-    ref = orc.conv2d(x, w, b, (2, 2), (1, 1))
-    if act != "none":
-        ref = orc.activation(act, ref)
-    if res:
-        ref = ref + r
-    got = hops.conv2d_s2poly(x, w, b, act1=act, residual=r)
-    assert got.shape == ref.shape
-    assert_parity(got, ref, what="polyphase stride-2 conv")
-    ref64 = orc.conv2d(x, w, b, (2, 2), (1, 1), path="naive")   # (fp64 accumulation)
-    plain = hops.conv2d_s2poly(x, w, b)
-    assert np.abs(plain - ref64).max() <= 2e-5 * np.abs(ref64).max()
-    one = hops.conv2d_s2poly(x[n - 1:n], w, b, act1=act, residual=None if r is None else r[n - 1:n])
-    assert_exact(one[0], got[n - 1], "an image's result does not depend on the batch")
-    # strided output (a concat slice) and input
-    sl = hops.conv2d_s2poly(x, w, b, act1=act, in_ld=ic + 8, out_ld=oc + 32, out_c_off=16)
-    assert_exact(sl, hops.conv2d_s2poly(x, w, b, act1=act), "strided tensors")

@@ -128,6 +128,27 @@ def test_bench_self_launches_two_ranks_sharing_the_device(gpu):
     assert r["cpu_baseline"] is None      # rank 0 at N = 1 only
 
 
+def test_bench_two_ranks_strong_scaling_with_both_transports_in_one_run(gpu):
+    """the code path the driver's scaling run takes first -- `bench.py --gpus 2 --global-batch 32 --gather both`
+    (strong scaling of the headline batch, the direct fan-out and RCCL's all-gather timed in ONE run) -- end to end on the shared
+    device.  Both `gather_ab` entries must be there (RCCL refuses two ranks on one device: its entry is then the structured error,
+    on two real devices a timing), `step_bound` says where a step's time went, and the run only returns 0 if every rank's gathered
+    buffer held every rank's slab after the warm-up and after each timed region (slab_checksums raises otherwise)."""
+    p, r = _bench("--gpus", 2, "--steps", 3, "--warmup", 1, "--size", 160, "--global-batch", 32, "--min-time", 0.3, "--gather", "both",
+                  env_extra={"SI_BENCH_SHARE_DEVICE": "1"}, timeout=900)
+    assert p.returncode == 0 and r is not None, p.stderr[-3000:]
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["per_gpu_batch"] == 16 and r["config"]["global_batch"] == 32
+    ab = r["gather_ab"]
+    assert set(ab) == {"p2p", "rccl"}
+    assert ab["p2p"]["value"] > 0 and ab["p2p"]["ms_per_step"] > 0 and ab["p2p"]["gather"]["transport"] == "direct"
+    assert abs(ab["p2p"]["value"] - r["value"]) / r["value"] < 1e-6          # `value` is the direct transport's
+    for k in ("gather_wait_ms", "gather_wait_copies_ms", "gather_wait_barrier_ms", "peer_copy_ms", "gather_gbps_per_peer"):
+        assert k in ab["p2p"]["gather"], k
+    assert ("value" in ab["rccl"] and ab["rccl"]["value"] > 0 and ab["rccl"]["gather"]["transport"] == "rccl") or "error" in ab["rccl"]
+    assert r["step_bound"] in ("compute", "gather (waiting for the peer copies)", "slowest rank (waiting in the node barrier)")
+    assert r["gather"] is not None and r["config"]["gather"] in ("both", "p2p")
+
+
 def test_bench_needs_as_many_devices_as_ranks(gpu):
     from simpleinfer_amd import device_count
     if device_count() >= 2:

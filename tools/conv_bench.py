@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--model", default="yolov5s")
     ap.add_argument("--only", default="")
     ap.add_argument("--act", default="silu")
-    ap.add_argument("--algo", default="direct", choices=["direct", "wino", "wino43", "s2poly"], help="wino: si_hip_conv2d_wino23_f32 on eligible shapes only")
+    ap.add_argument("--algo", default="direct", choices=["direct", "wino", "wino43"], help="wino: si_hip_conv2d_wino23_f32 on eligible shapes only")
     ap.add_argument("--shape", action="append", default=[], help="n,h,w,ci,co,k,s,p[,groups] (repeatable): custom shapes instead of a model")
     ap.add_argument("--graph", type=int, default=0, help="(--f16) time a replayed hipGraph of this many launches instead of host-issued launches")
     ap.add_argument("--f16", action="store_true", help="the fp16 storage path (si_hip_conv2d_f16; SI_CONV_F16_VARIANT picks the tile); stems are skipped")
@@ -137,7 +137,7 @@ def main():
                 buf.free()
             continue
         wino = args.algo != "direct"
-        fam = {"wino": "wino23", "wino43": "wino43", "s2poly": "s2poly"}.get(args.algo, "")
+        fam = {"wino": "wino23", "wino43": "wino43"}.get(args.algo, "")
         if wino and not getattr(H, "si_hip_conv2d_%s_eligible" % fam)(C.byref(d)):
             continue
         wn = getattr(H, "si_hip_conv2d_%s_weight_elems" % fam)(C.byref(d)) if wino else H.si_hip_conv2d_weight_elems(C.byref(d))
