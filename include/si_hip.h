@@ -403,6 +403,14 @@ int si_hip_conv2d_f16_set_s2c32(int on);
  * runs the whole K loop from LDS with the weights streamed from L2 in lane order); same bits as the generic tiles.  0 restores the
  * generic tiles (SI_CONV_F16_SLAB=0 at start-up). */
 int si_hip_conv2d_f16_set_slab(int on);
+/* Round 5: the C3 bottleneck's two convs in ONE launch with fp16 storage -- `pw`: 1x1, stride 1, c -> c (c = 128 / 256), bias, SiLU;
+ * `conv`: the 3x3 stride-1 pad-1 conv over its output that si_hip_conv2d_f16 runs as row slabs, SiLU, optional shortcut.  The slab kernel
+ * computes the 1x1 conv for the pixels of its input patch straight into LDS (conv_slab_f16.hip): the intermediate tensor is never
+ * written, one launch less.  Weights: si_hip_conv2d_f16_pack_weight_host of each conv.  Same bits as the two launches.
+ * _supported: 0 no, 1 the pair can run fused, 2 ... and under the plan the 3x3 conv would take alone, on a grid covering the chip. */
+int si_hip_conv2d_pw_slab_f16_supported(const SiConv2dDesc* pw, const SiConv2dDesc* conv);
+int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const void* in, const void* pw_w_packed, const float* pw_bias,
+                              const void* w_packed, const float* bias, const void* residual, void* out, si_stream_t stream);
 /* Round 4: YOLOv5's first two convs in one persistent kernel (conv_stem_s2c32_f16.hip): `stem` = 6x6 s2 p2, 3 -> 32, SiLU on the
  * dense fp32 image (src/layer/conv_2d.cpp:207-283), `conv` = 3x3 s2 p1, 32 -> 32 / 64, SiLU; the 32-channel intermediate is computed
  * tile by tile into LDS and never written.  Weights: si_hip_conv2d_stem_f16_pack_weight_host(stem) and

@@ -150,6 +150,8 @@ def hip():
         "si_hip_conv2d_yolo_f16_set_tile": (i, [i]),
         "si_hip_conv2d_f16_set_s2c32": (i, [i]),
         "si_hip_conv2d_f16_set_slab": (i, [i]),
+        "si_hip_conv2d_pw_slab_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_pw_slab_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_stem_s2c32_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_stem_s2c32_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_yolo_f16_tile": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiYoloLevel)]),

@@ -55,13 +55,17 @@ struct SlabArgs {
     int oc;
     int wl_nb, wl_ks;
     int th;                     // output rows per slab
-    int slabs_per_img, n_slabs, n_ocg;
+    int slabs_per_img, n_img, n_ocg;
     int rowp, blk_bytes;        // bytes per patch row / per channel block of the patch
     int pc, n_ppix;             // patch columns (ow + 2), patch pixels (th + 2) * pc
     unsigned mg_pc, mg_ow, mg_nocg, mg_spi;   // floor(2^32 / d) of the kernel's divisions (pc, ow, n_ocg, slabs_per_img)
     int act1, act2;
     float act_param;
     unsigned in_bytes, out_bytes, res_bytes;
+    // PW (a 1x1 conv + SiLU in front, computed into the patch): its lane-order weights and bias, patch rows, x pixels / bytes per block
+    const half_t* wlA;
+    const float* biasA;
+    int wlA_nb, wlA_ks, pr, n_xpix, x_blk;
 };
 
 constexpr unsigned OOB = 0xFFFFFF00u;
@@ -94,12 +98,15 @@ SI_STAMP_ARRAY(si_diag_stamps_slab);   // diagnostic build only (si_hip_internal
 // TM: 32-pixel blocks per wave (the slab has at most 32 TM pixels); NBLK: 64-channel blocks (input channels / 64); N_IT: staging
 // requests per thread and channel block (the patch's 16-byte chunks / 256, rounded up: exact for the two YOLOv5s forms, an upper
 // bound the host checks for the others)
-template <int TM, int NBLK, int N_IT, int ACT1, bool HAS_RES>
+// PW: the layer's input is itself the output of a 1x1 conv + SiLU over the same channel count (the C3 bottleneck's first conv): that conv
+// is computed HERE, for the slab's patch pixels, straight into the patch (below) -- one launch and one tensor round trip less
+template <int TM, int NBLK, int N_IT, int ACT1, bool HAS_RES, bool PW = false>
 __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabArgs a) {
     constexpr int NB = SI_SLAB_NB;             // weight fragments in flight per wave, in k-steps
     constexpr int KS_TOT = NBLK * 36;
     static_assert(36 % NB == 0, "ring depth must divide the k-steps of a channel block");
     static_assert(2 * N_IT + 1 <= 26, "the next block's requests are issued at the odd steps in front of its commit");
+    static_assert(!PW || ACT1 == SI_ACT_SILU, "the fused 1x1 form is the YOLOv5 bottleneck");
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_smem[];
 
     SI_STAMP_DECL;
@@ -112,13 +119,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
     // dependent rounds, a scalar-cache round trip each, in front of the first request; and the block's coordinates come from
     // reciprocal multiplies, not from two 30-instruction integer divisions)
     asm volatile("" ::"s"(a.in), "s"(a.wl), "s"(a.ih), "s"(a.iw), "s"(a.in_ld), "s"(a.oh), "s"(a.ow), "s"(a.wl_nb), "s"(a.wl_ks), "s"(a.th),
-                 "s"(a.slabs_per_img), "s"(a.n_slabs), "s"(a.n_ocg), "s"(a.rowp), "s"(a.blk_bytes), "s"(a.pc), "s"(a.n_ppix), "s"(a.mg_pc),
+                 "s"(a.slabs_per_img), "s"(a.n_img), "s"(a.n_ocg), "s"(a.rowp), "s"(a.blk_bytes), "s"(a.pc), "s"(a.n_ppix), "s"(a.mg_pc),
                  "s"(a.mg_ow), "s"(a.mg_nocg), "s"(a.mg_spi), "s"(a.in_bytes));
+    // block -> (image, slab of the image, output-channel group).  Blocks b and b + 8 share an XCD under round-robin placement (speed
+    // only): an XCD takes WHOLE images -- image 8 k + (b & 7) -- so that the halo rows two neighbouring slabs both fetch, and the patch
+    // the output-channel groups of a slab share, meet in one L2
     const int b8 = blockIdx.x & 7, bq = blockIdx.x >> 3;
     const int bqq = fdiv(bq, a.n_ocg, a.mg_nocg);
-    const int ocg = bq - bqq * a.n_ocg, slab = bqq * 8 + b8;
-    if (slab >= a.n_slabs) return;
-    const int img = fdiv(slab, a.slabs_per_img, a.mg_spi), y0 = (slab - img * a.slabs_per_img) * a.th;
+    const int ocg = bq - bqq * a.n_ocg;
+    const int imgq = fdiv(bqq, a.slabs_per_img, a.mg_spi);
+    const int img = imgq * 8 + b8, y0 = (bqq - imgq * a.slabs_per_img) * a.th;
+    if (img >= a.n_img) return;
     const int rows_here = min(a.th, a.oh - y0);
     const int npix = rows_here * a.ow;
 
@@ -128,15 +139,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
     const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.bias ? a.bias : reinterpret_cast<const float*>(a.in)), 0, a.bias ? (unsigned)a.oc * 4u : 0u, 0x00020000);
 
-    // ---- the patch of channel block 0.  A wave-level 16-byte load costs the CU's address path 16 cycles whatever its lanes fetch, and
-    // four waves issue them: a first version that requested every channel block, a 12-deep weight ring and the bias up front spent
-    // 4 000-6 500 cycles ISSUING (profiles/r05_slab_diag.txt) while the bytes of block 0 had long landed.  So only what the first MFMA
-    // needs is requested here -- block 0 and a short weight ring; the other blocks, the bias and the shortcut are requested under the
-    // MFMAs of the K loop.  Chunk c = tid + 256 i of the patch: patch pixel c >> 3 (row-major over (th + 2) x (ow + 2)), piece c & 7.
+    // this wave's 32 output channels: the weight ring
+    const int nb = ocg * 4 + wave;
+    const unsigned w_voff = nb < a.wl_nb ? (unsigned)nb * (unsigned)a.wl_ks * 1024u + (unsigned)lane * 16u : OOB_W;
+    f16x8 rb[NB];
     u32x4 rp[N_IT];
     int l_off[N_IT];
     unsigned g_off[N_IT];
-    {
+    // block 0 goes to LDS as soon as it has landed; block b + 1 is requested and committed under the MFMAs of block b (below)
+    auto commit = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < N_IT; ++i) *reinterpret_cast<u32x4*>(slab_smem + b * a.blk_bytes + l_off[i]) = rp[i];
+    };
+
+    if constexpr (!PW) {
+        // ---- the patch of channel block 0.  A wave-level 16-byte load costs the CU's address path 16 cycles whatever its lanes fetch, and
+        // four waves issue them: a first version that requested every channel block, a 12-deep weight ring and the bias up front spent
+        // 4 000-6 500 cycles ISSUING (profiles/r05_slab_diag.txt) while the bytes of block 0 had long landed.  So only what the first MFMA
+        // needs is requested here -- block 0 and a short weight ring; the other blocks, the bias and the shortcut are requested under the
+        // MFMAs of the K loop.  Chunk c = tid + 256 i of the patch: patch pixel c >> 3 (row-major over (th + 2) x (ow + 2)), piece c & 7.
         const int ch = tid & 7;
         const int gbase = (img * a.ih + y0 - 1) * a.iw - 1;
         const unsigned pitch = (unsigned)(a.in_ld * 2);
@@ -154,16 +175,147 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
             l_off[i] = live ? lo : a.rowp - 16;   // (a dead chunk lands in the unused tail of patch row 0)
             rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, g_off[i], 0, 0);
         }
-    }
 #ifdef SI_SLAB_STAMP_PRO
-    SI_STAMP(2);
+        SI_STAMP(2);
 #endif
-    // ---- this wave's 32 output channels: the weight ring
-    const int nb = ocg * 4 + wave;
-    const unsigned w_voff = nb < a.wl_nb ? (unsigned)nb * (unsigned)a.wl_ks * 1024u + (unsigned)lane * 16u : OOB_W;
-    f16x8 rb[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) rb[j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wl, w_voff, (unsigned)(j * 1024), 0));
+        for (int j = 0; j < NB; ++j) rb[j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wl, w_voff, (unsigned)(j * 1024), 0));
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef SI_SLAB_STAMP_PRO
+        SI_STAMP(3);
+#endif
+        commit(0);
+#ifdef SI_SLAB_STAMP_PRO
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        SI_STAMP(4);
+        __syncthreads();
+        SI_STAMP(5);
+#else
+        __syncthreads();
+#endif
+    } else {
+        // ---- PW: y = SiLU(W_A x + b_A) for the (th + 2) x ow pixels of the patch that lie in the image, written into the patch as the
+        // 3x3 conv's input; rows outside the image and the two pad columns are zeros (the 3x3 conv pads ITS input).  x: full-width
+        // rows are contiguous pixels, so chunk c = tid + 256 i is x pixel c / (C / 8), piece c % (C / 8), no division; LDS image per
+        // 64-channel block [pixel][144 B] (inside the patch region, which it does not outlive).  The same MFMA form as below: the
+        // weights as the A operand, 16-deep steps in ascending k -- the same bits as the 1x1 conv's own launch.
+        constexpr int C8 = NBLK * 8, LOG_C8 = NBLK == 2 ? 4 : 5;   // 16-byte pieces per pixel
+        constexpr int N_ITX = 18;                                  // x requests per thread (the host checks the x pixels fit)
+        constexpr int TMX = TM == 7 ? 9 : 5;                       // 32-pixel blocks of x per wave
+        constexpr int TNA = NBLK / 2;                              // 32-channel column blocks of y per wave
+        constexpr int KSA = NBLK * 4, NBA = 8;                     // k-steps of the 1x1, weight fragments in flight
+        static_assert(NBLK == 2 || NBLK == 4, "128 or 256 channels");
+        const int rlo = max(0, 1 - y0), rhi = min(a.pr, a.ih - y0 + 1);   // patch rows inside the image
+        const int qlo = rlo * a.ow, qhi = min(rhi * a.ow, a.n_xpix);
+        const int gpix0 = (img * a.ih + y0 - 1) * a.iw;
+        const unsigned pitch = (unsigned)(a.in_ld * 2);
+        u32x4 rx[N_ITX];
+#pragma unroll
+        for (int i = 0; i < N_ITX; ++i) {
+            const int c = tid + 256 * i;
+            const int q = c >> LOG_C8, ch = c & (C8 - 1);
+            const bool ok = q >= qlo && q < qhi && !(SI_SLAB_ABL & 1);
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? (unsigned)(gpix0 + q) * pitch + (unsigned)(ch * 16) : OOB, 0, 0);
+        }
+        const __amdgpu_buffer_rsrc_t rs_wlA = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<half_t*>(a.wlA), 0, (unsigned)a.wlA_nb * (unsigned)a.wlA_ks * 1024u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_biasA = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.biasA ? a.biasA : reinterpret_cast<const float*>(a.in)), 0, a.biasA ? (unsigned)(NBLK * 64) * 4u : 0u, 0x00020000);
+        unsigned wA_voff[TNA];
+        f16x8 rbA[NBA][TNA];
+#pragma unroll
+        for (int u = 0; u < TNA; ++u) wA_voff[u] = (unsigned)(wave * TNA + u) * (unsigned)a.wlA_ks * 1024u + (unsigned)lane * 16u;
+#pragma unroll
+        for (int j = 0; j < NBA; ++j)
+#pragma unroll
+            for (int u = 0; u < TNA; ++u)
+                rbA[j][u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wlA, wA_voff[u], (unsigned)(j * 1024), 0));
+#pragma unroll
+        for (int i = 0; i < N_ITX; ++i) {
+            const int c = tid + 256 * i;
+            const int q = c >> LOG_C8, ch = c & (C8 - 1);
+            // (a chunk behind the last x pixel lands behind the x images: the patch region is larger than they are)
+            const int lo = q < a.n_xpix ? (ch >> 3) * a.x_blk + q * 144 + (ch & 7) * 16 : NBLK * a.x_blk;
+            *reinterpret_cast<u32x4*>(slab_smem + lo) = rx[i];
+        }
+        __syncthreads();
+
+        unsigned xbase[TMX];
+#pragma unroll
+        for (int t = 0; t < TMX; ++t) {
+            const int q = t * 32 + l31;
+            xbase[t] = (unsigned)((q < a.n_xpix ? q : 0) * 144 + lh * 16);
+        }
+        f32x16 acc0[TMX][TNA];
+#pragma unroll
+        for (int t = 0; t < TMX; ++t)
+#pragma unroll
+            for (int u = 0; u < TNA; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc0[t][u][e] = 0.0f;
+        f16x8 fx[2][TMX];
+#pragma unroll
+        for (int t = 0; t < TMX; ++t) fx[0][t] = *reinterpret_cast<const f16x8*>(slab_smem + xbase[t]);
+#pragma unroll
+        for (int ks = 0; ks < KSA; ++ks) {
+            if (ks + 1 < KSA) {
+                const unsigned off = (unsigned)(((ks + 1) >> 2) * a.x_blk + ((ks + 1) & 3) * 32);
+#pragma unroll
+                for (int t = 0; t < TMX; ++t) fx[(ks + 1) & 1][t] = *reinterpret_cast<const f16x8*>(slab_smem + xbase[t] + off);
+            }
+#pragma unroll
+            for (int t = 0; t < TMX; ++t)
+#pragma unroll
+                for (int u = 0; u < TNA; ++u) acc0[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rbA[ks % NBA][u], fx[ks & 1][t], acc0[t][u], 0, 0, 0);
+            if (ks + NBA < KSA) {
+#pragma unroll
+                for (int u = 0; u < TNA; ++u)
+                    rbA[ks % NBA][u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wlA, wA_voff[u], (unsigned)((ks + NBA) * 1024), 0));
+            }
+            // (the 3x3 conv's weight ring is requested under these MFMAs)
+            if (ks < NB) rb[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wl, w_voff, (unsigned)(ks * 1024), 0));
+#pragma unroll
+            for (int t = 0; t < TMX; ++t) {
+                if (ks + 1 < KSA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TNA, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, TNA + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();   // every wave is done with x: y goes over it
+
+        // y: bias, SiLU, rounding (the 1x1 conv's own epilogue expressions), four channels of one pixel per 8-byte write at patch pixel
+        // (row, column + 1); rows outside the image are the 3x3 conv's zero padding
+#pragma unroll
+        for (int u = 0; u < TNA; ++u) {
+            const int chan0 = (wave * TNA + u) * 32 + 4 * lh;
+            f32x4 bA[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bA[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_biasA, (unsigned)((chan0 + 8 * g) * 4), 0, 0));
+#pragma unroll
+            for (int t = 0; t < TMX; ++t) {
+                const int q = t * 32 + l31;
+                const int r = fdiv(q < a.n_xpix ? q : 0, a.ow, a.mg_ow), cx = q - r * a.ow;
+                const bool row_ok = (unsigned)(y0 - 1 + r) < (unsigned)a.ih;
+                unsigned char* const yp = slab_smem + ((chan0 >> 6) * a.blk_bytes + r * a.rowp + (cx + 1) * 144 + (chan0 & 63) * 2);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hv[j] = row_ok ? si_store_cast<half_t>(act_ct<SI_ACT_SILU>(acc0[t][u][4 * g + j] + bA[g][j])) : (half_t)0.0f;
+                    if (q < a.n_xpix) *reinterpret_cast<f16x4*>(yp + g * 16) = hv;
+                }
+            }
+        }
+        // the two pad columns of every patch row and channel block
+        for (int z = tid; z < a.pr * 2 * NBLK * 8; z += 256) {
+            const int ch = z & 7, side = (z >> 3) & 1, rb2 = z >> 4;
+            const int blk = rb2 / a.pr, rr = rb2 - blk * a.pr;
+            *reinterpret_cast<u32x4*>(slab_smem + (blk * a.blk_bytes + rr * a.rowp + (side ? (a.ow + 1) * 144 : 0) + ch * 16)) = u32x4{0u, 0u, 0u, 0u};
+        }
+        __syncthreads();
+    }
 
     // A fragment bases: slab pixel p = 32 t + l31 -> (row, column) of the slab; a slot behind the last pixel re-reads pixel 0
     unsigned abase[TM];
@@ -175,23 +327,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
         abase[t] = (unsigned)(r * a.rowp + c * 144 + lh * 16);
     }
     __builtin_amdgcn_sched_barrier(0);   // (otherwise this arithmetic sinks between the first MFMAs)
-
-    // block 0 goes to LDS as soon as it has landed; block b + 1 is requested and committed under the MFMAs of block b (below)
-#ifdef SI_SLAB_STAMP_PRO
-    SI_STAMP(3);
-#endif
-    auto commit = [&](int b) {
-#pragma unroll
-        for (int i = 0; i < N_IT; ++i) *reinterpret_cast<u32x4*>(slab_smem + b * a.blk_bytes + l_off[i]) = rp[i];
-    };
-    commit(0);
-#ifdef SI_SLAB_STAMP_PRO
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-    SI_STAMP(4);
-    __syncthreads();
-    SI_STAMP(5);
-#else
-    __syncthreads();
+#ifndef SI_SLAB_STAMP_PRO
     SI_STAMP(2);
 #endif
 
@@ -263,7 +399,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
             int extra = 0;   // vector memory reads of this step besides the weight refill
-            if (MODE == 0 && b + 1 < NBLK && (s & 1) && s / 2 < N_IT) {
+            if (!PW && MODE == 0 && b + 1 < NBLK && (s & 1) && s / 2 < N_IT) {
                 // (the block's offset rides in the scalar offset: it takes no part in the range check, so a dead chunk stays dead)
                 rp[s / 2] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, g_off[s / 2], (unsigned)((b + 1) * 128), 0);
                 extra = 1;
@@ -281,8 +417,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
                     rres[t][g] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_res, p < npix ? ro + (unsigned)(g * 16) : OOB, 0, 0));
                 extra = 4;
             }
-            if (MODE == 0 && b + 1 < NBLK && s == 28) commit(b + 1);
-            if (MODE == 0 && b + 1 < NBLK && s == 34) __syncthreads();   // (the reads of step 35 reach into block b + 1)
+            if (!PW && MODE == 0 && b + 1 < NBLK && s == 28) commit(b + 1);
+            if (!PW && MODE == 0 && b + 1 < NBLK && s == 34) __syncthreads();   // (the reads of step 35 reach into block b + 1)
             const bool more = (s + 1 < 36 || !last_pass) && !(SI_SLAB_ABL & 16);
             const int r0 = s + 1 < 36 ? T0 : N0, r1 = s + 1 < 36 ? T1 : N1;
             if (more) {
@@ -413,13 +549,14 @@ constexpr int kLdsMax = 160 * 1024;
 // the slab height: over every (TM in {7, 4}, th) whose slab fits TM 32-pixel blocks, the LDS and the staging registers, the one with
 // the fewest MFMA slots on the busiest CU (rounds of the grid over the chip x TM); ties -> the larger grid; th is then evened
 // out over the slabs of an image
-bool slab_plan(const SiConv2dDesc* d, SlabPlan* out) {
+bool slab_plan(const SiConv2dDesc* d, SlabPlan* out, int only_tm = 0) {
     const int nblk = d->ic / 64;
     const int n_ocg = (d->oc + 127) / 128;
     const int rowp = d->ow * 144 + 512;
     long long best_cost = -1, best_grid = 0;
     SlabPlan best{};
     for (int tm : {7, 4}) {
+        if (only_tm && tm != only_tm) continue;
         const int n_it = tm == 7 ? 11 : 7;
         int th = tm * 32 / d->ow;
         if (th > d->oh) th = d->oh;
@@ -455,7 +592,7 @@ int launch_slab(const SlabArgs& a, const SiConv2dDesc* d, int lds, hipStream_t s
     auto go = [&](auto kern) {
         const hipError_t e = si_allow_dynamic_lds(kern, (size_t)lds);
         if (e != hipSuccess) return (int)e;
-        const int grid = (a.n_slabs + 7) / 8 * 8 * a.n_ocg;
+        const int grid = (a.n_img + 7) / 8 * 8 * a.slabs_per_img * a.n_ocg;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
         return (int)hipGetLastError();
     };
@@ -486,27 +623,52 @@ const char* si_conv_slab_f16_name(const SiConv2dDesc* d) {
     if (!slab_shape_ok(d) || !slab_plan(d, &p)) return "";
     const bool silu = d->act1 == SI_ACT_SILU && d->act2 == SI_ACT_NONE;
     static thread_local char name[64];
-    snprintf(name, sizeof(name), "conv3x3s1_slab_f16_kernel<%d, %d, %d, %d, %s>", p.tm, d->ic / 64, slab_nit(d, p), silu ? SI_ACT_SILU : SI_ACT_NONE,
+    snprintf(name, sizeof(name), "conv3x3s1_slab_f16_kernel<%d, %d, %d, %d, %s, false>", p.tm, d->ic / 64, slab_nit(d, p), silu ? SI_ACT_SILU : SI_ACT_NONE,
              d->has_residual ? "true" : "false");
     return name;
 }
 
-int si_conv_slab_f16_launch(const SiConv2dDesc* d, const void* in, const void* wl, int wl_nb, int wl_ks, const float* bias,
-                            const void* residual, void* out, hipStream_t s) {
+namespace {
+
+struct PwInfo {
+    const half_t* wlA;
+    const float* biasA;
+    int wlA_nb, wlA_ks;
+};
+
+// what the fused 1x1 form needs beyond slab_shape_ok / slab_plan of the 3x3 conv: the C3 bottleneck's first conv (1x1, stride 1, same
+// channel count, bias optional, SiLU), one of the two instantiated forms, x small enough for its staging requests and its image
+bool pw_pair_ok(const SiConv2dDesc* pw, const SiConv2dDesc* d, const SlabPlan& p) {
+    const bool pw_shape = pw->groups == 1 && pw->kh == 1 && pw->kw == 1 && pw->sh == 1 && pw->sw == 1 && pw->pt == 0 && pw->pl == 0 &&
+                          pw->dh == 1 && pw->dw == 1 && pw->ic == d->ic && pw->oc == d->ic && pw->n == d->n && pw->ih == d->ih && pw->iw == d->iw &&
+                          pw->oh == d->ih && pw->ow == d->iw && pw->act1 == SI_ACT_SILU && pw->act2 == SI_ACT_NONE && !pw->has_residual &&
+                          pw->in_ld % 8 == 0;
+    if (!pw_shape || d->act1 != SI_ACT_SILU || d->act2 != SI_ACT_NONE) return false;
+    if (!((p.tm == 7 && d->ic == 128) || (p.tm == 4 && d->ic == 256))) return false;
+    const int n_xpix = (p.th + 2) * d->ow, tmx = p.tm == 7 ? 9 : 5, nblk = d->ic / 64;
+    if (n_xpix > tmx * 32 || n_xpix * nblk * 8 > 18 * 256) return false;
+    return (long long)nblk * n_xpix * 144 + 16 <= (long long)p.lds;
+}
+
+// (the fused 1x1 form exists for 7 pixel blocks over 128 channels and 4 over 256: its plan is the best one with that block count)
+int pw_tm(const SiConv2dDesc* d) { return d->ic == 128 ? 7 : 4; }
+
+int slab_launch(const SiConv2dDesc* d, const void* in, unsigned long long in_bytes, int in_ld, const void* wl, int wl_nb, int wl_ks,
+                const float* bias, const void* residual, void* out, hipStream_t s, const PwInfo* pw) {
     SlabPlan p;
-    if (!slab_shape_ok(d) || !slab_plan(d, &p)) return SI_E_UNSUPPORTED;
+    if (!slab_shape_ok(d) || !slab_plan(d, &p, pw ? pw_tm(d) : 0)) return SI_E_UNSUPPORTED;
     SlabArgs a;
     a.in = static_cast<const half_t*>(in);
     a.wl = static_cast<const half_t*>(wl);
     a.bias = d->has_bias ? bias : nullptr;
     a.res = d->has_residual ? static_cast<const half_t*>(residual) : nullptr;
     a.out = static_cast<half_t*>(out);
-    a.ih = d->ih; a.iw = d->iw; a.in_ld = d->in_ld; a.oh = d->oh; a.ow = d->ow; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
+    a.ih = d->ih; a.iw = d->iw; a.in_ld = in_ld; a.oh = d->oh; a.ow = d->ow; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
     a.oc = d->oc;
     a.wl_nb = wl_nb; a.wl_ks = wl_ks;
     a.th = p.th;
     a.slabs_per_img = p.slabs_per_img;
-    a.n_slabs = d->n * p.slabs_per_img;
+    a.n_img = d->n;
     a.n_ocg = (d->oc + 127) / 128;
     a.rowp = p.rowp; a.blk_bytes = p.blk_bytes;
     a.pc = d->ow + 2;
@@ -518,14 +680,64 @@ int si_conv_slab_f16_launch(const SiConv2dDesc* d, const void* in, const void* w
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
     const unsigned long long out_bytes = (unsigned long long)d->n * d->oh * d->ow * d->out_ld * 2ull;
     const unsigned long long res_bytes = d->has_residual ? (unsigned long long)d->n * d->oh * d->ow * d->res_ld * 2ull : 0ull;
-    if (out_bytes >= 0xFFFFFF00ull || res_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
-    a.in_bytes = (unsigned)((unsigned long long)d->n * d->ih * d->iw * d->in_ld * 2ull);
+    if (out_bytes >= 0xFFFFFF00ull || res_bytes >= 0xFFFFFF00ull || in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+    a.in_bytes = (unsigned)in_bytes;
     a.out_bytes = (unsigned)out_bytes;
     a.res_bytes = (unsigned)res_bytes;
+    a.wlA = nullptr; a.biasA = nullptr; a.wlA_nb = a.wlA_ks = 0;
+    a.pr = p.th + 2;
+    a.n_xpix = a.pr * d->ow;
+    a.x_blk = a.n_xpix * 144;
     const int lds = p.lds + p.tm * 32 * 272;   // the patch, then the epilogue's [pixel][128 channels] image
+    if (pw) {
+        a.wlA = pw->wlA; a.biasA = pw->biasA; a.wlA_nb = pw->wlA_nb; a.wlA_ks = pw->wlA_ks;
+        auto go = [&](auto kern) {
+            const hipError_t e = si_allow_dynamic_lds(kern, (size_t)lds);
+            if (e != hipSuccess) return (int)e;
+            const int grid = (a.n_img + 7) / 8 * 8 * a.slabs_per_img * a.n_ocg;
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
+            return (int)hipGetLastError();
+        };
+        if (d->ic == 128) return d->has_residual ? go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, true, true>) : go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, false, true>);
+        return d->has_residual ? go(conv3x3s1_slab_f16_kernel<4, 4, 1, SI_ACT_SILU, true, true>) : go(conv3x3s1_slab_f16_kernel<4, 4, 1, SI_ACT_SILU, false, true>);
+    }
     const int nit = slab_nit(d, p);
     if (d->ic == 128) return p.tm == 7 ? (nit == 10 ? launch_slab<7, 2, 10>(a, d, lds, s) : launch_slab<7, 2, 11>(a, d, lds, s)) : launch_slab<4, 2, 7>(a, d, lds, s);
     return p.tm == 7 ? launch_slab<7, 4, 11>(a, d, lds, s) : (nit == 5 ? launch_slab<4, 4, 5>(a, d, lds, s) : launch_slab<4, 4, 7>(a, d, lds, s));
+}
+
+}  // namespace
+
+int si_conv_slab_f16_launch(const SiConv2dDesc* d, const void* in, const void* wl, int wl_nb, int wl_ks, const float* bias,
+                            const void* residual, void* out, hipStream_t s) {
+    return slab_launch(d, in, (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 2ull, d->in_ld, wl, wl_nb, wl_ks, bias, residual, out, s, nullptr);
+}
+
+extern "C" int si_hip_conv2d_pw_slab_f16_supported(const SiConv2dDesc* pw, const SiConv2dDesc* conv) {
+    SlabPlan p, natural;
+    if (!pw || !conv || !slab_on() || !slab_shape_ok(conv) || !slab_plan(conv, &p, pw_tm(conv)) || !pw_pair_ok(pw, conv, p)) return 0;
+    // 2: ... and it is the plan the 3x3 conv would run under by itself on a grid that covers most of the chip (what an engine fuses on)
+    const long long grid = (long long)conv->n * p.slabs_per_img * ((conv->oc + 127) / 128);
+    return (slab_plan(conv, &natural) && natural.tm == p.tm && natural.th == p.th && grid * 4 >= (long long)cu_count() * 3) ? 2 : 1;
+}
+
+extern "C" int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const void* in, const void* pw_w_packed,
+                                         const float* pw_bias, const void* w_packed, const float* bias, const void* residual, void* out,
+                                         si_stream_t stream) {
+    if (!pw || !conv || !in || !pw_w_packed || !w_packed || !out) return SI_E_BADARG;
+    if ((pw->has_bias && !pw_bias) || (conv->has_bias && !bias) || (conv->has_residual && !residual)) return SI_E_BADARG;
+    SlabPlan p;
+    if (!slab_shape_ok(conv) || !slab_plan(conv, &p, pw_tm(conv)) || !pw_pair_ok(pw, conv, p)) return SI_E_UNSUPPORTED;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (conv->has_bias ? reinterpret_cast<uintptr_t>(bias) : 0) |
+                         (pw->has_bias ? reinterpret_cast<uintptr_t>(pw_bias) : 0);
+    if ((al & 15) != 0 || (conv->has_residual && (reinterpret_cast<uintptr_t>(residual) & 7) != 0)) return SI_E_UNSUPPORTED;
+    const int c = conv->ic;
+    // (si_hip_conv2d_f16_pack_weight_host: the row-major image, then the lane-order one)
+    const half_t* const wA = static_cast<const half_t*>(pw_w_packed);
+    const half_t* const wB = static_cast<const half_t*>(w_packed);
+    PwInfo info{wA + (size_t)c * c, pw->has_bias ? pw_bias : nullptr, c / 32, c / 16};
+    return slab_launch(conv, in, (unsigned long long)pw->n * pw->ih * pw->iw * pw->in_ld * 2ull, pw->in_ld, wB + (size_t)conv->oc * 9 * c, conv->oc / 32, 9 * c / 16, bias,
+                       residual, out, static_cast<hipStream_t>(stream), &info);
 }
 
 #ifdef SI_DIAG_STAMPS

@@ -729,6 +729,41 @@ def conv_stem_s2c32_f16(x, w0, b0, w1, b1):
     return dy.to_numpy((n, oh, ow, oc), np.float16)
 
 
+def conv_pw_slab_f16(x, w0, b0, w1, b1, residual=None, out_ld=None, out_c_off=0, in_ld=None):
+    """si_hip_conv2d_pw_slab_f16: the C3 bottleneck's two convs (1x1 c -> c SiLU, 3x3 s1 p1 c -> oc SiLU, optional shortcut) in one
+    launch.  x NHWC fp16; returns NHWC fp16."""
+    H = _native.hip()
+    x, w0, w1 = _f16(x), _f32(w0), _f32(w1)
+    n, ih, iw, c = x.shape
+    oc = w1.shape[0]
+    in_ld = in_ld or c
+    out_ld = out_ld or oc
+    d0 = SiConv2dDesc(n, ih, iw, c, in_ld, ih, iw, c, c, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1 if b0 is not None else 0, ACT["silu"], 0, c, 0, 0.0)
+    d1 = SiConv2dDesc(n, ih, iw, c, c, ih, iw, oc, out_ld, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1 if b1 is not None else 0, ACT["silu"],
+                      1 if residual is not None else 0, oc, 0, 0.0)
+    if not H.si_hip_conv2d_pw_slab_f16_supported(C.byref(d0), C.byref(d1)):
+        raise HipError("si_hip_conv2d_pw_slab_f16: unsupported shape")
+    p0 = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d0)), np.float16)
+    _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d0), w0.ctypes.data_as(C.c_void_p), p0.ctypes.data_as(C.c_void_p)), "pack 1x1")
+    p1 = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d1)), np.float16)
+    _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d1), w1.ctypes.data_as(C.c_void_p), p1.ctypes.data_as(C.c_void_p)), "pack 3x3")
+    xs = x
+    if in_ld != c:
+        xs = np.zeros((n, ih, iw, in_ld), np.float16)
+        xs[..., :c] = x
+    dx, dp0, dp1 = DeviceBuffer.from_numpy(xs), DeviceBuffer.from_numpy(p0), DeviceBuffer.from_numpy(p1)
+    db0 = DeviceBuffer.from_numpy(_f32(b0)) if b0 is not None else None
+    db1 = DeviceBuffer.from_numpy(_f32(b1)) if b1 is not None else None
+    dr = DeviceBuffer.from_numpy(_f16(residual)) if residual is not None else None
+    dy = DeviceBuffer(n * ih * iw * out_ld * 2)
+    dy.fill(0)
+    _chk(H.si_hip_conv2d_pw_slab_f16(C.byref(d0), C.byref(d1), dx.ptr, dp0.ptr, db0.ptr if db0 else None, dp1.ptr, db1.ptr if db1 else None,
+                                     dr.ptr if dr else None, dy.ptr + 2 * out_c_off, None), "si_hip_conv2d_pw_slab_f16")
+    sync()
+    y = dy.to_numpy((n, ih, iw, out_ld), np.float16)
+    return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
+
+
 def yolo_detect_f16(feats, weights, biases, grids, anchor_grids, strides, na=3):
     """si_hip_conv2d_yolo_f16 per level: fp16 features, fp32 [n][rows_total][ne] detections."""
     H = _native.hip()

@@ -413,6 +413,38 @@ def test_slab_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, hh, ww, ic, o
     assert_parity(got.astype(np.float32), ref, F16_TOL, what="slab kernel")
 
 
+@pytest.mark.parametrize("n,hh,ww,c,res", [
+    (2, 40, 40, 128, True),       # YOLOv5s' 40x40 bottleneck: 5-row slabs, x = 7 x 40 pixels in nine 32-pixel blocks
+    (3, 20, 20, 256, True),       # ... 20x20: two output-channel groups per slab, each computes the whole 1x1
+    (2, 40, 40, 128, False),      # the head's bottlenecks have no shortcut
+    (2, 13, 17, 128, True),       # ragged: short last slab, image borders at every slab
+    (1, 7, 9, 256, False),        # one slab per image: both zero rows in one patch
+])
+def test_bottleneck_pair_in_one_launch_same_bits(hops, orc, gpu, n, hh, ww, c, res):
+    """Round 5: the C3 bottleneck's 1x1 conv + SiLU computed inside the slab kernel of the 3x3 conv that follows it
+    (si_hip_conv2d_pw_slab_f16; computation of src/layer/conv_2d.cpp:207-283 twice): the same MFMA steps in the same k order, the
+    same epilogue expressions, the intermediate rounded to fp16 exactly as the separate launch stores it, zero padding applied to the
+    INTERMEDIATE (not to x) -- bit-identical to the two launches, with the shortcut, into strided tensors, at any batch position."""
+    x = h(rng_uniform(910, (n, hh, ww, c), -1, 1))
+    w0 = h(rng_uniform(911, (c, c, 1, 1), -0.15, 0.15))
+    b0 = rng_uniform(912, (c,), -0.5, 0.5)
+    w1 = h(rng_uniform(913, (c, c, 3, 3), -0.1, 0.1))
+    b1 = rng_uniform(914, (c,), -0.5, 0.5)
+    r = x if res else None
+    mid = hops.conv2d_f16(x, w0, b0, (1, 1), (0, 0), act1="silu")
+    want = hops.conv2d_f16(mid, w1, b1, (1, 1), (1, 1), act1="silu", residual=r)
+    got = hops.conv_pw_slab_f16(x, w0, b0, w1, b1, residual=r)
+    assert_exact(got, want, "fused bottleneck pair vs two launches")
+    wide = hops.conv_pw_slab_f16(x, w0, b0, w1, b1, residual=r, out_ld=c + 32, out_c_off=16, in_ld=c + 8)
+    assert_exact(wide, want, "fused pair, strided tensors")
+    last = hops.conv_pw_slab_f16(x[n - 1:], w0, b0, w1, b1, residual=None if r is None else r[n - 1:])
+    assert_exact(last, got[n - 1:], "fused pair, batch position")
+    ref = orc.activation("silu", orc.conv2d(mid, w1, b1, (1, 1), (1, 1), path="naive"))
+    if res:
+        ref = ref + x.astype(np.float32)
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="fused pair (3x3 stage vs oracle on the rounded intermediate)")
+
+
 @pytest.mark.parametrize("n,ih,iw,oc", [
     (2, 128, 128, 64),     # whole tiles (32 x 32 outputs)
     (3, 76, 100, 64),      # ragged tiles both ways (19 x 25 outputs)
