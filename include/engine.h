@@ -70,6 +70,12 @@ public:
     //                          the reference does on the CPU; 0 = implicit GEMM everywhere; 2 = fused Winograd F(4,3)
     //   "fp16"            1/0  fp16 storage for internal activations and weights, fp16 MFMA with fp32 accumulation;
     //                          Input / Extract tensors stay fp32 (default 0: the reference's fp32 arithmetic)
+    //   "f32_split"       1/0  fp32 tensors everywhere, but the dense convs over multiples of 64 channels contract on the fp16 matrix
+    //                          cores: every operand as two fp16 halves (22 significant bits), three exact fp16 products per fp32
+    //                          product, fp32 accumulation (Ootomo & Yokota 2022; conv_split3.hip).  Measured closer to the float64
+    //                          convolution than the fp32 MFMA chain and 1.8-2.1x faster on the K-heavy layers; another arithmetic
+    //                          than the reference's fp32 (operands must lie in fp16's range).  Default 0 -- the headline path is
+    //                          true fp32; ignored with "fp16"
     //   "batch"           N>0  serve batch N whatever batch the .param file was traced with (default 0: as in the file)
     //   "host_slices"     G    host tensors in (Input) and out (Extract) -- the reference's calling convention: one synchronous
     //                          Forward() pipelines G batch slices over an upload, a compute and a download stream; 1 = off,

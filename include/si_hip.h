@@ -163,6 +163,17 @@ const char* si_hip_conv2d_kernel_name_form(const SiConv2dDesc* d, const float* i
  * element as one fma chain in the same k order.  Returns the previous setting. */
 int si_hip_conv2d_set_tile_variant(int variant);
 
+/* ---- fp32 convolution on the fp16 matrix cores by operand splitting (round 5, csrc/hip/conv_split3.hip; OPT-IN) -------------------
+ * Every operand as two fp16 halves, a = a_hi + 2^-11 a_lo (22 significant bits), a product from three exact fp16 MFMA products
+ * accumulated in fp32 in two accumulator sets (Ootomo & Yokota 2022).  fp32 tensors in and out; another arithmetic than the fp32
+ * kernels (not bit-compatible with them), operands must lie in fp16's range.  Dense convs with ic % 64 == 0.  The weights are split
+ * once: two lane-order fp16 images (_weight_elems counts halves).  Same descriptor / epilogue convention as si_hip_conv2d_f32. */
+int si_hip_conv2d_split3_supported(const SiConv2dDesc* d);
+size_t si_hip_conv2d_split3_weight_elems(const SiConv2dDesc* d);
+int si_hip_conv2d_split3_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
+int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const float* residual, float* out,
+                             si_stream_t stream);
+
 /* ---- Winograd F(2x2,3x3) for 3x3 stride-1 convolutions --------------------------------------------------------
  * One fused kernel replacing the reference's four-pass Conv2d::ForwardWinograd23 (src/layer/conv_2d.cpp:382-487):
  * Conv3x3s1Winograd23TransformInput (src/layer/simd/winograd_helper.cpp:413-580), the 16 GemmPack4F32 calls

@@ -99,6 +99,10 @@ def hip():
         "si_hip_conv2d_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
+        "si_hip_conv2d_split3_supported": (i, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_split3_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_split3_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
+        "si_hip_conv2d_split3_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_wino23_eligible": (i, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino23_set_form": (i, [i]),
         "si_hip_conv2d_wino23_preferred": (i, [C.POINTER(SiConv2dDesc)]),

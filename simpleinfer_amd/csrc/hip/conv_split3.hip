@@ -1,0 +1,333 @@
+// conv_split3.hip -- fp32 convolution on the fp16 matrix cores by operand splitting (round 5; opt-in, never the default path).
+//
+// The fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2) runs at 1/16 of the fp16 rate and the fp32 implicit GEMM has sat at 0.65 of it for
+// three rounds.  The published way past an fp32 matrix peak (Ootomo & Yokota 2022, "Recovering single precision accuracy from Tensor
+// Cores while surpassing the FP32 theoretical peak performance") splits every operand into two fp16 halves,
+//     a = a_hi + 2^-11 a_lo,   a_hi = fp16(a),   a_lo = fp16((a - a_hi) * 2^11)          (22 significant bits; a - a_hi is exact in fp32)
+// and forms a * b from THREE fp16 products with exact 22-bit results accumulated in fp32:
+//     a b  ~  a_hi b_hi  +  2^-11 (a_hi b_lo + a_lo b_hi)                                   (the a_lo b_lo term is 2^-22 relative: dropped)
+// The two scales get their own accumulators (the small terms do not drown in the large sum) and meet once, in the epilogue.
+// Weights are split once at load (two lane-order images, as conv_igemm_f16.hip's "bd" kernels read them: L2 -> registers, one coalesced
+// 16-byte load per lane and fragment); activations are fp32 in HBM -- the same bytes as the fp32 path -- and are split on their way into
+// LDS.  Structure: conv_igemm_f16_bd_kernel's (A through two LDS stages, one barrier per 64-channel K-tile, 1 x 4 waves of 64 x 32).
+// Not bit-compatible with the fp32 kernels (another arithmetic); error against the fp64 convolution is measured by tests / tools
+// (tools/split3_check.py).  Operands must lie in fp16's range (|x| < 65504); values below 6e-5 lose relative, not absolute, accuracy.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "si_hip.h"
+#include "si_hip_internal.h"
+
+#pragma clang fp contract(off)
+
+typedef _Float16 half_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct Split3Args {
+    const float* in;
+    const half_t* wl_hi;        // lane-order images [nb][ks][64 lanes][8]: hi halves, then lo halves (scaled by 2^11)
+    const half_t* wl_lo;
+    int wl_nb, wl_ks;
+    const float* bias;
+    const float* res;
+    float* out;
+    int ih, iw, in_ld, oh, ow, out_ld, res_ld;
+    int kh, kw, sh, sw, pt, pl;
+    int ic, oc, Kp, M, ohow;
+    unsigned mg_ohow, mg_ow;
+    int m_tiles, n_tiles;
+    int act1, act2;
+    float act_param;
+    unsigned in_bytes;
+};
+
+__device__ __forceinline__ int fdiv(int n, int d, unsigned mg) {
+    unsigned q = __umulhi((unsigned)n, mg);
+    if ((unsigned)n - q * (unsigned)d >= (unsigned)d) ++q;
+    return (int)q;
+}
+
+__device__ __forceinline__ float act_rt(int act, float v, float p) {
+    switch (act) {
+        case SI_ACT_RELU: return fmaxf(v, 0.0f);
+        case SI_ACT_SILU: return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        case SI_ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+        case SI_ACT_HARDSIGMOID: return fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_HARDSWISH: return v * fminf(fmaxf(v * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case SI_ACT_LEAKYRELU: return v > 0.0f ? v : v * p;
+        default: return v;
+    }
+}
+
+constexpr unsigned OOB_A = 0xFFFFFF00u;
+constexpr unsigned OOB_B = 0x80000000u;
+constexpr float kLoScale = 2048.0f;   // 2^11
+
+// BM x BN workgroup tile, 1 x 4 waves (every wave all BM rows x its own BN / 4 = 32 columns), 64-channel K-tiles
+template <int BM>
+__global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel(const Split3Args a) {
+    constexpr int BN = 128, BKH = 64, LDH = BKH + 8, QS = BKH / 16;
+    constexpr int TM = BM / 32;
+    constexpr int A_IT = BM * 16 / 256;   // float4 vectors per thread and K-tile (a row = 64 floats = 16 vectors)
+    // LDS: two stages x {hi, lo} x [BM][64 + 8] halves (dynamic: 72 KB for 128-row tiles)
+    extern __shared__ __attribute__((aligned(16))) unsigned char split3_smem[];
+    half_t (*lds)[2][BM * LDH] = reinterpret_cast<half_t (*)[2][BM * LDH]>(split3_smem);
+
+    const int per_chunk = 8 * a.n_tiles;
+    const int chunk = blockIdx.x / per_chunk;
+    const int r = blockIdx.x - chunk * per_chunk;
+    const int m_tile = chunk * 8 + (r & 7);
+    const int n_tile = r >> 3;
+    if (m_tile >= a.m_tiles) return;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    const int tid = threadIdx.x;
+    const int kv = tid & 15, r0 = tid >> 4;   // this thread's 4-channel vector of a row, base row (16 rows per pass)
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+    const unsigned wl_bytes = (unsigned)a.wl_nb * (unsigned)a.wl_ks * 1024u;
+    const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wl_hi), 0, wl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wl_lo), 0, wl_bytes, 0x00020000);
+
+    unsigned a_off[A_IT];
+    unsigned a_mask[A_IT];   // tap validity bits (at most 32 taps)
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int m = m0 + r0 + 16 * i;
+        a_off[i] = 0;
+        a_mask[i] = 0u;
+        if (m < a.M) {
+            const int img = fdiv(m, a.ohow, a.mg_ohow);
+            const int rem = m - img * a.ohow;
+            const int oy = fdiv(rem, a.ow, a.mg_ow);
+            const int ox = rem - oy * a.ow;
+            const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
+            a_off[i] = (unsigned)((img * a.ih + y0) * a.iw + x0) * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16);
+            unsigned mk = 0u;
+            for (int ky = 0; ky < a.kh; ++ky)
+                for (int kx = 0; kx < a.kw; ++kx) {
+                    const int y = y0 + ky, x = x0 + kx;
+                    if ((unsigned)y < (unsigned)a.ih && (unsigned)x < (unsigned)a.iw) mk |= 1u << (ky * a.kw + kx);
+                }
+            a_mask[i] = mk;
+        }
+    }
+    const int nb = (n0 >> 5) + wave;
+    const unsigned b_off = nb < a.wl_nb ? (unsigned)nb * (unsigned)a.wl_ks * 1024u + (unsigned)lane * 16u : OOB_B;
+
+    const int nk = a.Kp / BKH;
+    int cb = 0, ky = 0, kx = 0;
+    u32x4 ra[A_IT];
+    // weight fragments: a ring of NBF k-steps (hi and lo), the step NBF - 1 ahead requested while this one multiplies; a step behind the
+    // last one is an out-of-range offset
+    constexpr int NBF = 4;
+    static_assert(QS % NBF == 0 || NBF % QS == 0, "ring slots are compile-time per step of a K-tile");
+    f16x8 rbh[NBF], rbl[NBF];
+    const int ks_tot = nk * QS;
+    auto load_b = [&](int slot, int ks) {
+        const bool live = ks < ks_tot;
+        const unsigned kb = (unsigned)(live ? ks : 0) * 1024u;
+        const unsigned vo = live ? b_off : OOB_B;
+        rbh[slot] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, vo, kb, 0));
+        rbl[slot] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_lo, vo, kb, 0));
+    };
+    auto load_a = [&](int kt) {
+        const unsigned delta = (unsigned)((ky * a.iw + kx) * a.in_ld + cb * BKH) * 4u;
+        const int tapbit = ky * a.kw + kx;
+        const bool live = kt < nk;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const bool ok = ((a_mask[i] >> tapbit) & 1u) && live;
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
+        }
+        ++kx;
+        const int wx = kx == a.kw ? 1 : 0;
+        kx = wx ? 0 : kx;
+        ky += wx;
+        const int wy = ky == a.kh ? 1 : 0;
+        ky = wy ? 0 : ky;
+        cb += wy;
+    };
+    // fp32 -> (hi, lo) on the way into LDS
+    auto store_a = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const f32x4 x = __builtin_bit_cast(f32x4, ra[i]);
+            f16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = (half_t)x[j];
+                lo[j] = (half_t)((x[j] - (float)hi[j]) * kLoScale);
+            }
+            const int row = r0 + 16 * i;
+            *reinterpret_cast<f16x4*>(lds[stage][0] + row * LDH + kv * 4) = hi;
+            *reinterpret_cast<f16x4*>(lds[stage][1] + row * LDH + kv * 4) = lo;
+        }
+    };
+
+    f32x16 acc_h[TM], acc_x[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_h[t][e] = acc_x[t][e] = 0.0f;
+
+    load_a(0);
+#pragma unroll
+    for (int j = 0; j + 1 < NBF; ++j) load_b(j, j);
+    const int o = n0 + wave * 32 + l31;
+    const float bv = (a.bias && o < a.oc) ? a.bias[o] : 0.0f;
+    store_a(0);
+    load_a(1);
+    __syncthreads();
+
+    auto k_tile = [&](int kt, auto ph) {
+        constexpr int cur = decltype(ph)::value & 1;
+        store_a(cur ^ 1);           // tile kt + 1 (requested one tile ago) into the other stage
+        load_a(kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        const half_t* Ah = lds[cur][0] + l31 * LDH + lh * 8;
+        const half_t* Al = lds[cur][1] + l31 * LDH + lh * 8;
+#pragma unroll
+        for (int s = 0; s < QS; ++s) {
+            load_b((s + NBF - 1) % NBF, kt * QS + s + NBF - 1);
+            f16x8 fh[TM], fl[TM];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                fh[t] = *reinterpret_cast<const f16x8*>(Ah + t * 32 * LDH + s * 16);
+                fl[t] = *reinterpret_cast<const f16x8*>(Al + t * 32 * LDH + s * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], rbh[s % NBF], acc_h[t], 0, 0, 0);
+                acc_x[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], rbl[s % NBF], acc_x[t], 0, 0, 0);
+                acc_x[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[t], rbh[s % NBF], acc_x[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        k_tile(kt, std::integral_constant<int, 0>{});
+        k_tile(kt + 1, std::integral_constant<int, 1>{});
+    }
+    if (kt < nk) k_tile(kt, std::integral_constant<int, 0>{});
+
+    // epilogue: the two scales meet, then bias / activation / shortcut / activation (C/D map: col = lane & 31, rows (e & 3) + 8 (e >> 2) + 4 lh)
+    if (o < a.oc) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const int mb = m0 + t * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < a.M) {
+                    float v = acc_h[t][e] + acc_x[t][e] * (1.0f / kLoScale);
+                    v = act_rt(a.act1, v + bv, a.act_param);
+                    if (a.res) v += a.res[(size_t)m * a.res_ld + o];
+                    a.out[(size_t)m * a.out_ld + o] = act_rt(a.act2, v, a.act_param);
+                }
+            }
+        }
+    }
+}
+
+bool split3_ok(const SiConv2dDesc* d) {
+    return d && d->groups == 1 && d->ic > 0 && d->ic % 64 == 0 && d->oc > 0 && d->kh * d->kw <= 64 && d->dh == 1 && d->dw == 1 && d->in_ld % 4 == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int si_hip_conv2d_split3_supported(const SiConv2dDesc* d) { return split3_ok(d) ? 1 : 0; }
+
+// two lane-order fp16 images of the same weights, hi then lo (each [nb][ks][64][8] halves)
+size_t si_hip_conv2d_split3_weight_elems(const SiConv2dDesc* d) {
+    if (!split3_ok(d)) return 0;
+    return (size_t)2 * ((d->oc + 31) / 32) * (size_t)(d->kh * d->kw * d->ic / 16) * 512;
+}
+
+int si_hip_conv2d_split3_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed) {
+    if (!d || !w_oihw || !w_packed) return SI_E_BADARG;
+    if (!split3_ok(d)) return SI_E_UNSUPPORTED;
+    const int ntaps = d->kh * d->kw, nb_n = (d->oc + 31) / 32, ks_n = ntaps * d->ic / 16;
+    half_t* hi = static_cast<half_t*>(w_packed);
+    half_t* lo = hi + (size_t)nb_n * ks_n * 512;
+    for (int nb = 0; nb < nb_n; ++nb)
+        for (int ks = 0; ks < ks_n; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    // K order (c / 64, ky, kx, c % 64): k = ks * 16 + 8 (l >> 5) + j
+                    const int k = ks * 16 + 8 * (l >> 5) + j;
+                    const int blk = k / 64, cb = blk / ntaps, tap = blk - cb * ntaps, c = cb * 64 + (k % 64);
+                    const int o = nb * 32 + (l & 31);
+                    float v = 0.0f;
+                    if (o < d->oc) v = w_oihw[(((size_t)o * d->ic + c) * d->kh + tap / d->kw) * d->kw + tap % d->kw];
+                    const half_t h = (half_t)v;
+                    const size_t idx = (((size_t)nb * ks_n + ks) * 64 + l) * 8 + j;
+                    hi[idx] = h;
+                    lo[idx] = (half_t)((v - (float)h) * 2048.0f);
+                }
+    return 0;
+}
+
+int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const float* residual, float* out,
+                             si_stream_t stream) {
+    if (!d || !in || !w_packed || !out) return SI_E_BADARG;
+    if (!split3_ok(d) || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
+    if ((d->has_bias && !bias) || (d->has_residual && !residual)) return SI_E_BADARG;
+    const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 4ull;
+    if (in_bytes >= 0xFFFFFF00ull || (long long)d->n * d->oh * d->ow > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    Split3Args a;
+    a.in = in;
+    a.wl_nb = (d->oc + 31) / 32;
+    a.wl_ks = d->kh * d->kw * d->ic / 16;
+    a.wl_hi = static_cast<const half_t*>(w_packed);
+    a.wl_lo = a.wl_hi + (size_t)a.wl_nb * a.wl_ks * 512;
+    a.bias = d->has_bias ? bias : nullptr;
+    a.res = d->has_residual ? residual : nullptr;
+    a.out = out;
+    a.ih = d->ih; a.iw = d->iw; a.in_ld = d->in_ld; a.oh = d->oh; a.ow = d->ow; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
+    a.kh = d->kh; a.kw = d->kw; a.sh = d->sh; a.sw = d->sw; a.pt = d->pt; a.pl = d->pl;
+    a.ic = d->ic; a.oc = d->oc; a.Kp = d->kh * d->kw * d->ic;
+    a.M = d->n * d->oh * d->ow;
+    a.ohow = d->oh * d->ow;
+    a.mg_ohow = a.ohow > 1 ? (unsigned)(0x100000000ull / (unsigned)a.ohow) : 0xFFFFFFFFu;
+    a.mg_ow = d->ow > 1 ? (unsigned)(0x100000000ull / (unsigned)d->ow) : 0xFFFFFFFFu;
+    a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
+    a.in_bytes = (unsigned)in_bytes;
+    // 128-row tiles (a weight fragment feeds four pixel blocks: half the L2 -> L1 weight traffic per FLOP) where they still cover the chip
+    static const int forced_bm = [] { const char* e = getenv("SI_SPLIT3_BM"); return e ? atoi(e) : 0; }();
+    int cus = 256;
+    {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    }
+    const long long tiles128 = (((long long)a.M + 127) / 128) * ((d->oc + 127) / 128);
+    const int BM = forced_bm ? (forced_bm == 128 ? 128 : 64) : (tiles128 >= 2LL * cus ? 128 : 64);
+    a.m_tiles = (a.M + BM - 1) / BM;
+    a.n_tiles = (d->oc + 127) / 128;
+    const int chunks = (a.m_tiles + 7) / 8;
+    dim3 grid(chunks * 8 * a.n_tiles, 1, 1);
+    const size_t lds = (size_t)2 * 2 * BM * 72 * 2;
+    if (BM == 128) {
+        const hipError_t e = si_allow_dynamic_lds(conv_split3_f32_kernel<128>, lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(conv_split3_f32_kernel<128>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    } else {
+        hipLaunchKernelGGL(conv_split3_f32_kernel<64>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -57,6 +57,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "fuse_stem") opt_fuse_stem_ = value != 0;  // fp16: RGB stem conv + the 3x3 s2 conv behind it in one launch (default 1)
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
+    else if (key == "f32_split") opt_f32_split_ = value != 0;   // fp32 tensors, conv contraction from three fp16 MFMA products (default 0: true fp32)
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else if (key == "streams") opt_streams_ = value;  // 2: two half-batch lanes on two streams, 1 (default): one stream
     else if (key == "_fail_slicer") debug_fail_slicer_ = value != 0;  // tests: the sliced pipeline's setup fails half way
@@ -297,6 +298,7 @@ Status EngineImpl::CreateLayers() {
         if (Conv2d* cv = dynamic_cast<Conv2d*>(layer)) {
             if (!opt_winograd_) cv->algo_ = Conv2d::Algo::kImplicitGemm;
             cv->prefer_wino43_ = opt_winograd_ == 2;
+            cv->f32_split_ = opt_f32_split_ && !opt_fp16_;
         }
 
         std::vector<TensorNode*> ins, outs;
@@ -1061,6 +1063,7 @@ Status EngineImpl::LoadLanes(int lanes) {
         lane->opt_fuse_stem_ = opt_fuse_stem_;
         lane->opt_arena_ = opt_arena_;
         lane->opt_winograd_ = opt_winograd_;
+        lane->opt_f32_split_ = opt_f32_split_;
         lane->opt_detect_stream_ = opt_detect_stream_;
         lane->opt_fp16_ = opt_fp16_;
         lane->opt_graph_ = opt_graph_;        // every lane replays its OWN captured graph on its own stream; this engine only forks / joins
@@ -1195,6 +1198,7 @@ Status EngineImpl::SetupSlicer(int slices) {
     slicer_->opt_fuse_stem_ = opt_fuse_stem_;
     slicer_->opt_arena_ = opt_arena_;
     slicer_->opt_winograd_ = opt_winograd_;
+    slicer_->opt_f32_split_ = opt_f32_split_;
     slicer_->opt_detect_stream_ = opt_detect_stream_;
     slicer_->opt_fp16_ = opt_fp16_;
     slicer_->opt_graph_ = opt_graph_;          // one captured graph per slice (its I/O pointers key the cache) ...

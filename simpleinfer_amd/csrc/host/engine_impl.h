@@ -129,6 +129,7 @@ private:
     bool opt_alias_cat_ = true;
     bool opt_fuse_upsample_ = true;
     bool opt_fuse_stem_ = true;
+    bool opt_f32_split_ = false;
     bool opt_arena_ = true;      // intermediate operands share one HBM arena by lifetime (0: one allocation per operand, as the reference)
     bool opt_graph_ = false;
     bool opt_outputs_to_host_ = true;

@@ -196,6 +196,17 @@ Status Conv2d::PrepareDevice(int mode) {
         LOG(ERROR) << "Conv2d: no fp16 depthwise kernel for " << in_channels_ << " channels (needs a multiple of 8)";
         return Status::kUnsupport;
     }   // (mode 3 then packs the fp32 depthwise image below, exactly as mode 0 does)
+    if (mode == 4) {
+        wino_tile_ = 0;
+        use_winograd_ = false;
+        std::vector<uint16_t> packed(si_hip_conv2d_split3_weight_elems(&d));
+        CHECK_BOOL(!packed.empty());
+        CHECK_STATUS(CheckHip(si_hip_conv2d_split3_pack_weight_host(&d, weight_.data(), packed.data()), "split weights (hi / lo halves)"));
+        CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(uint16_t)), "upload weight"));
+        if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_.data(), bias_.size() * sizeof(float)), "upload bias"));
+        device_ready_ = true;
+        return Status::kSuccess;
+    }
     if (mode == 2) {
         wino_tile_ = 0;
         use_winograd_ = false;
@@ -270,8 +281,27 @@ Status Conv2d::PrepareDeviceHalf(const SiConv2dDesc& d) {
 
 // which kernel family serves this (input, output) storage pair; a non-stem conv fed an fp32 tensor inside an fp16 graph
 // converts its input first (in_half_)
+// (4: fp32 tensors, the contraction on the fp16 matrix cores by operand splitting -- engine option f32_split, opt-in)
+bool Conv2d::UseSplit3() const {
+    if (!f32_split_ || sibling_ || up_node_ || stem_producer_ || groups_ != 1 || dilation_h_ != 1 || dilation_w_ != 1) return false;
+    SiConv2dDesc d;
+    memset(&d, 0, sizeof(d));
+    d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
+    d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
+    d.in_ld = in_channels_;
+    if (!si_hip_conv2d_split3_supported(&d)) return false;
+    // Where it pays (YOLOv5s batch 32, per layer, profiles/r05_f32_split.txt): K >= 512 and >= 128 output channels -- the 3x3 stride-2
+    // layers (1.4-2.1x), the wide 1x1 layers (1.3-1.8x).  Thin-K layers are HBM-bound (the fp32 -> hi / lo conversion only costs), 64
+    // output channels leave half of the 64 x 128 tile's waves idle, and the 3x3 stride-1 layers below 256 channels are faster on the
+    // fused Winograd kernel (2.25x fewer multiplies).  A property of the layer, not of the batch: an image's bits do not depend on it.
+    const long long K = (long long)kernel_h_ * kernel_w_ * in_channels_;
+    if (K < 512 || out_channels_ < 128) return false;
+    const bool wino_shape = kernel_h_ == 3 && kernel_w_ == 3 && stride_h_ == 1 && stride_w_ == 1;
+    return !(wino_shape && in_channels_ < 256 && algo_ != Algo::kImplicitGemm);
+}
+
 int Conv2d::PrecisionMode(const Tensor& input, const Tensor& output) const {
-    if (!IsHalf(input) && !IsHalf(output)) return 0;
+    if (!IsHalf(input) && !IsHalf(output)) return UseSplit3() ? 4 : 0;
     if (groups_ > 1 && groups_ == in_channels_ && in_channels_ == out_channels_ && IsHalf(input) && IsHalf(output)) return 3;   // depthwise, fp16 storage
     if (!IsHalf(input)) {
         SiConv2dDesc d;
@@ -367,6 +397,15 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
     if (residual) {
         d.has_residual = 1;
         d.res_ld = residual->PixelStride();
+    }
+    if (mode == 4) {
+        const int rc = si_hip_conv2d_split3_f32(&d, input.Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream());
+        if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (fp32 by three fp16 products)");
+        // an unaligned / oversized view: the true-fp32 kernels from here on
+        f32_split_ = false;
+        device_ready_ = false;
+        return Launch(input, residual, output);
     }
     if (mode == 2)
         return CheckHip(si_hip_conv2d_stem_f16(&d, input.Data<float>(), weight_dev_.As<void>(),
@@ -515,6 +554,7 @@ const char* Conv2d::KernelName() const {
     }
     if (mode == 2) return "conv_stem_f16_kernel";
     if (mode == 3) return "conv_depthwise_f16_kernel<2>";
+    if (mode == 4) return "conv_split3_f32_kernel";
     const int tile = WinogradTile(d);
     if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
     return si_hip_conv2d_kernel_name_form(&d, in.Data<float>(), up_node_ ? 1 : 0);

@@ -105,6 +105,10 @@ public:
     // algorithm: the reference picks Winograd F(2,3) for every eligible 3x3 s1 conv (InitWinograd, conv_2d.cpp:182-205);
     // here kAuto does the same when the fused Winograd kernel supports the channel counts, else implicit GEMM
     enum class Algo { kAuto = 0, kImplicitGemm, kWinograd23, kWinograd43 } algo_ = Algo::kAuto;
+    // engine option f32_split (opt-in, round 5): fp32 tensors, the contraction on the fp16 matrix cores from three fp16 products per
+    // fp32 product (si_hip_conv2d_split3_f32) for the dense layers over multiples of 64 channels; everything else as without it
+    bool f32_split_ = false;
+    bool UseSplit3() const;
     bool prefer_wino43_ = false;  // kAuto: take F(4,3) instead of F(2,3) wherever F(2,3) would have been chosen
     bool use_winograd_ = false;  // resolved at PrepareDevice (same name as the reference's flag, conv_2d.h:60)
     int wino_tile_ = 0;          // 2 = F(2,3), 4 = F(4,3) when use_winograd_

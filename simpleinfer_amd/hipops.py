@@ -132,6 +132,27 @@ def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
     return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
 
 
+def conv2d_split3(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), act1="none", residual=None, act2="none"):
+    """si_hip_conv2d_split3_f32: fp32 conv on the fp16 matrix cores by operand splitting (three fp16 MFMAs per product, fp32 accumulate)"""
+    H = _native.hip()
+    x, w_oihw = _f32(x), _f32(w_oihw)
+    n, ih, iw, ic = x.shape
+    oc, _, kh, kw = w_oihw.shape
+    oh, ow = conv_out_hw(ih, iw, (kh, kw), stride, padding, (1, 1))
+    d = SiConv2dDesc(n, ih, iw, ic, ic, oh, ow, oc, oc, kh, kw, stride[0], stride[1], 1, 1, padding[0], padding[1], 1,
+                     1 if bias is not None else 0, ACT[act1], 1 if residual is not None else 0, oc, ACT[act2], 0.0)
+    if not H.si_hip_conv2d_split3_supported(C.byref(d)):
+        raise HipError("si_hip_conv2d_split3_f32: unsupported shape")
+    packed = np.zeros(H.si_hip_conv2d_split3_weight_elems(C.byref(d)), np.float16)
+    _chk(H.si_hip_conv2d_split3_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack split3")
+    dx, dw = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(packed)
+    db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
+    dr = DeviceBuffer.from_numpy(_f32(residual)) if residual is not None else None
+    dy = DeviceBuffer(n * oh * ow * oc * 4)
+    _chk(H.si_hip_conv2d_split3_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dr.ptr if dr else None, dy.ptr, None), "si_hip_conv2d_split3_f32")
+    return dy.to_numpy((n, oh, ow, oc))
+
+
 def conv2d_upcat(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1="none", split_oc=0):
     """si_hip_conv2d_upcat_f32: a 1x1 conv over cat([upsample(low), skip]) (or [skip, upsample(low)]) that reads `low` at the
     source pixel.  Returns y, or (y, y2) for the sibling-split form."""

@@ -74,6 +74,28 @@ def test_winograd_schedules_agree(si, orc, tmp_path):
     assert any("conv_wino43" in k for k in kernels[2])
 
 
+def test_f32_split_option_holds_the_fp32_parity_bars(si, orc, tmp_path):
+    """Engine option f32_split (round 5, opt-in): fp32 tensors, the dense convs over multiples of 64 channels contracted on the fp16
+    matrix cores from three fp16 products per fp32 product (conv_split3.hip).  Held to the UNCHANGED fp32 bars against the oracle
+    (src/layer/conv_2d.cpp:207-283: 1e-4 of the tensor's scale; Detect per column group), on YOLOv5s and ResNet18; the schedule
+    really runs the split kernel, an image's result does not depend on its batch, and the default engine does not use it."""
+    for name, mk, shape in (("ys", lambda mg: mg.build_yolov5s(2, 160), (2, 160, 160, 3)), ("rs", lambda mg: mg.build_resnet18(2, 64), (2, 64, 64, 3))):
+        pp, bp = _save(tmp_path, mk(si.modelgen), name)
+        x = si.modelgen.synth_input(shape)
+        ref = orc.run_graph(pp, bp, {"0": x})
+        e, oname, got = _run(si, pp, bp, x, f32_split=1)
+        (assert_detect_parity if name == "ys" else assert_parity)(got, ref[oname], what="f32_split " + name)
+        kernels = [L["kernel"] for L in e.profile()]
+        assert sum(k == "conv_split3_f32_kernel" for k in kernels) >= (10 if name == "ys" else 5), kernels
+        e0, _, got0 = _run(si, pp, bp, x)
+        assert not any("split3" in L["kernel"] for L in e0.profile())
+        one = si.Engine(f32_split=1, batch=1)
+        one.load_model(pp, bp)
+        one.input("0", x[1:])
+        one.forward()
+        assert_exact(one.extract(oname), got[1:], "f32_split: the second image alone vs in the batch")
+
+
 def test_yolov5s_640_batch1_parity(si, orc, tmp_path):
     """BASELINE.json configs[1]: YOLOv5s 1x3x640x640 fp32 parity vs the CPU outputs."""
     pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(1, 640), "y1")

@@ -680,3 +680,35 @@ def test_conv_general_groups(hops, orc, n, hw, ic, oc, k, s, p, g):
     assert_parity(hops.conv2d(x, w, b, (s, s), (p, p), (1, 1), g), orc.conv2d(x, w, b, (s, s), (p, p), (1, 1), g, path="auto"), what="vs the reference path")
     name = hops.conv2d_kernel_name(x.shape, w.shape, (s, s), (p, p), g)
     assert ("fast" in name) == (g != 6), name
+
+
+# ---- fp32 convolution from three fp16 MFMA products (round 5, csrc/hip/conv_split3.hip; engine option f32_split, opt-in) ----
+@pytest.mark.parametrize("n,hw,ic,oc,k,s,act,res", [
+    (2, 21, 128, 96, 3, 2, "silu", False),       # ragged M and oc, image borders
+    (1, 16, 256, 128, 3, 1, "none", True),
+    (3, 13, 64, 255, 1, 1, "relu", False),       # pointwise, ragged oc
+    (2, 10, 192, 64, 5, 1, "silu", True),        # 25 taps, three channel blocks
+])
+def test_conv_split3_vs_oracle_and_fp64(hops, orc, n, hw, ic, oc, k, s, act, res):
+    """si_hip_conv2d_split3_f32 against the reference's arithmetic restated (Conv2d::ForwardIm2Col, src/layer/conv_2d.cpp:207-283) at
+    the fp32 bars -- 1e-4 of the tensor's scale vs the oracle, 2e-5 vs the float64 convolution -- with the fused epilogue; and it is at
+    least as close to float64 as the true-fp32 kernel on the same data (exact 22-bit products, fp32 accumulation)."""
+    x = rng_uniform(800 + hw, (n, hw, hw, ic), -2, 2)
+    w = rng_uniform(801, (oc, ic, k, k), -0.2, 0.2)
+    b = rng_uniform(802, (oc,), -0.5, 0.5)
+    p = k // 2
+    oh = (hw + 2 * p - k) // s + 1
+    r = rng_uniform(803, (n, oh, oh, oc), -1, 1) if res else None
+    got = hops.conv2d_split3(x, w, b, (s, s), (p, p), act1=act, residual=r)
+    ref = orc.conv2d(x, w, b, (s, s), (p, p), path="auto")
+    ref = orc.activation(act, ref) if act != "none" else ref
+    if res:
+        ref = ref + r
+    assert_parity(got, ref, what="split3 vs the reference path")
+    plain = hops.conv2d_split3(x, w, b, (s, s), (p, p))
+    naive = orc.conv2d(x, w, b, (s, s), (p, p), path="naive")
+    e3 = np.abs(plain - naive).max() / np.abs(naive).max()
+    e32 = np.abs(hops.conv2d(x, w, b, (s, s), (p, p)) - naive).max() / np.abs(naive).max()
+    assert e3 <= 2e-5 and e3 <= 2.0 * e32 + 1e-7, (e3, e32)
+    one = hops.conv2d_split3(x[n - 1:], w, b, (s, s), (p, p), act1=act, residual=None if r is None else r[n - 1:])
+    assert_exact(one, got[n - 1:], "split3: batch position")
