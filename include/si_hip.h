@@ -418,7 +418,8 @@ int si_hip_conv2d_f16_set_slab(int on);
  * `conv`: the 3x3 stride-1 pad-1 conv over its output that si_hip_conv2d_f16 runs as row slabs, SiLU, optional shortcut.  The slab kernel
  * computes the 1x1 conv for the pixels of its input patch straight into LDS (conv_slab_f16.hip): the intermediate tensor is never
  * written, one launch less.  Weights: si_hip_conv2d_f16_pack_weight_host of each conv.  Same bits as the two launches.
- * _supported: 0 no, 1 the pair can run fused, 2 ... and under the plan the 3x3 conv would take alone, on a grid covering the chip. */
+ * _supported: 0 no, 1 the pair can run fused, 2 ... and it is the form measured FASTER than two launches (7 pixel blocks over 128
+ * channels on two waves per SIMD, on a grid covering the chip): what an engine fuses on. */
 int si_hip_conv2d_pw_slab_f16_supported(const SiConv2dDesc* pw, const SiConv2dDesc* conv);
 int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const void* in, const void* pw_w_packed, const float* pw_bias,
                               const void* w_packed, const float* bias, const void* residual, void* out, si_stream_t stream);

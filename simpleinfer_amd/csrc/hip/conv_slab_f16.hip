@@ -100,8 +100,13 @@ SI_STAMP_ARRAY(si_diag_stamps_slab);   // diagnostic build only (si_hip_internal
 // bound the host checks for the others)
 // PW: the layer's input is itself the output of a 1x1 conv + SiLU over the same channel count (the C3 bottleneck's first conv): that conv
 // is computed HERE, for the slab's patch pixels, straight into the patch (below) -- one launch and one tensor round trip less
-template <int TM, int NBLK, int N_IT, int ACT1, bool HAS_RES, bool PW = false>
-__global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabArgs a) {
+// W2: 512 threads -- TWO waves per SIMD, the slab's pixel blocks split between the wave pair of a channel block ([0, (TM + 1) / 2) and the
+// rest).  Every vector-bound phase (the prologue's index arithmetic, the 38-issue-cycle-per-element SiLU epilogues) then issues at twice
+// the rate a lone wave gets (4 cycles per instruction alone, 2 with a partner); the MFMA pipe is shared as before.
+template <int TM, int NBLK, int N_IT, int ACT1, bool HAS_RES, bool PW = false, bool W2 = false>
+__global__ __launch_bounds__(W2 ? 512 : 256, W2 ? 2 : 1) void conv3x3s1_slab_f16_kernel(const SlabArgs a) {
+    constexpr int NT = W2 ? 512 : 256;         // threads
+    static_assert(!W2 || (TM == 7 && NBLK == 2), "the 512-thread form exists (and is tested) for 7 pixel blocks over 128 channels");
     constexpr int NB = SI_SLAB_NB;             // weight fragments in flight per wave, in k-steps
     constexpr int KS_TOT = NBLK * 36;
     static_assert(36 % NB == 0, "ring depth must divide the k-steps of a channel block");
@@ -112,7 +117,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
     SI_STAMP_DECL;
     SI_STAMP_RT(0);
     SI_STAMP(1);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int wave = (tid >> 6) & 3, wm = tid >> 8;   // the wave's 32-channel block; (W2) its half of the pixel blocks
     // block -> (slab, output-channel group): the groups of one slab sit 8 blocks apart (same XCD under round-robin placement:
     // the second one finds the patch in that L2)
     // (every argument the prologue needs is pinned into scalar registers HERE: left alone hipcc fetches the argument block in four
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
         const unsigned pitch = (unsigned)(a.in_ld * 2);
 #pragma unroll
         for (int i = 0; i < N_IT; ++i) {
-            const int q = (tid >> 3) + 32 * i;
+            const int q = (tid >> 3) + (NT / 8) * i;
             const int pr = fdiv(q, a.pc, a.mg_pc), px = q - pr * a.pc;
             const int gy = y0 - 1 + pr, gx = px - 1;
             const bool live = q < a.n_ppix;
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
         // 64-channel block [pixel][144 B] (inside the patch region, which it does not outlive).  The same MFMA form as below: the
         // weights as the A operand, 16-deep steps in ascending k -- the same bits as the 1x1 conv's own launch.
         constexpr int C8 = NBLK * 8, LOG_C8 = NBLK == 2 ? 4 : 5;   // 16-byte pieces per pixel
-        constexpr int N_ITX = 18;                                  // x requests per thread (the host checks the x pixels fit)
+        constexpr int N_ITX = 18 * 256 / NT;                       // x requests per thread (the host checks the x pixels fit)
         constexpr int TMX = TM == 7 ? 9 : 5;                       // 32-pixel blocks of x per wave
         constexpr int TNA = NBLK / 2;                              // 32-channel column blocks of y per wave
         constexpr int KSA = NBLK * 4, NBA = 8;                     // k-steps of the 1x1, weight fragments in flight
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
         u32x4 rx[N_ITX];
 #pragma unroll
         for (int i = 0; i < N_ITX; ++i) {
-            const int c = tid + 256 * i;
+            const int c = tid + NT * i;
             const int q = c >> LOG_C8, ch = c & (C8 - 1);
             const bool ok = q >= qlo && q < qhi && !(SI_SLAB_ABL & 1);
             rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? (unsigned)(gpix0 + q) * pitch + (unsigned)(ch * 16) : OOB, 0, 0);
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
                 rbA[j][u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wlA, wA_voff[u], (unsigned)(j * 1024), 0));
 #pragma unroll
         for (int i = 0; i < N_ITX; ++i) {
-            const int c = tid + 256 * i;
+            const int c = tid + NT * i;
             const int q = c >> LOG_C8, ch = c & (C8 - 1);
             // (a chunk behind the last x pixel lands behind the x images: the patch region is larger than they are)
             const int lo = q < a.n_xpix ? (ch >> 3) * a.x_blk + q * 144 + (ch & 7) * 16 : NBLK * a.x_blk;
@@ -240,31 +246,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
         }
         __syncthreads();
 
+        // (W2: the x pixel blocks are split between the two waves of a channel block, as the slab's are below)
+        auto phase0 = [&](auto x0c, auto x1c) {
+        constexpr int X0 = decltype(x0c)::value, X1 = decltype(x1c)::value;
         unsigned xbase[TMX];
 #pragma unroll
-        for (int t = 0; t < TMX; ++t) {
+        for (int t = X0; t < X1; ++t) {
             const int q = t * 32 + l31;
             xbase[t] = (unsigned)((q < a.n_xpix ? q : 0) * 144 + lh * 16);
         }
         f32x16 acc0[TMX][TNA];
 #pragma unroll
-        for (int t = 0; t < TMX; ++t)
+        for (int t = X0; t < X1; ++t)
 #pragma unroll
             for (int u = 0; u < TNA; ++u)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc0[t][u][e] = 0.0f;
         f16x8 fx[2][TMX];
 #pragma unroll
-        for (int t = 0; t < TMX; ++t) fx[0][t] = *reinterpret_cast<const f16x8*>(slab_smem + xbase[t]);
+        for (int t = X0; t < X1; ++t) fx[0][t] = *reinterpret_cast<const f16x8*>(slab_smem + xbase[t]);
 #pragma unroll
         for (int ks = 0; ks < KSA; ++ks) {
             if (ks + 1 < KSA) {
                 const unsigned off = (unsigned)(((ks + 1) >> 2) * a.x_blk + ((ks + 1) & 3) * 32);
 #pragma unroll
-                for (int t = 0; t < TMX; ++t) fx[(ks + 1) & 1][t] = *reinterpret_cast<const f16x8*>(slab_smem + xbase[t] + off);
+                for (int t = X0; t < X1; ++t) fx[(ks + 1) & 1][t] = *reinterpret_cast<const f16x8*>(slab_smem + xbase[t] + off);
             }
 #pragma unroll
-            for (int t = 0; t < TMX; ++t)
+            for (int t = X0; t < X1; ++t)
 #pragma unroll
                 for (int u = 0; u < TNA; ++u) acc0[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rbA[ks % NBA][u], fx[ks & 1][t], acc0[t][u], 0, 0, 0);
             if (ks + NBA < KSA) {
@@ -275,14 +284,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
             // (the 3x3 conv's weight ring is requested under these MFMAs)
             if (ks < NB) rb[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wl, w_voff, (unsigned)(ks * 1024), 0));
 #pragma unroll
-            for (int t = 0; t < TMX; ++t) {
+            for (int t = X0; t < X1; ++t) {
                 if (ks + 1 < KSA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, TNA, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x020, TNA + 1, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();   // every wave is done with x: y goes over it
+        __syncthreads();   // every wave is done with x: y goes over it (both halves of a wave pair cross it)
 
         // y: bias, SiLU, rounding (the 1x1 conv's own epilogue expressions), four channels of one pixel per 8-byte write at patch pixel
         // (row, column + 1); rows outside the image are the 3x3 conv's zero padding
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
             for (int g = 0; g < 4; ++g)
                 bA[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_biasA, (unsigned)((chan0 + 8 * g) * 4), 0, 0));
 #pragma unroll
-            for (int t = 0; t < TMX; ++t) {
+            for (int t = X0; t < X1; ++t) {
                 const int q = t * 32 + l31;
                 const int r = fdiv(q < a.n_xpix ? q : 0, a.ow, a.mg_ow), cx = q - r * a.ow;
                 const bool row_ok = (unsigned)(y0 - 1 + r) < (unsigned)a.ih;
@@ -308,8 +317,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
                 }
             }
         }
+        };
+        {
+            using std::integral_constant;
+            constexpr int XH = W2 ? (TMX + 1) / 2 : TMX;
+            if (!W2 || wm == 0) phase0(integral_constant<int, 0>{}, integral_constant<int, XH>{});
+            else phase0(integral_constant<int, XH>{}, integral_constant<int, TMX>{});
+        }
         // the two pad columns of every patch row and channel block
-        for (int z = tid; z < a.pr * 2 * NBLK * 8; z += 256) {
+        for (int z = tid; z < a.pr * 2 * NBLK * 8; z += NT) {
             const int ch = z & 7, side = (z >> 3) & 1, rb2 = z >> 4;
             const int blk = rb2 / a.pr, rr = rb2 - blk * a.pr;
             *reinterpret_cast<u32x4*>(slab_smem + (blk * a.blk_bytes + rr * a.rowp + (side ? (a.ow + 1) * 144 : 0) + ch * 16)) = u32x4{0u, 0u, 0u, 0u};
@@ -344,13 +360,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
 #ifndef SI_SLAB_TM1
 #define SI_SLAB_TM1 3
 #endif
-    constexpr int TM1 = ACT1 == SI_ACT_SILU ? (TM == 7 ? SI_SLAB_TM1 : TM / 2) : 0;
+    constexpr int TM1 = (ACT1 == SI_ACT_SILU && !W2) ? (TM == 7 ? SI_SLAB_TM1 : TM / 2) : 0;   // (W2: one pass; the wave pair shares the epilogue)
     constexpr int STAGE_SP = 272;   // bytes per staged pixel: 128 channels + 16
     unsigned char* const stage = slab_smem + NBLK * a.blk_bytes;   // the epilogue's [pixel][128 channels] image, behind the patch
 
     f16x8 fa[2][TM];
-#pragma unroll
-    for (int t = 0; t < ((NBLK == 1 && TM1) ? TM1 : TM); ++t) fa[0][t] = *reinterpret_cast<const f16x8*>(slab_smem + abase[t]);
 
     // the shortcut's values in the accumulators' layout (four channels of one pixel = 8 bytes per register quad) and the bias (C/D map
     // with the weights as the A operand: row = (e & 3) + 8 (e >> 2) + 4 lh -> output channel nb * 32 + row, col = lane & 31 -> slab pixel
@@ -458,41 +472,53 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    if (!(SI_SLAB_ABL & 2)) {
-        typedef integral_constant<int, 0> c0;
-        typedef integral_constant<int, TM> cT;
-        typedef integral_constant<int, TM1> cT1;
-        typedef integral_constant<int, TM1 ? TM1 : TM> cF;   // the first pass over the last block covers [0, cF)
-        typedef integral_constant<int, TM1 ? 1 : 0> cM;
-        if constexpr (NBLK == 2) {
-            pass(integral_constant<int, 0>{}, c0{}, cT{}, c0{}, cF{}, c0{});
-        } else if constexpr (NBLK == 4) {
-            pass(integral_constant<int, 0>{}, c0{}, cT{}, c0{}, cT{}, c0{});
-            pass(integral_constant<int, 1>{}, c0{}, cT{}, c0{}, cT{}, c0{});
-            pass(integral_constant<int, 2>{}, c0{}, cT{}, c0{}, cF{}, c0{});
-        }
-        pass(integral_constant<int, NBLK - 1>{}, c0{}, cF{}, cT1{}, cT{}, cM{});
-        if constexpr (TM1 != 0) pass(integral_constant<int, NBLK - 1>{}, cT1{}, cT{}, c0{}, c0{}, integral_constant<int, 2>{});
-    }
-
-    // ---- what is left of the epilogue: the second group's (or every) register quad, then the slab leaves as whole channel rows
-#ifndef SI_SLAB_STAMP_PRO
-    SI_STAMP(3);
-#endif
-    auto finish = [&](auto a1c, auto a2c) {
+    // the wave's pixel blocks [LO, HI): all of them, or (W2) its half
+    auto run = [&](auto loc, auto hic) {
+        constexpr int LO = decltype(loc)::value, HI = decltype(hic)::value;
 #pragma unroll
-        for (int t = TM1; t < TM; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f16x4 hv;
-                quad_part(a1c, a2c, t, g, 0, 4, hv);
-                quad_store(hv, t, g);
+        for (int t = LO; t < HI; ++t) fa[0][t] = *reinterpret_cast<const f16x8*>(slab_smem + abase[t]);
+        if (!(SI_SLAB_ABL & 2)) {
+            typedef integral_constant<int, LO> cL;
+            typedef integral_constant<int, HI> cT;
+            typedef integral_constant<int, TM1> cT1;
+            typedef integral_constant<int, TM1 ? TM1 : HI> cF;   // the first pass over the last block covers [LO, cF)
+            typedef integral_constant<int, TM1 ? 1 : 0> cM;
+            typedef integral_constant<int, 0> m0;                // MODE 0: an ordinary block
+            if constexpr (NBLK == 2) {
+                pass(integral_constant<int, 0>{}, cL{}, cT{}, cL{}, cF{}, m0{});
+            } else if constexpr (NBLK == 4) {
+                pass(integral_constant<int, 0>{}, cL{}, cT{}, cL{}, cT{}, m0{});
+                pass(integral_constant<int, 1>{}, cL{}, cT{}, cL{}, cT{}, m0{});
+                pass(integral_constant<int, 2>{}, cL{}, cT{}, cL{}, cF{}, m0{});
             }
+            pass(integral_constant<int, NBLK - 1>{}, cL{}, cF{}, cT1{}, cT{}, cM{});
+            if constexpr (TM1 != 0) pass(integral_constant<int, NBLK - 1>{}, cT1{}, cT{}, cL{}, cL{}, integral_constant<int, 2>{});
+        }
+
+        // ---- what is left of the epilogue: the second group's (or every) register quad, then the slab leaves as whole channel rows
+#ifndef SI_SLAB_STAMP_PRO
+        SI_STAMP(3);
+#endif
+        auto finish = [&](auto a1c, auto a2c) {
+#pragma unroll
+            for (int t = (TM1 > LO ? TM1 : LO); t < HI; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 hv;
+                    quad_part(a1c, a2c, t, g, 0, 4, hv);
+                    quad_store(hv, t, g);
+                }
+        };
+        if (ACT1 == SI_ACT_SILU) finish(c_silu{}, c_none{});
+        else if (a.act1 == SI_ACT_RELU) finish(c_relu{}, c_none{});
+        else if (a.act2 == SI_ACT_RELU) finish(c_none{}, c_relu{});
+        else finish(c_none{}, c_none{});
     };
-    if (ACT1 == SI_ACT_SILU) finish(c_silu{}, c_none{});
-    else if (a.act1 == SI_ACT_RELU) finish(c_relu{}, c_none{});
-    else if (a.act2 == SI_ACT_RELU) finish(c_none{}, c_relu{});
-    else finish(c_none{}, c_none{});
+    {
+        constexpr int TH2 = W2 ? (TM + 1) / 2 : TM;
+        if (!W2 || wm == 0) run(integral_constant<int, 0>{}, integral_constant<int, TH2>{});
+        else run(integral_constant<int, TH2>{}, integral_constant<int, TM>{});
+    }
     __syncthreads();
 #ifndef SI_SLAB_STAMP_PRO
     SI_STAMP(4);
@@ -501,8 +527,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3s1_slab_f16_kernel(const SlabAr
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
         const unsigned obase = pix0 * (unsigned)(a.out_ld * 2) + (unsigned)(ocg * 256);
 #pragma unroll
-        for (int k = 0; k < 2 * TM; ++k) {
-            const int c = tid + 256 * k;
+        for (int k = 0; k < 2 * TM * 256 / NT; ++k) {
+            const int c = tid + NT * k;
             const int pixel = c >> 4, c16 = c & 15;
             const u32x4 val = *reinterpret_cast<const u32x4*>(stage + pixel * STAGE_SP + c16 * 16);
             const unsigned off = obase + (unsigned)pixel * (unsigned)(a.out_ld * 2) + (unsigned)(c16 * 16);
@@ -587,23 +613,36 @@ bool slab_shape_ok(const SiConv2dDesc* d) {
            d->out_ld % 8 == 0 && (!d->has_residual || d->res_ld % 4 == 0);
 }
 
-template <int TM, int NBLK, int N_IT>
+template <int TM, int NBLK, int N_IT, bool W2 = false>
 int launch_slab(const SlabArgs& a, const SiConv2dDesc* d, int lds, hipStream_t s) {
     auto go = [&](auto kern) {
         const hipError_t e = si_allow_dynamic_lds(kern, (size_t)lds);
         if (e != hipSuccess) return (int)e;
         const int grid = (a.n_img + 7) / 8 * 8 * a.slabs_per_img * a.n_ocg;
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(W2 ? 512 : 256), (size_t)lds, s, a);
         return (int)hipGetLastError();
     };
     const bool silu = d->act1 == SI_ACT_SILU && d->act2 == SI_ACT_NONE;
-    if (d->has_residual) return silu ? go(conv3x3s1_slab_f16_kernel<TM, NBLK, N_IT, SI_ACT_SILU, true>) : go(conv3x3s1_slab_f16_kernel<TM, NBLK, N_IT, SI_ACT_NONE, true>);
-    return silu ? go(conv3x3s1_slab_f16_kernel<TM, NBLK, N_IT, SI_ACT_SILU, false>) : go(conv3x3s1_slab_f16_kernel<TM, NBLK, N_IT, SI_ACT_NONE, false>);
+    if (d->has_residual)
+        return silu ? go(conv3x3s1_slab_f16_kernel<TM, NBLK, N_IT, SI_ACT_SILU, true, false, W2>) : go(conv3x3s1_slab_f16_kernel<TM, NBLK, N_IT, SI_ACT_NONE, true, false, W2>);
+    return silu ? go(conv3x3s1_slab_f16_kernel<TM, NBLK, N_IT, SI_ACT_SILU, false, false, W2>) : go(conv3x3s1_slab_f16_kernel<TM, NBLK, N_IT, SI_ACT_NONE, false, false, W2>);
 }
+
+// two waves per SIMD (512-thread workgroups): measured +4 % on the 7-block form (40x40x128: its vector-bound phases halve, 3.8 k of
+// 26 k cycles, the K loop pays 2 k for the doubled weight-fragment traffic) and 1.30x instead of 1.12x on its fused bottleneck pair;
+// -5 % on the 4-block form (20x20x256: two MFMAs per fragment and wave = 64 B/clk/CU through L1), which therefore keeps one wave per
+// SIMD and has no 512-thread instantiation.  SI_CONV_F16_SLAB_W2=0: one wave per SIMD everywhere (A/B runs).
+int slab_w2_mode() {
+    static const int m = [] { const char* e = getenv("SI_CONV_F16_SLAB_W2"); return (e && atoi(e) == 0) ? 0 : 2; }();
+    return m;
+}
+bool slab_w2(int tm) { return slab_w2_mode() == 2 && tm == 7; }
 
 // staging requests per thread of the instantiation that serves a plan: exact for the two YOLOv5s forms (10 for 5 x 40-pixel slabs over
 // 128 channels, 5 for 5 x 20 over 256), the upper bound 11 / 7 otherwise
 int slab_nit(const SiConv2dDesc* d, const SlabPlan& p) {
+    const int need512 = ((p.th + 2) * (d->ow + 2) * 8 + 511) / 512;
+    if (slab_w2(7) && p.tm == 7 && d->ic == 128 && need512 <= 5) return 5;     // (512-thread forms)
     const int need = ((p.th + 2) * (d->ow + 2) * 8 + 255) / 256;
     if (p.tm == 7 && d->ic == 128 && need <= 10) return 10;
     if (p.tm == 4 && d->ic == 256 && need <= 5) return 5;
@@ -623,8 +662,9 @@ const char* si_conv_slab_f16_name(const SiConv2dDesc* d) {
     if (!slab_shape_ok(d) || !slab_plan(d, &p)) return "";
     const bool silu = d->act1 == SI_ACT_SILU && d->act2 == SI_ACT_NONE;
     static thread_local char name[64];
-    snprintf(name, sizeof(name), "conv3x3s1_slab_f16_kernel<%d, %d, %d, %d, %s, false>", p.tm, d->ic / 64, slab_nit(d, p), silu ? SI_ACT_SILU : SI_ACT_NONE,
-             d->has_residual ? "true" : "false");
+    const int nit = slab_nit(d, p);
+    snprintf(name, sizeof(name), "conv3x3s1_slab_f16_kernel<%d, %d, %d, %d, %s, false, %s>", p.tm, d->ic / 64, nit, silu ? SI_ACT_SILU : SI_ACT_NONE,
+             d->has_residual ? "true" : "false", (p.tm == 7 && nit == 5) ? "true" : "false");
     return name;
 }
 
@@ -691,19 +731,25 @@ int slab_launch(const SiConv2dDesc* d, const void* in, unsigned long long in_byt
     const int lds = p.lds + p.tm * 32 * 272;   // the patch, then the epilogue's [pixel][128 channels] image
     if (pw) {
         a.wlA = pw->wlA; a.biasA = pw->biasA; a.wlA_nb = pw->wlA_nb; a.wlA_ks = pw->wlA_ks;
-        auto go = [&](auto kern) {
+        auto go = [&](auto kern, int threads) {
             const hipError_t e = si_allow_dynamic_lds(kern, (size_t)lds);
             if (e != hipSuccess) return (int)e;
             const int grid = (a.n_img + 7) / 8 * 8 * a.slabs_per_img * a.n_ocg;
-            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), (size_t)lds, s, a);
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), (size_t)lds, s, a);
             return (int)hipGetLastError();
         };
-        if (d->ic == 128) return d->has_residual ? go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, true, true>) : go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, false, true>);
-        return d->has_residual ? go(conv3x3s1_slab_f16_kernel<4, 4, 1, SI_ACT_SILU, true, true>) : go(conv3x3s1_slab_f16_kernel<4, 4, 1, SI_ACT_SILU, false, true>);
+        if (slab_w2(pw_tm(d)))
+            return d->has_residual ? go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, true, true, true>, 512) : go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, false, true, true>, 512);
+        if (d->ic == 128) return d->has_residual ? go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, true, true>, 256) : go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, false, true>, 256);
+        return d->has_residual ? go(conv3x3s1_slab_f16_kernel<4, 4, 1, SI_ACT_SILU, true, true>, 256) : go(conv3x3s1_slab_f16_kernel<4, 4, 1, SI_ACT_SILU, false, true>, 256);
     }
     const int nit = slab_nit(d, p);
-    if (d->ic == 128) return p.tm == 7 ? (nit == 10 ? launch_slab<7, 2, 10>(a, d, lds, s) : launch_slab<7, 2, 11>(a, d, lds, s)) : launch_slab<4, 2, 7>(a, d, lds, s);
-    return p.tm == 7 ? launch_slab<7, 4, 11>(a, d, lds, s) : (nit == 5 ? launch_slab<4, 4, 5>(a, d, lds, s) : launch_slab<4, 4, 7>(a, d, lds, s));
+    if (d->ic == 128) {
+        if (p.tm == 7) return nit == 5 ? launch_slab<7, 2, 5, true>(a, d, lds, s) : (nit == 10 ? launch_slab<7, 2, 10>(a, d, lds, s) : launch_slab<7, 2, 11>(a, d, lds, s));
+        return launch_slab<4, 2, 7>(a, d, lds, s);
+    }
+    if (p.tm == 7) return launch_slab<7, 4, 11>(a, d, lds, s);
+    return nit == 5 ? launch_slab<4, 4, 5>(a, d, lds, s) : launch_slab<4, 4, 7>(a, d, lds, s);
 }
 
 }  // namespace
@@ -718,7 +764,8 @@ extern "C" int si_hip_conv2d_pw_slab_f16_supported(const SiConv2dDesc* pw, const
     if (!pw || !conv || !slab_on() || !slab_shape_ok(conv) || !slab_plan(conv, &p, pw_tm(conv)) || !pw_pair_ok(pw, conv, p)) return 0;
     // 2: ... and it is the plan the 3x3 conv would run under by itself on a grid that covers most of the chip (what an engine fuses on)
     const long long grid = (long long)conv->n * p.slabs_per_img * ((conv->oc + 127) / 128);
-    return (slab_plan(conv, &natural) && natural.tm == p.tm && natural.th == p.th && grid * 4 >= (long long)cu_count() * 3) ? 2 : 1;
+    // (... and in the form measured faster than two launches: the 7-block one on two waves per SIMD, 1.30x; the 4-block one is 0.91x)
+    return (slab_plan(conv, &natural) && natural.tm == p.tm && natural.th == p.th && grid * 4 >= (long long)cu_count() * 3 && slab_w2(p.tm)) ? 2 : 1;
 }
 
 extern "C" int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const void* in, const void* pw_w_packed,

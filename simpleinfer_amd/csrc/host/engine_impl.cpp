@@ -54,6 +54,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "fp16") opt_fp16_ = value != 0;
     else if (key == "batch") opt_batch_ = value;  // > 0: re-batch the graph at load (the file bakes its batch into every shape)
     else if (key == "arena") opt_arena_ = value != 0;  // 1 (default): intermediates share one arena by lifetime; 0: one hipMalloc each
+    else if (key == "fuse_pw") opt_fuse_pw_ = value != 0;      // fp16: a C3 bottleneck's 1x1 conv computed inside the slab kernel of its 3x3 conv (default 1)
     else if (key == "fuse_stem") opt_fuse_stem_ = value != 0;  // fp16: RGB stem conv + the 3x3 s2 conv behind it in one launch (default 1)
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
@@ -387,6 +388,7 @@ Status EngineImpl::CreatePipeline() {
         CHECK_STATUS(FusePoolChains(order));
         if (opt_fuse_upsample_ && opt_alias_cat_) CHECK_STATUS(FuseUpsampleIntoConvs(order));   // (fp16 storage too since round 4)
         if (opt_fp16_ && opt_fuse_stem_) CHECK_STATUS(FuseStemPairs(order));
+        if (opt_fp16_ && opt_fuse_pw_) CHECK_STATUS(FuseBottleneckPairs(order));
     }
     if (opt_fp16_) {
         CHECK_STATUS(InsertOutputCasts(order));
@@ -703,6 +705,33 @@ Status EngineImpl::FuseStemPairs(std::vector<Step>& order) {
         Conv2d* conv = dynamic_cast<Conv2d*>(order[index[c]].layer);
         if (!conv || !conv->CanFuseStemProducer(*stem)) continue;
         conv->SetStemProducer(stem);
+        dead_operands_.insert(mid->name);
+        removed[i] = true;
+        fused_ops_.insert(order[i].op->name);
+    }
+    std::vector<Step> out;
+    for (size_t i = 0; i < order.size(); ++i)
+        if (!removed[i]) out.push_back(order[i]);
+    order.swap(out);
+    return Status::kSuccess;
+}
+
+// fp16 storage (round 5): conv A (1x1, c -> c, SiLU) whose ONLY consumer is conv B (3x3 s1 p1 over c channels that the slab kernel
+// serves, SiLU, optional shortcut) -- the C3 bottleneck's pair -- becomes one launch at B's slot; A's output is never allocated.
+Status EngineImpl::FuseBottleneckPairs(std::vector<Step>& order) {
+    std::map<const pnnx::Operator*, size_t> index;
+    for (size_t i = 0; i < order.size(); ++i) index[order[i].op] = i;
+    std::vector<bool> removed(order.size(), false);
+    for (size_t i = 0; i < order.size(); ++i) {
+        Conv2d* pw = dynamic_cast<Conv2d*>(order[i].layer);
+        if (!pw || order[i].op->type != "nn.Conv2d" || pw->InputNodes().size() != 1 || pw->OutputNodes().size() != 1) continue;
+        const pnnx::Operand* mid = pw->OutputNodes()[0]->operand;
+        if (!mid || output_tensor_nodes_.count(mid->name) || mid->consumers.size() != 1 || sibling_ops_.count(order[i].op->name)) continue;
+        const pnnx::Operator* c = mid->consumers[0];
+        if (!c || c->type != "nn.Conv2d" || !index.count(c) || sibling_ops_.count(c->name)) continue;
+        Conv2d* conv = dynamic_cast<Conv2d*>(order[index[c]].layer);
+        if (!conv || !conv->CanFusePointwiseProducer(*pw)) continue;
+        conv->SetPointwiseProducer(pw);
         dead_operands_.insert(mid->name);
         removed[i] = true;
         fused_ops_.insert(order[i].op->name);
@@ -1061,6 +1090,7 @@ Status EngineImpl::LoadLanes(int lanes) {
         lane->opt_alias_cat_ = opt_alias_cat_;
         lane->opt_fuse_upsample_ = opt_fuse_upsample_;
         lane->opt_fuse_stem_ = opt_fuse_stem_;
+        lane->opt_fuse_pw_ = opt_fuse_pw_;
         lane->opt_arena_ = opt_arena_;
         lane->opt_winograd_ = opt_winograd_;
         lane->opt_f32_split_ = opt_f32_split_;
@@ -1196,6 +1226,7 @@ Status EngineImpl::SetupSlicer(int slices) {
     slicer_->opt_alias_cat_ = opt_alias_cat_;
     slicer_->opt_fuse_upsample_ = opt_fuse_upsample_;
     slicer_->opt_fuse_stem_ = opt_fuse_stem_;
+    slicer_->opt_fuse_pw_ = opt_fuse_pw_;
     slicer_->opt_arena_ = opt_arena_;
     slicer_->opt_winograd_ = opt_winograd_;
     slicer_->opt_f32_split_ = opt_f32_split_;

@@ -98,6 +98,7 @@ private:
     Status FusePoolChains(std::vector<Step>& order);
     Status FuseUpsampleIntoConvs(std::vector<Step>& order);
     Status FuseStemPairs(std::vector<Step>& order);
+    Status FuseBottleneckPairs(std::vector<Step>& order);
     Status InsertOutputCasts(std::vector<Step>& order);
     Status InsertFp32Fallbacks(std::vector<Step>& order);
     Status AliasConcats();
@@ -129,6 +130,7 @@ private:
     bool opt_alias_cat_ = true;
     bool opt_fuse_upsample_ = true;
     bool opt_fuse_stem_ = true;
+    bool opt_fuse_pw_ = true;
     bool opt_f32_split_ = false;
     bool opt_arena_ = true;      // intermediate operands share one HBM arena by lifetime (0: one allocation per operand, as the reference)
     bool opt_graph_ = false;

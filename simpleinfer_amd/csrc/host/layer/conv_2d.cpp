@@ -133,6 +133,32 @@ void Conv2d::SetStemProducer(Conv2d* stem) {
     device_ready_ = false;
 }
 
+bool Conv2d::CanFusePointwiseProducer(const Conv2d& pw) const {
+    if (sibling_ || up_node_ || stem_producer_ || pw_producer_ || pw.residual_node_ || pw.sibling_ || pw.up_node_ || pw.stem_producer_ || pw.pw_producer_) return false;
+    if (input_tensor_nodes_.size() != 1 || output_tensor_nodes_.size() != 1 || pw.input_tensor_nodes_.size() != 1 ||
+        pw.output_tensor_nodes_.size() != 1 || pw.output_tensor_nodes_[0] != input_tensor_nodes_[0])
+        return false;
+    const Tensor& x = pw.input_tensor_nodes_[0]->tensor;
+    const Tensor& mid = input_tensor_nodes_[0]->tensor;
+    const Tensor& out = output_tensor_nodes_[0]->tensor;
+    if (!IsHalf(x) || !IsHalf(mid) || !IsHalf(out)) return false;
+    if (residual_node_ && !IsHalf(residual_node_->tensor)) return false;
+    if (x.Shape().size() != 4 || mid.Shape().size() != 4 || out.Shape().size() != 4) return false;
+    SiConv2dDesc d0 = pw.MakeDesc(x, mid), d1 = MakeDesc(mid, out);
+    d0.in_ld = d0.ic; d0.out_ld = d0.oc; d1.in_ld = d1.ic; d1.out_ld = d1.oc;   // (dense views: strides are checked again at the launch)
+    d1.has_residual = residual_node_ ? 1 : 0;
+    d1.res_ld = d1.oc;
+    // 2: the pair runs fused under the plan the 3x3 conv would take alone, on a grid that covers the chip (where the fused form pays)
+    return si_hip_conv2d_pw_slab_f16_supported(&d0, &d1) == 2;
+}
+
+void Conv2d::SetPointwiseProducer(Conv2d* pw) {
+    pw_producer_ = pw;
+    pw_mid_ = input_tensor_nodes_.empty() ? nullptr : input_tensor_nodes_[0];
+    if (pw) SetInputNodes(pw->InputNodes());
+    device_ready_ = false;
+}
+
 void Conv2d::SetSibling(Conv2d* other) {
     sibling_ = other;
     device_ready_ = false;
@@ -385,6 +411,23 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
                                                      Stream()),
                         "conv2d stem + 3x3 s2 (fp16, one launch)");
     }
+    if (pw_producer_) {
+        // the bottleneck's 1x1 conv and this 3x3 one in one launch: `input` is the 1x1 conv's input
+        if (!pw_mid_ || !IsHalf(input) || !IsHalf(output) || (residual && !IsHalf(*residual))) return Status::kUnsupport;
+        CHECK_STATUS(PrepareDevice(1));
+        CHECK_STATUS(pw_producer_->PrepareDevice(1));
+        SiConv2dDesc d0 = pw_producer_->MakeDesc(input, pw_mid_->tensor), d1 = MakeDesc(pw_mid_->tensor, output);
+        d0.out_ld = d0.oc; d1.in_ld = d1.ic;
+        if (residual) {
+            d1.has_residual = 1;
+            d1.res_ld = residual->PixelStride();
+        }
+        return CheckHip(si_hip_conv2d_pw_slab_f16(&d0, &d1, input.RawData(), pw_producer_->weight_dev_.As<void>(),
+                                                  pw_producer_->use_bias_ ? pw_producer_->bias_dev_.As<float>() : nullptr, weight_dev_.As<void>(),
+                                                  use_bias_ ? bias_dev_.As<float>() : nullptr, residual ? residual->RawData() : nullptr,
+                                                  output.RawData(), Stream()),
+                        "conv2d 1x1 + 3x3 (fp16, one launch)");
+    }
     const int mode = PrecisionMode(input, output);
     CHECK_STATUS(PrepareDevice(mode));
     Dims4 in, out;
@@ -545,6 +588,7 @@ const char* Conv2d::KernelName() const {
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
     if (stem_producer_) return "conv_stem_s2c32_f16_kernel";
+    if (pw_producer_) return "conv3x3s1_slab_f16_kernel<pw + 3x3>";
     SiConv2dDesc d = MakeDesc(in, out);
     if (sibling_) d.oc += sibling_->out_channels_;
     const int mode = PrecisionMode(in, out);
@@ -579,6 +623,7 @@ double Conv2d::Flops() const {
     double elems = 0.0;
     for (auto* n : output_tensor_nodes_) elems += (double)n->tensor.NumElements();
     double f = 2.0 * elems * kernel_h_ * kernel_w_ * (in_channels_ / groups_);
+    if (pw_producer_ && pw_mid_) f += 2.0 * (double)pw_mid_->tensor.NumElements() * pw_producer_->in_channels_;   // the fused-away 1x1 conv's multiplies
     if (stem_producer_ && stem_mid_)   // the fused-away stem's own multiplies (its recomputed seam not counted)
         f += 2.0 * (double)stem_mid_->tensor.NumElements() * stem_producer_->kernel_h_ * stem_producer_->kernel_w_ * stem_producer_->in_channels_;
     return f;
@@ -589,6 +634,7 @@ double Conv2d::Bytes() const {
     if (sibling_) b += (double)sibling_->weight_.size() * sizeof(float);
     if (residual_node_) b += (double)residual_node_->tensor.ByteSize();
     if (stem_producer_) b += (double)stem_producer_->weight_.size() * sizeof(float);
+    if (pw_producer_) b += (double)pw_producer_->weight_.size() * sizeof(float);
     return b;
 }
 
@@ -597,7 +643,7 @@ bool Conv2d::HalfStorageOk(std::string& why) const {
     const Tensor& in = input_tensor_nodes_[0]->tensor;
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (!IsHalf(in) && !IsHalf(out)) return true;
-    if (stem_producer_) return true;   // (asked of the kernel when the pair was fused: CanFuseStemProducer)
+    if (stem_producer_ || pw_producer_) return true;   // (asked of the kernel when the pair was fused: CanFuseStemProducer / CanFusePointwiseProducer)
     SiConv2dDesc d;
     memset(&d, 0, sizeof(d));
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;

@@ -73,6 +73,14 @@ public:
     void SetStemProducer(Conv2d* stem);
     Conv2d* StemProducer() const { return stem_producer_; }
 
+    // engine fusion hook (fp16 storage, round 5): `pw` is a 1x1 conv + SiLU over the same channel count whose only reader is this 3x3
+    // stride-1 conv (the C3 bottleneck's pair); this layer then reads pw's INPUT and computes both in one launch
+    // (si_hip_conv2d_pw_slab_f16: the 1x1 goes straight into the slab kernel's LDS patch), the intermediate is never written.  Same bits
+    // as the two launches.
+    bool CanFusePointwiseProducer(const Conv2d& pw) const;
+    void SetPointwiseProducer(Conv2d* pw);
+    Conv2d* PointwiseProducer() const { return pw_producer_; }
+
     Status PrepareDevice(int mode = 0);
     Status PrepareDeviceHalf(const SiConv2dDesc& d);
     int PrecisionMode(const Tensor& input, const Tensor& output) const;
@@ -122,6 +130,8 @@ public:
     TensorNode* up_node_ = nullptr;   // see SetUpsampledSource
     Conv2d* stem_producer_ = nullptr; // see SetStemProducer
     TensorNode* stem_mid_ = nullptr;  // the fused-away intermediate (shape only: it is never allocated)
+    Conv2d* pw_producer_ = nullptr;   // see SetPointwiseProducer
+    TensorNode* pw_mid_ = nullptr;    // its fused-away output (shape only)
     int up_c0_ = 0;
     float up_scale_h_ = 1.0f, up_scale_w_ = 1.0f;
 

@@ -31,7 +31,7 @@ def main():
         rng = np.random.default_rng(0)
         d0 = SiConv2dDesc(n, h, w, c, c, h, w, c, c, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, hipops.ACT["silu"], 0, c, 0, 0.0)
         d1 = SiConv2dDesc(n, h, w, c, c, h, w, c, c, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, hipops.ACT["silu"], 1, c, 0, 0.0)
-        assert H.si_hip_conv2d_pw_slab_f16_supported(C.byref(d0), C.byref(d1)) == 1
+        assert H.si_hip_conv2d_pw_slab_f16_supported(C.byref(d0), C.byref(d1)) >= 1
 
         def pack(d, shape):
             wts = ((rng.random(shape, dtype=np.float32) - 0.5) * 0.1)
