@@ -70,7 +70,7 @@ public:
     //                          the reference does on the CPU; 0 = implicit GEMM everywhere; 2 = fused Winograd F(4,3)
     //   "fp16"            1/0  fp16 storage for internal activations and weights, fp16 MFMA with fp32 accumulation;
     //                          Input / Extract tensors stay fp32 (default 0: the reference's fp32 arithmetic)
-    //   "f32_split"       1/0  fp32 tensors everywhere, but the dense convs over multiples of 64 channels contract on the fp16 matrix
+    //   "f32_split"       1/0  fp32 tensors everywhere, but the dense convs over multiples of 32 channels contract on the fp16 matrix
     //                          cores: every operand as two fp16 halves (22 significant bits), three exact fp16 products per fp32
     //                          product, fp32 accumulation (Ootomo & Yokota 2022; conv_split3.hip).  Measured closer to the float64
     //                          convolution than the fp32 MFMA chain and 1.8-2.1x faster on the K-heavy layers; another arithmetic

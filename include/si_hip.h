@@ -166,7 +166,7 @@ int si_hip_conv2d_set_tile_variant(int variant);
 /* ---- fp32 convolution on the fp16 matrix cores by operand splitting (round 5, csrc/hip/conv_split3.hip; OPT-IN) -------------------
  * Every operand as two fp16 halves, a = a_hi + 2^-11 a_lo (22 significant bits), a product from three exact fp16 MFMA products
  * accumulated in fp32 in two accumulator sets (Ootomo & Yokota 2022).  fp32 tensors in and out; another arithmetic than the fp32
- * kernels (not bit-compatible with them), operands must lie in fp16's range.  Dense convs with ic % 64 == 0.  The weights are split
+ * kernels (not bit-compatible with them), operands must lie in fp16's range.  Dense convs with ic % 32 == 0, at most 32 taps.  The weights are split
  * once: two lane-order fp16 images (_weight_elems counts halves).  Same descriptor / epilogue convention as si_hip_conv2d_f32. */
 int si_hip_conv2d_split3_supported(const SiConv2dDesc* d);
 size_t si_hip_conv2d_split3_weight_elems(const SiConv2dDesc* d);

@@ -72,13 +72,16 @@ constexpr unsigned OOB_A = 0xFFFFFF00u;
 constexpr unsigned OOB_B = 0x80000000u;
 constexpr float kLoScale = 2048.0f;   // 2^11
 
-// BM x BN workgroup tile, 1 x 4 waves (every wave all BM rows x its own BN / 4 = 32 columns), 64-channel K-tiles
-template <int BM>
-__global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel(const Split3Args a) {
-    constexpr int BN = 128, BKH = 64, LDH = BKH + 8, QS = BKH / 16;
-    constexpr int TM = BM / 32;
-    constexpr int A_IT = BM * 16 / 256;   // float4 vectors per thread and K-tile (a row = 64 floats = 16 vectors)
-    // LDS: two stages x {hi, lo} x [BM][64 + 8] halves (dynamic: 72 KB for 128-row tiles)
+// BM x (32 WN) workgroup tile, WM x WN waves (a wave: BM / WM rows x 32 columns of its own -- 1 x 4 for >= 128 output channels: every
+// weight fragment fetched once per workgroup; 2 x 2 for 64), BKH-channel K-tiles (64; 32 for 32-channel layers)
+template <int BM, int WM, int WN, int BKH>
+__global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Args a) {
+    static_assert(WM * WN == 4 && (BKH == 64 || BKH == 32), "4 waves; 64- or 32-channel K-tiles");
+    constexpr int BN = 32 * WN, LDH = BKH + 8, QS = BKH / 16;
+    constexpr int TM = BM / WM / 32;
+    constexpr int VPR = BKH / 4, RPP = 256 / VPR;   // float4 vectors per row of a K-tile, rows per pass of the 256 threads
+    constexpr int A_IT = BM / RPP;                  // vectors per thread and K-tile
+    // LDS: two stages x {hi, lo} x [BM][BKH + 8] halves (dynamic: 72 KB for 128-row tiles of 64 channels)
     extern __shared__ __attribute__((aligned(16))) unsigned char split3_smem[];
     half_t (*lds)[2][BM * LDH] = reinterpret_cast<half_t (*)[2][BM * LDH]>(split3_smem);
 
@@ -91,8 +94,9 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel
     const int m0 = m_tile * BM, n0 = n_tile * BN;
 
     const int tid = threadIdx.x;
-    const int kv = tid & 15, r0 = tid >> 4;   // this thread's 4-channel vector of a row, base row (16 rows per pass)
+    const int kv = tid % VPR, r0 = tid / VPR;   // this thread's 4-channel vector of a row, base row
     const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave - wm * WN;
 
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
     const unsigned wl_bytes = (unsigned)a.wl_nb * (unsigned)a.wl_ks * 1024u;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel
     unsigned a_mask[A_IT];   // tap validity bits (at most 32 taps)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int m = m0 + r0 + 16 * i;
+        const int m = m0 + r0 + RPP * i;
         a_off[i] = 0;
         a_mask[i] = 0u;
         if (m < a.M) {
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel
             a_mask[i] = mk;
         }
     }
-    const int nb = (n0 >> 5) + wave;
+    const int nb = (n0 >> 5) + wn;
     const unsigned b_off = nb < a.wl_nb ? (unsigned)nb * (unsigned)a.wl_ks * 1024u + (unsigned)lane * 16u : OOB_B;
 
     const int nk = a.Kp / BKH;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel
                 hi[j] = (half_t)x[j];
                 lo[j] = (half_t)((x[j] - (float)hi[j]) * kLoScale);
             }
-            const int row = r0 + 16 * i;
+            const int row = r0 + RPP * i;
             *reinterpret_cast<f16x4*>(lds[stage][0] + row * LDH + kv * 4) = hi;
             *reinterpret_cast<f16x4*>(lds[stage][1] + row * LDH + kv * 4) = lo;
         }
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel
     load_a(0);
 #pragma unroll
     for (int j = 0; j + 1 < NBF; ++j) load_b(j, j);
-    const int o = n0 + wave * 32 + l31;
+    const int o = n0 + wn * 32 + l31;
     const float bv = (a.bias && o < a.oc) ? a.bias[o] : 0.0f;
     store_a(0);
     load_a(1);
@@ -195,11 +199,11 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel
         store_a(cur ^ 1);           // tile kt + 1 (requested one tile ago) into the other stage
         load_a(kt + 2);
         __builtin_amdgcn_sched_barrier(0);
-        const half_t* Ah = lds[cur][0] + l31 * LDH + lh * 8;
-        const half_t* Al = lds[cur][1] + l31 * LDH + lh * 8;
+        const half_t* Ah = lds[cur][0] + (wm * TM * 32 + l31) * LDH + lh * 8;
+        const half_t* Al = lds[cur][1] + (wm * TM * 32 + l31) * LDH + lh * 8;
 #pragma unroll
         for (int s = 0; s < QS; ++s) {
-            load_b((s + NBF - 1) % NBF, kt * QS + s + NBF - 1);
+            load_b((cur * QS + s + NBF - 1) % NBF, kt * QS + s + NBF - 1);
             f16x8 fh[TM], fl[TM];
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
@@ -208,9 +212,9 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel
             }
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
-                acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], rbh[s % NBF], acc_h[t], 0, 0, 0);
-                acc_x[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], rbl[s % NBF], acc_x[t], 0, 0, 0);
-                acc_x[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[t], rbh[s % NBF], acc_x[t], 0, 0, 0);
+                acc_h[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], rbh[(cur * QS + s) % NBF], acc_h[t], 0, 0, 0);
+                acc_x[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[t], rbl[(cur * QS + s) % NBF], acc_x[t], 0, 0, 0);
+                acc_x[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[t], rbh[(cur * QS + s) % NBF], acc_x[t], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel
     if (o < a.oc) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
-            const int mb = m0 + t * 32 + 4 * lh;
+            const int mb = m0 + (wm * TM + t) * 32 + 4 * lh;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
@@ -242,8 +246,11 @@ __global__ __launch_bounds__(256, BM == 128 ? 2 : 3) void conv_split3_f32_kernel
 }
 
 bool split3_ok(const SiConv2dDesc* d) {
-    return d && d->groups == 1 && d->ic > 0 && d->ic % 64 == 0 && d->oc > 0 && d->kh * d->kw <= 64 && d->dh == 1 && d->dw == 1 && d->in_ld % 4 == 0;
+    return d && d->groups == 1 && d->ic > 0 && d->ic % 32 == 0 && d->oc > 0 && d->kh * d->kw <= 32 && d->dh == 1 && d->dw == 1 && d->in_ld % 4 == 0;
 }
+
+// channels per K-tile: the K order is (c / blk, ky, kx, c % blk)
+int split3_blk(const SiConv2dDesc* d) { return d->ic % 64 == 0 ? 64 : 32; }
 
 }  // namespace
 
@@ -260,16 +267,16 @@ size_t si_hip_conv2d_split3_weight_elems(const SiConv2dDesc* d) {
 int si_hip_conv2d_split3_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed) {
     if (!d || !w_oihw || !w_packed) return SI_E_BADARG;
     if (!split3_ok(d)) return SI_E_UNSUPPORTED;
-    const int ntaps = d->kh * d->kw, nb_n = (d->oc + 31) / 32, ks_n = ntaps * d->ic / 16;
+    const int ntaps = d->kh * d->kw, nb_n = (d->oc + 31) / 32, ks_n = ntaps * d->ic / 16, B = split3_blk(d);
     half_t* hi = static_cast<half_t*>(w_packed);
     half_t* lo = hi + (size_t)nb_n * ks_n * 512;
     for (int nb = 0; nb < nb_n; ++nb)
         for (int ks = 0; ks < ks_n; ++ks)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
-                    // K order (c / 64, ky, kx, c % 64): k = ks * 16 + 8 (l >> 5) + j
+                    // K order (c / B, ky, kx, c % B), B = 64 (32 for channel counts that are not multiples of 64): k = ks * 16 + 8 (l >> 5) + j
                     const int k = ks * 16 + 8 * (l >> 5) + j;
-                    const int blk = k / 64, cb = blk / ntaps, tap = blk - cb * ntaps, c = cb * 64 + (k % 64);
+                    const int blk = k / B, cb = blk / ntaps, tap = blk - cb * ntaps, c = cb * B + (k % B);
                     const int o = nb * 32 + (l & 31);
                     float v = 0.0f;
                     if (o < d->oc) v = w_oihw[(((size_t)o * d->ic + c) * d->kh + tap / d->kw) * d->kw + tap % d->kw];
@@ -306,28 +313,30 @@ int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void*
     a.mg_ow = d->ow > 1 ? (unsigned)(0x100000000ull / (unsigned)d->ow) : 0xFFFFFFFFu;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
     a.in_bytes = (unsigned)in_bytes;
-    // 128-row tiles (a weight fragment feeds four pixel blocks: half the L2 -> L1 weight traffic per FLOP) where they still cover the chip
-    static const int forced_bm = [] { const char* e = getenv("SI_SPLIT3_BM"); return e ? atoi(e) : 0; }();
     int cus = 256;
     {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
     }
-    const long long tiles128 = (((long long)a.M + 127) / 128) * ((d->oc + 127) / 128);
-    const int BM = forced_bm ? (forced_bm == 128 ? 128 : 64) : (tiles128 >= 2LL * cus ? 128 : 64);
-    a.m_tiles = (a.M + BM - 1) / BM;
-    a.n_tiles = (d->oc + 127) / 128;
-    const int chunks = (a.m_tiles + 7) / 8;
-    dim3 grid(chunks * 8 * a.n_tiles, 1, 1);
-    const size_t lds = (size_t)2 * 2 * BM * 72 * 2;
-    if (BM == 128) {
-        const hipError_t e = si_allow_dynamic_lds(conv_split3_f32_kernel<128>, lds);
+    auto go = [&](auto kern, int BM, int BN, int BKH) {
+        a.m_tiles = (a.M + BM - 1) / BM;
+        a.n_tiles = (d->oc + BN - 1) / BN;
+        const int chunks = (a.m_tiles + 7) / 8;
+        const size_t lds = (size_t)2 * 2 * BM * (BKH + 8) * 2;
+        const hipError_t e = si_allow_dynamic_lds(kern, lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(conv_split3_f32_kernel<128>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
-    } else {
-        hipLaunchKernelGGL(conv_split3_f32_kernel<64>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), a);
-    }
-    return (int)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3(chunks * 8 * a.n_tiles), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+        return (int)hipGetLastError();
+    };
+    // tiles: <= 64 output channels -> 128 x 64 as 2 x 2 waves (the 1 x 4 form would leave two waves without columns); 64 x 128 as 1 x 4
+    // waves otherwise, 128 x 128 for >= 512 output channels on a grid that still covers the chip twice (a weight fragment then feeds four
+    // pixel blocks: half the L2 -> L1 weight traffic per FLOP; measured 117 vs 125 us on 40x40x256 -> 512, 139 vs 118 on 80x80x128 -> 256)
+    static const int forced_bm = [] { const char* e = getenv("SI_SPLIT3_BM"); return e ? atoi(e) : 0; }();
+    if (split3_blk(d) == 32) return d->oc <= 64 ? go(conv_split3_f32_kernel<128, 2, 2, 32>, 128, 64, 32) : go(conv_split3_f32_kernel<64, 1, 4, 32>, 64, 128, 32);
+    if (d->oc <= 64) return go(conv_split3_f32_kernel<128, 2, 2, 64>, 128, 64, 64);
+    const long long tiles128 = (((long long)a.M + 127) / 128) * ((d->oc + 127) / 128);
+    const bool big = forced_bm ? forced_bm == 128 : (d->oc >= 512 && tiles128 >= 2LL * cus);
+    return big ? go(conv_split3_f32_kernel<128, 1, 4, 64>, 128, 128, 64) : go(conv_split3_f32_kernel<64, 1, 4, 64>, 64, 128, 64);
 }
 
 }  // extern "C"

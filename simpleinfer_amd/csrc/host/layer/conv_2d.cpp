@@ -317,11 +317,14 @@ bool Conv2d::UseSplit3() const {
     d.in_ld = in_channels_;
     if (!si_hip_conv2d_split3_supported(&d)) return false;
     // Where it pays (YOLOv5s batch 32, per layer, profiles/r05_f32_split.txt): K >= 512 and >= 128 output channels -- the 3x3 stride-2
-    // layers (1.4-2.1x), the wide 1x1 layers (1.3-1.8x).  Thin-K layers are HBM-bound (the fp32 -> hi / lo conversion only costs), 64
-    // output channels leave half of the 64 x 128 tile's waves idle, and the 3x3 stride-1 layers below 256 channels are faster on the
-    // fused Winograd kernel (2.25x fewer multiplies).  A property of the layer, not of the batch: an image's bits do not depend on it.
+    // layers (1.4-2.1x), the wide 1x1 layers (1.3-1.8x) -- and the strided spatial convs from K = 288 and 64 output channels (YOLOv5s
+    // conv_1, 320x320x32 -> 64: 1.34x on the 128 x 64 tile of 2 x 2 waves over 32-channel K-tiles).  Thin-K 1x1 layers are HBM-bound
+    // (the fp32 -> hi / lo conversion only costs: 0.54-0.62x at 64 output channels), and the 3x3 stride-1 layers below 256 channels are
+    // faster on the fused Winograd kernel (2.25x fewer multiplies).  A property of the layer, not of the batch: an image's bits do not
+    // depend on it.
     const long long K = (long long)kernel_h_ * kernel_w_ * in_channels_;
-    if (K < 512 || out_channels_ < 128) return false;
+    const bool strided_spatial = kernel_h_ * kernel_w_ > 1 && (stride_h_ > 1 || stride_w_ > 1);
+    if (strided_spatial ? (K < 288 || out_channels_ < 64) : (K < 512 || out_channels_ < 128)) return false;
     const bool wino_shape = kernel_h_ == 3 && kernel_w_ == 3 && stride_h_ == 1 && stride_w_ == 1;
     return !(wino_shape && in_channels_ < 256 && algo_ != Algo::kImplicitGemm);
 }

@@ -114,7 +114,7 @@ public:
     // here kAuto does the same when the fused Winograd kernel supports the channel counts, else implicit GEMM
     enum class Algo { kAuto = 0, kImplicitGemm, kWinograd23, kWinograd43 } algo_ = Algo::kAuto;
     // engine option f32_split (opt-in, round 5): fp32 tensors, the contraction on the fp16 matrix cores from three fp16 products per
-    // fp32 product (si_hip_conv2d_split3_f32) for the dense layers over multiples of 64 channels; everything else as without it
+    // fp32 product (si_hip_conv2d_split3_f32) for the dense layers where that is faster (UseSplit3); everything else as without it
     bool f32_split_ = false;
     bool UseSplit3() const;
     bool prefer_wino43_ = false;  // kAuto: take F(4,3) instead of F(2,3) wherever F(2,3) would have been chosen

@@ -687,7 +687,10 @@ def test_conv_general_groups(hops, orc, n, hw, ic, oc, k, s, p, g):
     (2, 21, 128, 96, 3, 2, "silu", False),       # ragged M and oc, image borders
     (1, 16, 256, 128, 3, 1, "none", True),
     (3, 13, 64, 255, 1, 1, "relu", False),       # pointwise, ragged oc
-    (2, 10, 192, 64, 5, 1, "silu", True),        # 25 taps, three channel blocks
+    (2, 10, 192, 64, 5, 1, "silu", True),        # 25 taps, three channel blocks; <= 64 columns: the 2 x 2-wave tile
+    (2, 23, 32, 64, 3, 2, "silu", False),        # 32-channel K-tiles (YOLOv5s conv_1's form), ragged M
+    (1, 14, 96, 160, 3, 1, "relu", True),        # 32-channel K-tiles, 64 x 128 tile, ragged oc
+    (3, 9, 160, 40, 1, 1, "none", False),        # pointwise over 32-channel K-tiles, 40 of 64 columns live
 ])
 def test_conv_split3_vs_oracle_and_fp64(hops, orc, n, hw, ic, oc, k, s, act, res):
     """si_hip_conv2d_split3_f32 against the reference's arithmetic restated (Conv2d::ForwardIm2Col, src/layer/conv_2d.cpp:207-283) at

@@ -33,7 +33,8 @@ def ref64(x, w, b, s, p):
 def main():
     H = _native.hip()
     print("== error against the float64 convolution (max |err| / max |ref|)")
-    for (n, hw, ic, oc, k, s, scale) in [(2, 20, 128, 256, 3, 2, 1.0), (1, 16, 256, 128, 3, 1, 1.0), (2, 12, 512, 128, 1, 1, 1.0), (2, 20, 128, 256, 3, 2, 50.0)]:
+    for (n, hw, ic, oc, k, s, scale) in [(2, 20, 128, 256, 3, 2, 1.0), (1, 16, 256, 128, 3, 1, 1.0), (2, 12, 512, 128, 1, 1, 1.0), (2, 20, 128, 256, 3, 2, 50.0),
+                                       (2, 24, 32, 64, 3, 2, 1.0), (1, 20, 64, 64, 3, 1, 1.0), (2, 12, 96, 160, 1, 1, 1.0), (1, 20, 128, 48, 3, 1, 1.0)]:
         rng = np.random.default_rng(5)
         x = (rng.standard_normal((n, hw, hw, ic)) * scale).astype(np.float32)
         w = (rng.standard_normal((oc, ic, k, k)) * 0.05).astype(np.float32)
@@ -46,7 +47,8 @@ def main():
     print("== time per launch, batch 32 (graph of 30 launches, sustained)")
     ev0, ev1, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
     H.si_hip_event_create(C.byref(ev0)); H.si_hip_event_create(C.byref(ev1)); H.si_hip_stream_create(C.byref(st))
-    for (n, hw, ic, oc, k, s) in [(32, 80, 128, 256, 3, 2), (32, 40, 256, 512, 3, 2), (32, 160, 64, 128, 3, 2), (32, 20, 512, 512, 1, 1), (32, 40, 256, 256, 1, 1)]:
+    for (n, hw, ic, oc, k, s) in [(32, 80, 128, 256, 3, 2), (32, 40, 256, 512, 3, 2), (32, 160, 64, 128, 3, 2), (32, 20, 512, 512, 1, 1), (32, 40, 256, 256, 1, 1),
+                               (32, 320, 32, 64, 3, 2), (32, 80, 64, 64, 3, 1), (32, 160, 64, 64, 1, 1), (32, 80, 128, 64, 1, 1)]:
         p = k // 2
         oh = (hw + 2 * p - k) // s + 1
         d = SiConv2dDesc(n, hw, hw, ic, ic, oh, oh, oc, oc, k, k, s, s, 1, 1, p, p, 1, 1, hipops.ACT["silu"], 0, oc, 0, 0.0)
