@@ -820,12 +820,56 @@ __global__ __launch_bounds__(256, NCH <= 2 ? SI_DET_MINW : 2) void detect_f16_ti
 
     // decode (si_yolo_tile_one_image's expressions) -> LDS -> the contiguous run, 32 pixels at a time
     const int per_pix = a.yna * a.yne;
+    const bool coco = a.yna == 3 && a.yne == 85 && valid == 64 && !(SI_DET_ABL & 17);   // workgroup-uniform
     float* const orun = static_cast<float*>(a.out) + ((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix0 * per_pix;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         __syncthreads();   // t = 0: every wave is done reading A; t = 1: the first half has left the stage
         const int rows = min(32, valid - 32 * t);
-        if (rows > 0) {
+        if (coco) {
+            // the common head (3 anchors x 85 entries, a full tile) with nothing per element but the sigmoid and one LDS write at a
+            // compile-time offset: the general form below spent ~25 instructions per element (a select chain the compiler turned
+            // into two exec-masked branches, a 32-bit multiply for the row offset, the dead-column test) -- ~35 us of vector issue
+            // per CU on level 0, as much as its 209 MB output stream takes.  Box columns (x, y, w, h of an anchor: 0-3, 85-88,
+            // 170-173) lie in three of the eight 32-column blocks; the other five never see the box arithmetic.  Same expressions,
+            // same bits (tests/test_gpu_f16.py).
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int blk = wave * 2 + u;   // wave-uniform
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[t][u][e] + bv[u])));
+                if (blk == 0 || blk == 2 || blk == 5) {
+                    const int oo = col[u] < 255 ? col[u] : 0;
+                    const int anc = oo / 85;
+                    const int e_ = oo - anc * 85;
+                    const bool is_xy = e_ < 2, is_box = e_ < 4;
+                    const float* const ap = (is_xy ? a.ygrid + e_ : a.yanchor + (is_box ? e_ - 2 : 0)) + anc * 2 + (size_t)(pix0 + 32 * t + 4 * lh) * 6;
+                    float auxv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) auxv[e] = 0.0f;
+                    if (is_box) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) auxv[e] = ap[((e & 3) + 8 * (e >> 2)) * 6];
+                    }
+                    const unsigned mxy = is_xy ? ~0u : 0u, mwh = (is_box && !is_xy) ? ~0u : 0u, msg = is_box ? 0u : ~0u;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float t2 = v[e] * 2.0f;
+                        const float xy = (t2 + auxv[e]) * a.ystride;
+                        const float wh = t2 * t2 * auxv[e];
+                        v[e] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, xy) & mxy) | (__builtin_bit_cast(unsigned, wh) & mwh) |
+                                                             (__builtin_bit_cast(unsigned, v[e]) & msg));
+                    }
+                }
+                if (col[u] < 255) {
+                    float* const sp = stage + 4 * lh * 255 + col[u];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sp[((e & 3) + 8 * (e >> 2)) * 255] = v[e];
+                }
+            }
+        } else if (rows > 0) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const bool live = col[u] < a.ocg;

@@ -472,18 +472,21 @@ def test_stem_s2c32_fused_same_bits(hops, orc, gpu, n, ih, iw, oc):
     assert_parity(got.astype(np.float32), ref, F16_TOL, what="fused stem + conv")
 
 
-@pytest.mark.parametrize("n,levels", [
-    (3, ((20, 128), (10, 256), (5, 512))),     # 400 / 100 / 25 pixels per image: whole tiles, a 16-pixel tail, a tile of 25
-    (2, ((9, 256), (3, 128), (1, 512))),       # 91 rows x 3: image bases only 4-byte aligned -> the dword form of the run
-    (1, ((16, 512), (8, 128), (4, 256))),
+@pytest.mark.parametrize("n,levels,ne", [
+    (3, ((20, 128), (10, 256), (5, 512)), 85),     # 400 / 100 / 25 pixels per image: whole tiles, a 16-pixel tail, a tile of 25
+    (2, ((9, 256), (3, 128), (1, 512)), 85),       # 91 rows x 3: image bases only 4-byte aligned -> the dword form of the run
+    (1, ((16, 512), (8, 128), (4, 256)), 85),
+    (2, ((16, 128), (8, 256), (4, 512)), 25),      # another head (20 classes): whole tiles through the general decode
 ])
-def test_detect_tile_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, levels):
+def test_detect_tile_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, levels, ne):
     """Round 4: a Detect level over 128 / 256 / 512 channels runs as detect_f16_tile_kernel (64 consecutive pixels x all 255 columns
     per workgroup, decoded rows staged through LDS, one contiguous run out).  Same MFMA sequence per element and the same decode
-    expressions as the generic tiles, so the two forms agree BIT for bit; and the oracle's bar holds (src/layer/yolo_detect.cpp:223-266)."""
+    expressions as the generic tiles, so the two forms agree BIT for bit; and the oracle's bar holds (src/layer/yolo_detect.cpp:223-266).
+    Round 5: whole tiles of the 3 x 85 head take a decode of their own (sigmoid + one LDS write per element, the box arithmetic only in
+    the three column blocks that hold box columns); every other shape the general one."""
     from simpleinfer_amd import _native
     H = _native.hip()
-    na, ne = 3, 85
+    na = 3
     feats, ws, bs, grids, anchors = [], [], [], [], []
     for i, (hh, c) in enumerate(levels):
         feats.append(h(rng_uniform(150 + i, (n, hh, hh, c), -1, 1)))
