@@ -419,7 +419,9 @@ int si_hip_conv2d_f16_set_slab(int on);
  * computes the 1x1 conv for the pixels of its input patch straight into LDS (conv_slab_f16.hip): the intermediate tensor is never
  * written, one launch less.  Weights: si_hip_conv2d_f16_pack_weight_host of each conv.  Same bits as the two launches.
  * _supported: 0 no, 1 the pair can run fused, 2 ... and it is the form measured FASTER than two launches (7 pixel blocks over 128
- * channels on two waves per SIMD, on a grid covering the chip): what an engine fuses on. */
+ * channels on two waves per SIMD, on a grid covering the chip): what an engine fuses on.
+ * The same entry points take the 64-channel pair (c = 64 on maps of whole 4 x 16-pixel tiles, YOLOv5s' 80x80 level): there the 1x1 is
+ * computed into the LDS patch of the persistent 3x3 patch kernel (conv_pw_patch_f16.hip); same bits as the two launches. */
 int si_hip_conv2d_pw_slab_f16_supported(const SiConv2dDesc* pw, const SiConv2dDesc* conv);
 int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const void* in, const void* pw_w_packed, const float* pw_bias,
                               const void* w_packed, const float* bias, const void* residual, void* out, si_stream_t stream);

@@ -759,7 +759,13 @@ int si_conv_slab_f16_launch(const SiConv2dDesc* d, const void* in, const void* w
     return slab_launch(d, in, (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 2ull, d->in_ld, wl, wl_nb, wl_ks, bias, residual, out, s, nullptr);
 }
 
+// (conv_pw_patch_f16.hip: the 64-channel pair on the persistent patch kernel)
+bool si_conv_pw_patch_f16_ok(const SiConv2dDesc* pw, const SiConv2dDesc* d);
+int si_conv_pw_patch_f16_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, const void* in, const void* wlA, const float* biasA, const void* wl,
+                                const float* bias, const void* residual, void* out, hipStream_t s);
+
 extern "C" int si_hip_conv2d_pw_slab_f16_supported(const SiConv2dDesc* pw, const SiConv2dDesc* conv) {
+    if (si_conv_pw_patch_f16_ok(pw, conv)) return 2;
     SlabPlan p, natural;
     if (!pw || !conv || !slab_on() || !slab_shape_ok(conv) || !slab_plan(conv, &p, pw_tm(conv)) || !pw_pair_ok(pw, conv, p)) return 0;
     // 2: ... and it is the plan the 3x3 conv would run under by itself on a grid that covers most of the chip (what an engine fuses on)
@@ -773,6 +779,12 @@ extern "C" int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dD
                                          si_stream_t stream) {
     if (!pw || !conv || !in || !pw_w_packed || !w_packed || !out) return SI_E_BADARG;
     if ((pw->has_bias && !pw_bias) || (conv->has_bias && !bias) || (conv->has_residual && !residual)) return SI_E_BADARG;
+    if (si_conv_pw_patch_f16_ok(pw, conv)) {
+        // (si_hip_conv2d_f16_pack_weight_host: the row-major image, then the lane-order one)
+        const half_t* const wA = static_cast<const half_t*>(pw_w_packed) + (size_t)64 * 64;
+        const half_t* const wB = static_cast<const half_t*>(w_packed) + (size_t)64 * 9 * 64;
+        return si_conv_pw_patch_f16_launch(pw, conv, in, wA, pw_bias, wB, bias, residual, out, static_cast<hipStream_t>(stream));
+    }
     SlabPlan p;
     if (!slab_shape_ok(conv) || !slab_plan(conv, &p, pw_tm(conv)) || !pw_pair_ok(pw, conv, p)) return SI_E_UNSUPPORTED;
     const uintptr_t al = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | (conv->has_bias ? reinterpret_cast<uintptr_t>(bias) : 0) |

@@ -423,6 +423,9 @@ def test_slab_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, hh, ww, ic, o
     (2, 40, 40, 128, False),      # the head's bottlenecks have no shortcut
     (2, 13, 17, 128, True),       # ragged: short last slab, image borders at every slab
     (1, 7, 9, 256, False),        # one slab per image: both zero rows in one patch
+    (2, 16, 32, 64, True),        # 64 channels: the persistent patch form (conv_pw_patch_f16.hip), 4 x 16-pixel tiles, more items than ...
+    (1, 80, 80, 64, True),        # ... YOLOv5s' 80x80 bottleneck
+    (3, 8, 16, 64, False),        # two tiles per image, every patch touches three image borders
 ])
 def test_bottleneck_pair_in_one_launch_same_bits(hops, orc, gpu, n, hh, ww, c, res):
     """Round 5: the C3 bottleneck's 1x1 conv + SiLU computed inside the slab kernel of the 3x3 conv that follows it
