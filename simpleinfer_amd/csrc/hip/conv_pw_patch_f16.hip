@@ -1,4 +1,4 @@
-// conv_pw_patch_f16.hip -- the 64-channel C3 bottleneck pair, 1x1 + SiLU -> 3x3 + SiLU (+ shortcut), as ONE persistent launch (round 5).
+// conv_pw_patch_f16.hip -- the 64- / 32-channel C3 bottleneck pair, 1x1 + SiLU -> 3x3 + SiLU (+ shortcut), as ONE persistent launch (round 5).
 //
 // YOLOv5s at batch 32 runs three such pairs over 80x80x64 maps (reference: models/common.py Bottleneck through
 // src/layer/conv_2d.cpp:207-283 twice).  As two launches the 26 MB intermediate is written and read back and the 1x1 is a launch of
@@ -8,7 +8,8 @@
 // is computed in front of every item's matrix loop: y = SiLU(W1 x + b1) on the same MFMA with the weights as its A operand (a lane
 // then ends with four consecutive channels of one pixel: 8-byte LDS writes straight into the patch layout), rounded to fp16 exactly
 // as the 1x1 launch would have stored it, ZERO where the patch pixel lies outside the image (the 3x3 pads its input, not the 1x1's).
-// Halo recompute 108 / 64 pixels; the 1x1 is 8 MFMAs per wave and item beside the 3x3's 36.
+// Halo recompute 108 / 64 pixels; the 1x1 is 8 MFMAs per wave and item beside the 3x3's 36.  The 160x160x32 pair (YOLOv5s' first C3)
+// takes the same kernel over the 32-channel geometry (8 x 16-pixel tiles, 180-pixel patches in six pixel blocks over four waves).
 // Same k order, same 16-deep steps, the same epilogue expressions as the two launches: the same bits (tests/test_gpu_f16.py).
 #include <hip/hip_runtime.h>
 
@@ -46,31 +47,33 @@ struct PwPatchArgs {
 
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
-template <bool HAS_RES>
-__global__ __launch_bounds__(256, 2) void conv_pw_c64_patch_f16_kernel(const PwPatchArgs a) {
-    // patch geometry of conv_c32_patch_f16_kernel<1, 2, .., 64>: 144-byte pixels (64 + 8 halves), 2816-byte rows of 18 pixels
-    constexpr int PITCH = 144, ROWP = 2816, TR = 4, PR = TR + 2, PC = 18, QS = 4, KS = 9 * QS;
-    constexpr int NPIX = PR * PC, NCH = NPIX * 8, N_IT = (NCH + 255) / 256;
+// CB = 64: the geometry of conv_c32_patch_f16_kernel<1, 2, .., 64> -- 4 x 16-pixel tiles, waves 2 (row pairs) x 2 (column blocks), 144-byte
+// pixels, 2816-byte patch rows; CB = 32: of <1, 1, .., 32> -- 8 x 16-pixel tiles, four row-pair waves, 80-byte pixels, 1536-byte rows.
+template <bool HAS_RES, int CB>
+__global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_pw_patch_f16_kernel(const PwPatchArgs a) {
+    static_assert(CB == 64 || CB == 32, "instantiated forms");
+    constexpr int PITCH = CB * 2 + 16, ROWP = CB == 64 ? 2816 : 1536, NBW = CB / 32, TR = 2 * (4 / NBW), PR = TR + 2, PC = 18, QS = CB / 16, KS = 9 * QS;
+    constexpr int CH8 = CB / 8, NPIX = PR * PC, NCH = NPIX * CH8, N_IT = (NCH + 255) / 256, MT0 = (NPIX + 31) / 32;
     __shared__ __attribute__((aligned(16))) unsigned char patch[PR * ROWP];
-    __shared__ __attribute__((aligned(16))) unsigned char xbuf[128 * PITCH];   // x over the patch, pixel-major; rows 108 .. 127 are never written
-    // the 1x1's weights (lane order: 2 column blocks x 4 k-steps x 64 lanes x 16 B) and bias: registers are what this kernel is short of
-    __shared__ __attribute__((aligned(16))) unsigned char wa_s[2 * QS * 1024];
-    __shared__ __attribute__((aligned(16))) float bias_a[64];
+    __shared__ __attribute__((aligned(16))) unsigned char xbuf[MT0 * 32 * PITCH];   // x over the patch, pixel-major; rows from NPIX on are never written
+    // the 1x1's weights (lane order: column blocks x k-steps x 64 lanes x 16 B) and bias: registers are what this kernel is short of
+    __shared__ __attribute__((aligned(16))) unsigned char wa_s[NBW * QS * 1024];
+    __shared__ __attribute__((aligned(16))) float bias_a[CB];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NBW, wn = wave - wm * NBW;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.x), 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wl), 0, 2u * KS * 1024u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_wa = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wlA), 0, 2u * QS * 1024u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wl = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wl), 0, (unsigned)NBW * KS * 1024u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wa = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wlA), 0, (unsigned)NBW * QS * 1024u, 0x00020000);
 
     // staging chunks of this thread: chunk c -> (patch pixel, 16-byte channel chunk); item-invariant
     int l_off[N_IT], c_pos[N_IT];   // (c_pos: patch row << 8 | patch column)
 #pragma unroll
     for (int i = 0; i < N_IT; ++i) {
         const int c = tid + 256 * i;
-        const int q = c >> 3, pr = q / PC;
+        const int q = c / CH8, pr = q / PC;
         c_pos[i] = (pr << 8) | (q - pr * PC);
-        l_off[i] = c < NCH ? q * PITCH + (c & 7) * 16 : -1;
+        l_off[i] = c < NCH ? q * PITCH + (c % CH8) * 16 : -1;
     }
     u32x4 rp[N_IT];
     auto prefetch = [&](int item) {
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_c64_patch_f16_kernel(const PwP
         for (int i = 0; i < N_IT; ++i) {
             const int gy = y0 + (c_pos[i] >> 8), gx = x0 + (c_pos[i] & 255);
             const bool ok = l_off[i] >= 0 && (unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw;
-            const unsigned off = (unsigned)((img * a.ih + gy) * a.iw + gx) * (unsigned)(a.x_ld * 2) + (unsigned)((tid & 7) * 16);
+            const unsigned off = (unsigned)((img * a.ih + gy) * a.iw + gx) * (unsigned)(a.x_ld * 2) + (unsigned)((tid % CH8) * 16);
             rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ok ? off : OOB, 0, 0);
         }
     };
@@ -100,22 +103,25 @@ __global__ __launch_bounds__(256, 2) void conv_pw_c64_patch_f16_kernel(const PwP
         const unsigned vo = (unsigned)wn * (unsigned)KS * 1024u + (unsigned)lane * 16u;
 #pragma unroll
         for (int s = 0; s < KS; ++s) wf[s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wl, vo, (unsigned)(s * 1024), 0));
-        // (256 threads x 2 x 16 B = the 1x1's 8 KB)
+        // (the 1x1's 8 KB / 2 KB: 16 bytes per thread and pass)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<u32x4*>(wa_s + (tid + 256 * i) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_wa, (unsigned)(tid + 256 * i) * 16u, 0, 0);
+        for (int i = 0; i < (NBW * QS * 64 + 255) / 256; ++i)
+            if (tid + 256 * i < NBW * QS * 64)
+                *reinterpret_cast<u32x4*>(wa_s + (tid + 256 * i) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_wa, (unsigned)(tid + 256 * i) * 16u, 0, 0);
     }
     const unsigned char* const WA = wa_s + wn * QS * 1024 + lane * 16;
     const int o = wn * 32 + l31;
     const float bv = a.bias ? a.bias[o] : 0.0f;
-    if (tid < 64) bias_a[tid] = a.biasA ? a.biasA[tid] : 0.0f;
+    if (tid < CB) bias_a[tid] = a.biasA ? a.biasA[tid] : 0.0f;
     // 1x1 bias of this lane's channels (weights = A operand: rows (e & 3) + 8 (e >> 2) + 4 lh of the 32-channel block), read per item
     const float* const ba = bias_a + wn * 32 + 4 * lh;
-    // the patch pixels this lane produces in phase 0 (pixel blocks 2 wm, 2 wm + 1 of the 108): patch offset of its channels, position
+    // the patch pixels this lane produces in phase 0 -- pixel blocks 2 wm, 2 wm + 1 of four (64 channels: this wave's column block of
+    // them), blocks wave, wave + 4 of six (32 channels) --: patch offset of its channels, position
+    const int tq0 = CB == 64 ? 2 * wm : wave, tqs = CB == 64 ? 1 : 4;
     int p_off[2], p_pos[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int q = (2 * wm + t) * 32 + l31, pr = q / PC, px = q - pr * PC;
+        const int q = (tq0 + tqs * t) * 32 + l31, pr = q / PC, px = q - pr * PC;
         p_pos[t] = (pr << 8) | px;
         p_off[t] = q < NPIX ? pr * ROWP + px * PITCH + wn * 64 + lh * 8 : -1;
     }
@@ -124,7 +130,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_c64_patch_f16_kernel(const PwP
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
 
-    const unsigned char* const X = xbuf + ((2 * wm) * 32 + l31) * PITCH + lh * 16;
+    const unsigned char* const X = xbuf + (tq0 * 32 + l31) * PITCH + lh * 16;
+    const bool two = CB == 64 || wave + 4 < MT0;   // (wave-uniform: this wave has a second pixel block)
+    const int x1 = two ? tqs * 32 * PITCH : 0;
     const unsigned char* const P = patch + (2 * wm + (l31 >> 4)) * ROWP + (l31 & 15) * PITCH + lh * 16;
     for (; item < a.items; item += gridDim.x) {
         const int next = item + gridDim.x;
@@ -134,28 +142,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_c64_patch_f16_kernel(const PwP
         const int oy0 = ty * TR + 2 * wm, ox0 = tx * 16;
         // ---- phase 0: the 1x1 conv + SiLU over the patch's pixels, into the patch
         {
-            f32x16 acc0[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc0[t][e] = 0.0f;
-            f16x8 xf[2][2], wa[2];
-            wa[0] = *reinterpret_cast<const f16x8*>(WA);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) xf[0][t] = *reinterpret_cast<const f16x8*>(X + t * 32 * PITCH);
-#pragma unroll
-            for (int s = 0; s < QS; ++s) {
-                if (s + 1 < QS) {
-                    wa[(s + 1) & 1] = *reinterpret_cast<const f16x8*>(WA + (s + 1) * 1024);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) xf[(s + 1) & 1][t] = *reinterpret_cast<const f16x8*>(X + t * 32 * PITCH + (s + 1) * 32);
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s & 1], xf[s & 1][t], acc0[t], 0, 0, 0);
-            }
             const int y0 = ty * TR - 1, x0 = tx * 16 - 1;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            auto finish = [&](const f32x16& acc0, int t) {
                 if (p_off[t] >= 0) {
                     const bool inside = (unsigned)(y0 + (p_pos[t] >> 8)) < (unsigned)a.ih && (unsigned)(x0 + (p_pos[t] & 255)) < (unsigned)a.iw;
 #pragma unroll
@@ -163,10 +151,52 @@ __global__ __launch_bounds__(256, 2) void conv_pw_c64_patch_f16_kernel(const PwP
                         const f32x4 bj = *reinterpret_cast<const f32x4*>(ba + 8 * j);
                         f16x4 hv;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) hv[i] = si_store_cast<half_t>(silu(acc0[t][4 * j + i] + bj[i]));
+                        for (int i = 0; i < 4; ++i) hv[i] = si_store_cast<half_t>(silu(acc0[4 * j + i] + bj[i]));
                         if (!inside) hv = f16x4{(half_t)0.0f, (half_t)0.0f, (half_t)0.0f, (half_t)0.0f};
                         *reinterpret_cast<f16x4*>(patch + p_off[t] + j * 16) = hv;
                     }
+                }
+            };
+            if constexpr (CB == 64) {
+                // both pixel blocks side by side (every weight fragment read once)
+                f32x16 acc0[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc0[t][e] = 0.0f;
+                f16x8 xf[2][2], wa[2];
+                wa[0] = *reinterpret_cast<const f16x8*>(WA);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) xf[0][t] = *reinterpret_cast<const f16x8*>(X + t * x1);
+#pragma unroll
+                for (int s = 0; s < QS; ++s) {
+                    if (s + 1 < QS) {
+                        wa[(s + 1) & 1] = *reinterpret_cast<const f16x8*>(WA + (s + 1) * 1024);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) xf[(s + 1) & 1][t] = *reinterpret_cast<const f16x8*>(X + t * x1 + (s + 1) * 32);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc0[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s & 1], xf[s & 1][t], acc0[t], 0, 0, 0);
+                }
+                finish(acc0[0], 0);
+                finish(acc0[1], 1);
+            } else {
+                // one pixel block after the other (one accumulator set: three workgroups per CU leave 168 registers)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    if (t == 1 && !two) break;
+                    f32x16 acc0;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc0[e] = 0.0f;
+                    f16x8 xf[QS], wa[QS];
+#pragma unroll
+                    for (int s = 0; s < QS; ++s) {
+                        wa[s] = *reinterpret_cast<const f16x8*>(WA + s * 1024);
+                        xf[s] = *reinterpret_cast<const f16x8*>(X + t * x1 + s * 32);
+                    }
+#pragma unroll
+                    for (int s = 0; s < QS; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[s], xf[s], acc0, 0, 0, 0);
+                    finish(acc0, t);
                 }
             }
         }
@@ -237,19 +267,21 @@ int cu_count() {
 
 }  // namespace
 
-// the pair's shapes: a 3x3 stride-1 pad-1 conv over 64 -> 64 channels with SiLU (optional shortcut) on maps of whole 4 x 16 tiles, behind a
-// 1x1 conv + SiLU over the same 64 channels and the same map
+// the pair's shapes: a 3x3 stride-1 pad-1 conv over c -> c channels (c = 64 on maps of whole 4 x 16-pixel tiles, c = 32 of whole 8 x 16 ones)
+// with SiLU (optional shortcut), behind a 1x1 conv + SiLU over the same c channels and the same map
 bool si_conv_pw_patch_f16_ok(const SiConv2dDesc* pw, const SiConv2dDesc* d) {
     if (!pw || !d || !pw_patch_on()) return false;
-    const bool conv = d->groups == 1 && d->ic == 64 && d->oc == 64 && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 &&
-                      d->pt == 1 && d->pl == 1 && d->oh == d->ih && d->ow == d->iw && d->ow % 16 == 0 && d->oh % 4 == 0 && d->act1 == SI_ACT_SILU &&
-                      d->act2 == SI_ACT_NONE && (!d->has_residual || d->res_ld % 2 == 0) && d->n > 0;
+    const int c = d->ic;
+    if (c != 64 && c != 32) return false;
+    const bool conv = d->groups == 1 && d->oc == c && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 &&
+                      d->pt == 1 && d->pl == 1 && d->oh == d->ih && d->ow == d->iw && d->ow % 16 == 0 && d->oh % (c == 64 ? 4 : 8) == 0 &&
+                      d->act1 == SI_ACT_SILU && d->act2 == SI_ACT_NONE && (!d->has_residual || d->res_ld % 2 == 0) && d->n > 0;
     const bool pwc = pw->groups == 1 && pw->kh == 1 && pw->kw == 1 && pw->sh == 1 && pw->sw == 1 && pw->pt == 0 && pw->pl == 0 && pw->dh == 1 && pw->dw == 1 &&
-                     pw->ic == 64 && pw->oc == 64 && pw->n == d->n && pw->ih == d->ih && pw->iw == d->iw && pw->oh == d->ih && pw->ow == d->iw &&
+                     pw->ic == c && pw->oc == c && pw->n == d->n && pw->ih == d->ih && pw->iw == d->iw && pw->oh == d->ih && pw->ow == d->iw &&
                      pw->act1 == SI_ACT_SILU && pw->act2 == SI_ACT_NONE && !pw->has_residual && pw->in_ld % 8 == 0;
     if (!conv || !pwc) return false;
     const unsigned long long xb = (unsigned long long)pw->n * pw->ih * pw->iw * pw->in_ld * 2ull;
-    const long long items = (long long)d->n * (d->ow / 16) * (d->oh / 4);
+    const long long items = (long long)d->n * (d->ow / 16) * (d->oh / (c == 64 ? 4 : 8));
     return xb < 0xFFFFFF00ull && items <= 0x7fffffffLL;
 }
 
@@ -269,7 +301,7 @@ int si_conv_pw_patch_f16_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, c
     a.out = static_cast<half_t*>(out);
     a.ih = d->ih; a.iw = d->iw; a.x_ld = pw->in_ld; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
     a.x_bytes = (unsigned)((unsigned long long)pw->n * pw->ih * pw->iw * pw->in_ld * 2ull);
-    a.tiles_x = d->ow / 16; a.tiles_y = d->oh / 4;
+    a.tiles_x = d->ow / 16; a.tiles_y = d->oh / (d->ic == 64 ? 4 : 8);
     a.items = d->n * a.tiles_x * a.tiles_y;
     auto go = [&](auto kern) {
         const int per_cu = si_resident_blocks(kern, 256, 0);
@@ -278,5 +310,6 @@ int si_conv_pw_patch_f16_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, c
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, a);
         return (int)hipGetLastError();
     };
-    return d->has_residual ? go(conv_pw_c64_patch_f16_kernel<true>) : go(conv_pw_c64_patch_f16_kernel<false>);
+    if (d->ic == 32) return d->has_residual ? go(conv_pw_patch_f16_kernel<true, 32>) : go(conv_pw_patch_f16_kernel<false, 32>);
+    return d->has_residual ? go(conv_pw_patch_f16_kernel<true, 64>) : go(conv_pw_patch_f16_kernel<false, 64>);
 }

@@ -781,8 +781,9 @@ extern "C" int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dD
     if ((pw->has_bias && !pw_bias) || (conv->has_bias && !bias) || (conv->has_residual && !residual)) return SI_E_BADARG;
     if (si_conv_pw_patch_f16_ok(pw, conv)) {
         // (si_hip_conv2d_f16_pack_weight_host: the row-major image, then the lane-order one)
-        const half_t* const wA = static_cast<const half_t*>(pw_w_packed) + (size_t)64 * 64;
-        const half_t* const wB = static_cast<const half_t*>(w_packed) + (size_t)64 * 9 * 64;
+        const size_t cc = (size_t)conv->ic * conv->ic;
+        const half_t* const wA = static_cast<const half_t*>(pw_w_packed) + cc;
+        const half_t* const wB = static_cast<const half_t*>(w_packed) + 9 * cc;
         return si_conv_pw_patch_f16_launch(pw, conv, in, wA, pw_bias, wB, bias, residual, out, static_cast<hipStream_t>(stream));
     }
     SlabPlan p;

@@ -591,7 +591,7 @@ const char* Conv2d::KernelName() const {
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
     if (stem_producer_) return "conv_stem_s2c32_f16_kernel";
-    if (pw_producer_) return "conv3x3s1_slab_f16_kernel<pw + 3x3>";
+    if (pw_producer_) return in_channels_ <= 64 ? "conv_pw_patch_f16_kernel<pw + 3x3>" : "conv3x3s1_slab_f16_kernel<pw + 3x3>";
     SiConv2dDesc d = MakeDesc(in, out);
     if (sibling_) d.oc += sibling_->out_channels_;
     const int mode = PrecisionMode(in, out);

@@ -194,19 +194,20 @@ def test_stem_pair_in_one_launch_with_fp16_storage(si, tmp_path):
 
 
 def test_bottleneck_pairs_in_one_launch_with_fp16_storage(si, tmp_path):
-    """Round 5 (FuseBottleneckPairs, si_hip_conv2d_pw_slab_f16): with fp16 storage, on a grid that covers the chip, the 1x1 conv of a C3
-    bottleneck over 128 channels is computed inside the slab kernel of the 3x3 conv behind it -- YOLOv5s 640x640 at batch 32: the five
-    40x40 pairs, five launches and five tensor round trips less.  Not a bit of difference against fuse_pw=0; a small batch (grid below
-    the chip) keeps two launches; hipGraph replay and repeated forwards agree; the fp32 schedule is untouched."""
+    """Round 5 (FuseBottleneckPairs, si_hip_conv2d_pw_slab_f16): with fp16 storage the 1x1 conv of a C3 bottleneck is computed inside
+    the kernel of the 3x3 conv behind it -- over 128 channels in the slab kernel when its grid covers the chip, over 64 channels in the
+    persistent patch kernel (also the 160x160x32 pair).  YOLOv5s 640x640 at batch 32: the five 40x40 pairs, the three 80x80 pairs and
+    the 160x160 one, nine launches and nine tensor round trips less.  Not a bit of difference against fuse_pw=0; at a small batch the 128-channel pairs keep two launches;
+    hipGraph replay and repeated forwards agree; the fp32 schedule is untouched."""
     pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(32, 640), "bp32")
     x = si.modelgen.synth_input((32, 640, 640, 3))
     e1, oname, fused = _run(si, pp, bp, x, fp16=1)
     e0, _, plain = _run(si, pp, bp, x, fp16=1, fuse_pw=0)
     assert_exact(fused, plain, "fp16: bottleneck pairs in one launch vs two")
     s1, s0 = e1.schedule(), e0.schedule()
-    assert len(s0["run"]) == len(s1["run"]) + 5, (len(s0["run"]), len(s1["run"]))
+    assert len(s0["run"]) == len(s1["run"]) + 9, (len(s0["run"]), len(s1["run"]))
     k1 = [L["kernel"] for L in e1.profile()]
-    assert k1.count("conv3x3s1_slab_f16_kernel<pw + 3x3>") == 5, k1
+    assert k1.count("conv3x3s1_slab_f16_kernel<pw + 3x3>") == 5 and k1.count("conv_pw_patch_f16_kernel<pw + 3x3>") == 4, k1
     assert not any("pw + 3x3" in L["kernel"] for L in e0.profile())
     for _ in range(2):
         e1.forward()
@@ -214,12 +215,13 @@ def test_bottleneck_pairs_in_one_launch_with_fp16_storage(si, tmp_path):
     eg, _, replay = _run(si, pp, bp, x, fp16=1, graph=1)
     eg.forward()
     assert_exact(eg.extract(oname), plain, "hipGraph replay")
-    # the same file served at batch 2: the 3x3 convs' grids do not cover the chip, nothing is fused, and an image's bits are the same
+    # the same file served at batch 2: the slab grids do not cover the chip, only the 64-channel pairs are fused, and an image's bits are the same
     e2 = si.Engine(fp16=1, batch=2)
     e2.load_model(pp, bp)
     e2.input("0", x[:2])
     e2.forward()
-    assert not any("pw + 3x3" in L["kernel"] for L in e2.profile())
+    k2 = [L["kernel"] for L in e2.profile()]
+    assert not any("slab_f16_kernel<pw + 3x3>" in k for k in k2) and k2.count("conv_pw_patch_f16_kernel<pw + 3x3>") == 4, k2
     assert_exact(e2.extract(oname), plain[:2], "batch 2 (two launches per pair) vs batch 32 (one)")
     e32 = si.Engine()
     e32.load_model(pp, bp)

@@ -426,6 +426,8 @@ def test_slab_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, hh, ww, ic, o
     (2, 16, 32, 64, True),        # 64 channels: the persistent patch form (conv_pw_patch_f16.hip), 4 x 16-pixel tiles, more items than ...
     (1, 80, 80, 64, True),        # ... YOLOv5s' 80x80 bottleneck
     (3, 8, 16, 64, False),        # two tiles per image, every patch touches three image borders
+    (2, 16, 48, 32, True),        # 32 channels (YOLOv5s' first C3): 8 x 16-pixel tiles, 180-pixel patches in six pixel blocks
+    (1, 8, 16, 32, False),
 ])
 def test_bottleneck_pair_in_one_launch_same_bits(hops, orc, gpu, n, hh, ww, c, res):
     """Round 5: the C3 bottleneck's 1x1 conv + SiLU computed inside the slab kernel of the 3x3 conv that follows it
