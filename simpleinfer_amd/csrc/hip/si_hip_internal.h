@@ -80,8 +80,8 @@ __device__ __forceinline__ unsigned si_pair_halves(float v0, float v1, bool odd)
 // YOLOv5 Detect decode of one workgroup's conv tile, straight-line form for a tile that lies inside ONE image and below M
 // (reference src/layer/yolo_detect.cpp:223-266: sigmoid, xy = (2s + grid) * stride, wh = (2s)^2 * anchor, rows
 // [img][row_off + pix*na + anchor][ne]).  Per lane (= output channel) the element kind, the grid / anchor pointer and
-// the output pointer are fixed before the 16-element loop; per element: sigmoid, one masked 4-byte load for the four
-// box channels, two selects, one store.  Args: the conv kernels' argument structs (ocg, bias, yna, yne, ohow, ygrid,
+// the output pointer are fixed before the 16-element loop; per element: sigmoid and one store, for the waves that hold box
+// columns also one masked 4-byte load and a bit-select.  Args: the conv kernels' argument structs (ocg, bias, yna, yne, ohow, ygrid,
 // yanchor, ystride, yrows_total, yrow_off).  C/D map of the 32x32 MFMA tile as everywhere: col = lane&31 (channel),
 // row = (e&3) + 8*(e>>2) + 4*(lane>>5) (pixel).
 // MT: the MFMA tile the accumulators come from -- 32 (16 registers, rows (e&3) + 8*(e>>2)) or 16 (v_mfma_f32_16x16x4_f32: 4
@@ -101,31 +101,44 @@ __device__ __forceinline__ void si_yolo_tile_one_image(const Args& a, float* out
         const int e_ = oo - anc * a.yne;
         const bool is_xy = e_ < 2, is_box = e_ < 4;
         const float* const auxp = (is_xy ? a.ygrid + e_ : a.yanchor + (is_box ? e_ - 2 : 0)) + anc * 2;
+        // a wave whose columns hold no box entry (x, y, w, h of an anchor: 12 of 255 columns, in three of eight 32-column blocks)
+        // never sees the box arithmetic (wave-uniform branch)
+        const bool any_box = __builtin_amdgcn_ballot_w64(is_box && live) != 0ull;
+        const unsigned mxy = is_xy ? ~0u : 0u, mwh = (is_box && !is_xy) ? ~0u : 0u, msg = is_box ? 0u : ~0u;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int pix0 = mrow0 + t * MT - img * a.ohow;
             float* const op = out + ((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix0 * per_pix + oo;
-            const float* const ap = auxp + (size_t)pix0 * a.yna * 2;
-            // the box lanes' grid / anchor values, ALL requested before the first one is used: with the load inside the element
-            // loop hipcc waits for each one in turn (16 L2 round trips per 32x32 block on the waves that own a box column)
             constexpr int NE = MT == 32 ? 16 : 4;
-            float auxv[NE];
+            // the sigmoid for every element, nothing else (round 5: the select chain below used to sit in this loop, and hipcc turned
+            // it into two exec-masked branches per element plus one around every store: ~25 instructions per element)
+            float v[NE];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) auxv[e] = 0.0f;
-            if (is_box) {
+            for (int e = 0; e < NE; ++e) v[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[t][u][e] + bv)));
+            if (any_box) {
+                const float* const ap = auxp + (size_t)pix0 * a.yna * 2;
+                // the box lanes' grid / anchor values, ALL requested before the first one is used: with the load inside the element
+                // loop hipcc waits for each one in turn (16 L2 round trips per 32x32 block on the waves that own a box column)
+                float auxv[NE];
 #pragma unroll
-                for (int e = 0; e < NE; ++e) auxv[e] = ap[(MT == 32 ? (e & 3) + 8 * (e >> 2) : e) * a.yna * 2];
+                for (int e = 0; e < NE; ++e) auxv[e] = 0.0f;
+                if (is_box) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) auxv[e] = ap[(MT == 32 ? (e & 3) + 8 * (e >> 2) : e) * a.yna * 2];
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const float t2 = v[e] * 2.0f;
+                    const float xy = (t2 + auxv[e]) * a.ystride;
+                    const float wh = t2 * t2 * auxv[e];
+                    // (the same three values as `is_xy ? xy : (is_box ? wh : sg)`, selected by bit masks: no branches)
+                    v[e] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, xy) & mxy) | (__builtin_bit_cast(unsigned, wh) & mwh) |
+                                                         (__builtin_bit_cast(unsigned, v[e]) & msg));
+                }
             }
+            if (live) {
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int dm = MT == 32 ? (e & 3) + 8 * (e >> 2) : e;
-                const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(acc[t][u][e] + bv)));
-                const float aux = auxv[e];
-                const float t2 = sg * 2.0f;
-                const float xy = (t2 + aux) * a.ystride;
-                const float wh = t2 * t2 * aux;
-                const float v = is_xy ? xy : (is_box ? wh : sg);
-                if (live) op[dm * per_pix] = v;
+                for (int e = 0; e < NE; ++e) op[(MT == 32 ? (e & 3) + 8 * (e >> 2) : e) * per_pix] = v[e];
             }
         }
     }
