@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-aux", action="store_true", help="skip the host-I/O and post-processing side measurements")
     ap.add_argument("--no-secondary", action="store_true", help="skip the bounded secondary configurations (fp16, ResNet18 b64, batch 8 / 4)")
     ap.add_argument("--secondary-time", type=float, default=1.0, help="seconds of timed windows per secondary configuration")
+    ap.add_argument("--secondary-warmup", type=float, default=0.3, help="seconds of untimed forwards in front of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24, help="images in the batch-1 CPU baseline sample")
     ap.add_argument("--cpu-batch", type=int, default=16, help="batch of the batched CPU baseline samples (BASELINE.md section 3); the three CPU legs together are bounded to ~20 s")
@@ -312,8 +313,8 @@ def roofline_from_profile(passes, fp16=False, workload=None):
 def secondary_measurements(args, si, hipops, H, mg, td, dev):
     """BASELINE.json's other single-GPU configurations and the per-GPU batches of the headline metric's 4 / 8-GPU points, in the
     driver's line: YOLOv5s fp16 batch 32 (configs[3]), ResNet18 224x224 fp32 batch 64 (configs[2]), YOLOv5s
-    fp32 batch 8 and batch 4 (batch 32 over 4 / 8 GPUs).  Each: device-resident input, >= --secondary-time seconds of 10-step
-    windows after a warm-up, median window.  `value` of the line stays the fp32 batch-32 headline; these are bounded (~6 s of
+    fp32 batch 8 and batch 4 (batch 32 over 4 / 8 GPUs).  Each: device-resident input, >= --secondary-time seconds of ~80 ms
+    windows after --secondary-warmup seconds of forwards, median window.  `value` of the line stays the fp32 batch-32 headline; these are bounded (~6 s of
     timing) side figures with the roofline each one sits under: fp32 nets against the conv-GEMM MFMA ceiling (direct-conv
     FLOPs / 157.3 TF/s), the fp16 net against HBM (algorithmic bytes of its conv layers / 8 TB/s) as BASELINE.md prices it."""
     out = {}
@@ -332,10 +333,18 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
             e.load_model(pp, bp)
             dx = hipops.DeviceBuffer.from_numpy(mg.synth_input(shape, seed=1))
             e.input_device(e.input_names()[0], dx.ptr)
-            for _ in range(3):
+            # warm-up by TIME (the clocks have followed the PCIe-bound side measurements down; three forwards of a 1 ms step do not
+            # bring them back), then windows of about the headline leg's length (20 steps x 4.2 ms), at least 10 steps each
+            t0 = time.perf_counter()
+            nw = 0
+            while nw < 3 or time.perf_counter() - t0 < args.secondary_warmup:
                 e.forward()
+                nw += 1
+                if nw % 8 == 0:
+                    H.si_hip_device_sync()
             H.si_hip_device_sync()
-            steps, ws, total = 10, [], 0.0
+            est = (time.perf_counter() - t0) / nw
+            steps, ws, total = max(10, min(100, int(0.08 / max(est, 1e-4)))), [], 0.0
             while total < args.secondary_time:
                 t0 = time.perf_counter()
                 for _ in range(steps):
@@ -345,7 +354,7 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
                 total += ws[-1]
             ws.sort()
             dt = ws[len(ws) // 2] / steps
-            rec = {"value": round(batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "windows": len(ws),
+            rec = {"value": round(batch / dt, 1), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "windows": len(ws), "steps_per_window": steps,
                    "workload": "%s %dx%d %s batch %d" % (model, shape[1], shape[2], "fp16" if fp16 else "fp32", batch)}
             # every entry carries its dominant kernel the way the headline does: template, largest instantiation with
             # the roofline IT sits under, PMC traffic when a table was recorded for this workload; a Winograd kernel is credited with
