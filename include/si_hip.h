@@ -231,6 +231,11 @@ typedef struct SiYoloLevel {
 int si_hip_conv2d_yolo_f32(const SiConv2dDesc* d, const float* in, const float* w_packed, const float* bias,
                            const SiYoloLevel* level, const float* grid_hwa2, const float* anchor_hwa2,
                            float* detect_out, si_stream_t stream);
+/* the same on the f32_split arithmetic (si_hip_conv2d_split3_f32 above: weights from si_hip_conv2d_split3_pack_weight_host; channel counts
+ * that are multiples of 64, more than 64 columns) -- engine option f32_split */
+int si_hip_conv2d_split3_yolo_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias,
+                                  const SiYoloLevel* level, const float* grid_hwa2, const float* anchor_hwa2,
+                                  float* detect_out, si_stream_t stream);
 
 /* ---- Linear ------------------------------------------------------------ */
 /* y[n,out] = x[n,in] W[out,in]^T + b   (src/layer/linear.cpp:74-117) */

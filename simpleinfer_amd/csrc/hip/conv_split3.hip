@@ -48,6 +48,12 @@ struct Split3Args {
     int act1, act2;
     float act_param;
     unsigned in_bytes;
+    // YOLO: the Detect decode in the epilogue (si_yolo_tile_one_image's argument names; conv_igemm.hip ConvArgs)
+    int ocg;
+    int yna, yne, yrows_total, yrow_off;
+    float ystride;
+    const float* ygrid;
+    const float* yanchor;
 };
 
 __device__ __forceinline__ int fdiv(int n, int d, unsigned mg) {
@@ -74,7 +80,9 @@ constexpr float kLoScale = 2048.0f;   // 2^11
 
 // BM x (32 WN) workgroup tile, WM x WN waves (a wave: BM / WM rows x 32 columns of its own -- 1 x 4 for >= 128 output channels: every
 // weight fragment fetched once per workgroup; 2 x 2 for 64), BKH-channel K-tiles (64; 32 for 32-channel layers)
-template <int BM, int WM, int WN, int BKH>
+// YOLO: a Detect level (1x1 conv to na * ne columns) with the decode of src/layer/yolo_detect.cpp:223-266 in the epilogue, written into the
+// [n][rows_total][ne] detections -- the fp32 kernels' epilogue (si_yolo_tile_one_image) on the combined accumulators
+template <int BM, int WM, int WN, int BKH, bool YOLO = false>
 __global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Args a) {
     static_assert(WM * WN == 4 && (BKH == 64 || BKH == 32), "4 waves; 64- or 32-channel K-tiles");
     constexpr int BN = 32 * WN, LDH = BKH + 8, QS = BKH / 16;
@@ -226,6 +234,42 @@ __global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Arg
     }
     if (kt < nk) k_tile(kt, std::integral_constant<int, 0>{});
 
+    if constexpr (YOLO) {
+        f32x16 accc[TM][1];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accc[t][0][e] = acc_h[t][e] + acc_x[t][e] * (1.0f / kLoScale);
+        const int mrow0 = m0 + wm * TM * 32 + 4 * lh;
+        const int img0 = fdiv(m0, a.ohow, a.mg_ohow);
+        if (m0 + BM <= a.M && m0 - img0 * a.ohow + BM <= a.ohow) {   // (workgroup-uniform: the tile lies inside one image)
+            si_yolo_tile_one_image<TM, 1>(a, a.out, accc, mrow0, o, img0);
+        } else if (o < a.oc) {
+            // a tile across image borders (the 20 x 20 level: 400 pixels per image) or the last, partial one: element by element
+            const int per_pix = a.yna * a.yne;
+            const int anc = o / a.yne, e_ = o - anc * a.yne;
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mrow0 + t * 32 + (e & 3) + 8 * (e >> 2);
+                    if (m < a.M) {
+                        const int img = fdiv(m, a.ohow, a.mg_ohow), pix = m - img * a.ohow;
+                        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(accc[t][0][e] + bv)));
+                        const size_t row = (size_t)pix * a.yna + anc;
+                        float v = sg;
+                        if (e_ < 2) {
+                            v = (sg * 2.0f + a.ygrid[row * 2 + e_]) * a.ystride;
+                        } else if (e_ < 4) {
+                            const float t2 = sg * 2.0f;
+                            v = t2 * t2 * a.yanchor[row * 2 + (e_ - 2)];
+                        }
+                        a.out[((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix * per_pix + o] = v;
+                    }
+                }
+        }
+        return;
+    }
     // epilogue: the two scales meet, then bias / activation / shortcut / activation (C/D map: col = lane & 31, rows (e & 3) + 8 (e >> 2) + 4 lh)
     if (o < a.oc) {
 #pragma unroll
@@ -288,8 +332,8 @@ int si_hip_conv2d_split3_pack_weight_host(const SiConv2dDesc* d, const float* w_
     return 0;
 }
 
-int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const float* residual, float* out,
-                             si_stream_t stream) {
+static int split3_launch(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const float* residual, float* out,
+                         si_stream_t stream, const SiYoloLevel* yolo, const float* ygrid, const float* yanchor) {
     if (!d || !in || !w_packed || !out) return SI_E_BADARG;
     if (!split3_ok(d) || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
     if ((d->has_bias && !bias) || (d->has_residual && !residual)) return SI_E_BADARG;
@@ -313,6 +357,14 @@ int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void*
     a.mg_ow = d->ow > 1 ? (unsigned)(0x100000000ull / (unsigned)d->ow) : 0xFFFFFFFFu;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
     a.in_bytes = (unsigned)in_bytes;
+    a.ocg = d->oc;
+    a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.0f; a.ygrid = a.yanchor = nullptr;
+    if (yolo) {
+        const bool pointwise = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow;
+        if (!pointwise || d->has_residual || yolo->na * yolo->ne != d->oc || !ygrid || !yanchor || d->ic % 64 != 0 || d->oc <= 64) return SI_E_UNSUPPORTED;
+        a.yna = yolo->na; a.yne = yolo->ne; a.yrows_total = yolo->rows_total; a.yrow_off = yolo->row_off; a.ystride = yolo->stride;
+        a.ygrid = ygrid; a.yanchor = yanchor;
+    }
     int cus = 256;
     {
         int dev = 0, n = 0;
@@ -332,11 +384,23 @@ int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void*
     // waves otherwise, 128 x 128 for >= 512 output channels on a grid that still covers the chip twice (a weight fragment then feeds four
     // pixel blocks: half the L2 -> L1 weight traffic per FLOP; measured 117 vs 125 us on 40x40x256 -> 512, 139 vs 118 on 80x80x128 -> 256)
     static const int forced_bm = [] { const char* e = getenv("SI_SPLIT3_BM"); return e ? atoi(e) : 0; }();
+    if (yolo) return go(conv_split3_f32_kernel<64, 1, 4, 64, true>, 64, 128, 64);
     if (split3_blk(d) == 32) return d->oc <= 64 ? go(conv_split3_f32_kernel<128, 2, 2, 32>, 128, 64, 32) : go(conv_split3_f32_kernel<64, 1, 4, 32>, 64, 128, 32);
     if (d->oc <= 64) return go(conv_split3_f32_kernel<128, 2, 2, 64>, 128, 64, 64);
     const long long tiles128 = (((long long)a.M + 127) / 128) * ((d->oc + 127) / 128);
     const bool big = forced_bm ? forced_bm == 128 : (d->oc >= 512 && tiles128 >= 2LL * cus);
     return big ? go(conv_split3_f32_kernel<128, 1, 4, 64>, 128, 128, 64) : go(conv_split3_f32_kernel<64, 1, 4, 64>, 64, 128, 64);
+}
+
+int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const float* residual, float* out,
+                             si_stream_t stream) {
+    return split3_launch(d, in, w_packed, bias, residual, out, stream, nullptr, nullptr, nullptr);
+}
+
+int si_hip_conv2d_split3_yolo_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const SiYoloLevel* level,
+                                  const float* grid, const float* anchor_grid, float* out, si_stream_t stream) {
+    if (!level) return SI_E_BADARG;
+    return split3_launch(d, in, w_packed, bias, nullptr, out, stream, level, grid, anchor_grid);
 }
 
 }  // extern "C"

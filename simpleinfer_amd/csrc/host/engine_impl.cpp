@@ -295,7 +295,10 @@ Status EngineImpl::CreateLayers() {
             return ret;
         }
         layer->SetContext(context_);
-        if (YoloDetect* yd = dynamic_cast<YoloDetect*>(layer)) yd->fuse_decode_ = opt_fuse_;
+        if (YoloDetect* yd = dynamic_cast<YoloDetect*>(layer)) {
+            yd->fuse_decode_ = opt_fuse_;
+            for (Conv2d& cv : yd->conv_2d_layer_) cv.f32_split_ = opt_f32_split_ && !opt_fp16_ && opt_fuse_;
+        }
         if (Conv2d* cv = dynamic_cast<Conv2d*>(layer)) {
             if (!opt_winograd_) cv->algo_ = Conv2d::Algo::kImplicitGemm;
             cv->prefer_wino43_ = opt_winograd_ == 2;

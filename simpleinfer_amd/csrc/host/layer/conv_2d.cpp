@@ -308,6 +308,9 @@ Status Conv2d::PrepareDeviceHalf(const SiConv2dDesc& d) {
 // which kernel family serves this (input, output) storage pair; a non-stem conv fed an fp32 tensor inside an fp16 graph
 // converts its input first (in_half_)
 // (4: fp32 tensors, the contraction on the fp16 matrix cores by operand splitting -- engine option f32_split, opt-in)
+// Detect levels under f32_split: from this channel count on (tools/split3_check.py --detect; profiles/r05_f32_split_detect.txt)
+static int kSplit3DetectMinChannels = [] { const char* e = getenv("SI_SPLIT3_DETECT_MIN_C"); return e ? atoi(e) : 128; }();
+
 bool Conv2d::UseSplit3() const {
     if (!f32_split_ || sibling_ || up_node_ || stem_producer_ || groups_ != 1 || dilation_h_ != 1 || dilation_w_ != 1) return false;
     SiConv2dDesc d;
@@ -557,7 +560,9 @@ Status Conv2d::MakeUpsampledSource(SiConv2dUpsampledSource& up) const {
 // Detect-head variant: device tensors only (called by YoloDetect inside its own RunOnDevice scope)
 Status Conv2d::ForwardYolo(const Tensor& input, const SiYoloLevel& level, const float* grid_dev, const float* anchor_dev,
                            Tensor& detect_out) {
-    const int mode = IsHalf(input) ? 1 : 0;
+    // (f32_split: the Detect levels take the three-fp16-products kernel too -- YOLOv5s batch 32: 147 -> 118, 64 -> 43, 33 -> 26 us per
+    // level, +3 % on the network; profiles/r05_f32_split_detect.txt)
+    const int mode = IsHalf(input) ? 1 : ((f32_split_ && in_channels_ % 64 == 0 && in_channels_ >= kSplit3DetectMinChannels && out_channels_ > 64) ? 4 : 0);
     CHECK_STATUS(PrepareDevice(mode));
     Dims4 in;
     if (!GetDims4(input, in) || in.c != in_channels_) return Status::kErrorShape;
@@ -565,6 +570,14 @@ Status Conv2d::ForwardYolo(const Tensor& input, const SiYoloLevel& level, const 
     Tensor conv_out(DataType::kFloat32, {in.n, in.h, in.w, out_channels_}, MemoryType::kDevice, false);  // shape only
     SiConv2dDesc d = MakeDesc(input, conv_out);
     d.act1 = d.act2 = SI_ACT_NONE;
+    if (mode == 4) {
+        const int rc = si_hip_conv2d_split3_yolo_f32(&d, input.Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                     &level, grid_dev, anchor_dev, detect_out.Data<float>(), Stream());
+        if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d+yolo (fp32 by three fp16 products)");
+        f32_split_ = false;   // an unaligned view: the true-fp32 kernel from here on
+        device_ready_ = false;
+        return ForwardYolo(input, level, grid_dev, anchor_dev, detect_out);
+    }
     if (mode == 1) {
         const int rc = si_hip_conv2d_yolo_f16(&d, input.RawData(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
                                               &level, grid_dev, anchor_dev, detect_out.Data<float>(), Stream());

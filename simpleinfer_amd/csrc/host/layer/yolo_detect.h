@@ -28,6 +28,7 @@ public:
     virtual const char* KernelName() const override {
         const bool half = !input_tensor_nodes_.empty() && IsHalf(input_tensor_nodes_[0]->tensor);
         if (half) return fuse_decode_ ? "conv_igemm_f16(yolo epilogue)" : "conv_igemm_f16+yolo_decode";
+        if (fuse_decode_ && conv_2d_layer_[0].f32_split_) return "conv_igemm_f32 / conv_split3_f32(yolo epilogue)";
         return fuse_decode_ ? "conv_igemm_f32(yolo epilogue)" : "conv_igemm_f32+yolo_decode";
     }
     virtual double Flops() const override;

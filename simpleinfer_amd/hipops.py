@@ -457,7 +457,13 @@ def yolo_detect(feats, weights, biases, grids, anchor_grids, strides, na=3, fuse
     return dout.to_numpy((n, rows_total, ne))
 
 
-def _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na):
+def yolo_detect_split3(feats, weights, biases, grids, anchor_grids, strides, na=3):
+    """si_hip_conv2d_split3_yolo_f32 per level: the Detect head on the f32_split arithmetic (fp32 features, three fp16 MFMA products per
+    fp32 product), decode + concat in the epilogue."""
+    return _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na, split3=True)
+
+
+def _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na, split3=False):
     from ._native import SiYoloLevel
     H = _native.hip()
     feats = [_f32(f) for f in feats]
@@ -471,14 +477,19 @@ def _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na)
         _, h, wd, cin = f.shape
         w = _f32(w)
         d = SiConv2dDesc(n, h, wd, cin, cin, h, wd, na * ne, na * ne, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, na * ne, 0, 0.0)
-        packed = np.zeros(H.si_hip_conv2d_weight_elems(C.byref(d)), np.float32)
-        _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack")
+        if split3:
+            packed = np.zeros(H.si_hip_conv2d_split3_weight_elems(C.byref(d)), np.float16)
+            _chk(H.si_hip_conv2d_split3_pack_weight_host(C.byref(d), w.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack")
+        else:
+            packed = np.zeros(H.si_hip_conv2d_weight_elems(C.byref(d)), np.float32)
+            _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack")
         g2 = _f32(np.transpose(_f32(g)[0], (1, 2, 0, 3)))
         a2 = _f32(np.transpose(_f32(a)[0], (1, 2, 0, 3)))
         bufs = [DeviceBuffer.from_numpy(v) for v in (f, packed, _f32(b), g2, a2)]
         lv = SiYoloLevel(na, ne, rows_total, off, float(s))
-        _chk(H.si_hip_conv2d_yolo_f32(C.byref(d), bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, C.byref(lv), bufs[3].ptr, bufs[4].ptr,
-                                      dout.ptr, None), "si_hip_conv2d_yolo_f32")
+        fn = H.si_hip_conv2d_split3_yolo_f32 if split3 else H.si_hip_conv2d_yolo_f32
+        _chk(fn(C.byref(d), bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, C.byref(lv), bufs[3].ptr, bufs[4].ptr, dout.ptr, None),
+             "si_hip_conv2d_split3_yolo_f32" if split3 else "si_hip_conv2d_yolo_f32")
         sync()
         off += h * wd * na
     return dout.to_numpy((n, rows_total, ne))

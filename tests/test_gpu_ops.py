@@ -461,6 +461,25 @@ def test_yolo_detect_head(hops, orc, n, levels):
     assert_detect_parity(hops.yolo_detect(feats, ws, bs, grids, anchors, strides, na, fused=True), ref, what="decode fused in conv epilogue")
 
 
+@pytest.mark.parametrize("n,levels", [(2, ((16, 128), (8, 256), (4, 512))), (5, ((8, 64), (5, 128), (3, 192)))])
+def test_yolo_detect_head_f32_split(hops, orc, n, levels):
+    """si_hip_conv2d_split3_yolo_f32 (round 5, engine option f32_split): the Detect levels on the three-fp16-products arithmetic with the
+    decode of src/layer/yolo_detect.cpp:223-266 in the epilogue -- the fp32 bars of test_yolo_detect_head.  Whole 64-pixel tiles
+    inside one image (the straight-line decode) and, in the second case, 64 / 25 / 9 pixels per image: tiles across image borders."""
+    na, ne = 3, 85
+    feats, ws, bs, grids, anchors = [], [], [], [], []
+    for i, (h, c) in enumerate(levels):
+        feats.append(rng_uniform(250 + i, (n, h, h, c), -1, 1))
+        ws.append(rng_uniform(260 + i, (na * ne, c, 1, 1), -0.3, 0.3))
+        bs.append(rng_uniform(270 + i, (na * ne,), -0.5, 0.5))
+        gy, gx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="ij")
+        grids.append(np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, h, h, 2)).copy())
+        anchors.append(np.broadcast_to(rng_uniform(280 + i, (1, na, 1, 1, 2), 5, 300), (1, na, h, h, 2)).copy())
+    strides = [8.0, 16.0, 32.0]
+    ref = orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na)
+    assert_detect_parity(hops.yolo_detect_split3(feats, ws, bs, grids, anchors, strides, na), ref, what="Detect on the f32_split arithmetic")
+
+
 # ---- letterbox + detection post-processing (test/test_yolo/test_yolo.cpp:194-259, 337-428) ----
 def test_letterbox_exact(hops, orc):
     assert hops.letterbox_geometry(1080, 810, 640, 640) == orc.letterbox_geometry(1080, 810, 640, 640)

@@ -92,5 +92,59 @@ def main():
             buf.free()
 
 
+def detect():
+    """Detect levels of YOLOv5s batch 32: si_hip_conv2d_yolo_f32 vs si_hip_conv2d_split3_yolo_f32, ms per launch (graph of 30)."""
+    from simpleinfer_amd._native import SiYoloLevel
+    H = _native.hip()
+    n, na, ne = 32, 3, 85
+    rows_total = (80 * 80 + 40 * 40 + 20 * 20) * na
+    dout = hipops.DeviceBuffer(n * rows_total * ne * 4)
+    ev0, ev1, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    H.si_hip_event_create(C.byref(ev0)); H.si_hip_event_create(C.byref(ev1)); H.si_hip_stream_create(C.byref(st))
+    off = 0
+    for hw, c in ((80, 128), (40, 256), (20, 512)):
+        rng = np.random.default_rng(0)
+        d = SiConv2dDesc(n, hw, hw, c, c, hw, hw, na * ne, na * ne, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, na * ne, 0, 0.0)
+        w = ((rng.random((na * ne, c, 1, 1), dtype=np.float32) - 0.5) * 0.1)
+        pk32 = np.zeros(H.si_hip_conv2d_weight_elems(C.byref(d)), np.float32)
+        assert H.si_hip_conv2d_pack_weight_host(C.byref(d), w.ctypes.data_as(C.c_void_p), pk32.ctypes.data_as(C.c_void_p)) == 0
+        pk3 = np.zeros(H.si_hip_conv2d_split3_weight_elems(C.byref(d)), np.float16)
+        assert H.si_hip_conv2d_split3_pack_weight_host(C.byref(d), w.ctypes.data_as(C.c_void_p), pk3.ctypes.data_as(C.c_void_p)) == 0
+        dx = hipops.DeviceBuffer.from_numpy((rng.random((n, hw, hw, c), dtype=np.float32) - 0.5))
+        d32, d3 = hipops.DeviceBuffer.from_numpy(pk32), hipops.DeviceBuffer.from_numpy(pk3)
+        db = hipops.DeviceBuffer.from_numpy(rng.random(na * ne, dtype=np.float32))
+        dg = hipops.DeviceBuffer.from_numpy(rng.random((hw * hw * na, 2), dtype=np.float32))
+        da = hipops.DeviceBuffer.from_numpy(rng.random((hw * hw * na, 2), dtype=np.float32))
+        lv = SiYoloLevel(na, ne, rows_total, off, 8.0)
+
+        def timed(fn):
+            gx = C.c_void_p()
+            assert H.si_hip_graph_begin_capture(st) == 0
+            for _ in range(30):
+                assert fn() == 0
+            assert H.si_hip_graph_end_capture(st, C.byref(gx)) == 0
+            reps, ms = 2, C.c_float()
+            while True:
+                H.si_hip_event_record(ev0, st)
+                for _ in range(reps):
+                    H.si_hip_graph_launch(gx, st)
+                H.si_hip_event_record(ev1, st)
+                H.si_hip_event_sync(ev1)
+                H.si_hip_event_elapsed_ms(ev0, ev1, C.byref(ms))
+                if ms.value >= 300:
+                    break
+                reps *= 2
+            H.si_hip_graph_destroy(gx)
+            return ms.value / (reps * 30) * 1e3
+        for r in range(2):
+            t32 = timed(lambda: H.si_hip_conv2d_yolo_f32(C.byref(d), dx.ptr, d32.ptr, db.ptr, C.byref(lv), dg.ptr, da.ptr, dout.ptr, st))
+            t3 = timed(lambda: H.si_hip_conv2d_split3_yolo_f32(C.byref(d), dx.ptr, d3.ptr, db.ptr, C.byref(lv), dg.ptr, da.ptr, dout.ptr, st))
+            print("  Detect level %dx%dx%d: fp32 kernel %.1f us   split3 %.1f us   %.2fx" % (hw, hw, c, t32, t3, t32 / t3))
+        off += hw * hw * na
+
+
 if __name__ == "__main__":
-    main()
+    if "--detect" in sys.argv:
+        detect()
+    else:
+        main()
