@@ -288,9 +288,7 @@ bool si_conv_pw_patch_f16_ok(const SiConv2dDesc* pw, const SiConv2dDesc* d) {
 int si_conv_pw_patch_f16_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, const void* in, const void* wlA, const float* biasA, const void* wl,
                                 const float* bias, const void* residual, void* out, hipStream_t s) {
     if (!si_conv_pw_patch_f16_ok(pw, d)) return SI_E_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (pw->has_bias && (reinterpret_cast<uintptr_t>(biasA) & 15) != 0) ||
-        (d->has_residual && (reinterpret_cast<uintptr_t>(residual) & 1) != 0))
-        return SI_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (d->has_residual && (reinterpret_cast<uintptr_t>(residual) & 1) != 0)) return SI_E_UNSUPPORTED;
     PwPatchArgs a;
     a.x = static_cast<const half_t*>(in);
     a.wlA = static_cast<const half_t*>(wlA);
