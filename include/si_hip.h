@@ -442,6 +442,8 @@ int si_hip_conv2d_yolo_f16_tile(const SiConv2dDesc* d, const SiYoloLevel* level)
 int si_hip_activation_f16(int act, float act_param, const void* in, size_t pixels, int c, int in_ld, void* out, int out_ld,
                           si_stream_t stream);
 /* same-shape add (op 0) / mul (op 2) */
+/* UnaryOp on fp16 tensors (round 5): si_hip_unary_f32's function on the widened value, rounded once */
+int si_hip_unary_f16(int op, const void* in, size_t pixels, int c, int in_ld, void* out, int out_ld, si_stream_t stream);
 int si_hip_binary_same_f16(int op, const void* a, int a_ld, const void* b, int b_ld, void* out, int out_ld, size_t pixels,
                            int c, si_stream_t stream);
 /* out[b][p][c] = a[b][p][c] (op) s[b][c] (op: 0 add, 2 mul): the squeeze-excite scale -- BinaryOp whose second operand is

@@ -161,6 +161,7 @@ def hip():
         "si_hip_conv2d_stem_s2c32_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_yolo_f16_tile": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiYoloLevel)]),
         "si_hip_activation_f16": (i, [i, f, vp, sz, i, i, vp, i, vp]),
+        "si_hip_unary_f16": (i, [i, vp, sz, i, i, vp, i, vp]),
         "si_hip_binary_same_f16": (i, [i, vp, i, vp, i, vp, i, sz, i, vp]),
         "si_hip_binary_bcast_f16": (i, [i, vp, i, vp, i, vp, i, i, sz, i, vp]),
         "si_hip_maxpool2d_f16": (i, [C.POINTER(SiPool2dDesc), vp, vp, vp]),

@@ -170,32 +170,7 @@ __global__ void binary_scalar_kernel(int op, const float* __restrict__ in, int i
     }
 }
 
-// UnaryOp codes of expand_expression.cpp:146-165 (ncnn's numbering): 0 abs 1 neg 2 floor 3 ceil 4 square 5 sqrt 6 rsqrt 7 exp
-// 8 log 9 sin 10 cos 11 tan 12 asin 13 acos 14 atan 15 reciprocal 16 tanh 17 log10.  Library-accurate functions, IEEE sqrt and
-// division: this is a standalone arithmetic operator, not a fused epilogue.
-__device__ __forceinline__ float unary_apply(int op, float x) {
-    switch (op) {
-        case 0: return fabsf(x);
-        case 1: return -x;
-        case 2: return floorf(x);
-        case 3: return ceilf(x);
-        case 4: return x * x;
-        case 5: return sqrtf(x);
-        case 6: return 1.0f / sqrtf(x);
-        case 7: return expf(x);
-        case 8: return logf(x);
-        case 9: return sinf(x);
-        case 10: return cosf(x);
-        case 11: return tanf(x);
-        case 12: return asinf(x);
-        case 13: return acosf(x);
-        case 14: return atanf(x);
-        case 15: return 1.0f / x;
-        case 16: return tanhf(x);
-        case 17: return log10f(x);
-        default: return x;
-    }
-}
+// (si_unary_apply: si_hip_internal.h -- shared with the fp16-storage form in ops_f16.hip)
 template <bool VEC>
 __global__ void unary_kernel(int op, const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, size_t pixels, int c) {
     const int cv = VEC ? c / 4 : c;
@@ -207,10 +182,10 @@ __global__ void unary_kernel(int op, const float* __restrict__ in, int in_ld, fl
             const f32x4 x = *reinterpret_cast<const f32x4*>(in + p * in_ld + ch * 4);
             f32x4 r;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) r[k] = unary_apply(op, x[k]);
+            for (int k = 0; k < 4; ++k) r[k] = si_unary_apply(op, x[k]);
             *reinterpret_cast<f32x4*>(out + p * out_ld + ch * 4) = r;
         } else {
-            out[p * out_ld + ch] = unary_apply(op, in[p * in_ld + ch]);
+            out[p * out_ld + ch] = si_unary_apply(op, in[p * in_ld + ch]);
         }
     }
 }

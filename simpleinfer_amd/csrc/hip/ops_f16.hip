@@ -50,6 +50,25 @@ __global__ void activation_h_kernel(int act, float ap, const half_t* __restrict_
     }
 }
 
+// UnaryOp with fp16 storage (round 5): the fp32 function of ops.hip on the widened value, one rounding on the way out
+template <bool VEC>
+__global__ void unary_h_kernel(int op, const half_t* __restrict__ in, size_t pixels, int c, int in_ld, half_t* __restrict__ out, int out_ld) {
+    const int cv = VEC ? c / 8 : c;
+    const size_t total = pixels * (size_t)cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / cv;
+        const int ch = (int)(i - p * cv);
+        if (VEC) {
+            f16x8 v = *reinterpret_cast<const f16x8*>(in + p * in_ld + ch * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = si_store_cast<half_t>(si_unary_apply(op, (float)v[k]));
+            *reinterpret_cast<f16x8*>(out + p * out_ld + ch * 8) = v;
+        } else {
+            out[p * out_ld + ch] = si_store_cast<half_t>(si_unary_apply(op, (float)in[p * in_ld + ch]));
+        }
+    }
+}
+
 template <bool VEC>
 __global__ void binary_same_h_kernel(int op, const half_t* __restrict__ a, int a_ld, const half_t* __restrict__ b, int b_ld,
                                      half_t* __restrict__ out, int out_ld, size_t pixels, int c) {
@@ -204,6 +223,21 @@ int si_hip_activation_f16(int act, float act_param, const void* in, size_t pixel
     else
         hipLaunchKernelGGL(activation_h_kernel<false>, dim3(si_grid_for(pixels * (size_t)c)), dim3(256), 0, s, act, act_param,
                            i, pixels, c, in_ld, o, out_ld);
+    return (int)hipGetLastError();
+}
+
+int si_hip_unary_f16(int op, const void* in, size_t pixels, int c, int in_ld, void* out, int out_ld, si_stream_t stream) {
+    if (!in || !out || c <= 0 || in_ld < c || out_ld < c) return SI_E_BADARG;
+    if (op < 0 || op > 17) return SI_E_UNSUPPORTED;
+    if (pixels == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const half_t* i = static_cast<const half_t*>(in);
+    half_t* o = static_cast<half_t*>(out);
+    const bool vec = (c % 8 == 0) && (in_ld % 8 == 0) && (out_ld % 8 == 0) && al16(in) && al16(out);
+    if (vec)
+        hipLaunchKernelGGL(unary_h_kernel<true>, dim3(si_grid_for(pixels * (size_t)(c / 8))), dim3(256), 0, s, op, i, pixels, c, in_ld, o, out_ld);
+    else
+        hipLaunchKernelGGL(unary_h_kernel<false>, dim3(si_grid_for(pixels * (size_t)c)), dim3(256), 0, s, op, i, pixels, c, in_ld, o, out_ld);
     return (int)hipGetLastError();
 }
 

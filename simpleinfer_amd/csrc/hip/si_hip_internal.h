@@ -77,6 +77,33 @@ __device__ __forceinline__ unsigned si_pair_halves(float v0, float v1, bool odd)
     return __builtin_bit_cast(unsigned, p);
 }
 
+// UnaryOp codes of expand_expression.cpp:146-165 (ncnn's numbering): 0 abs 1 neg 2 floor 3 ceil 4 square 5 sqrt 6 rsqrt 7 exp
+// 8 log 9 sin 10 cos 11 tan 12 asin 13 acos 14 atan 15 reciprocal 16 tanh 17 log10.  Library-accurate functions, IEEE sqrt and
+// division: this is a standalone arithmetic operator, not a fused epilogue.
+__device__ __forceinline__ float si_unary_apply(int op, float x) {
+    switch (op) {
+        case 0: return fabsf(x);
+        case 1: return -x;
+        case 2: return floorf(x);
+        case 3: return ceilf(x);
+        case 4: return x * x;
+        case 5: return sqrtf(x);
+        case 6: return 1.0f / sqrtf(x);
+        case 7: return expf(x);
+        case 8: return logf(x);
+        case 9: return sinf(x);
+        case 10: return cosf(x);
+        case 11: return tanf(x);
+        case 12: return asinf(x);
+        case 13: return acosf(x);
+        case 14: return atanf(x);
+        case 15: return 1.0f / x;
+        case 16: return tanhf(x);
+        case 17: return log10f(x);
+        default: return x;
+    }
+}
+
 // YOLOv5 Detect decode of one workgroup's conv tile, straight-line form for a tile that lies inside ONE image and below M
 // (reference src/layer/yolo_detect.cpp:223-266: sigmoid, xy = (2s + grid) * stride, wh = (2s)^2 * anchor, rows
 // [img][row_off + pix*na + anchor][ne]).  Per lane (= output channel) the element kind, the grid / anchor pointer and

@@ -403,6 +403,21 @@ def unary_op(op, x, in_ld=None, out_ld=None):
     return dy.to_numpy((pixels, old))[:, :c].reshape(x.shape)
 
 
+def unary_op_f16(op, x, in_ld=None, out_ld=None):
+    """si_hip_unary_f16: UnaryOp on fp16 tensors (the fp32 function on the widened value, one rounding)."""
+    H = _native.hip()
+    x = _f16(x)
+    c = x.shape[-1]
+    pixels = x.size // c
+    ild, old = in_ld or c, out_ld or c
+    xin = np.full((pixels, ild), np.nan, np.float16)
+    xin[:, :c] = x.reshape(pixels, c)
+    dx, dy = DeviceBuffer.from_numpy(xin), DeviceBuffer(pixels * old * 2)
+    dy.fill(0)
+    _chk(H.si_hip_unary_f16(op, dx.ptr, pixels, c, ild, dy.ptr, old, None), "si_hip_unary_f16")
+    return dy.to_numpy((pixels, old), np.float16)[:, :c].reshape(x.shape)
+
+
 def activation(kind, x, param=0.0):
     H = _native.hip()
     x = _f32(x)

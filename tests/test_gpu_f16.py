@@ -477,6 +477,23 @@ def test_stem_s2c32_fused_same_bits(hops, orc, gpu, n, ih, iw, oc):
     assert_parity(got.astype(np.float32), ref, F16_TOL, what="fused stem + conv")
 
 
+@pytest.mark.parametrize("op", list(range(18)))
+def test_unary_ops_with_fp16_storage(hops, orc, op):
+    """si_hip_unary_f16 (round 5; UnaryOp of expand_expression.cpp:123-165 on fp16 tensors): the fp32 function of si_hip_unary_f32 on the
+    widened value with ONE rounding on the way out -- so the result is the oracle's value for the same (half) input, rounded to fp16,
+    up to the few-ulp freedom of the library functions (one fp16 ulp here); dense and strided."""
+    from test_oracle import unary_input
+    x = unary_input(op, (2, 7, 9, 24)).astype(np.float16)
+    ref = orc.unary_op(op, x.astype(np.float32))
+    for kw in ({}, {"in_ld": 40, "out_ld": 32}, {"in_ld": 27, "out_ld": 25}):
+        got = hops.unary_op_f16(op, x, **kw).astype(np.float32)
+        fin = np.isfinite(ref) & (np.abs(ref) < 6.0e4)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), "unary %d: NaN pattern" % op
+        want = ref.astype(np.float16).astype(np.float32)
+        ulp = np.maximum(np.abs(want) * 2.0 ** -10, 2.0 ** -24)
+        assert np.all(np.abs(got[fin] - want[fin]) <= ulp[fin] + 1e-30), ("unary %d %s" % (op, kw), np.abs(got[fin] - want[fin]).max())
+
+
 @pytest.mark.parametrize("n,levels,ne", [
     (3, ((20, 128), (10, 256), (5, 512)), 85),     # 400 / 100 / 25 pixels per image: whole tiles, a 16-pixel tail, a tile of 25
     (2, ((9, 256), (3, 128), (1, 512)), 85),       # 91 rows x 3: image bases only 4-byte aligned -> the dword form of the run
