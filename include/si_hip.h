@@ -358,7 +358,8 @@ int si_hip_f16_to_f32_host(const void* src, float* dst, size_t n);
  * 2: stem (ic <= 3; 6x6, 7x7 or 3x3 RGB kernels): fp32 input image, fp16 output, weights packed by
  *    si_hip_conv2d_stem_f16_pack_weight_host (csrc/hip/conv_stem_f16.hip)
  * 3: depthwise (groups == ic == oc, ic % 8 == 0): si_hip_conv2d_depthwise_f16
- * (1 also covers ungrouped 1x1 convs with ic % 8 == 0: the K axis is zero-padded to whole 32-channel blocks) */
+ * (1 also covers ungrouped convs with ic % 8 == 0: every tap's channels are zero-padded to whole 32-channel blocks; round 5: any kernel
+ * size, until then 1x1 only) */
 int si_hip_conv2d_f16_supported(const SiConv2dDesc* d);
 size_t si_hip_conv2d_f16_weight_elems(const SiConv2dDesc* d);
 /* OIHW fp32 -> two fp16 images of the same weights, one behind the other (si_hip_conv2d_f16_weight_elems counts both):

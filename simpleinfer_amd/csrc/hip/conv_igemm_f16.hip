@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvArgsH a) 
     auto load_tile = [&](u32x4 (&qa)[A_IT], u32x4 (&qb)[B_IT], int kt) {
         const unsigned delta = (unsigned)((ky * a.dh * a.iw + kx * a.dw) * a.in_ld + cb * BKH) * 2u;
         const int tapbit = ky * a.kw + kx;
-        // (a 1x1 conv whose channel count is a multiple of 8 but not of 32 has its K axis zero-padded to whole blocks in the weights:
+        // (a conv whose channel count is a multiple of 8 but not of 32 has every tap's channels zero-padded to whole blocks in the weights:
         // a vector that lies behind the last channel must read zeros, not the next pixel)
         const bool cok = cb * BKH + kv * 8 < a.icg;
         const bool from_up = UPS && cb >= a.up_cb0 && cb < a.up_cb1;   // wave-uniform: this K-tile's channels are upsampled ones
@@ -1154,7 +1154,7 @@ struct SplitOutH {
 };
 
 // channel-block size of the K order (a property of the packed weights, so of the layer's static shape only)
-// channels per tap in the packed weights: ic / groups, or -- ungrouped 1x1 convs with a channel count that is a multiple of 8 but
+// channels per tap in the packed weights: ic / groups, or -- ungrouped convs with a channel count that is a multiple of 8 but
 // not of 32 (MobileNet's pointwise and squeeze-excite convs: 16 / 24 / 40 / 72 / 96 ...) -- that rounded up to x32 with zero weights
 int f16_icg_pad(const SiConv2dDesc* d) {
     const int icg = d->ic / d->groups;
@@ -1166,7 +1166,9 @@ bool f16_shape_ok(const SiConv2dDesc* d) {
     if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return false;
     const int icg = d->ic / d->groups;
     if (icg % 32 == 0) return d->kh * d->kw <= 64;
-    return d->kh * d->kw == 1 && d->groups == 1 && icg % 8 == 0 && icg >= 8;
+    // (round 5: any ungrouped conv over a multiple of 8 channels -- until then only the 1x1 ones: every tap's channels are zero-padded to
+    // whole 32-channel blocks in the weights, and a 16-byte A vector behind the last channel reads zeros, not the next pixel)
+    return d->kh * d->kw <= 64 && d->groups == 1 && icg % 8 == 0 && icg >= 8;
 }
 
 // extents of the lane-order weight image (per group): 32-channel column blocks x 16-deep k-steps x 1 KB

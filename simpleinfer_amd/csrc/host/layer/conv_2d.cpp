@@ -666,7 +666,7 @@ bool Conv2d::HalfStorageOk(std::string& why) const {
     d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
     if (si_hip_conv2d_f16_supported(&d) != 0) return true;
     why = "no fp16 conv kernel for " + std::to_string(in_channels_) + " -> " + std::to_string(out_channels_) + " channels, groups " +
-          std::to_string(groups_) + " (needs ic / groups % 32 == 0, an ungrouped 1x1 conv with ic % 8 == 0, a depthwise conv with ic % 8 == 0, or an RGB stem)";
+          std::to_string(groups_) + " (needs ic / groups % 32 == 0, an ungrouped conv with ic % 8 == 0, a depthwise conv with ic % 8 == 0, or an RGB stem)";
     return false;
 }
 

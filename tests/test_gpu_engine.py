@@ -621,13 +621,19 @@ def test_fp16_layers_without_an_fp16_kernel_run_in_fp32_between_casts(si, orc, t
     ub = mg.PnnxBuilder(0)
     ux = ub.input((2, 3, 32, 32))
     ub.output(ub.expression("sqrt(@0)", [mg._Conv(ub, ux, 32, 3, 2)]))
-    for name, builder, shape in (("toy16", mg.build_toy_yolo(2, 64), (2, 64, 64, 3)), ("unary", ub, (2, 32, 32, 3))):
+    # (round 5: a narrow YOLOv5's convs -- multiples of 8 channels -- have fp16 kernels now; what still has none is a conv over a
+    # channel count that is not a multiple of 8: the 3x3 conv over 12 channels in 32 -> 12 -> 24 -> 16)
+    ob = mg.PnnxBuilder(1)
+    ox = ob.input((2, 3, 32, 32))
+    oy = mg._Conv(ob, mg._Conv(ob, ox, 32, 3, 2), 12, 1, 1)
+    ob.output(mg._Conv(ob, mg._Conv(ob, oy, 24, 3, 1), 16, 1, 1))
+    for name, builder, shape in (("odd12", ob, (2, 32, 32, 3)), ("unary", ub, (2, 32, 32, 3))):
         pp, bp = _save(tmp_path, builder, name)
         x = mg.synth_input(shape)
         ref = orc.run_graph(pp, bp, {"0": x})
         e, oname, got = _run(si, pp, bp, x, fp16=1)
         assert got.dtype == np.float32
-        check = _f16_check("yolo" if name == "toy16" else name)
+        check = _f16_check(name)
         (want,) = ref.values()   # (expression lowering renames the output operand on the engine side)
         if name == "unary":
             # sqrt of a negative SiLU output is NaN on both sides; fp16 storage of the conv output may flip the sign of values

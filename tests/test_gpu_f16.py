@@ -64,7 +64,7 @@ def test_conv_f16_fused_epilogue_strides_and_batch_invariance(hops, orc):
     full = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), act1="silu")
     assert_exact(hops.conv2d_f16(x[1:2], w, b, (1, 1), (1, 1), act1="silu")[0], full[1], "an image's result does not depend on the batch")
     with pytest.raises(hops.HipError):
-        hops.conv2d_f16(h(rng_uniform(5, (1, 8, 8, 24), -1, 1)), h(rng_uniform(6, (32, 24, 3, 3))), None)  # 3x3 with ic % 32 != 0
+        hops.conv2d_f16(h(rng_uniform(5, (1, 8, 8, 12), -1, 1)), h(rng_uniform(6, (32, 12, 3, 3))), None)  # ic % 8 != 0: no 16-byte channel vectors
 
 
 @pytest.mark.parametrize("ic,oc", [(16, 64), (24, 72), (40, 120), (72, 24), (96, 576), (8, 16), (144, 40)])
@@ -81,6 +81,26 @@ def test_conv_f16_pointwise_padded_k(hops, orc, ic, oc):
     assert_parity(hops.conv2d_f16(x, w, b, act1="hardswish").astype(np.float32), orc.activation("hardswish", ref), F16_TOL, what="hardswish")
     got = hops.conv2d_f16(x, w, b, in_ld=ic + 24, in_fill=np.nan)
     assert_parity(got.astype(np.float32), ref, F16_TOL, what="strided input, NaN beyond the channels")
+
+
+@pytest.mark.parametrize("ic,oc,k,s", [(8, 16, 3, 2), (24, 32, 3, 1), (40, 72, 5, 1), (16, 8, 3, 1), (72, 130, 3, 2)])
+def test_conv_f16_spatial_padded_k(hops, orc, ic, oc, k, s):
+    """Round 5: ANY ungrouped conv over a multiple of 8 channels has an fp16 kernel (until then the 1x1 ones only: a narrow YOLOv5's
+    3x3 convs ran in fp32 between two casts).  Every tap's channels are zero-padded to whole 32-channel blocks in the weights and a
+    vector behind the last channel reads zeros -- shown with NaNs between the pixels' channels of a wider input; borders, strides,
+    the fused epilogue, and an image's bits do not depend on its batch position (src/layer/conv_2d.cpp:207-283)."""
+    p = k // 2
+    x = h(rng_uniform(300 + ic, (3, 11, 9, ic), -1, 1))
+    w = h(rng_uniform(301 + ic, (oc, ic, k, k), -0.3, 0.3))
+    b = rng_uniform(302 + ic, (oc,), -0.5, 0.5)
+    ref = orc.conv2d(x, w, b, (s, s), (p, p), path="naive")
+    got = hops.conv2d_f16(x, w, b, (s, s), (p, p))
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="dense")
+    assert_parity(hops.conv2d_f16(x, w, b, (s, s), (p, p), out_f32=True), ref, 2e-5, what="fp32 out")
+    assert_parity(hops.conv2d_f16(x, w, b, (s, s), (p, p), act1="silu").astype(np.float32), orc.activation("silu", ref), F16_TOL, what="silu")
+    wide = hops.conv2d_f16(x, w, b, (s, s), (p, p), in_ld=ic + 24, in_fill=np.nan)
+    assert_exact(wide, got, "strided input, NaN beyond the channels")
+    assert_exact(hops.conv2d_f16(x[2:], w, b, (s, s), (p, p)), got[2:], "batch position")
 
 
 @pytest.mark.parametrize("n,hw,c,k,s,p", [(2, 14, 16, 3, 1, 1), (2, 15, 72, 5, 2, 2), (3, 7, 96, 3, 2, 1), (1, 9, 240, 5, 1, 2), (2, 6, 8, 3, 1, 1)])
