@@ -174,6 +174,17 @@ int si_hip_conv2d_split3_pack_weight_host(const SiConv2dDesc* d, const float* w_
 int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const float* residual, float* out,
                              si_stream_t stream);
 
+/* ---- fused Winograd F(2x2,3x3) with its plane GEMMs on the fp16 matrix cores by operand splitting (round 5, late; csrc/hip/conv_wino23_split.hip;
+ * OPT-IN: engine option f32_split).  si_hip_conv2d_wino23_f32's kernel around another channel loop: the transformed input V and the
+ * filter image U = G g G^T as two fp16 halves each, three fp16 MFMA products per fp32 product, fp32 accumulation in two accumulator
+ * sets.  fp32 tensors in and out; another arithmetic than the fp32 Winograd kernel.  Same eligibility as si_hip_conv2d_wino23_eligible;
+ * _weight_elems counts halves (two images). */
+int si_hip_conv2d_wino23_split_supported(const SiConv2dDesc* d);
+size_t si_hip_conv2d_wino23_split_weight_elems(const SiConv2dDesc* d);
+int si_hip_conv2d_wino23_split_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* u_packed);
+int si_hip_conv2d_wino23_split_f32(const SiConv2dDesc* d, const float* in, const void* u_packed, const float* bias, const float* residual,
+                                   float* out, si_stream_t stream);
+
 /* ---- Winograd F(2x2,3x3) for 3x3 stride-1 convolutions --------------------------------------------------------
  * One fused kernel replacing the reference's four-pass Conv2d::ForwardWinograd23 (src/layer/conv_2d.cpp:382-487):
  * Conv3x3s1Winograd23TransformInput (src/layer/simd/winograd_helper.cpp:413-580), the 16 GemmPack4F32 calls

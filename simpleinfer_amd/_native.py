@@ -103,6 +103,10 @@ def hip():
         "si_hip_conv2d_split3_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_split3_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_split3_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
+        "si_hip_conv2d_wino23_split_supported": (i, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_wino23_split_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_wino23_split_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
+        "si_hip_conv2d_wino23_split_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_wino23_eligible": (i, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino23_set_form": (i, [i]),
         "si_hip_conv2d_wino23_preferred": (i, [C.POINTER(SiConv2dDesc)]),

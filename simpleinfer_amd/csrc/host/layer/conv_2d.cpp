@@ -233,6 +233,17 @@ Status Conv2d::PrepareDevice(int mode) {
         device_ready_ = true;
         return Status::kSuccess;
     }
+    if (mode == 5) {
+        wino_tile_ = 0;
+        use_winograd_ = false;
+        std::vector<uint16_t> packed(si_hip_conv2d_wino23_split_weight_elems(&d));
+        CHECK_BOOL(!packed.empty());
+        CHECK_STATUS(CheckHip(si_hip_conv2d_wino23_split_pack_weight_host(&d, weight_.data(), packed.data()), "winograd filter transform (hi / lo halves)"));
+        CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(uint16_t)), "upload weight"));
+        if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_.data(), bias_.size() * sizeof(float)), "upload bias"));
+        device_ready_ = true;
+        return Status::kSuccess;
+    }
     if (mode == 2) {
         wino_tile_ = 0;
         use_winograd_ = false;
@@ -332,8 +343,20 @@ bool Conv2d::UseSplit3() const {
     return !(wino_shape && in_channels_ < 256 && algo_ != Algo::kImplicitGemm);
 }
 
+// (5: f32_split on a layer the fused Winograd F(2,3) kernel serves -- the same kernel around a channel loop on the fp16 matrix cores,
+// conv_wino23_split.hip)
+bool Conv2d::UseWinoSplit() const {
+    static const bool on = [] { const char* e = getenv("SI_WINO_SPLIT"); return !(e && atoi(e) == 0); }();
+    if (!on || !f32_split_ || sibling_ || up_node_ || stem_producer_ || groups_ != 1) return false;
+    SiConv2dDesc d;
+    memset(&d, 0, sizeof(d));
+    d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
+    d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
+    return WinogradTile(d) == 2 && si_hip_conv2d_wino23_split_supported(&d) != 0;
+}
+
 int Conv2d::PrecisionMode(const Tensor& input, const Tensor& output) const {
-    if (!IsHalf(input) && !IsHalf(output)) return UseSplit3() ? 4 : 0;
+    if (!IsHalf(input) && !IsHalf(output)) return UseSplit3() ? 4 : (UseWinoSplit() ? 5 : 0);
     if (groups_ > 1 && groups_ == in_channels_ && in_channels_ == out_channels_ && IsHalf(input) && IsHalf(output)) return 3;   // depthwise, fp16 storage
     if (!IsHalf(input)) {
         SiConv2dDesc d;
@@ -453,6 +476,14 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
         if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (fp32 by three fp16 products)");
         // an unaligned / oversized view: the true-fp32 kernels from here on
         f32_split_ = false;
+        device_ready_ = false;
+        return Launch(input, residual, output);
+    }
+    if (mode == 5) {
+        const int rc = si_hip_conv2d_wino23_split_f32(&d, input.Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                      residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream());
+        if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (winograd, fp32 by three fp16 products)");
+        f32_split_ = false;   // an unaligned / oversized view: the true-fp32 kernels from here on
         device_ready_ = false;
         return Launch(input, residual, output);
     }
@@ -615,6 +646,7 @@ const char* Conv2d::KernelName() const {
     if (mode == 2) return "conv_stem_f16_kernel";
     if (mode == 3) return "conv_depthwise_f16_kernel<2>";
     if (mode == 4) return "conv_split3_f32_kernel";
+    if (mode == 5) return "conv_wino23s_kernel";
     const int tile = WinogradTile(d);
     if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
     return si_hip_conv2d_kernel_name_form(&d, in.Data<float>(), up_node_ ? 1 : 0);

@@ -117,6 +117,7 @@ public:
     // fp32 product (si_hip_conv2d_split3_f32) for the dense layers where that is faster (UseSplit3); everything else as without it
     bool f32_split_ = false;
     bool UseSplit3() const;
+    bool UseWinoSplit() const;   // ... and the Winograd layers on the split form of the fused Winograd kernel (si_hip_conv2d_wino23_split_f32)
     bool prefer_wino43_ = false;  // kAuto: take F(4,3) instead of F(2,3) wherever F(2,3) would have been chosen
     bool use_winograd_ = false;  // resolved at PrepareDevice (same name as the reference's flag, conv_2d.h:60)
     int wino_tile_ = 0;          // 2 = F(2,3), 4 = F(4,3) when use_winograd_

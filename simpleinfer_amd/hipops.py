@@ -153,6 +153,28 @@ def conv2d_split3(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), act1="non
     return dy.to_numpy((n, oh, ow, oc))
 
 
+def conv2d_wino23_split(x, w_oihw, bias=None, padding=(1, 1), act1="none", residual=None, act2="none"):
+    """si_hip_conv2d_wino23_split_f32: fused Winograd F(2,3) with the plane GEMMs on the fp16 matrix cores by operand splitting"""
+    H = _native.hip()
+    x, w_oihw = _f32(x), _f32(w_oihw)
+    n, ih, iw, ic = x.shape
+    oc = w_oihw.shape[0]
+    oh, ow = conv_out_hw(ih, iw, (3, 3), (1, 1), padding, (1, 1))
+    d = SiConv2dDesc(n, ih, iw, ic, ic, oh, ow, oc, oc, 3, 3, 1, 1, 1, 1, padding[0], padding[1], 1,
+                     1 if bias is not None else 0, ACT[act1], 1 if residual is not None else 0, oc, ACT[act2], 0.0)
+    if not H.si_hip_conv2d_wino23_split_supported(C.byref(d)):
+        raise HipError("si_hip_conv2d_wino23_split_f32: unsupported shape")
+    packed = np.zeros(H.si_hip_conv2d_wino23_split_weight_elems(C.byref(d)), np.float16)
+    _chk(H.si_hip_conv2d_wino23_split_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack wino split")
+    dx, dw = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(packed)
+    db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
+    dr = DeviceBuffer.from_numpy(_f32(residual)) if residual is not None else None
+    dy = DeviceBuffer(n * oh * ow * oc * 4)
+    _chk(H.si_hip_conv2d_wino23_split_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dr.ptr if dr else None, dy.ptr, None),
+         "si_hip_conv2d_wino23_split_f32")
+    return dy.to_numpy((n, oh, ow, oc))
+
+
 def conv2d_upcat(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1="none", split_oc=0):
     """si_hip_conv2d_upcat_f32: a 1x1 conv over cat([upsample(low), skip]) (or [skip, upsample(low)]) that reads `low` at the
     source pixel.  Returns y, or (y, y2) for the sibling-split form."""

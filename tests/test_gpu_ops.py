@@ -147,6 +147,29 @@ def test_winograd_vs_reference_path(hops, orc, n, h, w, ic, oc, pad):
     assert np.abs(got - orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="naive", acc64=False)).max() < 2e-3
 
 
+@pytest.mark.parametrize("n,h,w,ic,oc,pad", WINO_SHAPES)
+def test_winograd_split_vs_reference_path(hops, orc, n, h, w, ic, oc, pad):
+    """si_hip_conv2d_wino23_split_f32 (round 5, engine option f32_split): the fused Winograd kernel with its plane GEMMs on the fp16
+    matrix cores from three fp16 products per fp32 product -- held to the SAME bars as the fp32 Winograd kernel: the oracle's restated
+    reference pipeline (src/layer/conv_2d.cpp:382-487) at 1e-4, the float64 convolution at 2e-5, the reference test's own 2e-3; the
+    fused epilogue; and an image's bits do not depend on its batch position."""
+    x = rng_uniform(n * 1000 + h, (n, h, w, ic), -1, 1)
+    wt = rng_uniform(n * 1000 + h + 1, (oc, ic, 3, 3), -0.5, 0.5)
+    b = rng_uniform(n * 1000 + h + 2, (oc,), -0.5, 0.5)
+    got = hops.conv2d_wino23_split(x, wt, b, (pad, pad))
+    assert_parity(got, orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="winograd"), what="vs reference Winograd")
+    naive = orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="naive")
+    assert_parity(got, naive, 2e-5, what="vs fp64")
+    assert np.abs(got - orc.conv2d(x, wt, b, (1, 1), (pad, pad), path="naive", acc64=False)).max() < 2e-3
+    e_split = np.abs(got - naive).max() / np.abs(naive).max()
+    e_f32 = np.abs(hops.conv2d_winograd(x, wt, b, (pad, pad)) - naive).max() / np.abs(naive).max()
+    assert e_split <= 2.0 * e_f32 + 1e-7, (e_split, e_f32)
+    r = rng_uniform(n * 1000 + h + 3, got.shape, -1, 1)
+    full = hops.conv2d_wino23_split(x, wt, b, (pad, pad), act1="silu", residual=r)
+    assert_parity(full, orc.activation("silu", naive) + r, what="silu + residual")
+    assert_exact(hops.conv2d_wino23_split(x[n - 1:], wt, b, (pad, pad), act1="silu", residual=r[n - 1:])[0], full[n - 1], "batch position")
+
+
 def test_winograd_fused_epilogue_and_strides(hops, orc):
     x = rng_uniform(71, (2, 20, 20, 32), -1, 1)
     wt = rng_uniform(72, (64, 32, 3, 3), -0.3, 0.3)

@@ -143,8 +143,54 @@ def detect():
         off += hw * hw * na
 
 
+def wino():
+    """3x3 stride-1 layers of YOLOv5s (batch 32) and ResNet18 (batch 64): the fp32 Winograd kernel vs its split form, ms per launch."""
+    H = _native.hip()
+    ev0, ev1, st = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    H.si_hip_event_create(C.byref(ev0)); H.si_hip_event_create(C.byref(ev1)); H.si_hip_stream_create(C.byref(st))
+    for (n, hw, ic, oc) in [(32, 160, 32, 32), (32, 80, 64, 64), (32, 40, 128, 128), (32, 20, 256, 256), (64, 56, 64, 64), (64, 28, 128, 128), (64, 14, 256, 256), (64, 7, 512, 512)]:
+        d = SiConv2dDesc(n, hw, hw, ic, ic, hw, hw, oc, oc, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, hipops.ACT["silu"], 0, oc, 0, 0.0)
+        rng = np.random.default_rng(0)
+        w32 = (rng.standard_normal((oc, ic, 3, 3)) * 0.05).astype(np.float32)
+        u32 = np.zeros(H.si_hip_conv2d_wino23_weight_elems(C.byref(d)), np.float32)
+        assert H.si_hip_conv2d_wino23_pack_weight_host(C.byref(d), w32.ctypes.data_as(C.c_void_p), u32.ctypes.data_as(C.c_void_p)) == 0
+        u3 = np.zeros(H.si_hip_conv2d_wino23_split_weight_elems(C.byref(d)), np.float16)
+        assert H.si_hip_conv2d_wino23_split_pack_weight_host(C.byref(d), w32.ctypes.data_as(C.c_void_p), u3.ctypes.data_as(C.c_void_p)) == 0
+        dx = hipops.DeviceBuffer.from_numpy(rng.standard_normal((n, hw, hw, ic)).astype(np.float32))
+        d32, d3 = hipops.DeviceBuffer.from_numpy(u32), hipops.DeviceBuffer.from_numpy(u3)
+        db = hipops.DeviceBuffer.from_numpy(rng.standard_normal(oc).astype(np.float32))
+        dy = hipops.DeviceBuffer(n * hw * hw * oc * 4)
+
+        def timed(fn):
+            gx = C.c_void_p()
+            assert H.si_hip_graph_begin_capture(st) == 0
+            for _ in range(30):
+                assert fn() == 0
+            assert H.si_hip_graph_end_capture(st, C.byref(gx)) == 0
+            reps, ms = 2, C.c_float()
+            while True:
+                H.si_hip_event_record(ev0, st)
+                for _ in range(reps):
+                    H.si_hip_graph_launch(gx, st)
+                H.si_hip_event_record(ev1, st)
+                H.si_hip_event_sync(ev1)
+                H.si_hip_event_elapsed_ms(ev0, ev1, C.byref(ms))
+                if ms.value >= 300:
+                    break
+                reps *= 2
+            H.si_hip_graph_destroy(gx)
+            return ms.value / (reps * 30) * 1e3
+        flops = 2.0 * n * hw * hw * oc * 9 * ic
+        t32 = timed(lambda: H.si_hip_conv2d_wino23_f32(C.byref(d), dx.ptr, d32.ptr, db.ptr, None, dy.ptr, st))
+        t3 = timed(lambda: H.si_hip_conv2d_wino23_split_f32(C.byref(d), dx.ptr, d3.ptr, db.ptr, None, dy.ptr, st))
+        print("  batch %d %dx%dx%d -> %d: fp32 Winograd %.1f us (%.0f TF/s direct-equivalent)   split %.1f us (%.0f)   %.2fx" % (
+            n, hw, hw, ic, oc, t32, flops / t32 / 1e6, t3, flops / t3 / 1e6, t32 / t3))
+
+
 if __name__ == "__main__":
-    if "--detect" in sys.argv:
+    if "--wino" in sys.argv:
+        wino()
+    elif "--detect" in sys.argv:
         detect()
     else:
         main()
