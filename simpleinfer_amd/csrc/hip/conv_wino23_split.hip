@@ -61,6 +61,11 @@ __device__ __forceinline__ float wino_act(int act, float v, float p) {
 }
 
 constexpr int CB = 16;  // input channels per staged block
+// SI_WS_ABL (diagnostic builds only, tools/hip_variant.sh): bit 0 no MFMAs, 1 no transform / split (constant operands), 2 no staging stores
+// after block 0, 3 no filter loads after block 0, 4 no patch fetches after block 1, 5 no LDS reads -- wrong results, timing only
+#ifndef SI_WS_ABL
+#define SI_WS_ABL 0
+#endif
 
 // n / d for 0 <= n < 2^32 with mg = floor(2^32 / d) (0xFFFFFFFF for d = 1): the high product is the quotient or one less
 __device__ __forceinline__ int wino_div(int n, int d, unsigned mg) {
@@ -285,8 +290,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino23s_kernel(const WinoArgs a) 
         float v[4][8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float2 ta = *reinterpret_cast<const float2*>(patch + p0 + c * PLANE);
-            const float2 tb = *reinterpret_cast<const float2*>(patch + p1 + c * PLANE);
+            float2 ta = {1.0f, 2.0f}, tb = {3.0f, 4.0f};
+            if (!(SI_WS_ABL & 32)) {
+                ta = *reinterpret_cast<const float2*>(patch + p0 + c * PLANE);
+                tb = *reinterpret_cast<const float2*>(patch + p1 + c * PLANE);
+            }
             v[0][c] = ta.x - tb.x;
             v[1][c] = ta.y + tb.x;
             v[2][c] = tb.x - ta.y;
@@ -295,28 +303,42 @@ __global__ __launch_bounds__(256, 2) void conv_wino23s_kernel(const WinoArgs a) 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f16x8 hi, lo;
+            if (SI_WS_ABL & 2) {
+                hi = __builtin_bit_cast(f16x8, bh[q]);
+                lo = __builtin_bit_cast(f16x8, bl[q]);
+                asm volatile("" ::"v"(v[q][0]), "v"(v[q][7]));
+            } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const half_t hv = (half_t)v[q][c];
-                hi[c] = hv;
-                lo[c] = (half_t)((v[q][c] - (float)hv) * kLo);
+                for (int c = 0; c < 8; ++c) {
+                    const half_t hv = (half_t)v[q][c];
+                    hi[c] = hv;
+                    lo[c] = (half_t)((v[q][c] - (float)hv) * kLo);
+                }
             }
-            acc_h[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bh[q], acc_h[q], 0, 0, 0);
-            acc_x[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bl[q], acc_x[q], 0, 0, 0);
-            acc_x[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bh[q], acc_x[q], 0, 0, 0);
+            if (!(SI_WS_ABL & 1)) {
+                acc_h[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bh[q], acc_h[q], 0, 0, 0);
+                acc_x[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, bl[q], acc_x[q], 0, 0, 0);
+                acc_x[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, bh[q], acc_x[q], 0, 0, 0);
+            } else {
+                asm volatile("" ::"v"(hi), "v"(lo));
+            }
             // this column's filter fragments are free as soon as its MFMAs have issued: the next block's are requested here, the rest of
             // the block ahead of their use (requested behind the block they would wait for a whole L2 round trip in front of every block)
-            if (more) load_bq(cb + 1, q);
+            if (more && !(SI_WS_ABL & 8)) load_bq(cb + 1, q);
             SI_WINO_FENCE();   // (left alone hipcc sinks these requests behind the last MFMA of the block)
         }
         if (more) {
             // block cb + 1 (in the staging registers since the last block) into the other buffer; block cb + 2 requested; the block's one
             // barrier (every wave has read this block's buffer above)
-            store_rows(cpre, nbuf * BUF + c_dst, I0{}, I4{});
-            store_halo(nbuf * BUF);
+            if (!(SI_WS_ABL & 4)) {
+                store_rows(cpre, nbuf * BUF + c_dst, I0{}, I4{});
+                store_halo(nbuf * BUF);
+            }
             const bool live = cb + 2 < ncb;
-            fetch(cpre, cb + 2, live);
-            fetch_halo(cb + 2, live);
+            if (!(SI_WS_ABL & 16)) {
+                fetch(cpre, cb + 2, live);
+                fetch_halo(cb + 2, live);
+            }
             __syncthreads();
         }
     };
