@@ -210,7 +210,7 @@ def _traffic_of(table, name):
     return rec.get("hbm_bytes_per_launch") if isinstance(rec, dict) else rec
 
 
-WINOGRAD_MULT_REDUCTION = {"conv_wino23_kernel": 2.25, "conv_wino43_kernel": 4.0}   # direct multiplies per executed multiply
+WINOGRAD_MULT_REDUCTION = {"conv_wino23_kernel": 2.25, "conv_wino43_kernel": 4.0, "conv_wino23s_kernel": 2.25}   # direct multiplies per executed multiply
 
 
 def roofline_from_profile(passes, fp16=False, workload=None):
@@ -398,6 +398,16 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
                 sms, sfl = sum(L["ms"] for L in sp), sum(L["flops"] for L in sp)
                 rec["dtype"] = "f32 (3 x f16 split products, fp32 accumulate)"
                 rec["frac_is"] = "images/s / (157.3 TF/s / direct-conv FLOPs per image): DIRECT-CONV CREDIT against the FP32 peak; the split layers run on the fp16 pipe -- see split_kernel"
+                ws = [L for L in convs if L["kernel"].startswith("conv_wino23s")]
+                wms, wfl = sum(L["ms"] for L in ws), sum(L["flops"] for L in ws)
+                if ws and wms > 0:
+                    # the Winograd layers on the split form of the fused Winograd kernel: 16 / 36 of the direct multiplies, three fp16 products each
+                    rec["split_winograd_kernel"] = {"kernel": "conv_wino23s_kernel", "launches_per_step": len(ws), "ms_per_step": round(wms, 3),
+                                                    "share_of_conv_time": round(wms / sum(L["ms"] for L in convs), 3),
+                                                    "tflops_direct_equivalent": round(wfl / (wms * 1e-3) / 1e12, 1),
+                                                    "executed_f16_mfma_tflops": round(3.0 * wfl / 2.25 / (wms * 1e-3) / 1e12, 1), "bound": "vector issue (transform + split), not a pipe",
+                                                    "peak": PEAK_F16_MFMA_TFLOPS, "frac": round(3.0 * wfl / 2.25 / (wms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                                                    "frac_is": "3 x (direct-conv FLOPs / 2.25) of the Winograd layers / their event-timed durations / 2500 TF/s"}
                 if sp and sms > 0:
                     rec["split_kernel"] = {"kernel": "conv_split3_f32_kernel", "launches_per_step": len(sp), "ms_per_step": round(sms, 3),
                                            "share_of_conv_time": round(sms / sum(L["ms"] for L in convs), 3),
