@@ -92,6 +92,8 @@ public:
     //                          tile policy follows the launch size); with 2 the lanes, not host_slices, serve host tensors
     //   "detect_stream"   0/1/2  YOLOv5 Detect's finer levels on a second stream: 0 never, 1 (default) for levels with enough work,
     //                          2 always
+    //   "detect_priority" -1/0/1  priority of that second stream: -1 (default) the device's lowest -- the neck on the main stream is the
+    //                          critical path, Detect fills what it leaves --, 0 the default priority, 1 the highest
     //   "graph"           1/0  replay Forward() as a captured hipGraph (default 0)
     //   "outputs_to_host" 1/0  copy outputs to pinned host memory in Forward() (default 1);
     //                          with 0, Extract() returns device tensors

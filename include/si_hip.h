@@ -64,6 +64,8 @@ int si_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, si_stream_t stre
 int si_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, si_stream_t stream);
 int si_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, si_stream_t stream);
 int si_hip_stream_create(si_stream_t* stream);
+/* ... with a priority: -1 the device's lowest, +1 its highest, 0 the default (round 5: engine option detect_priority) */
+int si_hip_stream_create_priority(si_stream_t* stream, int level);
 int si_hip_stream_destroy(si_stream_t stream);
 int si_hip_stream_sync(si_stream_t stream);
 int si_hip_device_sync(void);

@@ -77,6 +77,7 @@ def hip():
         "si_hip_memcpy_d2h": (i, [vp, vp, sz, vp]),
         "si_hip_memcpy_d2d": (i, [vp, vp, sz, vp]),
         "si_hip_stream_create": (i, [C.POINTER(vp)]),
+        "si_hip_stream_create_priority": (i, [C.POINTER(vp), i]),
         "si_hip_stream_destroy": (i, [vp]),
         "si_hip_stream_sync": (i, [vp]),
         "si_hip_device_sync": (i, []),

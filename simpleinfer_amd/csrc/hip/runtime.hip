@@ -96,6 +96,16 @@ int si_hip_stream_create(si_stream_t* s) {
     *s = h;
     return 0;
 }
+// level: -1 the device's lowest stream priority, +1 its highest, 0 the default (hipDeviceGetStreamPriorityRange: numerically lower = higher)
+int si_hip_stream_create_priority(si_stream_t* s, int level) {
+    if (!s) return SI_E_BADARG;
+    int lo = 0, hi = 0;
+    SI_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t h;
+    SI_HIP_TRY(hipStreamCreateWithPriority(&h, hipStreamNonBlocking, level < 0 ? lo : (level > 0 ? hi : 0)));
+    *s = h;
+    return 0;
+}
 int si_hip_stream_destroy(si_stream_t s) { if (s) SI_HIP_TRY(hipStreamDestroy((hipStream_t)s)); return 0; }
 int si_hip_stream_sync(si_stream_t s) { SI_HIP_TRY(hipStreamSynchronize((hipStream_t)s)); return 0; }
 int si_hip_device_sync(void) { SI_HIP_TRY(hipDeviceSynchronize()); return 0; }

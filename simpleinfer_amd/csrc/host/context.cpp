@@ -10,7 +10,7 @@ Context::~Context() {
     if (owns_stream_ && stream_) si_hip_stream_destroy(stream_);
 }
 
-Status Context::Init(int device) {
+Status Context::Init(int device, int stream_priority) {
     int count = 0;
     if (si_hip_device_count(&count) != 0 || count <= 0) {
         LOG(ERROR) << "no HIP device available: the MI355X path has no CPU fallback";
@@ -29,7 +29,7 @@ Status Context::Init(int device) {
         return Status::kErrorContext;
     }
     device_ = device;
-    rc = si_hip_stream_create(&stream_);
+    rc = stream_priority ? si_hip_stream_create_priority(&stream_, stream_priority) : si_hip_stream_create(&stream_);
     if (rc != 0) {
         LOG(ERROR) << "hipStreamCreate: " << si_hip_error_string(rc);
         return Status::kErrorContext;

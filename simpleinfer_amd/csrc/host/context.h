@@ -15,7 +15,7 @@ public:
     virtual ~Context();
 
     // binds the device and creates the stream; kErrorContext when no HIP device is usable
-    Status Init(int device);
+    Status Init(int device, int stream_priority = 0);   // stream_priority: si_hip_stream_create_priority's level
 
     int device() const { return device_; }
     si_stream_t stream() const { return stream_; }

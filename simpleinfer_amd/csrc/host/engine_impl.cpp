@@ -57,6 +57,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "fuse_pw") opt_fuse_pw_ = value != 0;      // fp16: a C3 bottleneck's 1x1 conv computed inside the slab kernel of its 3x3 conv (default 1)
     else if (key == "fuse_stem") opt_fuse_stem_ = value != 0;  // fp16: RGB stem conv + the 3x3 s2 conv behind it in one launch (default 1)
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
+    else if (key == "detect_priority") opt_detect_priority_ = value < 0 ? -1 : (value > 0 ? 1 : 0);   // priority of Detect's side stream: -1 low, 0 default, +1 high
     else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
     else if (key == "f32_split") opt_f32_split_ = value != 0;   // fp32 tensors, conv contraction from three fp16 MFMA products (default 0: true fp32)
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
@@ -438,7 +439,7 @@ Status EngineImpl::PlanDetectStream() {
         if (!mask) continue;
         if (!side_context_) {
             side_context_ = new Context;
-            CHECK_STATUS(side_context_->Init(context_->device()));
+            CHECK_STATUS(side_context_->Init(context_->device(), opt_detect_priority_));
             SI_TRY_HIP(si_hip_event_create(&ev_fork_), "event create");
             SI_TRY_HIP(si_hip_event_create(&ev_join_), "event create");
         }
@@ -1098,6 +1099,7 @@ Status EngineImpl::LoadLanes(int lanes) {
         lane->opt_winograd_ = opt_winograd_;
         lane->opt_f32_split_ = opt_f32_split_;
         lane->opt_detect_stream_ = opt_detect_stream_;
+        lane->opt_detect_priority_ = opt_detect_priority_;
         lane->opt_fp16_ = opt_fp16_;
         lane->opt_graph_ = opt_graph_;        // every lane replays its OWN captured graph on its own stream; this engine only forks / joins
                                               // (one graph holding both branches measured 10 % SLOWER than one stream: profiles/r03_ab_streams.txt)
@@ -1234,6 +1236,7 @@ Status EngineImpl::SetupSlicer(int slices) {
     slicer_->opt_winograd_ = opt_winograd_;
     slicer_->opt_f32_split_ = opt_f32_split_;
     slicer_->opt_detect_stream_ = opt_detect_stream_;
+    slicer_->opt_detect_priority_ = opt_detect_priority_;
     slicer_->opt_fp16_ = opt_fp16_;
     slicer_->opt_graph_ = opt_graph_;          // one captured graph per slice (its I/O pointers key the cache) ...
     slicer_->max_graphs_ = std::max<size_t>(max_graphs_, (size_t)slices);   // ... so the cache holds at least one per slice

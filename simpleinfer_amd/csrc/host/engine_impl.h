@@ -138,6 +138,8 @@ private:
     int opt_winograd_ = 1;
     int opt_batch_ = 0;          // > 0: serve this batch whatever batch the file was traced with
     int opt_detect_stream_ = 1;        // Detect's early levels on a second stream beside the layers that follow their inputs: 0 never, 1 for levels with enough work, 2 always
+    int opt_detect_priority_ = -1;  // si_hip_stream_create_priority level of that stream (engine option detect_priority): low by default -- the neck on
+                                    // the main stream is the critical path, Detect fills what it leaves (fp16 batch 32 +0.7 %, fp32 flat: r05_ab_detect_priority.txt)
     bool opt_fp16_ = false;      // fp16 storage for internal activations and weights (BASELINE.json configs[3])
     int opt_streams_ = 1;        // 2: two half-batch lanes on two streams; 1 (default): one stream
     int opt_host_slices_ = 0;    // host inputs + host outputs: G batch slices pipelined over PCIe inside one Forward(); 1: off; 0 (default): auto
