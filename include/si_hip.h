@@ -117,7 +117,29 @@ typedef struct SiConv2dDesc {
     int res_ld;
     int act2;           /* applied after the residual add */
     float act_param;    /* leaky-relu slope */
+    /* -- trailing fields; all-zero (memset / fewer initialisers) = the defaults ------------------------------------------------------ */
+    const struct SiConvPlan* plan; /* kernel-form choices for THIS call (tests, sweeps, an engine's plan); NULL: the shape / launch-size policy */
+    unsigned int* range_flag;      /* f32_split entry points (si_hip_conv2d_split3_* / _wino23_split_f32) only: NULL, or a word the device can
+                                    * write (device memory or pinned host memory) that the kernel sets to 1 when an operand left fp16's range
+                                    * on its way through the split -- see the f32_split section below.  Never written otherwise. */
 } SiConv2dDesc;
+
+/* Kernel-form choices of ONE call (round 6; VERDICT r05 item 7: these were process-global setters and environment switches until then).  Every
+ * form of a family computes an output element as the same fma chain in the same k order -- the choice never changes a result (tests/test_gpu_tiles.py,
+ * test_gpu_f16.py hold every form to the same bits) -- so a plan is a performance choice only.  A field at its default leaves that choice to the
+ * policy (launch size, CU count, shape).  Initialise with SI_CONV_PLAN_DEFAULT. */
+typedef struct SiConvPlan {
+    int f32_tile;        /* si_hip_conv2d_f32 family: -1 policy, 0..22 a tile of conv_igemm.hip's table (a few ids are retired: SI_E_BADARG) */
+    int wino23_form;     /* si_hip_conv2d_wino23_f32: 0 policy, 32 / 16 the 32-tile / 16-tile work unit (16 needs ic % 32 == 0) */
+    int f16_tile;        /* si_hip_conv2d_f16 family: -1 policy; 0-2 the one-stage kernel (64x64, 128x64, 128x128); 3, 7, 9, 10, 11 the kernels
+                          * with lane-order weights (128x128 as 2x2 waves, 128x32 as 4x1, 128x128 as 1x4, 64x128 as 1x4, 9 at three waves per SIMD) */
+    int f16_detect_tile; /* si_hip_conv2d_yolo_f16: -1 policy (the Detect tile where it applies), 0 the generic tiles */
+    int f16_s2c32;       /* 3x3 over one 32 / 64-channel block: -1 policy (the persistent patch kernel), 0 the generic tiles */
+    int f16_slab;        /* 3x3 s1 over 128 / 256 channels: -1 policy (row slabs), 0 the generic tiles */
+    int f16_slab_w2;     /* ... the slab kernel's 128-channel form: -1 policy (two waves per SIMD), 0 one wave per SIMD */
+    int f16_pw_patch;    /* 64 / 32-channel bottleneck pair: -1 policy (si_hip_conv2d_pw_slab_f16_supported may say 2), 0 never 2 */
+} SiConvPlan;
+#define SI_CONV_PLAN_DEFAULT { -1, 0, -1, -1, -1, -1, -1, -1 }
 
 /* Weight layout expected by the kernels: [oc][kh][kw][icg_pad] ("OHWI",
  * K = kh*kw*icg_pad contiguous per output channel), icg_pad = ic/groups

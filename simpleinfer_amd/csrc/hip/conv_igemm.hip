@@ -767,7 +767,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_fast_kernel(const ConvArgs
 #pragma unroll
             for (int e = 0; e < Mma<MT>::NE; ++e) acc[t][u][e] = 0.0f;
 
+#if defined(SI_EXP_NOKLOOP)
+    // experiment build only (tools/r06_small_batch_floor.sh): the K loop compiled out -- what is left is the launch,
+    // the prologue (index arithmetic, the first K-tile's loads, its LDS round trip, one barrier) and the epilogue
+    const int nk = 0;
+#else
     const int nk = a.Kp / BK;  // icg_pad % 32 == 0
+#endif
+#if defined(SI_EXP_EMPTY)
+    if (a.M >= 0) return;      // experiment build only: the launch alone
+#endif
 
     load_tile(pa_[0], pb_[0], 0);
 #pragma unroll
