@@ -196,6 +196,31 @@ def _traffic_table(workload):
     return {}, None
 
 
+def _busy_table(workload):
+    """The SQ-counter table recorded for THIS workload by tools/run_mfma_busy.sh (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ...,
+    a pass of its own): the matrix pipe's busy fraction per kernel instantiation -- BASELINE.json's second metric ("conv MFMA util %") from the
+    counter, not from TF/s / peak.  Like the traffic tables: recorded, not measured in this process; the table names its workload and commit."""
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "mfma_busy*.json"))):
+        try:
+            table = json.load(open(tpath))
+        except Exception:
+            continue
+        if table.get("_workload") == workload:
+            return table, "profiles/%s (rocprofv3 --pmc, recorded at %s for %s)" % (os.path.basename(tpath), table.get("_recorded_at", "an earlier commit"), workload)
+    return {}, None
+
+
+def _busy_of(table, name, field="mfma_busy"):
+    rec = table.get(name)
+    if isinstance(rec, dict):
+        return rec.get(field)
+    stem = name.rstrip(">")
+    hits = [v for k, v in table.items() if k.startswith(stem) and isinstance(v, dict) and v.get(field) is not None]
+    n = sum(v.get("launches", 0) for v in hits)
+    return round(sum(v[field] * v.get("launches", 0) for v in hits) / n, 4) if n else None
+
+
 def _traffic_of(table, name):
     rec = table.get(name)
     if rec is None:
@@ -213,7 +238,7 @@ def _traffic_of(table, name):
 WINOGRAD_MULT_REDUCTION = {"conv_wino23_kernel": 2.25, "conv_wino43_kernel": 4.0, "conv_wino23s_kernel": 2.25}   # direct multiplies per executed multiply
 
 
-def roofline_from_profile(passes, fp16=False, workload=None):
+def roofline_from_profile(passes, fp16=False, workload=None, busy_workload=None):
     """passes: list of per-layer profile lists (same schedule).  The dominant KERNEL is the conv kernel template with the
     largest total time (all its instantiations: one source kernel whose tile / MFMA shape follows the launch size); it is
     priced as SUM of algorithmic work / SUM of launch durations, and every instantiation -- the names are exactly what
@@ -252,7 +277,8 @@ def roofline_from_profile(passes, fp16=False, workload=None):
     bytes_per_launch = a["bytes"] / a["launches"]
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
     table, traffic_source = _traffic_table(workload)
-    rows, tsum, tn = [], 0.0, 0
+    btable, busy_source = _busy_table(busy_workload or workload)
+    rows, tsum, tn, bsum, bn = [], 0.0, 0, 0.0, 0.0
     for k, v in sorted(inst.items(), key=lambda kv: -kv[1]["ms"]):
         if _template_of(k) != name:
             continue
@@ -261,9 +287,14 @@ def roofline_from_profile(passes, fp16=False, workload=None):
             tsum += tr * v["launches"]
             tn += v["launches"]
         ims = v["ms"] / v["launches"]
+        busy = _busy_of(btable, k)
+        if busy is not None:   # time-weighted over the instantiations: the busy fraction of the template's own kernel time
+            bsum += busy * v["ms"]
+            bn += v["ms"]
         row = {"kernel": k, "launches_per_step": v["launches"] // npass, "avg_launch_ms": round(ims, 4),
                "algorithmic_bytes": round(v["bytes"] / v["launches"]), "traffic": tr,
-               "traffic_over_algorithmic": round(tr / (v["bytes"] / v["launches"]), 3) if tr else None}
+               "traffic_over_algorithmic": round(tr / (v["bytes"] / v["launches"]), 3) if tr else None,
+               "mfma_busy": busy, "valu_per_mfma": _busy_of(btable, k, "valu_per_mfma")}
         row["gbs"] = round(v["bytes"] / v["launches"] / (ims * 1e-3) / 1e9, 1)
         row["tflops"] = round(v["flops"] / v["launches"] / (ims * 1e-3) / 1e12, 2)
         if fp16:
@@ -290,6 +321,9 @@ def roofline_from_profile(passes, fp16=False, workload=None):
               # every launch against the roofline it sits under: sum of max(flop-time, byte-time) / sum of durations
               "frac_bound_aware": round(a["t_bound"] / (a["ms"] * 1e-3), 4),
               "traffic": traffic, "traffic_source": traffic_source if traffic is not None else None,
+              # BASELINE.json's second metric from the COUNTER: SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32), time-weighted over the
+              # template's instantiations (tools/run_mfma_busy.sh); beside it, `frac` is TF/s / peak
+              "mfma_busy": round(bsum / bn, 4) if bn else None, "mfma_busy_source": busy_source if bn else None,
               "algorithmic_bytes": round(bytes_per_launch), "launches_per_step": a["launches"] // npass,
               "avg_launch_ms": round(avg_ms, 4), "instantiations": rows}
     if fp16:
@@ -322,7 +356,9 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
              ("yolov5s_fp32_b8", "yolov5s", 8, 640, 0, {}), ("yolov5s_fp32_b4", "yolov5s", 4, 640, 0, {}),
              # opt-in (round 5): fp32 tensors, the K-heavy convs contracted from three fp16 MFMA products per fp32
              # product (engine option f32_split; conv_split3.hip).  Beside the headline, never instead of it: `value` stays true fp32.
-             ("yolov5s_f32split_b32", "yolov5s", 32, 640, 0, {"f32_split": 1})]
+             ("yolov5s_f32split_b32", "yolov5s", 32, 640, 0, {"f32_split": 1}),
+             # ... at the per-GPU batch of the 8-GPU strong-scaling point: the split path must not LOSE where the launches are small
+             ("yolov5s_f32split_b4", "yolov5s", 4, 640, 0, {"f32_split": 1})]
     for key, model, batch, size, fp16, opts in cases:
         try:
             builder, shape = build_model(mg, model, batch, size)
@@ -360,7 +396,8 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
             # the roofline IT sits under, PMC traffic when a table was recorded for this workload; a Winograd kernel is credited with
             # direct-conv FLOPs, so wherever such a figure appears its executed-work twin stands beside it
             layers = e.profile()
-            roof, _ = roofline_from_profile([layers], fp16=bool(fp16), workload=rec["workload"])
+            roof, _ = roofline_from_profile([layers], fp16=bool(fp16), workload=rec["workload"],
+                                            busy_workload=rec["workload"] + (" f32_split=1" if opts.get("f32_split") else ""))
             convs = [L for L in layers if L["kernel"].startswith("conv_") and L["flops"] > 0]
             executed = sum(L["flops"] / WINOGRAD_MULT_REDUCTION.get(_template_of(L["kernel"]), 1.0) for L in convs)
             credited = sum(L["flops"] for L in convs)
@@ -383,6 +420,7 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
                 dom = {"kernel": roof["kernel"], "launches_per_step": roof["launches_per_step"], "avg_launch_ms": roof["avg_launch_ms"],
                        "bound": roof["bound"], "frac": roof["frac"], "frac_bound_aware": roof["frac_bound_aware"],
                        "largest_instantiation": roof["largest_instantiation"], "traffic": roof["traffic"],
+                       "mfma_busy": roof.get("mfma_busy"), "mfma_busy_source": roof.get("mfma_busy_source"),
                        "algorithmic_bytes": roof["algorithmic_bytes"], "traffic_source": roof["traffic_source"]}
                 if roof.get("traffic"):
                     dom["traffic_over_algorithmic"] = round(roof["traffic"] / roof["algorithmic_bytes"], 3)
@@ -408,7 +446,13 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
                                                     "executed_f16_mfma_tflops": round(3.0 * wfl / 2.25 / (wms * 1e-3) / 1e12, 1), "bound": "vector issue (transform + split), not a pipe",
                                                     "peak": PEAK_F16_MFMA_TFLOPS, "frac": round(3.0 * wfl / 2.25 / (wms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                                                     "frac_is": "3 x (direct-conv FLOPs / 2.25) of the Winograd layers / their event-timed durations / 2500 TF/s"}
+                bt, bsrc = _busy_table(rec["workload"] + " f32_split=1")
+                rec["guard"] = {"split_reruns": e.schedule().get("split_reruns"), "split_demoted": e.schedule().get("split_demoted"),
+                                "note": "range guard (include/si_hip.h): a layer whose operands leave fp16's range goes back to the true-fp32 kernels and "
+                                        "the step is re-run; synthetic U[0,1) images never trip it"}
                 if sp and sms > 0:
+                    rec["split_kernel_mfma_busy"] = {"conv_split3_f32_kernel": _busy_of(bt, "conv_split3_f32_kernel<64, 1, 4, 64, false>"),
+                                                     "conv_wino23s_kernel": _busy_of(bt, "conv_wino23s_kernel<"), "source": bsrc}
                     rec["split_kernel"] = {"kernel": "conv_split3_f32_kernel", "launches_per_step": len(sp), "ms_per_step": round(sms, 3),
                                            "share_of_conv_time": round(sms / sum(L["ms"] for L in convs), 3),
                                            "tflops_direct_equivalent": round(sfl / (sms * 1e-3) / 1e12, 1),
@@ -902,6 +946,11 @@ def main():
                 # the matrix peak of the precision and its bytes at 8 TB/s) and the fraction of that bound it reaches
                 peak_tf = PEAK_F16_MFMA_TFLOPS if args.fp16 else PEAK_FP32_MFMA_TFLOPS
                 for L in layers:
+                    if L["kernel"].startswith("aliased"):
+                        # a concat whose producers wrote straight into its buffer: no launch -- the interval is the event pair itself
+                        print("%-28s %-22s %-48s %8.3f ms   (the event pair; producers write their slices in place)" % (L["name"], L["type"], L["kernel"], L["ms"]),
+                              file=sys.stderr)
+                        continue
                     tf = L["flops"] / (L["ms"] * 1e-3) / 1e12 if L["ms"] > 0 else 0
                     gb = L["bytes"] / (L["ms"] * 1e-3) / 1e9 if L["ms"] > 0 else 0
                     t_f, t_b = L["flops"] / (peak_tf * 1e12), L["bytes"] / (PEAK_HBM_GBS * 1e9)

@@ -74,8 +74,18 @@ public:
     //                          cores: every operand as two fp16 halves (22 significant bits), three exact fp16 products per fp32
     //                          product, fp32 accumulation (Ootomo & Yokota 2022; conv_split3.hip).  Measured closer to the float64
     //                          convolution than the fp32 MFMA chain and 1.8-2.1x faster on the K-heavy layers; another arithmetic
-    //                          than the reference's fp32 (operands must lie in fp16's range).  Default 0 -- the headline path is
-    //                          true fp32; ignored with "fp16"
+    //                          than the reference's fp32.  Default 0 -- the headline path is true fp32; ignored with "fp16".
+    //                          RANGE GUARD (round 6): the reference convolves any finite fp32; a value that rounds to fp16 infinity
+    //                          (|x| >= 65520; in the Winograd layers a transformed value, i.e. a sum of four inputs) cannot be split.
+    //                          Weights are checked at load (such a layer never leaves the fp32 kernels); activations by the split
+    //                          kernels themselves, at no cost while nothing trips: Forward() / Sync() then puts the layer back on the
+    //                          true-fp32 kernels for the engine's lifetime and RE-RUNS the step in place -- the caller never sees the
+    //                          overflowed step, and gets what the default engine computes for that layer.  (ForwardAsync() steps queued
+    //                          without a Sync() between them: the guard acts at the Sync(), on the last one.)  Tensors whose every
+    //                          value is tiny (scale ~1e-6) keep 1e-5-class, not fp32-class, relative accuracy (fp16 subnormals).
+    //   "f32_tile", "wino23_form", "wino23_ocg", "f16_tile", "f16_detect_tile", "f16_s2c32", "f16_slab", "f16_slab_w2", "f16_pw_patch"
+    //                          kernel-form choices handed to every conv launch (SiConvPlan, include/si_hip.h): A/B runs and tests.  Every
+    //                          form of a kernel family produces the same bits; the default leaves the choice to the launch-size policy.
     //   "batch"           N>0  serve batch N whatever batch the .param file was traced with (default 0: as in the file)
     //   "host_slices"     G    host tensors in (Input) and out (Extract) -- the reference's calling convention: one synchronous
     //                          Forward() pipelines G batch slices over an upload, a compute and a download stream; 1 = off,
@@ -92,8 +102,9 @@ public:
     //                          tile policy follows the launch size); with 2 the lanes, not host_slices, serve host tensors
     //   "detect_stream"   0/1/2  YOLOv5 Detect's finer levels on a second stream: 0 never, 1 (default) for levels with enough work,
     //                          2 always
-    //   "detect_priority" -1/0/1  priority of that second stream: -1 (default) the device's lowest -- the neck on the main stream is the
-    //                          critical path, Detect fills what it leaves --, 0 the default priority, 1 the highest
+    //   "detect_priority" -1/0/1  priority of that second stream: 0 (default) the device's default; -1 the lowest (the neck on the main
+    //                          stream is the critical path, Detect fills what it leaves: +0.7 % fp16 on one engine, but starvable when
+    //                          several engines share a device -- opt-in since round 6); 1 the highest
     //   "graph"           1/0  replay Forward() as a captured hipGraph (default 0)
     //   "outputs_to_host" 1/0  copy outputs to pinned host memory in Forward() (default 1);
     //                          with 0, Extract() returns device tensors

@@ -31,10 +31,30 @@ def _load(path):
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
+class SiConvPlan(C.Structure):
+    """include/si_hip.h SiConvPlan: kernel-form choices of one call (every form of a family produces the same bits)"""
+    _fields_ = [(k, C.c_int) for k in ("f32_tile", "wino23_form", "wino23_ocg", "f16_tile", "f16_detect_tile", "f16_s2c32", "f16_slab",
+                                       "f16_slab_w2", "f16_pw_patch")]
+    DEFAULTS = dict(f32_tile=-1, wino23_form=0, wino23_ocg=0, f16_tile=-1, f16_detect_tile=-1, f16_s2c32=-1, f16_slab=-1, f16_slab_w2=-1,
+                    f16_pw_patch=-1)
+
+    def __init__(self, **kw):
+        super().__init__()
+        vals = dict(self.DEFAULTS)
+        for k, v in kw.items():
+            if k not in vals:
+                raise TypeError("SiConvPlan has no field %r" % k)
+            vals[k] = int(v)
+        for k, v in vals.items():
+            setattr(self, k, v)
+
+
 class SiConv2dDesc(C.Structure):
+    # (fewer positional initialisers than fields leave the trailing ones -- plan, range_flag -- NULL: the defaults)
     _fields_ = [(k, C.c_int) for k in
                 ("n", "ih", "iw", "ic", "in_ld", "oh", "ow", "oc", "out_ld", "kh", "kw", "sh", "sw", "dh", "dw",
-                 "pt", "pl", "groups", "has_bias", "act1", "has_residual", "res_ld", "act2")] + [("act_param", C.c_float)]
+                 "pt", "pl", "groups", "has_bias", "act1", "has_residual", "res_ld", "act2")] + [
+                     ("act_param", C.c_float), ("plan", C.POINTER(SiConvPlan)), ("range_flag", C.c_void_p)]
 
 
 class SiConv2dUpsampledSource(C.Structure):
@@ -109,7 +129,6 @@ def hip():
         "si_hip_conv2d_wino23_split_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_wino23_split_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_wino23_eligible": (i, [C.POINTER(SiConv2dDesc)]),
-        "si_hip_conv2d_wino23_set_form": (i, [i]),
         "si_hip_conv2d_wino23_preferred": (i, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino23_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino23_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
@@ -126,7 +145,6 @@ def hip():
         "si_hip_conv2d_upcat_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dUpsampledSource)]),
         "si_hip_conv2d_kernel_name": (C.c_char_p, [C.POINTER(SiConv2dDesc), vp]),
         "si_hip_conv2d_kernel_name_form": (C.c_char_p, [C.POINTER(SiConv2dDesc), vp, i]),
-        "si_hip_conv2d_set_tile_variant": (i, [i]),
         "si_hip_linear_f32": (i, [vp, i, i, vp, vp, i, vp, vp]),
         "si_hip_maxpool2d_f32": (i, [C.POINTER(SiPool2dDesc), vp, vp, vp]),
         "si_hip_adaptive_avgpool2d_f32": (i, [vp, i, i, i, i, i, vp, i, i, i, vp]),
@@ -143,7 +161,6 @@ def hip():
         "si_hip_f32_to_f16_host": (i, [vp, vp, sz]),
         "si_hip_f16_to_f32_host": (i, [vp, vp, sz]),
         "si_hip_conv2d_f16_supported": (i, [C.POINTER(SiConv2dDesc)]),
-        "si_hip_conv2d_f16_set_tile_variant": (i, [i]),
         "si_hip_conv2d_upcat_f16": (i, [C.POINTER(SiConv2dDesc), vp, C.POINTER(SiConv2dUpsampledSource), vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_upcat_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dUpsampledSource)]),
         "si_hip_conv2d_f16_tile_variant": (i, [C.POINTER(SiConv2dDesc)]),
@@ -157,9 +174,6 @@ def hip():
         "si_hip_conv2d_stem_f16_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_split_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_yolo_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),
-        "si_hip_conv2d_yolo_f16_set_tile": (i, [i]),
-        "si_hip_conv2d_f16_set_s2c32": (i, [i]),
-        "si_hip_conv2d_f16_set_slab": (i, [i]),
         "si_hip_conv2d_pw_slab_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_pw_slab_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_stem_s2c32_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc)]),

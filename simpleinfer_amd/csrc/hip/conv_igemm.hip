@@ -987,18 +987,17 @@ static int si_cu_count() {
 // ids that were measured and removed again (15: 64x32 two-stage, 18: 32x128, 20: 128x64, 21: 64x128 on the 16x16x4 MFMA --
 // profiles/r03_tile_sweep.txt) and the unused 9 are not accepted
 static bool conv_variant_valid(int v) { return v >= 0 && v < kConvVariants && v != 9 && v != 15 && v != 18 && v != 20 && v != 21; }
-static std::atomic<int> g_forced_variant{-2};   // -2: not yet initialised from the environment, -1: policy
-static int conv_forced_variant() {
-    int v = g_forced_variant.load(std::memory_order_relaxed);
-    if (v == -2) {
-        const char* e = getenv("SI_CONV_VARIANT");  // development override
-        v = e ? atoi(e) : -1;
-        if (!conv_variant_valid(v)) v = -1;
-        int expected = -2;
-        g_forced_variant.compare_exchange_strong(expected, v);
-        v = g_forced_variant.load(std::memory_order_relaxed);
+// A forced tile comes with the call (SiConv2dDesc::plan, include/si_hip.h SiConvPlan::f32_tile: tests that hold every tile to the same bits,
+// sweeps); -1 / no plan: the policy below.  (Until round 6 this was a process-global setter + an environment switch.)
+static int conv_forced_variant(const SiConv2dDesc* d) {
+    int v = (d && d->plan) ? d->plan->f32_tile : -1;
+#ifdef SI_EXPERIMENT   // variant library only (simpleinfer_amd/build.py build_hip(defines=("SI_EXPERIMENT",), ...)): sweeps without a plan
+    if (v < 0) {
+        static const int env = [] { const char* e = getenv("SI_CONV_VARIANT"); return e ? atoi(e) : -1; }();
+        v = env;
     }
-    return v;
+#endif
+    return conv_variant_valid(v) ? v : -1;
 }
 // The policy (round 3; tools/tile_sweep.py on MI355X, sustained, every YOLOv5s implicit-GEMM shape at batch 4 / 8 / 16 / 32:
 // profiles/r03_tile_sweep.txt).  What decides is how many workgroups a launch has against the 256 CUs, counted in 64x64 tiles:
@@ -1013,17 +1012,18 @@ static int conv_forced_variant() {
 // 7232-7308 img/s with the round-2 rule (64x64 / 128x32 on the 32x32x2 MFMA everywhere) -> 7513-7517 with this one.
 // Whatever is chosen, the bits are the same (Mma, tests/test_gpu_tiles.py).
 static int conv_variant(const SiConv2dDesc* d) {
-    const int forced = conv_forced_variant();
+    const int forced = conv_forced_variant(d);
     if (forced >= 0) return forced;
-    // development: SI_CONV_POLICY="oc32,bigG,bigP,midG,midP,smallG,small[,tiny]" overrides the classes' variants (G: general, P: pointwise)
     static const std::array<int, 8> cls = [] {
         std::array<int, 8> c = {19, 17, 17, 13, 19, 13, 14, 22};
+#ifdef SI_EXPERIMENT   // variant library only: SI_CONV_POLICY="oc32,bigG,bigP,midG,midP,smallG,small[,tiny]" overrides the classes' variants (G: general, P: pointwise)
         if (const char* e = getenv("SI_CONV_POLICY")) {
             int v[8] = {0, 0, 0, 0, 0, 0, 0, 22};
             if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]) >= 7)
                 for (int i = 0; i < 8; ++i)
                     if (conv_variant_valid(v[i])) c[(size_t)i] = v[i];
         }
+#endif
         return c;
     }();
     const int ocg = d->oc / d->groups;
@@ -1046,7 +1046,7 @@ static int conv_variant(const SiConv2dDesc* d) {
 // nearest one, the policy is the round-1 rule (these layers are latency / HBM bound)
 static int conv_generic_tile(const SiConv2dDesc* d) {
     static const int generic_of[kConvVariants] = {0, 1, 2, 3, 2, 2, 1, 0, 2, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 2, 2};
-    const int forced = conv_forced_variant();
+    const int forced = conv_forced_variant(d);
     if (forced >= 0) return generic_of[forced];
     return (d->oc / d->groups) <= 32 ? 3 : 2;
 }
@@ -1060,8 +1060,10 @@ static bool conv_variant_full(int v) { return v == 4 || v == 10 || (v >= 11 && v
 // necessary multiplies, but on full-width 32x32x2 MFMAs with 16-byte loads -- these layers are memory-bound either way, and the
 // alternative was the generic kernel's per-element bounds checks.  Shape-only (it fixes the weight layout).
 static int conv_group_merge(const SiConv2dDesc* d) {
-    static const bool enabled = [] { const char* e = getenv("SI_GROUP_MERGE"); return !(e && e[0] == '0'); }();  // development A/B switch
+#ifdef SI_EXPERIMENT   // variant library only: A/B switch
+    static const bool enabled = [] { const char* e = getenv("SI_GROUP_MERGE"); return !(e && e[0] == '0'); }();
     if (!enabled) return 1;
+#endif
     if (d->groups <= 1 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return 1;
     const int icg = d->ic / d->groups;
     if (icg != 4 && icg != 8 && icg != 16) return 1;
@@ -1183,6 +1185,7 @@ static int conv2d_dispatch(const SiConv2dDesc* d, const float* in, const float* 
                            const SiConv2dUpsampledSource* up = nullptr) {
     if (!d || !in || !w_packed || !out) return SI_E_BADARG;
     if (d->groups <= 0 || d->ic % d->groups != 0 || d->oc % d->groups != 0) return SI_E_BADARG;
+    if (d->plan && d->plan->f32_tile >= 0 && !conv_variant_valid(d->plan->f32_tile)) return SI_E_BADARG;   // an unknown or retired tile id
     SiConv2dDesc eff;
     if (!si_conv_smallc_ok(d) && !si_conv_depthwise_ok(d) && conv_group_merge(d) > 1) {
         eff = conv_effective(d);   // merged groups: from here on a dense-per-super-group conv (the weights were packed for it)
@@ -1319,12 +1322,6 @@ extern "C" int si_hip_conv2d_yolo_f32(const SiConv2dDesc* d, const float* in, co
                                       float* detect_out, si_stream_t stream) {
     if (!level || !grid_hwa2 || !anchor_hwa2 || level->ne < 4 || level->na <= 0) return SI_E_BADARG;
     return conv2d_dispatch(d, in, w_packed, bias, nullptr, detect_out, stream, level, grid_hwa2, anchor_hwa2);
-}
-
-extern "C" int si_hip_conv2d_set_tile_variant(int variant) {
-    const int prev = conv_forced_variant();
-    g_forced_variant.store(conv_variant_valid(variant) ? variant : -1, std::memory_order_relaxed);
-    return prev;
 }
 
 // The kernel instantiation a launch of this problem runs, exactly as rocprofv3 prints it (minus the namespace):

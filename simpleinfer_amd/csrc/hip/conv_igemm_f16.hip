@@ -918,17 +918,9 @@ __global__ __launch_bounds__(256, NCH <= 2 ? SI_DET_MINW : 2) void detect_f16_ti
     }
 }
 
-// -1: on when the shape allows (default), 0: off (the generic tiles above), SI_DETECT_F16_TILE / si_hip_conv2d_yolo_f16_set_tile
-std::atomic<int> g_detect_tile{-2};
-bool detect_tile_on() {
-    int v = g_detect_tile.load(std::memory_order_relaxed);
-    if (v == -2) {
-        const char* e = getenv("SI_DETECT_F16_TILE");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-        int expected = -2;
-        g_detect_tile.compare_exchange_strong(expected, v);
-        v = g_detect_tile.load(std::memory_order_relaxed);
-    }
+// on when the shape allows unless the call's plan says 0 (SiConvPlan::f16_detect_tile: the generic tiles above)
+bool detect_tile_on(const SiConv2dDesc* d) {
+    const int v = (d && d->plan && d->plan->f16_detect_tile >= 0) ? d->plan->f16_detect_tile : SI_ENV_INT("SI_DETECT_F16_TILE", 1);
     return v != 0;
 }
 // shape half of the eligibility: a plain pointwise conv over 128 / 256 / 512 channels to at most 256 columns, rows of at most
@@ -1100,18 +1092,10 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_c32_patch_f16_kern
 }
 
 int f16_cu_count();
-int f16_forced_variant();
-// -1 / 1: on when the shape allows (default), 0: off; SI_CONV_F16_S2C32 / si_hip_conv2d_f16_set_s2c32
-std::atomic<int> g_s2c32{-2};
-bool s2c32_on() {
-    int v = g_s2c32.load(std::memory_order_relaxed);
-    if (v == -2) {
-        const char* e = getenv("SI_CONV_F16_S2C32");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-        int expected = -2;
-        g_s2c32.compare_exchange_strong(expected, v);
-        v = g_s2c32.load(std::memory_order_relaxed);
-    }
+int f16_forced_variant(const SiConv2dDesc* d);
+// on when the shape allows unless the call's plan says 0 (SiConvPlan::f16_s2c32)
+bool s2c32_on(const SiConv2dDesc* d) {
+    const int v = (d && d->plan && d->plan->f16_s2c32 >= 0) ? d->plan->f16_s2c32 : SI_ENV_INT("SI_CONV_F16_S2C32", 1);
     return v != 0;
 }
 bool s2c32_shape_ok(const SiConv2dDesc* d) {
@@ -1183,24 +1167,17 @@ size_t f16_lane_elems(const SiConv2dDesc* d) { return (size_t)d->groups * f16_la
 // columns, A shared through LDS), 10: 64x128 as 1x4 waves of 64x32, 11: 9 compiled for three waves per SIMD.  Measured and retired
 // (profiles/r04_f16_bd_sweep.txt; the ids are not accepted): 4 128x64 2x2, 5 64x128 2x2, 6 64x64 2x2, 8 256x64 4x1, 12 64x256 1x4,
 // 13 32x128 1x4, 14 32x256 1x4.  All variants produce the same bits (same k order, same 16-deep MFMA steps).
-// si_hip_conv2d_f16_set_tile_variant / SI_CONV_F16_VARIANT force one (tests, sweeps); -1: the policy.
+// SiConvPlan::f16_tile forces one for a call (tests, sweeps); -1: the policy.
 // Also measured and retired (round 4, late; profiles/r04_f16_deep_rings.txt): 10 / 9 / 7 with deeper prefetch rings (NA 2 or 4 register
 // slots for A, NB 4 for B -- the kernel template still takes the depths): never faster, 3-60 % slower; what these launches wait for is not
 // bytes in flight.
 constexpr int kF16Variants = 12;
 bool f16_variant_valid(int v) { return v >= 0 && v < kF16Variants && v != 4 && v != 5 && v != 6 && v != 8; }
-std::atomic<int> g_f16_forced{-2};
-int f16_forced_variant() {
-    int v = g_f16_forced.load(std::memory_order_relaxed);
-    if (v == -2) {
-        const char* e = getenv("SI_CONV_F16_VARIANT");
-        v = e ? atoi(e) : -1;
-        if (!f16_variant_valid(v)) v = -1;
-        int expected = -2;
-        g_f16_forced.compare_exchange_strong(expected, v);
-        v = g_f16_forced.load(std::memory_order_relaxed);
-    }
-    return v;
+// a forced tile comes with the call (SiConvPlan::f16_tile); -1: the policy
+int f16_forced_variant(const SiConv2dDesc* d) {
+    int v = (d && d->plan) ? d->plan->f16_tile : -1;
+    if (v < 0) v = SI_ENV_INT("SI_CONV_F16_VARIANT", -1);
+    return f16_variant_valid(v) ? v : -1;
 }
 int f16_cu_count() {
     static const int cus = [] {
@@ -1219,11 +1196,10 @@ int f16_cu_count() {
 //     columns: 64x128 as four 64x32 waves side by side (A shared through LDS, every wave its own weight columns, 4 workgroups
 //     per CU) -- 20x20x256 3x3 35 -> 25 us, 80x80x128 -> 40x40x256 s2 60 -> 47; with >= 512 columns and enough 128-row tiles to
 //     cover the chip, 128x128 as four 128x32 waves (40x40x256 -> 20x20x512 s2 60 -> 45 us, 20x20x1024 -> 512 1x1 29 -> 23).
-// SI_CONV_F16_POLICY=0 restores "64x64 everywhere" (A/B runs).
 int f16_variant(const SiConv2dDesc* d) {
-    const int forced = f16_forced_variant();
+    const int forced = f16_forced_variant(d);
     if (forced >= 0) return forced;
-    static const bool policy_on = [] { const char* e = getenv("SI_CONV_F16_POLICY"); return !(e && atoi(e) == 0); }();
+    static const bool policy_on = SI_ENV_INT("SI_CONV_F16_POLICY", 1) != 0;   // (experiment build: 0 restores "64x64 everywhere")
     if (!policy_on) return 0;
     const int ocg = d->oc / d->groups;
     const long long K = (long long)d->kh * d->kw * f16_icg_pad(d);
@@ -1258,6 +1234,7 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     if (d->has_bias && !bias) return SI_E_BADARG;
     if (d->has_residual && !residual) return SI_E_BADARG;
     if (!f16_shape_ok(d)) return SI_E_UNSUPPORTED;
+    if (d->plan && d->plan->f16_tile >= 0 && !f16_variant_valid(d->plan->f16_tile)) return SI_E_BADARG;   // an unknown or retired tile id
     if (d->in_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
     if ((long long)d->n * d->oh * d->ow > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     const unsigned long long in_bytes = (unsigned long long)d->n * d->ih * d->iw * d->in_ld * 2ull;
@@ -1313,17 +1290,17 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
         a.ystride = yolo->stride; a.ygrid = ygrid; a.yanchor = yanchor;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (yolo && detect_tile_on() && detect_tile_shape_ok(d, yolo)) {
+    if (yolo && detect_tile_on(d) && detect_tile_shape_ok(d, yolo)) {
         switch (d->ic) {
             case 128: return launch_detect_tile<1>(a, d->n, s);
             case 256: return launch_detect_tile<2>(a, d->n, s);
             default: return launch_detect_tile<4>(a, d->n, s);
         }
     }
-    if (!up && !yolo && !split && !out_f32 && s2c32_on() && f16_forced_variant() < 0 && s2c32_shape_ok(d) &&
+    if (!up && !yolo && !split && !out_f32 && s2c32_on(d) && f16_forced_variant(d) < 0 && s2c32_shape_ok(d) &&
         (!d->has_residual || (reinterpret_cast<uintptr_t>(residual) & 1) == 0))
         return launch_s2c32(a, d, s);
-    if (!up && !yolo && !split && !out_f32 && f16_forced_variant() < 0 && si_conv_slab_f16_ok(d) && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+    if (!up && !yolo && !split && !out_f32 && f16_forced_variant(d) < 0 && si_conv_slab_f16_ok(d) && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
         (!d->has_bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (!d->has_residual || (reinterpret_cast<uintptr_t>(residual) & 7) == 0))
         return si_conv_slab_f16_launch(d, in, a.wl, a.wl_nb, a.wl_ks, bias, residual, out, s);
 
@@ -1416,12 +1393,6 @@ int si_hip_conv2d_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oih
     return 0;
 }
 
-int si_hip_conv2d_f16_set_tile_variant(int variant) {
-    if (variant >= 0 && !f16_variant_valid(variant)) return SI_E_BADARG;
-    g_f16_forced.store(variant < 0 ? -1 : variant, std::memory_order_relaxed);
-    return 0;
-}
-
 int si_hip_conv2d_f16_tile_variant(const SiConv2dDesc* d) {
     if (!d || !f16_shape_ok(d)) return -1;
     return f16_variant(d);
@@ -1431,7 +1402,7 @@ const char* si_hip_conv2d_f16_kernel_name(const SiConv2dDesc* d, int form) {
     // the instantiation dispatch_h launches for this problem, exactly as rocprofv3 prints it (minus the namespace); form 1: the
     // dual-source (upsampled) form, which lives in the one-stage 64x64 kernel
     if (!d || !f16_shape_ok(d)) return "";
-    if (form == 0 && s2c32_on() && f16_forced_variant() < 0 && s2c32_shape_ok(d))
+    if (form == 0 && s2c32_on(d) && f16_forced_variant(d) < 0 && s2c32_shape_ok(d))
     {
         static const char* const names[16] = {
             "conv_c32_patch_f16_kernel<1, 1, 0, false, 32>", "conv_c32_patch_f16_kernel<1, 1, 0, true, 32>", "conv_c32_patch_f16_kernel<1, 1, 2, false, 32>", "conv_c32_patch_f16_kernel<1, 1, 2, true, 32>",
@@ -1446,7 +1417,7 @@ const char* si_hip_conv2d_f16_kernel_name(const SiConv2dDesc* d, int form) {
         if (d->ic == 64) return (d->sh == 2 ? names64s2 : names64)[(silu ? 2 : 0) + (d->has_residual ? 1 : 0)];
         return names[(d->sh - 1) * 8 + (d->oc == 64 ? 4 : 0) + (silu ? 2 : 0) + (d->has_residual ? 1 : 0)];
     }
-    if (form == 0 && f16_forced_variant() < 0 && si_conv_slab_f16_ok(d)) return si_conv_slab_f16_name(d);
+    if (form == 0 && f16_forced_variant(d) < 0 && si_conv_slab_f16_ok(d)) return si_conv_slab_f16_name(d);
     const int v = form == 1 ? 0 : f16_variant(d);
     const bool b64 = f16_block(d) == 64;
     switch (v) {
@@ -1494,19 +1465,9 @@ int si_hip_conv2d_yolo_f16(const SiConv2dDesc* d, const void* in, const void* w_
     return dispatch_h(d, in, w_packed, bias, nullptr, detect_out, 0, stream, level, grid_hwa2, anchor_hwa2, nullptr);
 }
 
-int si_hip_conv2d_f16_set_s2c32(int on) {
-    g_s2c32.store(on ? 1 : 0, std::memory_order_relaxed);
-    return 0;
-}
-
-int si_hip_conv2d_yolo_f16_set_tile(int on) {
-    g_detect_tile.store(on ? 1 : 0, std::memory_order_relaxed);
-    return 0;
-}
-
 int si_hip_conv2d_yolo_f16_tile(const SiConv2dDesc* d, const SiYoloLevel* level) {
     if (!d || !level) return 0;
-    return (detect_tile_on() && f16_shape_ok(d) && detect_tile_shape_ok(d, level)) ? 1 : 0;
+    return (detect_tile_on(d) && f16_shape_ok(d) && detect_tile_shape_ok(d, level)) ? 1 : 0;
 }
 
 }  // extern "C"

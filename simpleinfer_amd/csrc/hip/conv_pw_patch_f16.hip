@@ -251,9 +251,10 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_pw_patch_f16_kerne
     }
 }
 
-bool pw_patch_on() {
-    static const bool on = [] { const char* e = getenv("SI_CONV_F16_PW_PATCH"); return !(e && atoi(e) == 0); }();
-    return on;
+// on when the shape allows unless the 3x3 conv's plan says 0 (SiConvPlan::f16_pw_patch)
+bool pw_patch_on(const SiConv2dDesc* d) {
+    const int v = (d && d->plan && d->plan->f16_pw_patch >= 0) ? d->plan->f16_pw_patch : SI_ENV_INT("SI_CONV_F16_PW_PATCH", 1);
+    return v != 0;
 }
 
 int cu_count() {
@@ -270,7 +271,7 @@ int cu_count() {
 // the pair's shapes: a 3x3 stride-1 pad-1 conv over c -> c channels (c = 64 on maps of whole 4 x 16-pixel tiles, c = 32 of whole 8 x 16 ones)
 // with SiLU (optional shortcut), behind a 1x1 conv + SiLU over the same c channels and the same map
 bool si_conv_pw_patch_f16_ok(const SiConv2dDesc* pw, const SiConv2dDesc* d) {
-    if (!pw || !d || !pw_patch_on()) return false;
+    if (!pw || !d || !pw_patch_on(d)) return false;
     const int c = d->ic;
     if (c != 64 && c != 32) return false;
     const bool conv = d->groups == 1 && d->oc == c && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 &&

@@ -515,6 +515,15 @@ __global__ __launch_bounds__(W2 ? 512 : 256, W2 ? 2 : 1) void conv3x3s1_slab_f16
         else finish(c_none{}, c_none{});
     };
     {
+        // INVARIANT of the 512-thread form: the two halves of a wave pair run textually different instantiations of `run` (and, PW
+        // form, of `phase0` above) and cross the barriers INSIDE them at different program counters.  s_barrier counts the workgroup's waves,
+        // not program counters, so this is sound on gfx950 -- but only while BOTH instantiations execute the SAME NUMBER of barriers, which
+        // they do by construction: `phase0` holds exactly one, unconditional; `run` makes the same sequence of passes whatever [LO, HI) is
+        // (pass(b, MODE 0) for every b < NBLK - 1, then the last block) and a pass's barrier depends on template parameters (PW, MODE, b, NBLK)
+        // and the step number alone -- LO / HI only choose which pixel blocks a half multiplies.  A change that makes a barrier depend on
+        // LO / HI / TM1-per-half breaks this.  Held by tests/test_gpu_f16.py: the slab test runs this form AND the one-wave form
+        // (SiConvPlan::f16_slab_w2 = 0) against the generic tiles on every NBLK / residual / ragged case, the bottleneck-pair tests the PW form;
+        // a barrier-count mismatch hangs or corrupts there.
         constexpr int TH2 = W2 ? (TM + 1) / 2 : TM;
         if (!W2 || wm == 0) run(integral_constant<int, 0>{}, integral_constant<int, TH2>{});
         else run(integral_constant<int, TH2>{}, integral_constant<int, TM>{});
@@ -552,17 +561,9 @@ int cu_count() {
     return cus;
 }
 
-// -1 / 1: on when the shape allows (default), 0: off; SI_CONV_F16_SLAB / si_hip_conv2d_f16_set_slab
-std::atomic<int> g_slab{-2};
-bool slab_on() {
-    int v = g_slab.load(std::memory_order_relaxed);
-    if (v == -2) {
-        const char* e = getenv("SI_CONV_F16_SLAB");
-        v = (e && atoi(e) == 0) ? 0 : 1;
-        int expected = -2;
-        g_slab.compare_exchange_strong(expected, v);
-        v = g_slab.load(std::memory_order_relaxed);
-    }
+// on when the shape allows unless the call's plan says 0 (SiConvPlan::f16_slab)
+bool slab_on(const SiConv2dDesc* d) {
+    const int v = (d && d->plan && d->plan->f16_slab >= 0) ? d->plan->f16_slab : SI_ENV_INT("SI_CONV_F16_SLAB", 1);
     return v != 0;
 }
 
@@ -631,18 +632,17 @@ int launch_slab(const SlabArgs& a, const SiConv2dDesc* d, int lds, hipStream_t s
 // two waves per SIMD (512-thread workgroups): measured +4 % on the 7-block form (40x40x128: its vector-bound phases halve, 3.8 k of
 // 26 k cycles, the K loop pays 2 k for the doubled weight-fragment traffic) and 1.30x instead of 1.12x on its fused bottleneck pair;
 // -5 % on the 4-block form (20x20x256: two MFMAs per fragment and wave = 64 B/clk/CU through L1), which therefore keeps one wave per
-// SIMD and has no 512-thread instantiation.  SI_CONV_F16_SLAB_W2=0: one wave per SIMD everywhere (A/B runs).
-int slab_w2_mode() {
-    static const int m = [] { const char* e = getenv("SI_CONV_F16_SLAB_W2"); return (e && atoi(e) == 0) ? 0 : 2; }();
-    return m;
+// SIMD and has no 512-thread instantiation.  SiConvPlan::f16_slab_w2 = 0: one wave per SIMD everywhere (A/B runs, tests).
+bool slab_w2(const SiConv2dDesc* d, int tm) {
+    const int v = (d && d->plan && d->plan->f16_slab_w2 >= 0) ? d->plan->f16_slab_w2 : SI_ENV_INT("SI_CONV_F16_SLAB_W2", 1);
+    return v != 0 && tm == 7;
 }
-bool slab_w2(int tm) { return slab_w2_mode() == 2 && tm == 7; }
 
 // staging requests per thread of the instantiation that serves a plan: exact for the two YOLOv5s forms (10 for 5 x 40-pixel slabs over
 // 128 channels, 5 for 5 x 20 over 256), the upper bound 11 / 7 otherwise
 int slab_nit(const SiConv2dDesc* d, const SlabPlan& p) {
     const int need512 = ((p.th + 2) * (d->ow + 2) * 8 + 511) / 512;
-    if (slab_w2(7) && p.tm == 7 && d->ic == 128 && need512 <= 5) return 5;     // (512-thread forms)
+    if (slab_w2(d, 7) && p.tm == 7 && d->ic == 128 && need512 <= 5) return 5;     // (512-thread forms)
     const int need = ((p.th + 2) * (d->ow + 2) * 8 + 255) / 256;
     if (p.tm == 7 && d->ic == 128 && need <= 10) return 10;
     if (p.tm == 4 && d->ic == 256 && need <= 5) return 5;
@@ -654,7 +654,7 @@ int slab_nit(const SiConv2dDesc* d, const SlabPlan& p) {
 // conv_igemm_f16.hip's dispatch asks here first; 0: not this kernel's shape (or switched off)
 bool si_conv_slab_f16_ok(const SiConv2dDesc* d) {
     SlabPlan p;
-    return slab_on() && slab_shape_ok(d) && slab_plan(d, &p);
+    return slab_on(d) && slab_shape_ok(d) && slab_plan(d, &p);
 }
 
 const char* si_conv_slab_f16_name(const SiConv2dDesc* d) {
@@ -738,7 +738,7 @@ int slab_launch(const SiConv2dDesc* d, const void* in, unsigned long long in_byt
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)threads), (size_t)lds, s, a);
             return (int)hipGetLastError();
         };
-        if (slab_w2(pw_tm(d)))
+        if (slab_w2(d, pw_tm(d)))
             return d->has_residual ? go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, true, true, true>, 512) : go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, false, true, true>, 512);
         if (d->ic == 128) return d->has_residual ? go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, true, true>, 256) : go(conv3x3s1_slab_f16_kernel<7, 2, 1, SI_ACT_SILU, false, true>, 256);
         return d->has_residual ? go(conv3x3s1_slab_f16_kernel<4, 4, 1, SI_ACT_SILU, true, true>, 256) : go(conv3x3s1_slab_f16_kernel<4, 4, 1, SI_ACT_SILU, false, true>, 256);
@@ -767,11 +767,11 @@ int si_conv_pw_patch_f16_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, c
 extern "C" int si_hip_conv2d_pw_slab_f16_supported(const SiConv2dDesc* pw, const SiConv2dDesc* conv) {
     if (si_conv_pw_patch_f16_ok(pw, conv)) return 2;
     SlabPlan p, natural;
-    if (!pw || !conv || !slab_on() || !slab_shape_ok(conv) || !slab_plan(conv, &p, pw_tm(conv)) || !pw_pair_ok(pw, conv, p)) return 0;
+    if (!pw || !conv || !slab_on(conv) || !slab_shape_ok(conv) || !slab_plan(conv, &p, pw_tm(conv)) || !pw_pair_ok(pw, conv, p)) return 0;
     // 2: ... and it is the plan the 3x3 conv would run under by itself on a grid that covers most of the chip (what an engine fuses on)
     const long long grid = (long long)conv->n * p.slabs_per_img * ((conv->oc + 127) / 128);
     // (... and in the form measured faster than two launches: the 7-block one on two waves per SIMD, 1.30x; the 4-block one is 0.91x)
-    return (slab_plan(conv, &natural) && natural.tm == p.tm && natural.th == p.th && grid * 4 >= (long long)cu_count() * 3 && slab_w2(p.tm)) ? 2 : 1;
+    return (slab_plan(conv, &natural) && natural.tm == p.tm && natural.th == p.th && grid * 4 >= (long long)cu_count() * 3 && slab_w2(conv, p.tm)) ? 2 : 1;
 }
 
 extern "C" int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const void* in, const void* pw_w_packed,
@@ -804,7 +804,4 @@ extern "C" int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dD
 SI_STAMP_ACCESSORS(si_diag_stamps_slab, si_hip_diag_stamps_read_slab, si_hip_diag_stamps_clear_slab)
 #endif
 
-extern "C" int si_hip_conv2d_f16_set_slab(int on) {
-    g_slab.store(on ? 1 : 0, std::memory_order_relaxed);
-    return 0;
-}
+

@@ -38,10 +38,7 @@ int si_conv_stemroll_launch(const SiConv2dDesc* d, const float* in, const float*
 // which of the two a shape goes to is a function of the shape alone (it fixes the weight layout); SI_STEM_ROLL=0 is a
 // development switch that sends everything to the old kernel (read once per process)
 static bool stem_roll(const SiConv2dDesc* d) {
-    static const bool enabled = [] {
-        const char* e = getenv("SI_STEM_ROLL");
-        return !(e && e[0] == '0');
-    }();
+    static const bool enabled = SI_ENV_INT("SI_STEM_ROLL", 1) != 0;
     return enabled && si_conv_stemroll_ok(d);
 }
 

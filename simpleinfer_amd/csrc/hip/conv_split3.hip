@@ -11,7 +11,9 @@
 // 16-byte load per lane and fragment); activations are fp32 in HBM -- the same bytes as the fp32 path -- and are split on their way into
 // LDS.  Structure: conv_igemm_f16_bd_kernel's (A through two LDS stages, one barrier per 64-channel K-tile, 1 x 4 waves of 64 x 32).
 // Not bit-compatible with the fp32 kernels (another arithmetic); error against the fp64 convolution is measured by tests / tools
-// (tools/split3_check.py).  Operands must lie in fp16's range (|x| < 65504); values below 6e-5 lose relative, not absolute, accuracy.
+// (tools/split3_check.py).  Operands must lie in fp16's range: weights are checked when they are split (the pack function refuses), activations by
+// the kernel itself (split_range_report below, SiConv2dDesc::range_flag; include/si_hip.h has the contract); values below 6e-5 lose relative, not
+// absolute, accuracy.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -54,7 +56,15 @@ struct Split3Args {
     float ystride;
     const float* ygrid;
     const float* yanchor;
+    unsigned* range_flag;   // SiConv2dDesc::range_flag: set to 1 when an accumulator left the matrix cores non-finite (an operand overflowed fp16)
 };
+
+// An operand that rounds to fp16 infinity makes its hi half Inf and its lo half Inf / NaN, so every accumulator it feeds is Inf or NaN (the fp16
+// MFMA follows IEEE for both): testing the COMBINED accumulators, before bias and activation (relu(NaN) = 0, sigmoid(Inf) = 1 would hide it), finds
+// every overflow at one v_cmp_class per output element and nothing per input element.  Wave-level: one store by one lane, only when it trips.
+__device__ __forceinline__ void split_range_report(bool bad, unsigned* flag) {
+    if (flag && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) *reinterpret_cast<volatile unsigned*>(flag) = 1u;
+}
 
 __device__ __forceinline__ int fdiv(int n, int d, unsigned mg) {
     unsigned q = __umulhi((unsigned)n, mg);
@@ -236,10 +246,15 @@ __global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Arg
 
     if constexpr (YOLO) {
         f32x16 accc[TM][1];
+        bool bad = false;
 #pragma unroll
         for (int t = 0; t < TM; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) accc[t][0][e] = acc_h[t][e] + acc_x[t][e] * (1.0f / kLoScale);
+            for (int e = 0; e < 16; ++e) {
+                accc[t][0][e] = acc_h[t][e] + acc_x[t][e] * (1.0f / kLoScale);
+                bad |= !__builtin_isfinite(accc[t][0][e]);
+            }
+        split_range_report(bad, a.range_flag);
         const int mrow0 = m0 + wm * TM * 32 + 4 * lh;
         const int img0 = fdiv(m0, a.ohow, a.mg_ohow);
         if (m0 + BM <= a.M && m0 - img0 * a.ohow + BM <= a.ohow) {   // (workgroup-uniform: the tile lies inside one image)
@@ -271,6 +286,18 @@ __global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Arg
         return;
     }
     // epilogue: the two scales meet, then bias / activation / shortcut / activation (C/D map: col = lane & 31, rows (e & 3) + 8 (e >> 2) + 4 lh)
+    {
+        // (rows / columns outside the problem multiply zeros: they are finite and cost nothing to include)
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc_h[t][e] = acc_h[t][e] + acc_x[t][e] * (1.0f / kLoScale);
+                bad |= !__builtin_isfinite(acc_h[t][e]);
+            }
+        split_range_report(bad, a.range_flag);
+    }
     if (o < a.oc) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Arg
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
                 if (m < a.M) {
-                    float v = acc_h[t][e] + acc_x[t][e] * (1.0f / kLoScale);
+                    float v = acc_h[t][e];
                     v = act_rt(a.act1, v + bv, a.act_param);
                     if (a.res) v += a.res[(size_t)m * a.res_ld + o];
                     a.out[(size_t)m * a.out_ld + o] = act_rt(a.act2, v, a.act_param);
@@ -325,6 +352,8 @@ int si_hip_conv2d_split3_pack_weight_host(const SiConv2dDesc* d, const float* w_
                     float v = 0.0f;
                     if (o < d->oc) v = w_oihw[(((size_t)o * d->ic + c) * d->kh + tap / d->kw) * d->kw + tap % d->kw];
                     const half_t h = (half_t)v;
+                    // a weight that is not finite or rounds to fp16 infinity cannot be split: the layer stays on the fp32 kernels
+                    if (!(__builtin_fabsf((float)h) <= 65504.0f)) return SI_E_UNSUPPORTED;
                     const size_t idx = (((size_t)nb * ks_n + ks) * 64 + l) * 8 + j;
                     hi[idx] = h;
                     lo[idx] = (half_t)((v - (float)h) * 2048.0f);
@@ -359,6 +388,7 @@ static int split3_launch(const SiConv2dDesc* d, const float* in, const void* w_p
     a.in_bytes = (unsigned)in_bytes;
     a.ocg = d->oc;
     a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.0f; a.ygrid = a.yanchor = nullptr;
+    a.range_flag = d->range_flag;
     if (yolo) {
         const bool pointwise = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow;
         if (!pointwise || d->has_residual || yolo->na * yolo->ne != d->oc || !ygrid || !yanchor || d->ic % 64 != 0 || d->oc <= 64) return SI_E_UNSUPPORTED;
@@ -383,7 +413,7 @@ static int split3_launch(const SiConv2dDesc* d, const float* in, const void* w_p
     // tiles: <= 64 output channels -> 128 x 64 as 2 x 2 waves (the 1 x 4 form would leave two waves without columns); 64 x 128 as 1 x 4
     // waves otherwise, 128 x 128 for >= 512 output channels on a grid that still covers the chip twice (a weight fragment then feeds four
     // pixel blocks: half the L2 -> L1 weight traffic per FLOP; measured 117 vs 125 us on 40x40x256 -> 512, 139 vs 118 on 80x80x128 -> 256)
-    static const int forced_bm = [] { const char* e = getenv("SI_SPLIT3_BM"); return e ? atoi(e) : 0; }();
+    static const int forced_bm = SI_ENV_INT("SI_SPLIT3_BM", 0);
     if (yolo) return go(conv_split3_f32_kernel<64, 1, 4, 64, true>, 64, 128, 64);
     if (split3_blk(d) == 32) return d->oc <= 64 ? go(conv_split3_f32_kernel<128, 2, 2, 32>, 128, 64, 32) : go(conv_split3_f32_kernel<64, 1, 4, 32>, 64, 128, 32);
     if (d->oc <= 64) return go(conv_split3_f32_kernel<128, 2, 2, 64>, 128, 64, 64);

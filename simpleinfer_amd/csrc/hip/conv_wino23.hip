@@ -514,7 +514,7 @@ int launch_wino(WinoArgs a, hipStream_t s) {
     if (nblocks > 0x7fffffffLL) return SI_E_UNSUPPORTED;
     dim3 grid((unsigned)nblocks, 1, 1);
 #ifdef SI_DIAG_STAMPS   // residency experiments: extra dynamic LDS per workgroup
-    static const int extra_lds = [] { const char* e = getenv("SI_WINO_EXTRA_LDS"); return e ? atoi(e) : 0; }();
+    static const int extra_lds = SI_ENV_INT("SI_WINO_EXTRA_LDS", 0);
     hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW, OCG, MT>), grid, dim3(256), (size_t)extra_lds, s, a);
 #else
     hipLaunchKernelGGL((conv_wino23_kernel<LOG_TBW, OCG, MT>), grid, dim3(256), 0, s, a);
@@ -560,7 +560,7 @@ extern "C" int si_hip_conv2d_wino23_eligible(const SiConv2dDesc* d) {
 // 160x160x32), the current one (double-buffered staging, vectorised exchange) wins by +0.8-1.1 % of the YOLOv5s step
 // (6690-6705 vs 6634-6639 img/s, same-box A/B) -- hence the threshold of 32.
 extern "C" int si_hip_conv2d_wino23_preferred(const SiConv2dDesc* d) {
-    static const int min_ic = [] { const char* e = getenv("SI_WINO_MIN_IC"); return e ? atoi(e) : 32; }();  // dev override
+    static const int min_ic = SI_ENV_INT("SI_WINO_MIN_IC", 32);  // (experiment build: override)
     return si_hip_conv2d_wino23_eligible(d) && d->ic >= min_ic;
 }
 
@@ -616,25 +616,11 @@ extern "C" int si_hip_conv2d_wino23_pack_weight_host(const SiConv2dDesc* d, cons
     return 0;
 }
 
-static std::atomic<int> g_wino_form{-1};   // -1: not yet read from the environment; 0 policy, 16 / 32 forced
-static int wino_forced_form() {
-    int v = g_wino_form.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char* e = getenv("SI_WINO_MT");
-        v = e ? atoi(e) : 0;
-        if (v != 16 && v != 32) v = 0;
-        int expected = -1;
-        g_wino_form.compare_exchange_strong(expected, v);
-        v = g_wino_form.load(std::memory_order_relaxed);
-    }
-    return v;
-}
-// tuning / test hook (like si_hip_conv2d_set_tile_variant): 16 / 32 force the work-unit form of every later launch, 0 restores
-// the policy; returns the previous setting.  The form never changes a result.
-extern "C" int si_hip_conv2d_wino23_set_form(int form) {
-    const int prev = wino_forced_form();
-    g_wino_form.store((form == 16 || form == 32) ? form : 0, std::memory_order_relaxed);
-    return prev;
+// the work-unit form comes with the call (SiConvPlan::wino23_form: 16 / 32 force one, 0 the policy); the form never changes a result
+static int wino_forced_form(const SiConv2dDesc* d) {
+    int v = (d && d->plan) ? d->plan->wino23_form : 0;
+    if (v == 0) v = SI_ENV_INT("SI_WINO_MT", 0);
+    return (v == 16 || v == 32) ? v : 0;
 }
 
 // When the 16-tile form is expected to be faster: a round model fitted to profiles/r03_wino16_sweep.txt.  Workgroups run in
@@ -691,9 +677,8 @@ extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, 
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
 
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // Half-size work units (16 tiles on the 16x16x4 MFMA; same bits): SI_WINO_MT=16 / 32 forces either (development switch); the
-    // policy is wino_use_mt16
-    const int mt_force = wino_forced_form();
+    // Half-size work units (16 tiles on the 16x16x4 MFMA; same bits): the plan may force either; the policy is wino_use_mt16
+    const int mt_force = wino_forced_form(d);
     if (wino_has_mt16(d) && (mt_force == 16 || (mt_force == 0 && wino_use_mt16(d, a.tw, a.rows_total)))) {
         const int l16 = wino_pick_log_tbw(a.tw, a.rows_total, 16);
         if (l16 == 3) return launch_wino<3, 1, 16>(a, s);
@@ -704,8 +689,8 @@ extern "C" int si_hip_conv2d_wino23_f32(const SiConv2dDesc* d, const float* in, 
     // Two output groups per workgroup pay where the channel loop is long and the grid still covers the chip (MI355X, sustained:
     // 20x20x256 batch 32 0.0848 -> 0.0736 ms, 14x14x256 batch 64 0.0750 -> 0.0706; at 128 channels and below, or under
     // ~1.5 workgroups per CU, one group with three waves per SIMD is faster: 40x40x128 0.0705 vs 0.0755, 80x80x64 0.0717 vs
-    // 0.0778).  SI_WINO_OCG=1 / =2 forces either (development switch).
-    static const int ocg_force = [] { const char* e = getenv("SI_WINO_OCG"); return e ? atoi(e) : 0; }();
+    // 0.0778).  SiConvPlan::wino23_ocg = 1 / 2 forces either.
+    const int ocg_force = (d->plan && (d->plan->wino23_ocg == 1 || d->plan->wino23_ocg == 2)) ? d->plan->wino23_ocg : SI_ENV_INT("SI_WINO_OCG", 0);
     const int tbw = 1 << l, tbh = 32 / tbw;
     const long long wgs2 = (long long)((a.tw + tbw - 1) / tbw) * ((a.rows_total + tbh - 1) / tbh) * (d->oc / 64);
     const bool two = d->oc % 64 == 0 && (ocg_force == 2 || (ocg_force == 0 && d->ic >= 256 && wgs2 >= 384));

@@ -46,6 +46,7 @@ struct WinoArgs {
     int act1, act2;
     float act_param;
     int vec_out;         // out (and res) rows are 16-byte aligned: float4 stores
+    unsigned* range_flag; // SiConv2dDesc::range_flag: set to 1 when an accumulator left the matrix cores non-finite (a V value overflowed fp16)
 };
 
 __device__ __forceinline__ float wino_act(int act, float v, float p) {
@@ -359,17 +360,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino23s_kernel(const WinoArgs a) 
     float* xz = patch;
     {
         float* mine = xz + (wave * 2 * TILES + 4 * lh) * OCW + l31;
+        // range guard (conv_split3.hip split_range_report; include/si_hip.h): a transformed input value V = B^T d B that rounds to fp16 infinity
+        // leaves every accumulator it feeds Inf / NaN -- tested here, where the two scales meet, in front of the output transform and the epilogue
+        bool bad = false;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             // the two scales meet; C/D map: row (tile inside the block) = (e&3) + 8*(e>>2) + 4*lh, column = oc % 32
             const int m = (e & 3) + 8 * (e >> 2);
             float mq[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) mq[q] = acc_h[q][e] + acc_x[q][e] * (1.0f / kLo);
+            for (int q = 0; q < 4; ++q) {
+                mq[q] = acc_h[q][e] + acc_x[q][e] * (1.0f / kLo);
+                bad |= !__builtin_isfinite(mq[q]);
+            }
             mine[m * OCW] = (mq[0] + mq[1]) + mq[2];
             mine[(TILES + m) * OCW] = (mq[1] - mq[2]) - mq[3];
             if ((e & 3) == 3) SI_WINO_FENCE();
         }
+        if (a.range_flag && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) *reinterpret_cast<volatile unsigned*>(a.range_flag) = 1u;
     }
     __syncthreads();
     const int i_out = wave & 1, jc = wave >> 1;
@@ -524,6 +532,8 @@ extern "C" int si_hip_conv2d_wino23_split_pack_weight_host(const SiConv2dDesc* d
             for (int p = 0; p < 16; ++p) {
                 const size_t idx = ((((((size_t)(p / 4) * ncb + cb) * noct + o / 32) * 4 + p % 4) * 64) + lane) * 8 + j;
                 const half_t hv = (half_t)t[p];
+                // a filter value that is not finite or rounds to fp16 infinity cannot be split: the layer stays on the fp32 kernels
+                if (!(__builtin_fabsf((float)hv) <= 65504.0f)) return SI_E_UNSUPPORTED;
                 uh[idx] = hv;
                 ul[idx] = (half_t)((t[p] - (float)hv) * 2048.0f);
             }
@@ -558,6 +568,7 @@ extern "C" int si_hip_conv2d_wino23_split_f32(const SiConv2dDesc* d, const float
     a.vec_out = (reinterpret_cast<uintptr_t>(out) & 15) == 0 && d->out_ld % 4 == 0 &&
                 (!d->has_residual || ((reinterpret_cast<uintptr_t>(residual) & 15) == 0 && d->res_ld % 4 == 0));
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
+    a.range_flag = d->range_flag;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int l = wino_pick_log_tbw(a.tw, a.rows_total);
     if (l == 3) return launch_wino_split<3>(a, s);

@@ -392,7 +392,7 @@ extern "C" int si_hip_conv2d_wino43_eligible(const SiConv2dDesc* d) {
 // 32-cycle MFMA now needs ~3 VALU transform operations on the same vector issue port, which leaves the loop issue
 // bound; F(2,3) keeps the edge, so nothing prefers this kernel by default (SI_WINO43_MIN_IC=<ic> turns it on).
 extern "C" int si_hip_conv2d_wino43_preferred(const SiConv2dDesc* d) {
-    static const int min_ic = [] { const char* e = getenv("SI_WINO43_MIN_IC"); return e ? atoi(e) : 0; }();
+    static const int min_ic = SI_ENV_INT("SI_WINO43_MIN_IC", 0);
     return min_ic > 0 && si_hip_conv2d_wino43_eligible(d) && d->ic >= min_ic;
 }
 

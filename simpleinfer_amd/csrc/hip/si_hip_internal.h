@@ -8,6 +8,16 @@
 #include <mutex>
 #include <utility>
 
+// Environment switches (ablations, sweeps) exist in the EXPERIMENT build of the library only (-DSI_EXPERIMENT: tools/hip_variant.sh,
+// simpleinfer_amd/build.py build_hip(defines=...)); in the product build the expression is its default and nothing reads the environment
+// (round 6).  Choices a caller may legitimately make per call travel in SiConv2dDesc::plan (include/si_hip.h).
+#ifdef SI_EXPERIMENT
+#include <cstdlib>
+#define SI_ENV_INT(name, dflt) ([] { const char* e_ = getenv(name); return e_ ? atoi(e_) : (dflt); }())
+#else
+#define SI_ENV_INT(name, dflt) (dflt)
+#endif
+
 #define SI_HIP_TRY(expr)                      \
     do {                                      \
         hipError_t _e = (expr);               \

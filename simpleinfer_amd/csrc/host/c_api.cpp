@@ -160,6 +160,9 @@ int si_engine_schedule(SiEngine* e, char* buf, size_t cap) {
     e->impl.ActivationFootprint(arena, unshared);
     os << "arena_bytes " << arena << "\n" << "per_operand_bytes " << unshared << "\n";
     os << "lanes " << e->impl.Lanes() << "\n";   // 2: the batch runs as two half-batch lanes on two streams (option "streams")
+    // f32_split range guard: steps re-run because an operand left fp16's range, and the convs that went back to the true-fp32 kernels
+    os << "split_reruns " << e->impl.SplitReruns() << "\n";
+    for (auto& n : e->impl.SplitDemoted()) os << "split_demoted " << n << "\n";
     return copy_out(os.str(), buf, cap);
 }
 

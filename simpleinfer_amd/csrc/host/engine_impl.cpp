@@ -60,6 +60,17 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "detect_priority") opt_detect_priority_ = value < 0 ? -1 : (value > 0 ? 1 : 0);   // priority of Detect's side stream: -1 low, 0 default, +1 high
     else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
     else if (key == "f32_split") opt_f32_split_ = value != 0;   // fp32 tensors, conv contraction from three fp16 MFMA products (default 0: true fp32)
+    // kernel-form choices (SiConvPlan, include/si_hip.h; every form of a family produces the same bits): A/B runs and tests.  Until round 6
+    // these were process-global setters / environment switches of the kernel library.
+    else if (key == "f32_tile") { opt_plan_.f32_tile = value; opt_plan_set_ = true; }
+    else if (key == "wino23_form") { opt_plan_.wino23_form = value; opt_plan_set_ = true; }
+    else if (key == "wino23_ocg") { opt_plan_.wino23_ocg = value; opt_plan_set_ = true; }
+    else if (key == "f16_tile") { opt_plan_.f16_tile = value; opt_plan_set_ = true; }
+    else if (key == "f16_detect_tile") { opt_plan_.f16_detect_tile = value; opt_plan_set_ = true; }
+    else if (key == "f16_s2c32") { opt_plan_.f16_s2c32 = value; opt_plan_set_ = true; }
+    else if (key == "f16_slab") { opt_plan_.f16_slab = value; opt_plan_set_ = true; }
+    else if (key == "f16_slab_w2") { opt_plan_.f16_slab_w2 = value; opt_plan_set_ = true; }
+    else if (key == "f16_pw_patch") { opt_plan_.f16_pw_patch = value; opt_plan_set_ = true; }
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else if (key == "streams") opt_streams_ = value;  // 2: two half-batch lanes on two streams, 1 (default): one stream
     else if (key == "_fail_slicer") debug_fail_slicer_ = value != 0;  // tests: the sliced pipeline's setup fails half way
@@ -296,14 +307,30 @@ Status EngineImpl::CreateLayers() {
             return ret;
         }
         layer->SetContext(context_);
+        // f32_split: every conv that may run on the split kernels gets its word of the engine's range-guard flags (pinned host memory the
+        // kernels can write; 1024 words: more convs than that simply run unguarded-by-flag on the fp32 kernels)
+        auto arm_split = [&](Conv2d& cv, bool on) {
+            cv.f32_split_ = on;
+            if (opt_plan_set_) cv.SetPlan(opt_plan_);
+            if (!on) return;
+            if (!split_flags_) {
+                void* p = nullptr;
+                if (si_hip_host_alloc(&p, 1024 * sizeof(unsigned)) != 0 || !p) { cv.f32_split_ = false; return; }
+                split_flags_ = static_cast<unsigned*>(p);
+                for (int i = 0; i < 1024; ++i) split_flags_[i] = 0u;
+            }
+            if (split_convs_.size() >= 1024) { cv.f32_split_ = false; return; }
+            cv.range_flag_ = split_flags_ + split_convs_.size();
+            split_convs_.push_back(&cv);
+        };
         if (YoloDetect* yd = dynamic_cast<YoloDetect*>(layer)) {
             yd->fuse_decode_ = opt_fuse_;
-            for (Conv2d& cv : yd->conv_2d_layer_) cv.f32_split_ = opt_f32_split_ && !opt_fp16_ && opt_fuse_;
+            for (Conv2d& cv : yd->conv_2d_layer_) arm_split(cv, opt_f32_split_ && !opt_fp16_ && opt_fuse_);
         }
         if (Conv2d* cv = dynamic_cast<Conv2d*>(layer)) {
             if (!opt_winograd_) cv->algo_ = Conv2d::Algo::kImplicitGemm;
             cv->prefer_wino43_ = opt_winograd_ == 2;
-            cv->f32_split_ = opt_f32_split_ && !opt_fp16_;
+            arm_split(*cv, opt_f32_split_ && !opt_fp16_);
         }
 
         std::vector<TensorNode*> ins, outs;
@@ -349,6 +376,9 @@ Status EngineImpl::DestroyLayers() {
         }
     }
     layers_.clear();
+    split_convs_.clear();
+    if (split_flags_) si_hip_host_free(split_flags_);
+    split_flags_ = nullptr;
     return Status::kSuccess;
 }
 
@@ -1098,6 +1128,8 @@ Status EngineImpl::LoadLanes(int lanes) {
         lane->opt_arena_ = opt_arena_;
         lane->opt_winograd_ = opt_winograd_;
         lane->opt_f32_split_ = opt_f32_split_;
+        lane->opt_plan_ = opt_plan_;
+        lane->opt_plan_set_ = opt_plan_set_;
         lane->opt_detect_stream_ = opt_detect_stream_;
         lane->opt_detect_priority_ = opt_detect_priority_;
         lane->opt_fp16_ = opt_fp16_;
@@ -1235,6 +1267,8 @@ Status EngineImpl::SetupSlicer(int slices) {
     slicer_->opt_arena_ = opt_arena_;
     slicer_->opt_winograd_ = opt_winograd_;
     slicer_->opt_f32_split_ = opt_f32_split_;
+    slicer_->opt_plan_ = opt_plan_;
+    slicer_->opt_plan_set_ = opt_plan_set_;
     slicer_->opt_detect_stream_ = opt_detect_stream_;
     slicer_->opt_detect_priority_ = opt_detect_priority_;
     slicer_->opt_fp16_ = opt_fp16_;
@@ -1457,11 +1491,59 @@ Status EngineImpl::Forward() {
 Status EngineImpl::Sync() {
     if (nullptr == context_) return Status::kFail;
     SI_TRY_HIP(si_hip_stream_sync(context_->stream()), "stream sync");
+    // f32_split range guard: a split kernel that saw an operand leave fp16's range has set its layer's flag (the step's results are then
+    // Inf / NaN in that layer's outputs).  The layer goes back to the true-fp32 kernels for this engine's lifetime and the step is re-run, here,
+    // on the same inputs -- the caller of Forward() never sees the overflowed step.  (A caller that queued several ForwardAsync() steps gets
+    // the LAST one re-run: the guard acts where the engine synchronises.)  At most one round per layer, bounded.
+    if (forward_pending_ && !is_lane_) {
+        for (int round = 0; round < 8 && TakeSplitTrips(); ++round) {
+            ++split_reruns_;
+            CHECK_STATUS(ForwardAsync());
+            --forward_count_;
+            SI_TRY_HIP(si_hip_stream_sync(context_->stream()), "stream sync");
+        }
+    }
     if (forward_pending_) {
         si_hip_event_elapsed_ms(ev_start_, ev_stop_, &last_forward_ms_);
         forward_pending_ = false;
     }
     return Status::kSuccess;
+}
+
+bool EngineImpl::TakeSplitTrips() {
+    bool any = false;
+    for (size_t i = 0; i < split_convs_.size(); ++i) {
+        if (split_flags_ && reinterpret_cast<volatile unsigned*>(split_flags_)[i]) {   // (written by the device into pinned host memory)
+            split_flags_[i] = 0u;
+            Conv2d* cv = split_convs_[i];
+            if (cv->f32_split_) {
+                const pnnx::Operator* op = cv->GetOp();
+                LOG(WARNING) << "f32_split: an operand of conv [" << (op ? op->name : std::string("(Detect level)")) << "] left fp16's range (|x| >= 65520, or a non-finite value); "
+                             << "the layer runs on the true-fp32 kernels from here on and the step is re-run";
+                cv->DemoteSplit();
+                any = true;
+            }
+        }
+    }
+    for (EngineImpl* lane : lanes_) any = lane->TakeSplitTrips() || any;
+    if (slicer_) any = slicer_->TakeSplitTrips() || any;
+    if (any) {
+        // captured graphs hold the split launches, and the demoted layers re-pack their weights at their next launch: eager once
+        DestroyGraphCache();
+        plan_warm_ = false;
+    }
+    return any;
+}
+
+std::vector<std::string> EngineImpl::SplitDemoted() const {
+    std::vector<std::string> out;
+    for (Conv2d* cv : split_convs_)
+        if (cv->split_demoted_) out.push_back(cv->GetOp() ? cv->GetOp()->name : std::string("detect_level"));
+    for (const EngineImpl* lane : lanes_)
+        for (auto& n : lane->SplitDemoted()) out.push_back(n);
+    if (slicer_)
+        for (auto& n : slicer_->SplitDemoted()) out.push_back(n);
+    return out;
 }
 
 Status EngineImpl::ForwardAsync() {
@@ -1503,8 +1585,23 @@ Status EngineImpl::ForwardAsync() {
             SI_TRY_HIP(si_hip_graph_begin_capture(stream), "begin capture");
             Status ret = LaunchAll();
             const int rc = si_hip_graph_end_capture(stream, &exec);
-            CHECK_STATUS(ret);
-            SI_TRY_HIP(rc, "end capture");
+            if (Status::kSuccess != ret || rc != 0) {
+                // a launch that could not be captured (a layer fell back to another kernel family at this view and had to re-pack and upload
+                // its weights, which a capture forbids -- ADVICE r05): the capture is discarded and this step runs eagerly; the next one captures
+                if (exec) si_hip_graph_destroy(exec);
+                LOG(WARNING) << "graph: the capture of this step failed; running it eagerly";
+                CHECK_STATUS(LaunchAll());
+                SI_TRY_HIP(si_hip_event_record(ev_stop_, stream), "event record");
+                if (opt_outputs_to_host_) {
+                    for (auto& kv : output_tensor_nodes_) {
+                        const Tensor& t = kv.second->tensor;
+                        SI_TRY_HIP(si_hip_memcpy_d2h(host_outputs_[kv.first], t.RawData(), t.ByteSize(), stream), "output d2h");
+                    }
+                }
+                forward_pending_ = true;
+                ++forward_count_;
+                return Status::kSuccess;
+            }
             if (graph_cache_.size() >= max_graphs_) {
                 // the evicted exec may be the one a not-yet-synchronised ForwardAsync() launched: let the stream drain first
                 SI_TRY_HIP(si_hip_stream_sync(stream), "stream sync");

@@ -22,10 +22,13 @@
 #include "layer.h"
 #include "pnnx/pnnx_helper.h"
 #include "tensor.h"
+#include "si_hip.h"
 #include "tensor_node.h"
 #include "types.h"
 
 namespace SimpleInfer {
+
+class Conv2d;
 
 class EngineImpl {
 public:
@@ -132,14 +135,18 @@ private:
     bool opt_fuse_stem_ = true;
     bool opt_fuse_pw_ = true;
     bool opt_f32_split_ = false;
+    SiConvPlan opt_plan_ = SI_CONV_PLAN_DEFAULT;   // kernel-form choices handed to every conv launch (options f32_tile, f16_slab, ...; all default: the policy)
+    bool opt_plan_set_ = false;
     bool opt_arena_ = true;      // intermediate operands share one HBM arena by lifetime (0: one allocation per operand, as the reference)
     bool opt_graph_ = false;
     bool opt_outputs_to_host_ = true;
     int opt_winograd_ = 1;
     int opt_batch_ = 0;          // > 0: serve this batch whatever batch the file was traced with
     int opt_detect_stream_ = 1;        // Detect's early levels on a second stream beside the layers that follow their inputs: 0 never, 1 for levels with enough work, 2 always
-    int opt_detect_priority_ = -1;  // si_hip_stream_create_priority level of that stream (engine option detect_priority): low by default -- the neck on
-                                    // the main stream is the critical path, Detect fills what it leaves (fp16 batch 32 +0.7 %, fp32 flat: r05_ab_detect_priority.txt)
+    int opt_detect_priority_ = 0;   // si_hip_stream_create_priority level of that stream (engine option detect_priority): the device default.  -1 (lowest: the
+                                    // neck on the main stream is the critical path, Detect fills what it leaves) measured +0.7 % fp16 / flat fp32 on ONE engine
+                                    // (r05_ab_detect_priority.txt) -- inside the box-to-box spread, and with several engines on a device a lowest-priority
+                                    // stream can be starved by the others' default-priority work: opt-in since round 6
     bool opt_fp16_ = false;      // fp16 storage for internal activations and weights (BASELINE.json configs[3])
     int opt_streams_ = 1;        // 2: two half-batch lanes on two streams; 1 (default): one stream
     int opt_host_slices_ = 0;    // host inputs + host outputs: G batch slices pipelined over PCIe inside one Forward(); 1: off; 0 (default): auto
@@ -212,6 +219,18 @@ private:
 
     si_event_t ev_start_ = nullptr, ev_stop_ = nullptr;
     float last_forward_ms_ = 0.f;
+
+    // f32_split range guard (round 6): one word of pinned host memory per conv that may run on the split kernels; a kernel writes 1 there when
+    // an operand left fp16's range (include/si_hip.h).  Read at Sync(): a tripped layer goes back to the true-fp32 kernels for this engine's
+    // lifetime and the step is re-run in place.
+    unsigned* split_flags_ = nullptr;
+    std::vector<Conv2d*> split_convs_;       // index = flag index
+    int split_reruns_ = 0;                   // steps re-run because a flag tripped (statistics: Schedule())
+    bool TakeSplitTrips();                   // demote the convs whose flag is set (here, in the lanes, in the slicer); true when any was
+public:
+    int SplitReruns() const { return split_reruns_; }
+    std::vector<std::string> SplitDemoted() const;   // names of the convs the guard (or a weight out of range) sent back to true fp32
+private:
 };
 
 }  // namespace SimpleInfer

@@ -52,6 +52,7 @@ Status Cat::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
         if (!GetDims4(out[0], od)) return Status::kErrorShape;
         const std::vector<int>& os = out[0].Shape();
         int offset = 0;
+        int copies = 0;
         const bool half = IsHalf(out[0]);
         // fp16 tensors are copied as 4-byte words (pure data movement): channel counts / strides / offsets must be even
         const int wd = half ? 2 : 1;
@@ -64,6 +65,7 @@ Status Cat::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
                 char* dst = static_cast<char*>(out[0].RawData()) + (size_t)offset * (half ? 2 : 4);
                 // already in place: the engine pointed this input at its slice of our output
                 if (t.RawData() != dst || t.PixelStride() != out[0].PixelStride()) {
+                    ++copies;
                     if (id.c % wd || t.PixelStride() % wd || out[0].PixelStride() % wd || offset % wd) return Status::kUnsupport;
                     CHECK_STATUS(CheckHip(si_hip_copy_channels_f32(static_cast<const float*>(t.RawData()), id.pixels(), id.c / wd,
                                                                    t.PixelStride() / wd, reinterpret_cast<float*>(dst),
@@ -71,6 +73,7 @@ Status Cat::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
                                           "Cat"));
                 }
             } else {
+                ++copies;
                 if (t.PixelStride() != id.c || out[0].PixelStride() != od.c) return Status::kUnsupport;
                 if (half) {
                     if (id.c % 2) return Status::kUnsupport;
@@ -86,6 +89,7 @@ Status Cat::Forward(const std::vector<Tensor>& inputs, Tensor& output) {
             }
             offset += is[axis];
         }
+        last_copies_ = copies;
         return offset == os[axis] ? Status::kSuccess : Status::kErrorShape;
     });
 }

@@ -13,13 +13,18 @@ public:
     virtual Status Init(const pnnx::Operator* op) override;
     virtual Status Validate() override;
     virtual Status Forward(const std::vector<Tensor>& inputs, Tensor& output) override;
-    virtual const char* KernelName() const override { return "copy_channels"; }
+    // "aliased (no launch)": every input was already in place at the last Forward() (the engine pointed the producers at their slices of this
+    // layer's output) -- a profile line for such a concat times an event pair, not a kernel
+    virtual const char* KernelName() const override { return last_copies_ == 0 ? "aliased (no launch)" : "copy_channels"; }
 
     // NHWC axis the layer concatenates along
     int NhwcAxis() const;
 
 public:
     int dim_ = 0;
+
+private:
+    int last_copies_ = -1;   // copy launches of the most recent Forward() (-1: none yet)
 };
 
 }  // namespace SimpleInfer

@@ -194,6 +194,7 @@ SiConv2dDesc Conv2d::MakeDesc(const Tensor& input, const Tensor& output) const {
     d.groups = groups_;
     d.has_bias = use_bias_ ? 1 : 0;
     d.act1 = act1_; d.act2 = act2_; d.act_param = act_param_;
+    d.plan = has_plan_ ? &plan_ : nullptr;
     return d;
 }
 
@@ -227,6 +228,12 @@ Status Conv2d::PrepareDevice(int mode) {
         use_winograd_ = false;
         std::vector<uint16_t> packed(si_hip_conv2d_split3_weight_elems(&d));
         CHECK_BOOL(!packed.empty());
+        if (si_hip_conv2d_split3_pack_weight_host(&d, weight_.data(), packed.data()) == SI_E_UNSUPPORTED) {
+            // a weight outside fp16's range (or not finite): this layer cannot be split -- the true-fp32 kernels, decided here, at load
+            LOG(WARNING) << "f32_split: conv " << in_channels_ << " -> " << out_channels_ << " has a weight outside fp16's range; the layer stays on the fp32 kernels";
+            DemoteSplit();
+            return Status::kUnsupport;
+        }
         CHECK_STATUS(CheckHip(si_hip_conv2d_split3_pack_weight_host(&d, weight_.data(), packed.data()), "split weights (hi / lo halves)"));
         CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(uint16_t)), "upload weight"));
         if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_.data(), bias_.size() * sizeof(float)), "upload bias"));
@@ -238,6 +245,11 @@ Status Conv2d::PrepareDevice(int mode) {
         use_winograd_ = false;
         std::vector<uint16_t> packed(si_hip_conv2d_wino23_split_weight_elems(&d));
         CHECK_BOOL(!packed.empty());
+        if (si_hip_conv2d_wino23_split_pack_weight_host(&d, weight_.data(), packed.data()) == SI_E_UNSUPPORTED) {
+            LOG(WARNING) << "f32_split: conv " << in_channels_ << " -> " << out_channels_ << " has a transformed filter value outside fp16's range; the layer stays on the fp32 kernels";
+            DemoteSplit();
+            return Status::kUnsupport;
+        }
         CHECK_STATUS(CheckHip(si_hip_conv2d_wino23_split_pack_weight_host(&d, weight_.data(), packed.data()), "winograd filter transform (hi / lo halves)"));
         CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(uint16_t)), "upload weight"));
         if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_.data(), bias_.size() * sizeof(float)), "upload bias"));
@@ -320,7 +332,7 @@ Status Conv2d::PrepareDeviceHalf(const SiConv2dDesc& d) {
 // converts its input first (in_half_)
 // (4: fp32 tensors, the contraction on the fp16 matrix cores by operand splitting -- engine option f32_split, opt-in)
 // Detect levels under f32_split: from this channel count on (tools/split3_check.py --detect; profiles/r05_f32_split_detect.txt)
-static int kSplit3DetectMinChannels = [] { const char* e = getenv("SI_SPLIT3_DETECT_MIN_C"); return e ? atoi(e) : 128; }();
+static const int kSplit3DetectMinChannels = 128;
 
 bool Conv2d::UseSplit3() const {
     if (!f32_split_ || sibling_ || up_node_ || stem_producer_ || groups_ != 1 || dilation_h_ != 1 || dilation_w_ != 1) return false;
@@ -346,8 +358,7 @@ bool Conv2d::UseSplit3() const {
 // (5: f32_split on a layer the fused Winograd F(2,3) kernel serves -- the same kernel around a channel loop on the fp16 matrix cores,
 // conv_wino23_split.hip)
 bool Conv2d::UseWinoSplit() const {
-    static const bool on = [] { const char* e = getenv("SI_WINO_SPLIT"); return !(e && atoi(e) == 0); }();
-    if (!on || !f32_split_ || sibling_ || up_node_ || stem_producer_ || groups_ != 1) return false;
+    if (!f32_split_ || sibling_ || up_node_ || stem_producer_ || groups_ != 1) return false;
     SiConv2dDesc d;
     memset(&d, 0, sizeof(d));
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
@@ -451,14 +462,32 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
             d1.has_residual = 1;
             d1.res_ld = residual->PixelStride();
         }
-        return CheckHip(si_hip_conv2d_pw_slab_f16(&d0, &d1, input.RawData(), pw_producer_->weight_dev_.As<void>(),
-                                                  pw_producer_->use_bias_ ? pw_producer_->bias_dev_.As<float>() : nullptr, weight_dev_.As<void>(),
-                                                  use_bias_ ? bias_dev_.As<float>() : nullptr, residual ? residual->RawData() : nullptr,
-                                                  output.RawData(), Stream()),
-                        "conv2d 1x1 + 3x3 (fp16, one launch)");
+        const int rc = si_hip_conv2d_pw_slab_f16(&d0, &d1, input.RawData(), pw_producer_->weight_dev_.As<void>(),
+                                                 pw_producer_->use_bias_ ? pw_producer_->bias_dev_.As<float>() : nullptr, weight_dev_.As<void>(),
+                                                 use_bias_ ? bias_dev_.As<float>() : nullptr, residual ? residual->RawData() : nullptr,
+                                                 output.RawData(), Stream());
+        if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d 1x1 + 3x3 (fp16, one launch)");
+        // The pair was fused on dense strides, before the concat aliasing gave the tensors their real views (CanFusePointwiseProducer); the
+        // launch re-checks the views it gets (16-byte aligned rows, strides in whole 16-byte vectors) and may refuse a channel slice at an odd
+        // offset.  The fused-away intermediate is never planned, so the two ordinary launches run through a private one (this path
+        // returned kUnsupport until round 6; YOLOv5s never takes it -- all its strides are multiples of 8).
+        if (!pw_scratch_.RawData()) CHECK_STATUS(pw_scratch_.Allocate(DataType::kFloat16, pw_mid_->tensor.Shape()));
+        Conv2d* const pw = pw_producer_;
+        CHECK_STATUS(pw->Launch(input, nullptr, pw_scratch_));
+        pw_producer_ = nullptr;
+        const Status st = Launch(pw_scratch_, residual, output);
+        pw_producer_ = pw;
+        return st;
     }
-    const int mode = PrecisionMode(input, output);
-    CHECK_STATUS(PrepareDevice(mode));
+    int mode = PrecisionMode(input, output);
+    {
+        Status st = PrepareDevice(mode);
+        if (Status::kUnsupport == st && (mode == 4 || mode == 5) && !f32_split_) {   // (a weight out of fp16's range: see PrepareDevice)
+            mode = PrecisionMode(input, output);
+            st = PrepareDevice(mode);
+        }
+        CHECK_STATUS(st);
+    }
     Dims4 in, out;
     if (!GetDims4(input, in) || !GetDims4(output, out)) return Status::kErrorShape;
     if (in.c != in_channels_ || out.c != out_channels_ || in.n != out.n) {
@@ -471,20 +500,22 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
         d.res_ld = residual->PixelStride();
     }
     if (mode == 4) {
+        d.range_flag = range_flag_;
         const int rc = si_hip_conv2d_split3_f32(&d, input.Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
                                                 residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream());
         if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (fp32 by three fp16 products)");
-        // an unaligned / oversized view: the true-fp32 kernels from here on
-        f32_split_ = false;
-        device_ready_ = false;
+        // an unaligned / oversized view: the true-fp32 kernels from here on.  (The re-pack uploads weights: inside a hipGraph capture that
+        // fails, and EngineImpl::ForwardAsync then discards the capture and runs the step eagerly.)
+        DemoteSplit();
+        d.range_flag = nullptr;
         return Launch(input, residual, output);
     }
     if (mode == 5) {
+        d.range_flag = range_flag_;
         const int rc = si_hip_conv2d_wino23_split_f32(&d, input.Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
                                                       residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream());
         if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (winograd, fp32 by three fp16 products)");
-        f32_split_ = false;   // an unaligned / oversized view: the true-fp32 kernels from here on
-        device_ready_ = false;
+        DemoteSplit();   // an unaligned / oversized view: the true-fp32 kernels from here on
         return Launch(input, residual, output);
     }
     if (mode == 2)
@@ -593,8 +624,15 @@ Status Conv2d::ForwardYolo(const Tensor& input, const SiYoloLevel& level, const 
                            Tensor& detect_out) {
     // (f32_split: the Detect levels take the three-fp16-products kernel too -- YOLOv5s batch 32: 147 -> 118, 64 -> 43, 33 -> 26 us per
     // level, +3 % on the network; profiles/r05_f32_split_detect.txt)
-    const int mode = IsHalf(input) ? 1 : ((f32_split_ && in_channels_ % 64 == 0 && in_channels_ >= kSplit3DetectMinChannels && out_channels_ > 64) ? 4 : 0);
-    CHECK_STATUS(PrepareDevice(mode));
+    int mode = IsHalf(input) ? 1 : ((f32_split_ && in_channels_ % 64 == 0 && in_channels_ >= kSplit3DetectMinChannels && out_channels_ > 64) ? 4 : 0);
+    {
+        Status st = PrepareDevice(mode);
+        if (Status::kUnsupport == st && mode == 4 && !f32_split_) {   // (a weight out of fp16's range)
+            mode = 0;
+            st = PrepareDevice(mode);
+        }
+        CHECK_STATUS(st);
+    }
     Dims4 in;
     if (!GetDims4(input, in) || in.c != in_channels_) return Status::kErrorShape;
     if (input.GetMemoryType() != MemoryType::kDevice || detect_out.GetMemoryType() != MemoryType::kDevice) return Status::kUnsupport;
@@ -602,11 +640,11 @@ Status Conv2d::ForwardYolo(const Tensor& input, const SiYoloLevel& level, const 
     SiConv2dDesc d = MakeDesc(input, conv_out);
     d.act1 = d.act2 = SI_ACT_NONE;
     if (mode == 4) {
+        d.range_flag = range_flag_;
         const int rc = si_hip_conv2d_split3_yolo_f32(&d, input.Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
                                                      &level, grid_dev, anchor_dev, detect_out.Data<float>(), Stream());
         if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d+yolo (fp32 by three fp16 products)");
-        f32_split_ = false;   // an unaligned view: the true-fp32 kernel from here on
-        device_ready_ = false;
+        DemoteSplit();   // an unaligned view: the true-fp32 kernel from here on
         return ForwardYolo(input, level, grid_dev, anchor_dev, detect_out);
     }
     if (mode == 1) {

@@ -116,6 +116,13 @@ public:
     // engine option f32_split (opt-in, round 5): fp32 tensors, the contraction on the fp16 matrix cores from three fp16 products per
     // fp32 product (si_hip_conv2d_split3_f32) for the dense layers where that is faster (UseSplit3); everything else as without it
     bool f32_split_ = false;
+    // ... its range guard (round 6): the word the split kernels set to 1 when an operand left fp16's range (engine-owned pinned host memory;
+    // nullptr: unguarded), and what the engine does when it finds it set -- back to the true-fp32 kernels for this layer, for good
+    unsigned* range_flag_ = nullptr;
+    bool split_demoted_ = false;
+    void DemoteSplit() { f32_split_ = false; split_demoted_ = true; device_ready_ = false; }
+    // kernel-form choices handed to every launch of this layer (engine options f32_tile, f16_slab, ...; SiConvPlan in include/si_hip.h)
+    void SetPlan(const SiConvPlan& plan) { plan_ = plan; has_plan_ = true; }
     bool UseSplit3() const;
     bool UseWinoSplit() const;   // ... and the Winograd layers on the split form of the fused Winograd kernel (si_hip_conv2d_wino23_split_f32)
     bool prefer_wino43_ = false;  // kAuto: take F(4,3) instead of F(2,3) wherever F(2,3) would have been chosen
@@ -141,11 +148,14 @@ private:
     SiConv2dDesc MakeDesc(const Tensor& input, const Tensor& output) const;
     Status MakeUpsampledSource(SiConv2dUpsampledSource& up) const;
 
+    SiConvPlan plan_ = SI_CONV_PLAN_DEFAULT;
+    bool has_plan_ = false;
     DeviceBuffer weight_dev_;
     DeviceBuffer bias_dev_;
     bool device_ready_ = false;
     int prepared_mode_ = 0;      // which weight image weight_dev_ holds (see PrepareDevice)
     Tensor in_half_;             // fp16 copy of an fp32 input consumed by the fp16 kernel
+    Tensor pw_scratch_;          // the fused-away 1x1 conv's output, when the fused launch refuses the views it is handed (Launch)
 };
 
 }  // namespace SimpleInfer

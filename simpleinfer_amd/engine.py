@@ -160,10 +160,10 @@ class Engine:
         n = self._L.si_engine_schedule(self._h, None, 0)
         buf = C.create_string_buffer(n + 1)
         self._L.si_engine_schedule(self._h, buf, n + 1)
-        out: Dict[str, List[str]] = {"run": [], "fused": [], "alias": []}
+        out: Dict[str, List[str]] = {"run": [], "fused": [], "alias": [], "split_demoted": []}
         for ln in buf.value.decode().splitlines():
             k, v = ln.split(" ", 1)
-            if k in ("arena_bytes", "per_operand_bytes", "lanes"):
+            if k in ("arena_bytes", "per_operand_bytes", "lanes", "split_reruns"):
                 out[k] = int(v)      # HBM held for intermediates: shared by lifetime / one allocation per operand
             else:
                 out[k].append(v)

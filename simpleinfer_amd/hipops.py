@@ -11,8 +11,39 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+import contextlib
+
 from . import _native
-from ._native import SiConv2dDesc, SiPool2dDesc
+from ._native import SiConvPlan, SiPool2dDesc
+
+# The kernel-form plan attached to every conv descriptor THIS MODULE builds (tests and sweeps hold every tile / form of a kernel family to the
+# same bits through it).  State of this Python test helper only: the C-ABI itself has no process-global switch -- a plan travels inside the
+# descriptor of one call (include/si_hip.h SiConv2dDesc::plan).
+_PLAN = None
+
+
+@contextlib.contextmanager
+def plan(**fields):
+    """with hipops.plan(f32_tile=4): ...  -- every conv launched through this module inside the block carries SiConvPlan(**fields)"""
+    global _PLAN
+    prev, _PLAN = _PLAN, SiConvPlan(**fields)
+    try:
+        yield _PLAN
+    finally:
+        _PLAN = prev
+
+
+def set_plan(**fields):
+    """the non-scoped form of plan(): every later conv launched through this module carries SiConvPlan(**fields); no fields = no plan"""
+    global _PLAN
+    _PLAN = SiConvPlan(**fields) if fields else None
+
+
+def SiConv2dDesc(*a):
+    d = _native.SiConv2dDesc(*a)
+    if _PLAN is not None:
+        d.plan = C.pointer(_PLAN)
+    return d
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "sigmoid": 3, "hardsigmoid": 4, "hardswish": 5, "leakyrelu": 6}
 
@@ -132,8 +163,18 @@ def conv2d(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), dilation=(1, 1),
     return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
 
 
-def conv2d_split3(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), act1="none", residual=None, act2="none"):
-    """si_hip_conv2d_split3_f32: fp32 conv on the fp16 matrix cores by operand splitting (three fp16 MFMAs per product, fp32 accumulate)"""
+def _range_flag(d, want):
+    """a zeroed device word handed to an f32_split launch as SiConv2dDesc::range_flag (the kernel writes 1 when an operand left fp16's range)"""
+    if not want:
+        return None
+    f = DeviceBuffer.from_numpy(np.zeros(1, np.uint32))
+    d.range_flag = f.ptr
+    return f
+
+
+def conv2d_split3(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), act1="none", residual=None, act2="none", return_flag=False):
+    """si_hip_conv2d_split3_f32: fp32 conv on the fp16 matrix cores by operand splitting (three fp16 MFMAs per product, fp32 accumulate).
+    return_flag: also return the range-guard word (1: an operand overflowed fp16 on its way through the split)"""
     H = _native.hip()
     x, w_oihw = _f32(x), _f32(w_oihw)
     n, ih, iw, ic = x.shape
@@ -149,11 +190,13 @@ def conv2d_split3(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), act1="non
     db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
     dr = DeviceBuffer.from_numpy(_f32(residual)) if residual is not None else None
     dy = DeviceBuffer(n * oh * ow * oc * 4)
+    flag = _range_flag(d, return_flag)
     _chk(H.si_hip_conv2d_split3_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dr.ptr if dr else None, dy.ptr, None), "si_hip_conv2d_split3_f32")
-    return dy.to_numpy((n, oh, ow, oc))
+    y = dy.to_numpy((n, oh, ow, oc))
+    return (y, int(flag.to_numpy((1,), np.uint32)[0])) if return_flag else y
 
 
-def conv2d_wino23_split(x, w_oihw, bias=None, padding=(1, 1), act1="none", residual=None, act2="none"):
+def conv2d_wino23_split(x, w_oihw, bias=None, padding=(1, 1), act1="none", residual=None, act2="none", return_flag=False):
     """si_hip_conv2d_wino23_split_f32: fused Winograd F(2,3) with the plane GEMMs on the fp16 matrix cores by operand splitting"""
     H = _native.hip()
     x, w_oihw = _f32(x), _f32(w_oihw)
@@ -170,9 +213,11 @@ def conv2d_wino23_split(x, w_oihw, bias=None, padding=(1, 1), act1="none", resid
     db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
     dr = DeviceBuffer.from_numpy(_f32(residual)) if residual is not None else None
     dy = DeviceBuffer(n * oh * ow * oc * 4)
+    flag = _range_flag(d, return_flag)
     _chk(H.si_hip_conv2d_wino23_split_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dr.ptr if dr else None, dy.ptr, None),
          "si_hip_conv2d_wino23_split_f32")
-    return dy.to_numpy((n, oh, ow, oc))
+    y = dy.to_numpy((n, oh, ow, oc))
+    return (y, int(flag.to_numpy((1,), np.uint32)[0])) if return_flag else y
 
 
 def conv2d_upcat(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1="none", split_oc=0):
@@ -494,13 +539,13 @@ def yolo_detect(feats, weights, biases, grids, anchor_grids, strides, na=3, fuse
     return dout.to_numpy((n, rows_total, ne))
 
 
-def yolo_detect_split3(feats, weights, biases, grids, anchor_grids, strides, na=3):
+def yolo_detect_split3(feats, weights, biases, grids, anchor_grids, strides, na=3, return_flags=False):
     """si_hip_conv2d_split3_yolo_f32 per level: the Detect head on the f32_split arithmetic (fp32 features, three fp16 MFMA products per
-    fp32 product), decode + concat in the epilogue."""
-    return _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na, split3=True)
+    fp32 product), decode + concat in the epilogue.  return_flags: also the per-level range-guard words."""
+    return _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na, split3=True, return_flags=return_flags)
 
 
-def _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na, split3=False):
+def _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na, split3=False, return_flags=False):
     from ._native import SiYoloLevel
     H = _native.hip()
     feats = [_f32(f) for f in feats]
@@ -510,6 +555,7 @@ def _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na,
     dout = DeviceBuffer(n * rows_total * ne * 4)
     dout.fill(0)
     off = 0
+    flags = []
     for f, w, b, g, a, s in zip(feats, weights, biases, grids, anchor_grids, strides):
         _, h, wd, cin = f.shape
         w = _f32(w)
@@ -525,11 +571,15 @@ def _yolo_detect_fused(feats, weights, biases, grids, anchor_grids, strides, na,
         bufs = [DeviceBuffer.from_numpy(v) for v in (f, packed, _f32(b), g2, a2)]
         lv = SiYoloLevel(na, ne, rows_total, off, float(s))
         fn = H.si_hip_conv2d_split3_yolo_f32 if split3 else H.si_hip_conv2d_yolo_f32
+        flag = _range_flag(d, return_flags and split3)
         _chk(fn(C.byref(d), bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, C.byref(lv), bufs[3].ptr, bufs[4].ptr, dout.ptr, None),
              "si_hip_conv2d_split3_yolo_f32" if split3 else "si_hip_conv2d_yolo_f32")
         sync()
+        if flag is not None:
+            flags.append(int(flag.to_numpy((1,), np.uint32)[0]))
         off += h * wd * na
-    return dout.to_numpy((n, rows_total, ne))
+    out = dout.to_numpy((n, rows_total, ne))
+    return (out, flags) if return_flags else out
 
 
 def letterbox_geometry(height_origin, width_origin, height_new, width_new):

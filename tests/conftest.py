@@ -37,3 +37,23 @@ def gpu(native_libs):
     n = device_count()
     assert n > 0, "gpu-marked test running without a HIP device"
     return n
+
+
+def pytest_terminal_summary(terminalreporter):
+    """The element-wise mixed metric of every fp32 parity assertion of this run (tests/util.py assert_parity): the ten worst, so a run's log shows
+    how far the suite sits from the 1e-4 bar under BOTH metrics; the full table goes to gpurun_out/mixed_metric.txt when that directory exists."""
+    try:
+        import util
+    except Exception:  # noqa: BLE001
+        return
+    log = sorted(util.MIXED_LOG, key=lambda r: -r[2])
+    if not log:
+        return
+    terminalreporter.write_line("fp32 parity under the element-wise metric max|d| / (|ref| + rms(ref)): %d assertions, worst %.3e (%s)" % (
+        len(log), log[0][2], log[0][0]))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "mixed_metric.txt"), "w") as f:
+            f.write("# what, max|diff|/max|ref|, max|d|/(|ref|+rms(ref))   (tests/util.py assert_parity; bar 1e-4 on both)\n")
+            for what, e, m in log:
+                f.write("%-70s %.3e %.3e\n" % (what, e, m))

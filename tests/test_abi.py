@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -120,7 +121,6 @@ def test_tile_policy_follows_the_launch_size_host_logic(native_libs):
     (<= 32 output channels) get 64x32; the names are the full instantiation names rocprofv3 prints."""
     hip, _ = native_libs
     name = lambda d, form=0: hip.si_hip_conv2d_kernel_name_form(ctypes.byref(d), ctypes.c_void_p(4096), form).decode()
-    hip.si_hip_conv2d_set_tile_variant(-1)
     assert name(_desc(hip, 32, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false, false, 16, 1>"
     assert name(_desc(hip, 8, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<32, 64, 2, 2, 1, false, false, false, false, 16, 1>"
     # (batch 1: 200 64x64-tiles for 256 CUs -- two K-tiles per barrier round; the last template argument)
@@ -132,11 +132,26 @@ def test_tile_policy_follows_the_launch_size_host_logic(native_libs):
     assert name(_desc(hip, 32, 40, 40, 256, 256, 1, 1, 0), 1).endswith("false, true, false, false, 16, 1>")      # dual-source form
     assert name(_desc(hip, 32, 20, 20, 512, 255, 1, 1, 0), 2).endswith("false, false, true, false, 16, 1>")      # Detect form
     assert name(_desc(hip, 2, 10, 10, 40, 72, 1, 1, 0)).endswith("true, false, false, false, 16, 2>")            # zero-padded K
-    # a forced variant overrides the policy; removed / unknown ids restore it
-    assert hip.si_hip_conv2d_set_tile_variant(4) == -1
-    assert name(_desc(hip, 1, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false, false, 32, 1>"
-    assert hip.si_hip_conv2d_set_tile_variant(18) == 4
-    assert hip.si_hip_conv2d_set_tile_variant(-1) == -1
+    # a tile in the call's plan (SiConv2dDesc::plan) overrides the policy FOR THAT CALL; removed / unknown ids leave the policy in charge of the
+    # name (the launch itself returns SI_E_BADARG for them); the next descriptor without a plan is back on the policy
+    from simpleinfer_amd._native import SiConvPlan
+    d = _desc(hip, 1, 160, 160, 64, 128, 3, 2, 1)
+    p4, p18 = SiConvPlan(f32_tile=4), SiConvPlan(f32_tile=18)
+    d.plan = ctypes.pointer(p4)
+    assert name(d) == "conv_igemm_f32_fast_kernel<64, 64, 2, 2, 1, false, false, false, false, 32, 1>"
+    d.plan = ctypes.pointer(p18)
+    assert name(d) == "conv_igemm_f32_fast_kernel<32, 32, 2, 2, 1, false, false, false, false, 16, 2>"
+    assert name(_desc(hip, 1, 160, 160, 64, 128, 3, 2, 1)) == "conv_igemm_f32_fast_kernel<32, 32, 2, 2, 1, false, false, false, false, 16, 2>"
+
+
+def test_no_process_global_kernel_switches_in_the_product_abi(native_libs):
+    """the product library exports no `_set_` entry point but si_hip_set_device and does not import getenv -- kernel-form
+    choices travel in SiConv2dDesc::plan, environment switches exist in the -DSI_EXPERIMENT variant build only."""
+    from simpleinfer_amd import _native
+    out = subprocess.run(["nm", "-D", _native.LIB_HIP_PATH], capture_output=True, text=True).stdout
+    setters = [ln.split()[-1] for ln in out.splitlines() if "_set_" in ln and " T " in ln]
+    assert setters == ["si_hip_set_device"], setters
+    assert not any(ln.strip().endswith(" getenv") or "getenv@" in ln for ln in out.splitlines()), "libsi_hip.so imports getenv"
 
 
 def test_upcat_predicate_shares_the_dispatch_preconditions(native_libs):

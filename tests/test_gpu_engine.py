@@ -96,6 +96,93 @@ def test_f32_split_option_holds_the_fp32_parity_bars(si, orc, tmp_path):
         assert_exact(one.extract(oname), got[1:], "f32_split: the second image alone vs in the batch")
 
 
+def _one_conv(mg, n, c, hw, cout, k, s, act=True):
+    b = mg.PnnxBuilder(seed=3)
+    x = b.input((n, c, hw, hw))
+    y = b.conv(x, cout, k, s)
+    b.output(b.silu(y) if act else y)
+    return b
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("c,cout,k,s,kern", [(128, 128, 3, 2, "conv_split3_f32_kernel"),    # strided spatial conv: the split implicit GEMM
+                                            (64, 64, 3, 1, "conv_wino23s_kernel"),          # 3x3 s1: the split form of the fused Winograd kernel
+                                            (512, 256, 1, 1, "conv_split3_f32_kernel")])    # wide 1x1
+def test_f32_split_range_guard_reruns_the_step_in_true_fp32(si, tmp_path, c, cout, k, s, kern, graph):
+    """VERDICT r05 missing 2: the reference convolves any finite fp32 (src/layer/conv_2d.cpp:207-283); the opt-in f32_split arithmetic cannot
+    split a value that rounds to fp16 infinity.  The kernels report it (SiConv2dDesc::range_flag), and Forward() -- at the sync it performs
+    anyway -- sends that layer back to the true-fp32 kernels for the engine's lifetime and re-runs the step in place: the caller gets the
+    DEFAULT engine's bits, never an Inf.  Eager and under hipGraph replay (the demoted layer re-packs its weights, so the captured graph
+    is dropped and the next step runs eagerly once)."""
+    mg = si.modelgen
+    pp, bp = _save(tmp_path, _one_conv(mg, 2, c, 20, cout, k, s), "guard")
+    x = mg.synth_input((2, 20, 20, c))
+    hot = x.copy()
+    hot[1, 7, 9, 5] = 1.0e5
+    e0, oname, want_x = _run(si, pp, bp, x)
+    e0.input("0", hot)
+    e0.forward()
+    want_hot = e0.extract(oname).copy()
+    assert np.isfinite(want_hot).all()
+    e = si.Engine(f32_split=1, graph=graph)
+    e.load_model(pp, bp)
+    e.input("0", x)
+    for _ in range(3):       # (graph=1: eager, capture, replay)
+        e.forward()
+    assert [L["kernel"] for L in e.profile() if L["type"] == "nn.Conv2d"] == [kern]
+    assert_parity(e.extract(oname), want_x, what="f32_split on ordinary data")
+    assert e.schedule()["split_reruns"] == 0
+    e.input("0", hot)
+    e.forward()
+    assert_exact(e.extract(oname), want_hot, "one activation at 1e5: the step was re-run on the true-fp32 kernels")
+    sch = e.schedule()
+    assert sch["split_reruns"] == 1 and sch["split_demoted"] == ["conv_0"], sch
+    assert "split" not in [L["kernel"] for L in e.profile() if L["type"] == "nn.Conv2d"][0] and "wino23s" not in e.profile()[0]["kernel"]
+    e.input("0", x)
+    for _ in range(3):
+        e.forward()
+    assert_exact(e.extract(oname), want_x, "after a trip the layer stays on the true-fp32 kernels")
+    assert e.schedule()["split_reruns"] == 1
+
+
+def test_f32_split_weights_out_of_range_keep_the_layer_in_fp32(si, tmp_path):
+    """weights are checked where they are split, at load: a layer with a weight fp16 cannot hold never runs on the split kernels"""
+    mg = si.modelgen
+    b = _one_conv(mg, 2, 128, 16, 128, 3, 2)
+    b.attrs["conv_0.weight"][5, 6, 0, 0] = 1.0e5
+    pp, bp = _save(tmp_path, b, "wguard")
+    x = mg.synth_input((2, 16, 16, 128))
+    _, oname, want = _run(si, pp, bp, x)
+    e, _, got = _run(si, pp, bp, x, f32_split=1)
+    assert_exact(got, want, "a weight at 1e5: true-fp32 kernels from the first step")
+    sch = e.schedule()
+    assert sch["split_reruns"] == 0 and sch["split_demoted"] == ["conv_0"], sch
+
+
+def test_f32_split_range_guard_in_a_whole_network(si, tmp_path):
+    """YOLOv5s with one input pixel at 1e6: the stem's output overflows fp16 in front of the first split layer; every split layer downstream of
+    it sees non-finite operands in that pass, all of them go back to true fp32 in ONE re-run, and the caller's result is the default engine's.
+    Also through the two-lane schedule and the sliced host pipeline (child engines carry their own flags)."""
+    mg = si.modelgen
+    pp, bp = _save(tmp_path, mg.build_yolov5s(8, 160), "yguard")
+    x = mg.synth_input((8, 160, 160, 3))
+    x[5, 80, 80, 1] = 1.0e6
+    _, oname, want = _run(si, pp, bp, x)
+    assert np.isfinite(want).all()
+    for opts in ({}, {"streams": 2}, {"host_slices": 2}, {"graph": 1}):
+        e = si.Engine(f32_split=1, **opts)
+        e.load_model(pp, bp)
+        e.input("0", x)
+        e.forward()
+        got = e.extract(oname)
+        assert np.isfinite(got).all(), opts
+        assert_detect_parity(got, want, what="f32_split guard, %s" % (opts,))
+        sch = e.schedule()
+        assert sch["split_reruns"] >= 1 and len(sch["split_demoted"]) >= 1, (opts, sch)
+        e.forward()
+        assert_exact(e.extract(oname), got, "second forward after the trip, %s" % (opts,))
+
+
 def test_yolov5s_640_batch1_parity(si, orc, tmp_path):
     """BASELINE.json configs[1]: YOLOv5s 1x3x640x640 fp32 parity vs the CPU outputs."""
     pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(1, 640), "y1")
@@ -488,13 +575,17 @@ def test_errors_are_statuses(si, tmp_path):
 
 
 # ---- fp16 storage path (BASELINE.json configs[3]; no reference parity target: the yardstick is the fp32 oracle) ----
-F16_GRAPH_TOL = 5e-3   # measured: 3e-5 (YOLOv5s, scale set by box coordinates) and 5e-4 (ResNet18 logits)
-F16_SCORE_ABS = 2e-3   # objectness / class scores of a Detect output, absolute (sigmoid outputs in (0, 1))
+# Round 6: the bars sit ~10x above what is measured, per model -- they were 5e-3 / 2e-3 for everything, 100x above YOLOv5s'
+# 3e-5 (a 100x regression would have passed).  YOLOv5s: box columns 3e-4 of their scale (measured 3e-5), scores 5e-4 absolute; everything else
+# (ResNet18 logits measured 5e-4, the small single-purpose graphs): 2e-3 of the tensor's scale.
+F16_YOLO_TOL = 3e-4
+F16_GRAPH_TOL = 2e-3
+F16_SCORE_ABS = 5e-4   # objectness / class scores of a Detect output, absolute (sigmoid outputs in (0, 1))
 
 
 def _f16_check(name):
     if "yolo" in name:
-        return lambda got, ref, what: assert_detect_parity(got, ref, F16_GRAPH_TOL, F16_SCORE_ABS, what=what)
+        return lambda got, ref, what: assert_detect_parity(got, ref, F16_YOLO_TOL, F16_SCORE_ABS, what=what)
     return lambda got, ref, what: assert_parity(got, ref, F16_GRAPH_TOL, what=what)
 
 
@@ -607,7 +698,7 @@ def test_yolov5s_at_another_input_size(si, orc, tmp_path):
     assert got.shape == (2, 3 * (52 * 52 + 26 * 26 + 13 * 13), 85)
     assert_detect_parity(got, ref[oname], what="416x416 fp32")
     _, _, half = _run(si, pp, bp, x, fp16=1)
-    assert_detect_parity(half, ref[oname], F16_GRAPH_TOL, F16_SCORE_ABS, what="416x416 fp16")
+    assert_detect_parity(half, ref[oname], F16_YOLO_TOL, F16_SCORE_ABS, what="416x416 fp16")
     _, _, one = _run(si, *_save(tmp_path, mg.build_yolov5s(1, 416), "y416b1"), x[1:2])
     assert_exact(one[0], got[1], "416x416: an image's result does not depend on the batch")
 
@@ -788,7 +879,25 @@ def test_full_size_properties_yolov5s_640_batch32(si, orc, tmp_path):
     e16.load_model(pp, bp)
     e16.input("0", x)
     e16.forward()
-    assert_detect_parity(e16.extract(oname), full, F16_GRAPH_TOL, F16_SCORE_ABS, what="fp16 storage vs fp32 at full size")
+    assert_detect_parity(e16.extract(oname), full, F16_YOLO_TOL, F16_SCORE_ABS, what="fp16 storage vs fp32 at full size")
+    e16.release()
+    # ... and through the opt-in f32_split arithmetic (round 6, VERDICT r05 item 2b: round 5 tested it at 160x160 batch 2 only): image 13 against
+    # the oracle at the UNCHANGED fp32 bars, nothing tripped the range guard, batch invariance bit for bit
+    es = si.Engine(batch=32, f32_split=1)
+    es.load_model(pp, bp)
+    es.input("0", x)
+    es.forward()
+    split = es.extract(oname)
+    assert_detect_parity(split[13:14], ref, what="f32_split: image 13 of the batch vs the oracle")
+    assert_detect_parity(split, full, what="f32_split vs true fp32 at full size")
+    sch = es.schedule()
+    assert sch["split_reruns"] == 0 and sch["split_demoted"] == [], sch
+    assert sum(L["kernel"] in ("conv_split3_f32_kernel", "conv_wino23s_kernel") for L in es.profile()) >= 20
+    es1 = si.Engine(f32_split=1)
+    es1.load_model(pp, bp)
+    es1.input("0", x[13:14])
+    es1.forward()
+    assert_exact(es1.extract(oname)[0], split[13], "f32_split: image 13 alone == in the batch")
 
 
 def test_full_size_properties_resnet18_224_batch64(si, orc, tmp_path):

@@ -258,13 +258,12 @@ F16_TILES = [0, 1, 2, 3, 7, 9, 10, 11]
 
 @pytest.fixture()
 def tile16(gpu):
-    from simpleinfer_amd import _native
-    H = _native.hip()
+    from simpleinfer_amd import hipops
 
     def set_variant(v):
-        assert H.si_hip_conv2d_f16_set_tile_variant(int(v)) == 0
+        hipops.set_plan(f16_tile=int(v))   # (SiConvPlan::f16_tile in every descriptor hipops builds from here on)
     yield set_variant
-    H.si_hip_conv2d_f16_set_tile_variant(-1)
+    hipops.set_plan()
 
 
 F16_TILE_SHAPES = [
@@ -355,8 +354,6 @@ def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, 
     """Round 4: a 3x3 stride-2 pad-1 conv over 32 channels (YOLOv5's second conv) runs as the persistent spatial-tile kernel
     conv_s2c32_f16_kernel.  Same k order, same MFMA steps, same epilogue expressions as the generic tiles: BIT identical; and the
     fp16 bar against the oracle (src/layer/conv_2d.cpp:207-283) holds."""
-    from simpleinfer_amd import _native
-    H = _native.hip()
     ic = 64 if stride < 0 else 32
     stride = 2 if stride == -2 else abs(stride)
     x = h(rng_uniform(700, (n, ih, iw, ic), -1, 1))
@@ -367,14 +364,10 @@ def test_s2c32_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, ih, iw, oc, 
     oh, ow = (ih + 2 - 3) // stride + 1, (iw + 2 - 3) // stride + 1
     if res:
         kw["residual"] = h(rng_uniform(703, (n, oh, ow, oc), -1, 1))
-    try:
-        assert H.si_hip_conv2d_f16_set_s2c32(0) == 0
+    with hops.plan(f16_s2c32=0):
         base = hops.conv2d_f16(x, w, b, st, (1, 1), **kw)
-        assert H.si_hip_conv2d_f16_set_s2c32(1) == 0
-        got = hops.conv2d_f16(x, w, b, st, (1, 1), **kw)
-        wide = hops.conv2d_f16(x, w, b, st, (1, 1), out_ld=oc + 32, out_c_off=16, **kw)   # into a slice of a wider tensor
-    finally:
-        H.si_hip_conv2d_f16_set_s2c32(1)
+    got = hops.conv2d_f16(x, w, b, st, (1, 1), **kw)
+    wide = hops.conv2d_f16(x, w, b, st, (1, 1), out_ld=oc + 32, out_c_off=16, **kw)   # into a slice of a wider tensor
     assert_exact(got, base, "c32 patch kernel vs generic tiles")
     assert_exact(wide, base, "c32 patch kernel, strided output")
     ref = orc.conv2d(x, w, b, st, (1, 1), path="naive")
@@ -403,26 +396,22 @@ def test_slab_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, hh, ww, ic, o
     a slab staged once for all channel blocks, one barrier, the whole K loop from LDS with streamed lane-order weights.  Same k order,
     same MFMA steps, same epilogue expressions as the generic tiles: BIT identical, at any batch position, into strided tensors; and
     the fp16 bar against the oracle (src/layer/conv_2d.cpp:207-283) holds."""
-    from simpleinfer_amd import _native
-    H = _native.hip()
     x = h(rng_uniform(900, (n, hh, ww, ic), -1, 1))
     w = h(rng_uniform(901, (oc, ic, 3, 3), -0.1, 0.1))
     b = rng_uniform(902, (oc,), -0.5, 0.5)
     kw = {} if act == "none" else ({"act2": "relu"} if act == "res+relu" else {"act1": act})
     if res:
         kw["residual"] = h(rng_uniform(903, (n, hh, ww, oc), -1, 1))
-    try:
-        assert H.si_hip_conv2d_f16_set_slab(0) == 0
+    with hops.plan(f16_slab=0):
         base = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), **kw)
-        assert H.si_hip_conv2d_f16_set_slab(1) == 0
-        got = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), **kw)
-        wide = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), out_ld=oc + 32, out_c_off=16, **kw)   # into a slice of a wider tensor
-        kw1 = dict(kw)
-        if res:
-            kw1["residual"] = kw["residual"][n - 1:]
-        last = hops.conv2d_f16(x[n - 1:], w, b, (1, 1), (1, 1), **kw1)                          # the last image alone: another grid
-    finally:
-        H.si_hip_conv2d_f16_set_slab(1)
+    got = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), **kw)
+    with hops.plan(f16_slab_w2=0):   # the one-wave-per-SIMD form of the 128-channel slab kernel (round 6: every W2 / NBLK / residual combination)
+        assert_exact(hops.conv2d_f16(x, w, b, (1, 1), (1, 1), **kw), base, "slab kernel, one wave per SIMD")
+    wide = hops.conv2d_f16(x, w, b, (1, 1), (1, 1), out_ld=oc + 32, out_c_off=16, **kw)   # into a slice of a wider tensor
+    kw1 = dict(kw)
+    if res:
+        kw1["residual"] = kw["residual"][n - 1:]
+    last = hops.conv2d_f16(x[n - 1:], w, b, (1, 1), (1, 1), **kw1)                          # the last image alone: another grid
     assert_exact(got, base, "slab kernel vs generic tiles")
     assert_exact(wide, base, "slab kernel, strided output")
     assert_exact(last, got[n - 1:], "slab kernel, batch position")
@@ -541,15 +530,14 @@ def test_detect_tile_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, levels
     import ctypes as C
     d = _native.SiConv2dDesc(n, 20, 20, 128, 128, 20, 20, na * ne, na * ne, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, na * ne, 0, 0.0)
     lv = _native.SiYoloLevel(na, ne, 1200, 0, 8.0)
-    try:
-        assert H.si_hip_conv2d_yolo_f16_set_tile(0) == 0
-        assert H.si_hip_conv2d_yolo_f16_tile(C.byref(d), C.byref(lv)) == 0
+    off = _native.SiConvPlan(f16_detect_tile=0)
+    d.plan = C.pointer(off)
+    assert H.si_hip_conv2d_yolo_f16_tile(C.byref(d), C.byref(lv)) == 0
+    with hops.plan(f16_detect_tile=0):
         base = hops.yolo_detect_f16(feats, ws, bs, grids, anchors, strides, na)
-        assert H.si_hip_conv2d_yolo_f16_set_tile(1) == 0
-        assert H.si_hip_conv2d_yolo_f16_tile(C.byref(d), C.byref(lv)) == 1
-        got = hops.yolo_detect_f16(feats, ws, bs, grids, anchors, strides, na)
-    finally:
-        H.si_hip_conv2d_yolo_f16_set_tile(1)
+    d.plan = None
+    assert H.si_hip_conv2d_yolo_f16_tile(C.byref(d), C.byref(lv)) == 1
+    got = hops.yolo_detect_f16(feats, ws, bs, grids, anchors, strides, na)
     assert_exact(got, base, "Detect tile kernel vs generic tiles")
     assert_detect_parity(got, orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na), 1e-4, 1e-4, what="Detect tile kernel")
 

@@ -194,37 +194,29 @@ def test_winograd_half_size_units_same_bits(hops, gpu, n, h, w, ic, oc, pad):
     DESIGN.md 3g) against its 32-tile form on v_mfma_f32_32x32x2_f32: the same transforms and the same ascending channel order
     in one fma chain per output, hence the SAME BITS -- every tile-block shape (2x8 / 4x4 / 8x2 tiles of 16), odd sizes, blocks
     spanning images, ragged oc blocks, fused epilogues and strided tensors."""
-    from simpleinfer_amd import _native
-    H = _native.hip()
     x = rng_uniform(n * 1000 + h, (n, h, w, ic), -1, 1)
     wt = rng_uniform(n * 1000 + h + 1, (oc, ic, 3, 3), -0.5, 0.5)
     b = rng_uniform(n * 1000 + h + 2, (oc,), -0.5, 0.5)
     r = rng_uniform(n * 1000 + h + 3, (n, h + 2 * pad - 2, w + 2 * pad - 2, oc), -1, 1)
     outs = {}
-    try:
-        for form in (32, 16):
-            H.si_hip_conv2d_wino23_set_form(form)
+    for form in (32, 16):
+        with hops.plan(wino23_form=form):
             outs[form] = [hops.conv2d_winograd(x, wt, b, (pad, pad)),
                           hops.conv2d_winograd(x, wt, b, (pad, pad), act1="silu", residual=r),
                           hops.conv2d_winograd(x, wt, b, (pad, pad), residual=r, act2="relu", in_ld=ic + 16, out_ld=oc + 32, out_c_off=16)]
-    finally:
-        H.si_hip_conv2d_wino23_set_form(0)
     for a, c, what in zip(outs[32], outs[16], ("plain", "silu + residual", "residual + relu, strided")):
         assert_exact(c, a, "16-tile form vs 32-tile form: " + what)
 
 
-def test_winograd_64_channel_workgroups_and_unaligned_outputs():
+def test_winograd_64_channel_workgroups_and_unaligned_outputs(hops, orc):
     """The 64-output-channel form of the kernel (two accumulator groups per wave; picked by itself only for ic >= 256 on large
-    grids) is forced onto every eligible shape of the two tests above in a child process (the switch is read once per process):
-    same parity bars, same bit-exact batch invariance, the strided / offset-output cases included."""
-    import os, subprocess, sys
-    env = dict(os.environ, SI_WINO_OCG="2")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), "-q", "-x", "-m", "gpu", "-k",
-                        "test_winograd_vs_reference_path or test_winograd_fused_epilogue_and_strides"],
-                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+    grids) is forced onto every eligible shape of the two tests above (SiConvPlan::wino23_ocg = 2 in the calls' descriptors; until round 6
+    a process-wide environment switch and a child process): same parity bars, same bit-exact batch invariance, the strided /
+    offset-output cases included."""
+    with hops.plan(wino23_ocg=2):
+        for shape in WINO_SHAPES:
+            test_winograd_vs_reference_path(hops, orc, *shape)
+        test_winograd_fused_epilogue_and_strides(hops, orc)
 
 
 # F(4x4, 3x3): same shapes (tile-block shapes 2x8 / 4x4 / 8x2 / 16x1, clipped 4x4 stores on odd sizes, image-spanning
@@ -757,3 +749,119 @@ def test_conv_split3_vs_oracle_and_fp64(hops, orc, n, hw, ic, oc, k, s, act, res
     assert e3 <= 2e-5 and e3 <= 2.0 * e32 + 1e-7, (e3, e32)
     one = hops.conv2d_split3(x[n - 1:], w, b, (s, s), (p, p), act1=act, residual=None if r is None else r[n - 1:])
     assert_exact(one, got[n - 1:], "split3: batch position")
+
+
+# ---- f32_split: the range guard and the dynamic range (round 6; VERDICT r05 missing 2 / weak 1) ----
+def _split_kernels(hops):
+    return {"split3": lambda x, w, b, **kw: hops.conv2d_split3(x, w, b, (1, 1), (1, 1), **kw),
+            "wino_split": lambda x, w, b, **kw: hops.conv2d_wino23_split(x, w, b, (1, 1), **kw)}
+
+
+@pytest.mark.parametrize("kernel", ["split3", "wino_split"])
+def test_f32_split_range_guard_flags_an_overflow_and_nothing_else(hops, orc, kernel):
+    """An activation that rounds to fp16 infinity cannot be split (the reference convolves any finite fp32, src/layer/conv_2d.cpp:207-283): the
+    kernel reports it through SiConv2dDesc::range_flag -- one pixel at 1e5 sets the flag (and the outputs it feeds are non-finite: the flag
+    is what tells the caller to recompute in true fp32); the same tensor without it, values right at fp16's largest finite number, and tiny
+    values do not.  For the Winograd form the guard is on the TRANSFORMED input: four inputs of 3e4 each overflow their sum, no single one does.
+    relu would have hidden a NaN (relu(NaN) = 0): the test is on the accumulators, in front of the activation."""
+    conv = _split_kernels(hops)[kernel]
+    x = rng_uniform(4100, (2, 12, 12, 64), -2, 2)
+    w = rng_uniform(4101, (64, 64, 3, 3), -0.2, 0.2)
+    b = rng_uniform(4102, (64,), -0.5, 0.5)
+    y, flag = conv(x, w, b, act1="relu", return_flag=True)
+    assert flag == 0 and np.isfinite(y).all()
+    assert_parity(y, orc.activation("relu", orc.conv2d(x, w, b, (1, 1), (1, 1), path="naive")), what=kernel)
+    hot = x.copy()
+    hot[1, 5, 7, 13] = 1.0e5
+    y, flag = conv(hot, w, b, act1="relu", return_flag=True)
+    assert flag == 1, "one activation at 1e5 must trip the guard"
+    # the largest finite fp16 neighbourhood still splits (65519 rounds to 65504, hi + lo carries the rest); split3 only: B^T d B sums inputs
+    if kernel == "split3":
+        edge = x.copy()
+        edge[0, 3, 3, 5] = 65519.0
+        y, flag = conv(edge, w, b, return_flag=True)
+        assert flag == 0
+        assert_parity(y, orc.conv2d(edge, w, b, (1, 1), (1, 1), path="naive"), what="split3 at fp16's edge")
+    else:
+        quad = np.zeros_like(x)
+        quad[0, 4:8, 4:8, 3] = np.array([[3.0e4, 0, -3.0e4, 0]] * 4, np.float32) * np.array([[1], [0], [-1], [0]], np.float32)
+        y, flag = conv(quad, w, b, return_flag=True)   # d00 - d02 - d20 + d22 = 1.2e5 > 65504 although every input is 3e4
+        assert flag == 1, "a transformed input value above fp16's range must trip the guard"
+    tiny = x * np.float32(1e-7)
+    y, flag = conv(tiny, w, b, return_flag=True)
+    assert flag == 0 and np.isfinite(y).all()
+    # weights outside fp16's range: refused where they are split (the layer then stays on the fp32 kernels)
+    wbig = w.copy()
+    wbig[3, 4, 1, 1] = 7.0e4 if kernel == "split3" else 2.0e5
+    with pytest.raises(hops.HipError):
+        conv(x, wbig, b)
+
+
+@pytest.mark.parametrize("kernel", ["split3", "wino_split"])
+def test_f32_split_dynamic_range_sweep_elementwise(hops, orc, kernel):
+    """The opt-in arithmetic across the dynamic range (round 5 tested x in U[-2, 2] only): tensor scales 1e-6 ... 1e4, under
+    the ELEMENT-WISE bar |d| <= 1e-4 (|ref| + rms(ref)) against the float64 convolution -- and, from scale 1e-3 up, an error at most twice the
+    true-fp32 kernel's under the same metric.  (Below 6e-5 the hi half is an fp16 subnormal: the pair still resolves 2.9e-11 absolute, i.e.
+    ~1e-5 of a tensor whose scale is 1e-6 -- inside the bar, no longer fp32-class; include/si_hip.h states it.)  Where the scale makes the
+    operands overflow fp16 (the Winograd form from ~1.6e4) the guard must say so instead."""
+    from util import mixed_err
+    conv = _split_kernels(hops)[kernel]
+    f32 = (lambda x, w, b: hops.conv2d(x, w, b, (1, 1), (1, 1))) if kernel == "split3" else (lambda x, w, b: hops.conv2d_winograd(x, w, b, (1, 1)))
+    x0 = rng_uniform(4200, (2, 14, 14, 128), -2, 2)
+    w = rng_uniform(4201, (64, 128, 3, 3), -0.2, 0.2)
+    b0 = rng_uniform(4202, (64,), -0.5, 0.5)
+    for scale in (1e-6, 1e-4, 1e-2, 1.0, 1e2, 1e4):
+        x, b = x0 * np.float32(scale), b0 * np.float32(scale)
+        ref = orc.conv2d(x, w, b, (1, 1), (1, 1), path="naive")
+        y, flag = conv(x, w, b, return_flag=True)
+        if flag:
+            assert kernel == "wino_split" and scale >= 1e4, "guard tripped at scale %g" % scale   # |B^T d B| up to 8e4
+            continue
+        m, m32 = mixed_err(y, ref), mixed_err(f32(x, w, b), ref)
+        assert m <= 1e-4, "scale %g: element-wise error %.3e" % (scale, m)
+        if scale >= 1e-3:
+            assert m <= 2.0 * m32 + 1e-7, "scale %g: %.3e vs the fp32 kernel's %.3e" % (scale, m, m32)
+
+
+@pytest.mark.parametrize("kernel", ["split3", "wino_split"])
+def test_f32_split_mixed_magnitude_channels(hops, orc, kernel):
+    """A wide dynamic range INSIDE one tensor: input channels of magnitude 1e-4 beside channels of magnitude 1e2, and output channels whose
+    filters are 1e-3 of the others' -- held PER OUTPUT CHANNEL (|d| <= 1e-4 (|ref| + rms of that channel)), so that a small-magnitude channel
+    cannot hide behind the tensor's largest value, and to at most twice the true-fp32 kernel's error under the same metric."""
+    from util import mixed_err
+    conv = _split_kernels(hops)[kernel]
+    f32 = (lambda x, w, b: hops.conv2d(x, w, b, (1, 1), (1, 1))) if kernel == "split3" else (lambda x, w, b: hops.conv2d_winograd(x, w, b, (1, 1)))
+    x = rng_uniform(4300, (2, 14, 14, 128), -2, 2)
+    cs = np.where(np.arange(128) % 2 == 0, np.float32(1e-4), np.float32(1e2))
+    x = x * cs
+    w = rng_uniform(4301, (64, 128, 3, 3), -0.2, 0.2)
+    w[::4] *= np.float32(1e-3)
+    b = np.zeros(64, np.float32)
+    ref = orc.conv2d(x, w, b, (1, 1), (1, 1), path="naive")
+    y, flag = conv(x, w, b, return_flag=True)
+    assert flag == 0
+    m, m32 = mixed_err(y, ref, per_channel=True), mixed_err(f32(x, w, b), ref, per_channel=True)
+    assert m <= 1e-4 and m <= 2.0 * m32 + 1e-7, (m, m32)
+    # the small-magnitude INPUT channels alone (the large ones zeroed): what the max-based metric of round 5 could not see
+    xs = x * (cs < 1).astype(np.float32)
+    ref = orc.conv2d(xs, w, b, (1, 1), (1, 1), path="naive")
+    m = mixed_err(conv(xs, w, b), ref, per_channel=True)
+    assert m <= 1e-4, m
+
+
+def test_detect_split3_range_guard(hops):
+    """si_hip_conv2d_split3_yolo_f32 tests its accumulators in front of the sigmoid (sigmoid(Inf) = 1 would hide an overflow)"""
+    na, ne, n = 3, 85, 2
+    feats, ws, bs, grids, anchors = [], [], [], [], []
+    for i, (h, c) in enumerate([(8, 128), (4, 256)]):
+        feats.append(rng_uniform(4400 + i, (n, h, h, c), -1, 1))
+        ws.append(rng_uniform(4410 + i, (na * ne, c, 1, 1), -0.3, 0.3))
+        bs.append(rng_uniform(4420 + i, (na * ne,), -0.5, 0.5))
+        gy, gx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="ij")
+        grids.append(np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, h, h, 2)).copy())
+        anchors.append(np.broadcast_to(rng_uniform(4430 + i, (1, na, 1, 1, 2), 5, 300), (1, na, h, h, 2)).copy())
+    _, flags = hops.yolo_detect_split3(feats, ws, bs, grids, anchors, [8.0, 16.0], na, return_flags=True)
+    assert flags == [0, 0]
+    feats[1][1, 2, 3, 7] = 3.0e5
+    _, flags = hops.yolo_detect_split3(feats, ws, bs, grids, anchors, [8.0, 16.0], na, return_flags=True)
+    assert flags == [0, 1]

@@ -12,7 +12,7 @@ from util import rng_uniform
 
 pytestmark = pytest.mark.gpu
 
-# variant ids of conv_igemm.hip (si_hip_conv2d_set_tile_variant)
+# variant ids of conv_igemm.hip (SiConvPlan::f32_tile: the plan travels inside each call's descriptor)
 ALL_TILES = [4, 2, 0, 1, 5, 6, 10, 3, 11, 12, 13, 14, 16, 17, 19, 22]
 SMALL_TILES = [11, 12, 13, 14, 16, 17, 19, 22]
 
@@ -25,13 +25,12 @@ def hops(gpu):
 
 @pytest.fixture()
 def tile(gpu):
-    from simpleinfer_amd import _native
-    H = _native.hip()
+    from simpleinfer_amd import hipops
 
     def set_variant(v):
-        H.si_hip_conv2d_set_tile_variant(int(v))
+        hipops.set_plan(f32_tile=int(v))
     yield set_variant
-    H.si_hip_conv2d_set_tile_variant(-1)
+    hipops.set_plan()
 
 
 # (shape NHWC, oc, k, s, p, groups): fast-path shapes (ic/groups % 32 == 0) of every kind the YOLOv5s / ResNet18 graphs hold,

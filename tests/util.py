@@ -17,10 +17,38 @@ def rel_err(got: np.ndarray, ref: np.ndarray) -> float:
     return float(np.abs(got - ref).max()) / scale
 
 
-def assert_parity(got, ref, rel=REL_TOL, what=""):
+def mixed_err(got: np.ndarray, ref: np.ndarray, per_channel: bool = False) -> float:
+    """The ELEMENT-WISE metric: max over elements of |got - ref| / (|ref| + rms(ref)).  An element is held to its OWN
+    magnitude, with the tensor's rms as the floor under near-cancelling outputs (a pure element-wise relative error is meaningless where
+    cancellation leaves an output near 0; max|diff| / max|ref| hides every element much smaller than the largest).  per_channel: the rms of the
+    element's last-axis channel instead of the whole tensor's -- small-magnitude channels then stand on their own.  The reference's own
+    contract is element-wise too (test/test_layer/test_conv_2d.cpp:100-131: abs 2e-4 on U[0,1) data)."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if per_channel and ref.ndim >= 2:
+        rms = np.sqrt((ref.reshape(-1, ref.shape[-1]) ** 2).mean(axis=0))
+        rms = np.maximum(rms, 1e-30)
+    else:
+        rms = max(float(np.sqrt((ref ** 2).mean())), 1e-30)
+    return float((np.abs(got - ref) / (np.abs(ref) + rms)).max())
+
+
+MIXED_LOG = []   # (what, max|d|/max|ref|, mixed) of every assert_parity call at the fp32 bar: tests/conftest.py prints the worst at the end of a run
+
+
+def assert_parity(got, ref, rel=REL_TOL, what="", mixed=None):
+    """max|diff| / max|ref| <= rel, and -- for the fp32 bar (rel <= 1e-4) unless mixed=False -- the element-wise mixed metric (mixed_err) at the
+    same number: it holds on every fp32 kernel of the suite (measured round 6; the list of exceptions is empty)."""
     assert np.isfinite(np.asarray(got)).all(), "%s: non-finite values" % what
     e = rel_err(got, ref)
     assert e <= rel, "%s: max|diff|/max|ref| = %.3e > %.1e" % (what, e, rel)
+    if mixed is None:
+        mixed = rel <= REL_TOL
+    if mixed:
+        m = mixed_err(got, ref)
+        MIXED_LOG.append((what, e, m))
+        assert m <= rel, "%s: element-wise max|d| / (|ref| + rms(ref)) = %.3e > %.1e" % (what, m, rel)
     return e
 
 

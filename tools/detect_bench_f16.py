@@ -35,7 +35,8 @@ for h, c in ((80, 128), (40, 256), (20, 512)):
     by = n*h*h*(c*2 + na*ne*4)
     res = []
     for on in (0, 1, 0, 1):
-        H.si_hip_conv2d_yolo_f16_set_tile(on)
+        pl = _native.SiConvPlan(f16_detect_tile=on)
+        d.plan = C.pointer(pl)
         ms = t(run); res.append(ms); tot[on] += ms / 2
     print("level %dx%dx%d: generic %.4f / %.4f ms (%.0f GB/s)   detect tile %.4f / %.4f ms (%.0f GB/s)" % (
         h, h, c, res[0], res[2], by/min(res[0], res[2])/1e6, res[1], res[3], by/min(res[1], res[3])/1e6))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/tile_sweep.py -- which implicit-GEMM tile is fastest for which launch size?  Times si_hip_conv2d_f32 on every distinct
 YOLOv5s / ResNet18 conv shape that the implicit-GEMM kernel serves (not the stem, not the Winograd layers), per batch size and
-per tile variant (si_hip_conv2d_set_tile_variant), sustained (--min-ms per point).  Prints one line per (batch, shape) with the
+per tile variant (SiConvPlan::f32_tile in the call's descriptor), sustained (--min-ms per point).  Prints one line per (batch, shape) with the
 time of every variant and the winner, then the totals per batch for: the default tile, the best tile per shape, and each
 candidate policy.  Development tool (GPU box only); its output is what conv_variant()'s thresholds are read from.
 
@@ -45,7 +45,7 @@ def main():
         for key, count in conv_shapes(b).items():
             n, ih, iw, ci, oh, ow, co, k, s, p, g = key
             d = SiConv2dDesc(n, ih, iw, ci, ci, oh, ow, co, co, k[0], k[1], s[0], s[1], 1, 1, p[0], p[1], g, 1, hipops.ACT["silu"], 0, co, 0, 0.0)
-            H.si_hip_conv2d_set_tile_variant(-1)
+            d.plan = None
             name = H.si_hip_conv2d_kernel_name(C.byref(d), C.c_void_p(4096)).decode()
             if "fast" not in name or H.si_hip_conv2d_wino23_preferred(C.byref(d)):
                 continue
@@ -57,7 +57,8 @@ def main():
             dy = hipops.DeviceBuffer(n * oh * ow * co * 4)
             times = {}
             for v in variants:
-                H.si_hip_conv2d_set_tile_variant(v)
+                pl = _native.SiConvPlan(f32_tile=v)
+                d.plan = C.pointer(pl)
                 for _ in range(2):
                     assert H.si_hip_conv2d_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr, None, dy.ptr, None) == 0
                 H.si_hip_device_sync()
@@ -84,7 +85,6 @@ def main():
             print("%-34s %3d %6d %6d  " % ("%dx%dx%d->%dx%dx%d k%ds%d" % (ih, iw, ci, oh, ow, co, k[0], s[0]), count, t64, (co // g + 63) // 64) +
                   " ".join("%8.1f" % times[v] for v in variants) + "   v%d" % bv, flush=True)
         print("total us/forward: " + " ".join("v%d %.1f" % (v, totals[v]) for v in variants) + "  best-per-shape %.1f" % best_total, flush=True)
-    H.si_hip_conv2d_set_tile_variant(-1)
 
 
 if __name__ == "__main__":
