@@ -478,6 +478,18 @@ int si_hip_conv2d_stem_s2c32_f16_supported(const SiConv2dDesc* stem, const SiCon
 int si_hip_conv2d_stem_s2c32_f16(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const float* in, const void* stem_w_packed,
                                  const float* stem_bias, const void* conv_w_packed, const float* conv_bias, void* out,
                                  si_stream_t stream);
+/* Round 6: ... and the 1x1 conv behind them in the same launch -- `pw`: 1x1, stride 1, 64 -> 64 over conv's 64 output channels, SiLU (YOLOv5's
+ * first C3: cv1 | cv2 as one conv over the concatenated filters, as si_hip_conv2d_split_f16 takes them).  The tile of `conv`'s output is
+ * multiplied while it is still in the CU (LDS [pixel][channel], four 16-deep MFMA steps): the 64-channel tensor between the two -- 105 MB at
+ * batch 32, written and read back by the two launches this replaces -- never exists.  split_oc = 32: output channels [0, 32) to `out` (stride
+ * pw->out_ld), [32, 64) to `out2` (stride out2_ld); split_oc = 0: all 64 to `out`.  Weights: the three convs' own pack functions.  Same bits as
+ * si_hip_conv2d_stem_s2c32_f16 followed by si_hip_conv2d_split_f16 / si_hip_conv2d_f16 (replaces three Conv2d::Forward calls of the
+ * reference, src/layer/conv_2d.cpp:108-118, 207-283). */
+int si_hip_conv2d_stem_s2c32_pw_f16_supported(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const SiConv2dDesc* pw, int split_oc);
+int si_hip_conv2d_stem_s2c32_pw_f16(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const SiConv2dDesc* pw, const float* in,
+                                    const void* stem_w_packed, const float* stem_bias, const void* conv_w_packed, const float* conv_bias,
+                                    const void* pw_w_packed, const float* pw_bias, void* out, int split_oc, void* out2, int out2_ld,
+                                    si_stream_t stream);
 int si_hip_conv2d_yolo_f16_tile(const SiConv2dDesc* d, const SiYoloLevel* level);
 int si_hip_activation_f16(int act, float act_param, const void* in, size_t pixels, int c, int in_ld, void* out, int out_ld,
                           si_stream_t stream);

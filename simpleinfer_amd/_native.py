@@ -178,6 +178,9 @@ def hip():
         "si_hip_conv2d_pw_slab_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_stem_s2c32_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_stem_s2c32_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp, vp]),
+        "si_hip_conv2d_stem_s2c32_pw_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), i]),
+        "si_hip_conv2d_stem_s2c32_pw_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp,
+                                                vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_yolo_f16_tile": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiYoloLevel)]),
         "si_hip_activation_f16": (i, [i, f, vp, sz, i, i, vp, i, vp]),
         "si_hip_unary_f16": (i, [i, vp, sz, i, i, vp, i, vp]),

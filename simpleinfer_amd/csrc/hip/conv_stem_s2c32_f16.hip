@@ -44,6 +44,12 @@ struct FusedArgs {
     int oh, ow, oc, out_ld, nb;
     int tiles_x, tiles_y, items;
     unsigned in_bytes;
+    // PW form (round 6): a 1x1 conv over conv_1's 64 channels behind it -- YOLOv5's first C3's cv1 | cv2 as ONE 64 -> 64 conv with a split
+    // destination -- computed from the tile while it is still in the CU: conv_1's output is never written
+    const half_t* wp;     // its weights in MFMA lane order: [2 column blocks][4 k-steps][64 lanes][8]
+    const float* bp;      // its bias (64) or null
+    half_t* out_b;        // destination of output channels [32, 64) (`out` takes [0, 32)); strides in elements
+    int out_b_ld;
 };
 
 // SI_FUSED_ABL (diagnostic builds only, tools/stem_fused_ablate.sh): bit 0 no SiLU (bias add only), 1 no stem MFMAs, 2 no phase B,
@@ -76,10 +82,17 @@ constexpr int PATCH_BYTES = PR * ROWP, STAGE_BYTES = IR * RL * 2, WS_BYTES = 9 *
 #ifndef SI_FUSED_MINW
 #define SI_FUSED_MINW 2
 #endif
+constexpr int TP = 72;   // PW form: halves per pixel of the tile image [64 pixels][64 channels + 8] (144-byte pitch: conflict-free ds_read_b128)
+// PW: phase C behind phase B -- the tile (4 x 16 pixels x 64 channels, SiLU'd and rounded to fp16 exactly as it would have been stored) goes
+// to LDS as [pixel][channel]; after one barrier every wave multiplies ITS 32 pixels by ITS 32 output columns of the 1x1 conv (four 16-deep MFMA
+// steps over the 64 channels, ascending: the generic fp16 tiles' k order, so the bits are si_hip_conv2d_split_f16's), bias + SiLU, and writes
+// output channels [0, 32) to `out`, [32, 64) to `out_b` (the C3's cv1 result and cv2's slice of the concat buffer).
+template <bool PW>
 __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel(const FusedArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[PATCH_BYTES];
     __shared__ __attribute__((aligned(16))) half_t stage[IR * RL];
     __shared__ __attribute__((aligned(16))) half_t wsl[9 * 2 * 32 * 8];
+    __shared__ __attribute__((aligned(16))) half_t tile[PW ? 64 * TP : 8];
 
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
@@ -133,6 +146,16 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
     const float bsv = a.bs ? a.bs[l31] : 0.0f;
     const int o = wn * 32 + l31;
     const float bcv = (a.bc && o < a.oc) ? a.bc[o] : 0.0f;
+    // PW: this wave's column block of the 1x1 conv's weights (four k-steps), resident as well, and its bias
+    f16x8 wpf[PW ? 4 : 1];
+    float bpv = 0.0f;
+    if (PW) {
+        const __amdgpu_buffer_rsrc_t rs_wp = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wp), 0, 2u * 4u * 1024u, 0x00020000);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            wpf[s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, (unsigned)wn * 4096u + (unsigned)lane * 16u, (unsigned)(s * 1024), 0));
+        bpv = a.bp ? a.bp[o] : 0.0f;
+    }
     // the stem's B fragments of this lane, resident too (SI_FUSED_WS_REGS=0: re-read from LDS per MFMA, as conv_stem_f16.hip does)
 #ifndef SI_FUSED_WS_REGS
 #define SI_FUSED_WS_REGS 1
@@ -244,6 +267,40 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
                 for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[g & 1][i], wf[3 * g + i], acc, 0, 0, 0);
             }
             const int oy0 = ty * 4 + 2 * wm, ox0 = tx * 16;
+            if constexpr (PW) {
+                // the tile into LDS as [pixel 32 wm + r][channel o] (conv_1's own epilogue expressions and rounding: silu2_bits)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    unsigned h0, h1;
+                    silu2_bits(acc[e], acc[e + 1], bcv, h0, h1);
+                    *reinterpret_cast<unsigned short*>(tile + (32 * wm + r) * TP + o) = (unsigned short)h0;
+                    *reinterpret_cast<unsigned short*>(tile + (32 * wm + r + 1) * TP + o) = (unsigned short)h1;
+                }
+                __syncthreads();   // both column-block waves of a pixel block have written their channels
+                f32x16 acc2;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
+                const half_t* const T = tile + (32 * wm + l31) * TP + 8 * lh;
+                f16x8 ta[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) ta[s] = *reinterpret_cast<const f16x8*>(T + 16 * s);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[s], wpf[s], acc2, 0, 0, 0);
+                half_t* const ob = wn == 0 ? a.out + l31 : a.out_b + l31;
+                const int old = wn == 0 ? a.out_ld : a.out_b_ld;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+                    unsigned h0, h1;
+                    silu2_bits(acc2[e], acc2[e + 1], bpv, h0, h1);
+                    unsigned short* const op = reinterpret_cast<unsigned short*>(ob + (size_t)((img * a.oh + oy) * a.ow + ox) * old);
+                    if (oy < a.oh && ox < a.ow) op[0] = (unsigned short)h0;
+                    if (oy < a.oh && ox + 1 < a.ow) op[old] = (unsigned short)h1;
+                }
+                continue;   // (the next item's commit() writes `stage`, its barrier orders this item's tile reads before the next tile writes)
+            }
             half_t* const ob = a.out + o;
             if (o < a.oc) {
 #pragma unroll
@@ -273,6 +330,55 @@ bool conv_ok(const SiConv2dDesc* d) {
            d->oh == (d->ih + 2 - 3) / 2 + 1 && d->ow == (d->iw + 2 - 3) / 2 + 1 && d->oh > 0 && d->ow > 0;
 }
 
+// the 1x1 conv of the PW form: 64 -> 64 over conv_1's output, bias optional, SiLU, no shortcut (YOLOv5's first C3: cv1 | cv2 fused)
+bool pw_ok(const SiConv2dDesc* d) {
+    return d->groups == 1 && d->ic == 64 && d->oc == 64 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->dh == 1 && d->dw == 1 &&
+           d->pt == 0 && d->pl == 0 && !d->has_residual && d->act1 == SI_ACT_SILU && d->act2 == SI_ACT_NONE && d->oh == d->ih && d->ow == d->iw;
+}
+
+int fused_launch(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const SiConv2dDesc* pw, const float* in, const void* stem_w_packed,
+                 const float* stem_bias, const void* conv_w_packed, const float* conv_bias, const void* pw_w_packed, const float* pw_bias,
+                 void* out, int split_oc, void* out2, int out2_ld, si_stream_t stream) {
+    const unsigned long long in_bytes = (unsigned long long)stem->n * stem->ih * stem->iw * 3ull * 4ull;
+    if (in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+    FusedArgs a;
+    a.in = in;
+    a.ws = static_cast<const half_t*>(stem_w_packed);
+    a.bs = stem->has_bias ? stem_bias : nullptr;
+    // the lane-order image sits behind the row-major one in si_hip_conv2d_f16_pack_weight_host's buffer ([oc][9 * 32] rows first)
+    a.wl = static_cast<const half_t*>(conv_w_packed) + (size_t)conv->oc * 9 * 32;
+    a.bc = conv->has_bias ? conv_bias : nullptr;
+    a.out = static_cast<half_t*>(out);
+    a.ih = stem->ih; a.iw = stem->iw; a.soh = stem->oh; a.sow = stem->ow;
+    a.oh = conv->oh; a.ow = conv->ow; a.oc = conv->oc; a.out_ld = conv->out_ld; a.nb = conv->oc / 32;
+    a.tiles_x = (conv->ow + 15) / 16; a.tiles_y = (conv->oh + 3) / 4;
+    const long long items = (long long)conv->n * a.tiles_x * a.tiles_y;
+    if (items > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    a.items = (int)items;
+    a.in_bytes = (unsigned)in_bytes;
+    a.wp = nullptr; a.bp = nullptr; a.out_b = nullptr; a.out_b_ld = 0;
+    if (pw) {
+        a.wp = static_cast<const half_t*>(pw_w_packed) + (size_t)64 * 64;   // (row-major image first, as above)
+        a.bp = pw->has_bias ? pw_bias : nullptr;
+        a.out_ld = pw->out_ld;
+        a.out_b = split_oc ? static_cast<half_t*>(out2) : static_cast<half_t*>(out) + 32;
+        a.out_b_ld = split_oc ? out2_ld : pw->out_ld;
+    }
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    auto go = [&](auto kern) {
+        const int per_cu = si_resident_blocks(kern, 256, 0);
+        long long grid = (long long)cus * per_cu;
+        if (grid > items) grid = items;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+        return (int)hipGetLastError();
+    };
+    return pw ? go(conv_stem_s2c32_f16_kernel<true>) : go(conv_stem_s2c32_f16_kernel<false>);
+}
+
 }  // namespace
 
 extern "C" {
@@ -292,33 +398,25 @@ int si_hip_conv2d_stem_s2c32_f16(const SiConv2dDesc* stem, const SiConv2dDesc* c
     if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (reinterpret_cast<uintptr_t>(conv_w_packed) & 15) != 0 ||
         (reinterpret_cast<uintptr_t>(stem_w_packed) & 15) != 0)
         return SI_E_UNSUPPORTED;
-    const unsigned long long in_bytes = (unsigned long long)stem->n * stem->ih * stem->iw * 3ull * 4ull;
-    if (in_bytes >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
-    FusedArgs a;
-    a.in = in;
-    a.ws = static_cast<const half_t*>(stem_w_packed);
-    a.bs = stem->has_bias ? stem_bias : nullptr;
-    // the lane-order image sits behind the row-major one in si_hip_conv2d_f16_pack_weight_host's buffer ([oc][9 * 32] rows first)
-    a.wl = static_cast<const half_t*>(conv_w_packed) + (size_t)conv->oc * 9 * 32;
-    a.bc = conv->has_bias ? conv_bias : nullptr;
-    a.out = static_cast<half_t*>(out);
-    a.ih = stem->ih; a.iw = stem->iw; a.soh = stem->oh; a.sow = stem->ow;
-    a.oh = conv->oh; a.ow = conv->ow; a.oc = conv->oc; a.out_ld = conv->out_ld; a.nb = conv->oc / 32;
-    a.tiles_x = (conv->ow + 15) / 16; a.tiles_y = (conv->oh + 3) / 4;
-    const long long items = (long long)conv->n * a.tiles_x * a.tiles_y;
-    if (items > 0x7fffffffLL) return SI_E_UNSUPPORTED;
-    a.items = (int)items;
-    a.in_bytes = (unsigned)in_bytes;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n;
-    }();
-    const int per_cu = si_resident_blocks(conv_stem_s2c32_f16_kernel, 256, 0);
-    long long grid = (long long)cus * per_cu;
-    if (grid > items) grid = items;
-    hipLaunchKernelGGL(conv_stem_s2c32_f16_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    return (int)hipGetLastError();
+    return fused_launch(stem, conv, nullptr, in, stem_w_packed, stem_bias, conv_w_packed, conv_bias, nullptr, nullptr, out, 0, nullptr, 0, stream);
+}
+
+int si_hip_conv2d_stem_s2c32_pw_f16_supported(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const SiConv2dDesc* pw, int split_oc) {
+    if (!pw || !si_hip_conv2d_stem_s2c32_f16_supported(stem, conv)) return 0;
+    return (conv->oc == 64 && pw_ok(pw) && pw->n == conv->n && pw->ih == conv->oh && pw->iw == conv->ow && (split_oc == 0 || split_oc == 32)) ? 1 : 0;
+}
+
+int si_hip_conv2d_stem_s2c32_pw_f16(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const SiConv2dDesc* pw, const float* in,
+                                    const void* stem_w_packed, const float* stem_bias, const void* conv_w_packed, const float* conv_bias,
+                                    const void* pw_w_packed, const float* pw_bias, void* out, int split_oc, void* out2, int out2_ld,
+                                    si_stream_t stream) {
+    if (!stem || !conv || !pw || !in || !stem_w_packed || !conv_w_packed || !pw_w_packed || !out || (split_oc && !out2)) return SI_E_BADARG;
+    if ((stem->has_bias && !stem_bias) || (conv->has_bias && !conv_bias) || (pw->has_bias && !pw_bias)) return SI_E_BADARG;
+    if (!si_hip_conv2d_stem_s2c32_pw_f16_supported(stem, conv, pw, split_oc)) return SI_E_UNSUPPORTED;
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(conv_w_packed) | reinterpret_cast<uintptr_t>(stem_w_packed) |
+          reinterpret_cast<uintptr_t>(pw_w_packed)) & 15) != 0)
+        return SI_E_UNSUPPORTED;
+    return fused_launch(stem, conv, pw, in, stem_w_packed, stem_bias, conv_w_packed, conv_bias, pw_w_packed, pw_bias, out, split_oc, out2, out2_ld, stream);
 }
 
 }  // extern "C"

@@ -55,7 +55,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "batch") opt_batch_ = value;  // > 0: re-batch the graph at load (the file bakes its batch into every shape)
     else if (key == "arena") opt_arena_ = value != 0;  // 1 (default): intermediates share one arena by lifetime; 0: one hipMalloc each
     else if (key == "fuse_pw") opt_fuse_pw_ = value != 0;      // fp16: a C3 bottleneck's 1x1 conv computed inside the slab kernel of its 3x3 conv (default 1)
-    else if (key == "fuse_stem") opt_fuse_stem_ = value != 0;  // fp16: RGB stem conv + the 3x3 s2 conv behind it in one launch (default 1)
+    else if (key == "fuse_stem") opt_fuse_stem_ = value;       // fp16: 1 RGB stem conv + the 3x3 s2 conv behind it in one launch; 2 (default) ... and the 1x1 conv(s) reading that; 0 off
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "detect_priority") opt_detect_priority_ = value < 0 ? -1 : (value > 0 ? 1 : 0);   // priority of Detect's side stream: -1 low, 0 default, +1 high
     else if (key == "detect_stream") opt_detect_stream_ = value;  // Detect's early levels on a second stream: 0 never, 1 (default) where they have enough work, 2 always
@@ -422,6 +422,7 @@ Status EngineImpl::CreatePipeline() {
         CHECK_STATUS(FusePoolChains(order));
         if (opt_fuse_upsample_ && opt_alias_cat_) CHECK_STATUS(FuseUpsampleIntoConvs(order));   // (fp16 storage too since round 4)
         if (opt_fp16_ && opt_fuse_stem_) CHECK_STATUS(FuseStemPairs(order));
+        if (opt_fp16_ && opt_fuse_stem_ > 1) CHECK_STATUS(FuseStemTriples(order));
         if (opt_fp16_ && opt_fuse_pw_) CHECK_STATUS(FuseBottleneckPairs(order));
     }
     if (opt_fp16_) {
@@ -739,6 +740,43 @@ Status EngineImpl::FuseStemPairs(std::vector<Step>& order) {
         Conv2d* conv = dynamic_cast<Conv2d*>(order[index[c]].layer);
         if (!conv || !conv->CanFuseStemProducer(*stem)) continue;
         conv->SetStemProducer(stem);
+        dead_operands_.insert(mid->name);
+        removed[i] = true;
+        fused_ops_.insert(order[i].op->name);
+    }
+    std::vector<Step> out;
+    for (size_t i = 0; i < order.size(); ++i)
+        if (!removed[i]) out.push_back(order[i]);
+    order.swap(out);
+    return Status::kSuccess;
+}
+
+// fp16 storage (round 6): the conv that took the stem (FuseStemPairs) and the 1x1 conv over its 64 channels that is its only reader -- with the
+// sibling that conv computes as well: YOLOv5's first C3 reads the tensor twice, cv1 and cv2, which FuseSiblingConvs has made ONE conv -- become
+// one launch at the 1x1 conv's slot (si_hip_conv2d_stem_s2c32_pw_f16); the 64-channel tensor between them is never allocated.
+Status EngineImpl::FuseStemTriples(std::vector<Step>& order) {
+    std::map<const pnnx::Operator*, size_t> index;
+    for (size_t i = 0; i < order.size(); ++i) index[order[i].op] = i;
+    std::vector<bool> removed(order.size(), false);
+    for (size_t i = 0; i < order.size(); ++i) {
+        Conv2d* c1 = dynamic_cast<Conv2d*>(order[i].layer);
+        if (!c1 || order[i].op->type != "nn.Conv2d" || !c1->StemProducer() || c1->OutputNodes().size() != 1) continue;
+        const pnnx::Operand* mid = c1->OutputNodes()[0]->operand;
+        if (!mid || output_tensor_nodes_.count(mid->name) || mid->consumers.empty()) continue;
+        // every reader of `mid` is the same scheduled 1x1 conv or the sibling it computes
+        Conv2d* pw = nullptr;
+        bool ok = true;
+        for (const pnnx::Operator* c : mid->consumers) {
+            if (!c || c->type != "nn.Conv2d") { ok = false; break; }
+            if (sibling_ops_.count(c->name)) continue;
+            if (!index.count(c) || pw) { ok = false; break; }
+            pw = dynamic_cast<Conv2d*>(order[index[c]].layer);
+        }
+        if (!ok || !pw) continue;
+        for (const pnnx::Operator* c : mid->consumers)
+            if (sibling_ops_.count(c->name) && (!pw->Sibling() || pw->Sibling()->GetOp() != c)) ok = false;
+        if (!ok || !pw->CanFuseStemPairProducer(*c1)) continue;
+        pw->SetStemPairProducer(c1);
         dead_operands_.insert(mid->name);
         removed[i] = true;
         fused_ops_.insert(order[i].op->name);

@@ -101,6 +101,7 @@ private:
     Status FusePoolChains(std::vector<Step>& order);
     Status FuseUpsampleIntoConvs(std::vector<Step>& order);
     Status FuseStemPairs(std::vector<Step>& order);
+    Status FuseStemTriples(std::vector<Step>& order);
     Status FuseBottleneckPairs(std::vector<Step>& order);
     Status InsertOutputCasts(std::vector<Step>& order);
     Status InsertFp32Fallbacks(std::vector<Step>& order);
@@ -132,7 +133,7 @@ private:
     bool opt_fuse_ = true;
     bool opt_alias_cat_ = true;
     bool opt_fuse_upsample_ = true;
-    bool opt_fuse_stem_ = true;
+    int opt_fuse_stem_ = 2;
     bool opt_fuse_pw_ = true;
     bool opt_f32_split_ = false;
     SiConvPlan opt_plan_ = SI_CONV_PLAN_DEFAULT;   // kernel-form choices handed to every conv launch (options f32_tile, f16_slab, ...; all default: the policy)

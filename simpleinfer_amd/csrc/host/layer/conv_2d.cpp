@@ -133,6 +133,60 @@ void Conv2d::SetStemProducer(Conv2d* stem) {
     device_ready_ = false;
 }
 
+bool Conv2d::CanFuseStemPairProducer(const Conv2d& c1) const {
+    if (!c1.stem_producer_ || !c1.stem_mid_ || c1.residual_node_ || c1.sibling_ || c1.up_node_ || c1.pw_producer_ || c1.stem_pair_) return false;
+    if (residual_node_ || up_node_ || stem_producer_ || pw_producer_ || stem_pair_ || act2_ != SI_ACT_NONE) return false;
+    if (input_tensor_nodes_.size() != 1 || c1.output_tensor_nodes_.size() != 1 || c1.output_tensor_nodes_[0] != input_tensor_nodes_[0]) return false;
+    if (output_tensor_nodes_.size() != (sibling_ ? 2u : 1u) || c1.input_tensor_nodes_.size() != 1) return false;
+    const Tensor& img = c1.input_tensor_nodes_[0]->tensor;   // (c1 reads the image since it took the stem)
+    const Tensor& smid = c1.stem_mid_->tensor;
+    const Tensor& mid = input_tensor_nodes_[0]->tensor;
+    if (IsHalf(img) || !IsHalf(mid)) return false;
+    for (const TensorNode* o : output_tensor_nodes_)
+        if (!IsHalf(o->tensor) || o->tensor.Shape().size() != 4) return false;
+    if (img.Shape().size() != 4 || mid.Shape().size() != 4) return false;
+    SiConv2dDesc d0 = c1.stem_producer_->MakeDesc(img, smid), d1 = c1.MakeDesc(smid, mid), d2 = MakeDesc(mid, output_tensor_nodes_[0]->tensor);
+    d0.in_ld = d0.ic; d0.out_ld = d0.oc; d1.in_ld = d1.ic; d1.out_ld = d1.oc; d2.in_ld = d2.ic;
+    int split = 0;
+    if (sibling_) {
+        split = out_channels_;
+        d2.oc = out_channels_ + sibling_->out_channels_;
+    }
+    return si_hip_conv2d_stem_s2c32_pw_f16_supported(&d0, &d1, &d2, split) == 1;
+}
+
+void Conv2d::SetStemPairProducer(Conv2d* c1) {
+    stem_pair_ = c1;
+    stem_pair_mid_ = input_tensor_nodes_.empty() ? nullptr : input_tensor_nodes_[0];
+    if (c1) SetInputNodes(c1->InputNodes());
+    device_ready_ = false;
+}
+
+// the RGB stem, the 3x3 stride-2 conv behind it and this 1x1 conv (+ its sibling) in one launch: `image` is the fp32 image
+Status Conv2d::LaunchStemTriple(const Tensor& image, Tensor& out0, Tensor* out1) {
+    Conv2d* const c1 = stem_pair_;
+    Conv2d* const stem = c1 ? c1->stem_producer_ : nullptr;
+    if (!stem || !c1->stem_mid_ || !stem_pair_mid_ || IsHalf(image) || !IsHalf(out0) || (out1 && !IsHalf(*out1)) || (sibling_ != nullptr) != (out1 != nullptr))
+        return Status::kUnsupport;
+    CHECK_STATUS(PrepareDevice(1));
+    CHECK_STATUS(c1->PrepareDevice(1));
+    CHECK_STATUS(stem->PrepareDevice(2));
+    SiConv2dDesc d0 = stem->MakeDesc(image, c1->stem_mid_->tensor), d1 = c1->MakeDesc(c1->stem_mid_->tensor, stem_pair_mid_->tensor);
+    SiConv2dDesc d2 = MakeDesc(stem_pair_mid_->tensor, out0);
+    d0.out_ld = d0.oc; d1.in_ld = d1.ic; d1.out_ld = d1.oc; d2.in_ld = d2.ic;
+    int split = 0;
+    if (sibling_) {
+        split = out_channels_;
+        d2.oc = out_channels_ + sibling_->out_channels_;
+    }
+    return CheckHip(si_hip_conv2d_stem_s2c32_pw_f16(&d0, &d1, &d2, image.Data<float>(), stem->weight_dev_.As<void>(),
+                                                    stem->use_bias_ ? stem->bias_dev_.As<float>() : nullptr, c1->weight_dev_.As<void>(),
+                                                    c1->use_bias_ ? c1->bias_dev_.As<float>() : nullptr, weight_dev_.As<void>(),
+                                                    use_bias_ ? bias_dev_.As<float>() : nullptr, out0.RawData(), split,
+                                                    out1 ? out1->RawData() : nullptr, out1 ? out1->PixelStride() : 0, Stream()),
+                    "conv2d stem + 3x3 s2 + 1x1 (fp16, one launch)");
+}
+
 bool Conv2d::CanFusePointwiseProducer(const Conv2d& pw) const {
     if (sibling_ || up_node_ || stem_producer_ || pw_producer_ || pw.residual_node_ || pw.sibling_ || pw.up_node_ || pw.stem_producer_ || pw.pw_producer_) return false;
     if (input_tensor_nodes_.size() != 1 || output_tensor_nodes_.size() != 1 || pw.input_tensor_nodes_.size() != 1 ||
@@ -397,6 +451,7 @@ Status Conv2d::HalfInput(const Tensor& input, Tensor& half) {
 Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
     if (!sibling_ || outputs.size() != 2) return Status::kUnsupport;
     return RunOnDevice({&input}, {&outputs[0], &outputs[1]}, [this](const std::vector<Tensor>& in, std::vector<Tensor>& out) {
+        if (stem_pair_) return LaunchStemTriple(in[0], out[0], &out[1]);
         const int mode = PrecisionMode(in[0], out[0]);
         if (IsHalf(out[0]) != IsHalf(out[1])) return Status::kUnsupport;
         CHECK_STATUS(PrepareDevice(mode));
@@ -438,6 +493,7 @@ Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
 }
 
 Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& output) {
+    if (stem_pair_) return residual ? Status::kUnsupport : LaunchStemTriple(input, output, nullptr);
     if (stem_producer_) {
         // the stem conv and this one in one launch: `input` is the fp32 image
         if (residual || !stem_mid_ || IsHalf(input) || !IsHalf(output)) return Status::kUnsupport;
@@ -672,7 +728,8 @@ const char* Conv2d::KernelName() const {
     const Tensor& in = input_tensor_nodes_[0]->tensor;
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
-    if (stem_producer_) return "conv_stem_s2c32_f16_kernel";
+    if (stem_pair_) return "conv_stem_s2c32_f16_kernel<true>";
+    if (stem_producer_) return "conv_stem_s2c32_f16_kernel<false>";
     if (pw_producer_) return in_channels_ <= 64 ? "conv_pw_patch_f16_kernel<pw + 3x3>" : "conv3x3s1_slab_f16_kernel<pw + 3x3>";
     SiConv2dDesc d = MakeDesc(in, out);
     if (sibling_) d.oc += sibling_->out_channels_;
@@ -712,6 +769,12 @@ double Conv2d::Flops() const {
     if (pw_producer_ && pw_mid_) f += 2.0 * (double)pw_mid_->tensor.NumElements() * pw_producer_->in_channels_;   // the fused-away 1x1 conv's multiplies
     if (stem_producer_ && stem_mid_)   // the fused-away stem's own multiplies (its recomputed seam not counted)
         f += 2.0 * (double)stem_mid_->tensor.NumElements() * stem_producer_->kernel_h_ * stem_producer_->kernel_w_ * stem_producer_->in_channels_;
+    if (stem_pair_ && stem_pair_mid_) {   // the fused-away 3x3 stride-2 conv and the stem inside it
+        f += 2.0 * (double)stem_pair_mid_->tensor.NumElements() * 9.0 * stem_pair_->in_channels_;
+        if (stem_pair_->stem_producer_ && stem_pair_->stem_mid_)
+            f += 2.0 * (double)stem_pair_->stem_mid_->tensor.NumElements() * stem_pair_->stem_producer_->kernel_h_ * stem_pair_->stem_producer_->kernel_w_ *
+                 stem_pair_->stem_producer_->in_channels_;
+    }
     return f;
 }
 
@@ -720,6 +783,10 @@ double Conv2d::Bytes() const {
     if (sibling_) b += (double)sibling_->weight_.size() * sizeof(float);
     if (residual_node_) b += (double)residual_node_->tensor.ByteSize();
     if (stem_producer_) b += (double)stem_producer_->weight_.size() * sizeof(float);
+    if (stem_pair_) {
+        b += (double)stem_pair_->weight_.size() * sizeof(float);
+        if (stem_pair_->stem_producer_) b += (double)stem_pair_->stem_producer_->weight_.size() * sizeof(float);
+    }
     if (pw_producer_) b += (double)pw_producer_->weight_.size() * sizeof(float);
     return b;
 }
@@ -729,7 +796,7 @@ bool Conv2d::HalfStorageOk(std::string& why) const {
     const Tensor& in = input_tensor_nodes_[0]->tensor;
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (!IsHalf(in) && !IsHalf(out)) return true;
-    if (stem_producer_ || pw_producer_) return true;   // (asked of the kernel when the pair was fused: CanFuseStemProducer / CanFusePointwiseProducer)
+    if (stem_producer_ || pw_producer_ || stem_pair_) return true;   // (asked of the kernel when the pair was fused: CanFuseStemProducer / CanFusePointwiseProducer)
     SiConv2dDesc d;
     memset(&d, 0, sizeof(d));
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;

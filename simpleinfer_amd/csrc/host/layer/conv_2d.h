@@ -81,6 +81,13 @@ public:
     void SetPointwiseProducer(Conv2d* pw);
     Conv2d* PointwiseProducer() const { return pw_producer_; }
 
+    // engine fusion hook (fp16 storage, round 6): `conv` is the 3x3 stride-2 conv that already carries the RGB stem (SetStemProducer) and whose
+    // only readers are this 1x1 conv over its 64 channels (and its fused sibling: the first C3's cv1 | cv2); this layer then reads the fp32
+    // IMAGE and computes all three in one launch (si_hip_conv2d_stem_s2c32_pw_f16), conv's output is never written.  Same bits.
+    bool CanFuseStemPairProducer(const Conv2d& conv) const;
+    void SetStemPairProducer(Conv2d* conv);
+    Conv2d* StemPairProducer() const { return stem_pair_; }
+
     Status PrepareDevice(int mode = 0);
     Status PrepareDeviceHalf(const SiConv2dDesc& d);
     int PrecisionMode(const Tensor& input, const Tensor& output) const;
@@ -138,6 +145,8 @@ public:
     TensorNode* up_node_ = nullptr;   // see SetUpsampledSource
     Conv2d* stem_producer_ = nullptr; // see SetStemProducer
     TensorNode* stem_mid_ = nullptr;  // the fused-away intermediate (shape only: it is never allocated)
+    Conv2d* stem_pair_ = nullptr;     // see SetStemPairProducer
+    TensorNode* stem_pair_mid_ = nullptr;
     Conv2d* pw_producer_ = nullptr;   // see SetPointwiseProducer
     TensorNode* pw_mid_ = nullptr;    // its fused-away output (shape only)
     int up_c0_ = 0;
@@ -145,6 +154,7 @@ public:
 
 private:
     Status Launch(const Tensor& input, const Tensor* residual, Tensor& output);
+    Status LaunchStemTriple(const Tensor& image, Tensor& out0, Tensor* out1);
     SiConv2dDesc MakeDesc(const Tensor& input, const Tensor& output) const;
     Status MakeUpsampledSource(SiConv2dUpsampledSource& up) const;
 

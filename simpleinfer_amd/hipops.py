@@ -848,6 +848,46 @@ def conv_stem_s2c32_f16(x, w0, b0, w1, b1):
     return dy.to_numpy((n, oh, ow, oc), np.float16)
 
 
+def conv_stem_s2c32_pw_f16(x, w0, b0, w1, b1, w2, b2, split_oc=32, out2_ld=None, out2_c_off=0):
+    """si_hip_conv2d_stem_s2c32_pw_f16: YOLOv5's first two convs AND the 1x1 conv behind them (64 -> 64, SiLU: the first C3's cv1 | cv2 over the
+    concatenated filters w2 [64][64][1][1]) in one launch.  x fp32 [n][h][w][3].  split_oc = 32: returns (fp16 [n][oh][ow][32], fp16
+    [n][oh][ow][32]) -- the second one written at channel offset out2_c_off of a buffer with pixel stride out2_ld; split_oc = 0: one fp16
+    [n][oh][ow][64]."""
+    H = _native.hip()
+    x, w0, w1, w2 = _f32(x), _f32(w0), _f32(w1), _f32(w2)
+    n, ih, iw, _ = x.shape
+    sh_, sw_ = conv_out_hw(ih, iw, (6, 6), (2, 2), (2, 2), (1, 1))
+    oh, ow = conv_out_hw(sh_, sw_, (3, 3), (2, 2), (1, 1), (1, 1))
+    oc = w1.shape[0]
+    d0 = SiConv2dDesc(n, ih, iw, 3, 3, sh_, sw_, 32, 32, 6, 6, 2, 2, 1, 1, 2, 2, 1, 1 if b0 is not None else 0, ACT["silu"], 0, 32, 0, 0.0)
+    d1 = SiConv2dDesc(n, sh_, sw_, 32, 32, oh, ow, oc, oc, 3, 3, 2, 2, 1, 1, 1, 1, 1, 1 if b1 is not None else 0, ACT["silu"], 0, oc, 0, 0.0)
+    ld_a = 32 if split_oc else 64
+    d2 = SiConv2dDesc(n, oh, ow, oc, oc, oh, ow, 64, ld_a, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1 if b2 is not None else 0, ACT["silu"], 0, 64, 0, 0.0)
+    if not H.si_hip_conv2d_stem_s2c32_pw_f16_supported(C.byref(d0), C.byref(d1), C.byref(d2), split_oc):
+        raise HipError("si_hip_conv2d_stem_s2c32_pw_f16: unsupported shape")
+    p0 = np.zeros(H.si_hip_conv2d_stem_f16_weight_elems(C.byref(d0)), np.float16)
+    _chk(H.si_hip_conv2d_stem_f16_pack_weight_host(C.byref(d0), w0.ctypes.data_as(C.c_void_p), p0.ctypes.data_as(C.c_void_p)), "pack stem f16")
+    p1 = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d1)), np.float16)
+    _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d1), w1.ctypes.data_as(C.c_void_p), p1.ctypes.data_as(C.c_void_p)), "pack f16")
+    p2 = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d2)), np.float16)
+    _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d2), w2.ctypes.data_as(C.c_void_p), p2.ctypes.data_as(C.c_void_p)), "pack f16")
+    bufs = [DeviceBuffer.from_numpy(v) for v in (x, p0, p1, p2)]
+    db = [DeviceBuffer.from_numpy(_f32(b)) if b is not None else None for b in (b0, b1, b2)]
+    out2_ld = out2_ld or 32
+    dy = DeviceBuffer(n * oh * ow * ld_a * 2)
+    dy.fill(0)
+    dy2 = DeviceBuffer(n * oh * ow * out2_ld * 2)
+    dy2.fill(0)
+    _chk(H.si_hip_conv2d_stem_s2c32_pw_f16(C.byref(d0), C.byref(d1), C.byref(d2), bufs[0].ptr, bufs[1].ptr, db[0].ptr if db[0] else None, bufs[2].ptr,
+                                           db[1].ptr if db[1] else None, bufs[3].ptr, db[2].ptr if db[2] else None, dy.ptr, split_oc,
+                                           dy2.ptr + 2 * out2_c_off if split_oc else None, out2_ld, None), "si_hip_conv2d_stem_s2c32_pw_f16")
+    sync()
+    if not split_oc:
+        return dy.to_numpy((n, oh, ow, 64), np.float16)
+    y2 = dy2.to_numpy((n, oh, ow, out2_ld), np.float16)
+    return dy.to_numpy((n, oh, ow, 32), np.float16), y2[..., out2_c_off:out2_c_off + 32].copy()
+
+
 def conv_pw_slab_f16(x, w0, b0, w1, b1, residual=None, out_ld=None, out_c_off=0, in_ld=None):
     """si_hip_conv2d_pw_slab_f16: the C3 bottleneck's two convs (1x1 c -> c SiLU, 3x3 s1 p1 c -> oc SiLU, optional shortcut) in one
     launch.  x NHWC fp16; returns NHWC fp16."""

@@ -15,8 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (test infrastructure): oracle/liboracle.so through oracle/orc.py."""
+    # (before libgomp initialises) idle oracle threads sleep instead of spinning: the GPU box has far more cores than this container
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     from oracle import orc as _orc
-    _orc.lib()
+    # 16 threads, the reference's intra-op pool (engine_impl.cpp:133), not one per core: on the GPU box's 100+ cores the oracle's many small
+    # parallel regions spent their time in fork / join (round 5: 118 CPU-minutes for an 8-minute suite; toy_yolo 20-46 s there against 1 s here)
+    _orc.lib().orc_set_num_threads(min(16, os.cpu_count() or 1))
     return _orc
 
 

@@ -486,6 +486,37 @@ def test_stem_s2c32_fused_same_bits(hops, orc, gpu, n, ih, iw, oc):
     assert_parity(got.astype(np.float32), ref, F16_TOL, what="fused stem + conv")
 
 
+@pytest.mark.parametrize("n,ih,iw,split", [
+    (2, 128, 128, 32),     # whole tiles, the C3's split destination
+    (3, 76, 100, 32),      # ragged tiles both ways
+    (1, 20, 24, 0),        # one partial tile, all 64 columns to one tensor
+    (4, 64, 192, 32),
+])
+def test_stem_pair_plus_pointwise_fused_same_bits(hops, orc, gpu, n, ih, iw, split):
+    """Round 6: the 1x1 conv behind YOLOv5's first two convs (the first C3's cv1 | cv2 as ONE 64 -> 64 conv with a split destination) computed
+    from the tile while it is in the CU (si_hip_conv2d_stem_s2c32_pw_f16): conv_1's 64-channel output is never written.  Same MFMA steps in the
+    same k order, same epilogues and the same fp16 rounding of both intermediates as the three launches it replaces: BIT identical (also into a
+    slice of a wider buffer); and the fp16 bar against the oracle's three convs holds (src/layer/conv_2d.cpp:207-283)."""
+    x = rng_uniform(820, (n, ih, iw, 3), 0, 1)
+    w0, b0 = rng_uniform(821, (32, 3, 6, 6), -0.3, 0.3), rng_uniform(822, (32,), -0.5, 0.5)
+    w1, b1 = h(rng_uniform(823, (64, 32, 3, 3), -0.3, 0.3)), rng_uniform(824, (64,), -0.5, 0.5)
+    w2, b2 = h(rng_uniform(825, (64, 64, 1, 1), -0.3, 0.3)), rng_uniform(826, (64,), -0.5, 0.5)
+    mid = hops.conv_stem_s2c32_f16(x, w0, b0, w1, b1)
+    want = hops.conv2d_f16(mid, w2, b2, act1="silu")
+    if split:
+        ya, yb = hops.conv_stem_s2c32_pw_f16(x, w0, b0, w1, b1, w2, b2, split_oc=32, out2_ld=64, out2_c_off=32)
+        got = np.concatenate([ya, yb], -1)
+        sa, sb = hops.conv2d_split_f16(mid, w2[:32], b2[:32], w2[32:], b2[32:], act1="silu")
+        assert_exact(got, np.concatenate([sa, sb], -1), "fused stem + conv + 1x1 vs the sibling-fused launch")
+    else:
+        got = hops.conv_stem_s2c32_pw_f16(x, w0, b0, w1, b1, w2, b2, split_oc=0)
+    assert_exact(got, want, "fused stem + conv + 1x1 vs the three launches")
+    ref0 = orc.activation("silu", orc.conv2d(x, h(w0), b0, (2, 2), (2, 2), path="naive"))
+    ref1 = orc.activation("silu", orc.conv2d(ref0, w1, b1, (2, 2), (1, 1), path="naive"))
+    ref = orc.activation("silu", orc.conv2d(ref1, w2, b2, (1, 1), (0, 0), path="naive"))
+    assert_parity(got.astype(np.float32), ref, 2 * F16_TOL, what="fused stem + conv + 1x1")
+
+
 @pytest.mark.parametrize("op", list(range(18)))
 def test_unary_ops_with_fp16_storage(hops, orc, op):
     """si_hip_unary_f16 (round 5; UnaryOp of expand_expression.cpp:123-165 on fp16 tensors): the fp32 function of si_hip_unary_f32 on the

@@ -792,7 +792,7 @@ def test_f32_split_range_guard_flags_an_overflow_and_nothing_else(hops, orc, ker
     assert flag == 0 and np.isfinite(y).all()
     # weights outside fp16's range: refused where they are split (the layer then stays on the fp32 kernels)
     wbig = w.copy()
-    wbig[3, 4, 1, 1] = 7.0e4 if kernel == "split3" else 2.0e5
+    wbig[3, 4, 0, 0] = 2.0e5   # (a corner tap: U[0][0] = g[0][0] itself -- the centre tap only reaches U through quarters)
     with pytest.raises(hops.HipError):
         conv(x, wbig, b)
 

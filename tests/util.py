@@ -39,16 +39,19 @@ MIXED_LOG = []   # (what, max|d|/max|ref|, mixed) of every assert_parity call at
 
 def assert_parity(got, ref, rel=REL_TOL, what="", mixed=None):
     """max|diff| / max|ref| <= rel, and -- for the fp32 bar (rel <= 1e-4) unless mixed=False -- the element-wise mixed metric (mixed_err) at the
-    same number: it holds on every fp32 kernel of the suite (measured round 6; the list of exceptions is empty)."""
+    fp32 bar, 1e-4: it holds on every fp32 kernel of the suite (measured round 6, worst 4.0e-5 -- F(4,3) Winograd; the list of exceptions is
+    empty)."""
     assert np.isfinite(np.asarray(got)).all(), "%s: non-finite values" % what
     e = rel_err(got, ref)
     assert e <= rel, "%s: max|diff|/max|ref| = %.3e > %.1e" % (what, e, rel)
     if mixed is None:
         mixed = rel <= REL_TOL
     if mixed:
+        # (at the fp32 bar itself, 1e-4, also where the caller's max-based bar is tighter -- the fp64 bounds at 2e-5: an element-wise
+        # metric runs 3-4x above the max-based one on the same data, the tensor's rms being that much below its maximum)
         m = mixed_err(got, ref)
         MIXED_LOG.append((what, e, m))
-        assert m <= rel, "%s: element-wise max|d| / (|ref| + rms(ref)) = %.3e > %.1e" % (what, m, rel)
+        assert m <= REL_TOL, "%s: element-wise max|d| / (|ref| + rms(ref)) = %.3e > %.1e" % (what, m, REL_TOL)
     return e
 
 
