@@ -139,8 +139,9 @@ typedef struct SiConvPlan {
     int f16_slab;        /* 3x3 s1 over 128 / 256 channels: -1 policy (row slabs), 0 the generic tiles */
     int f16_slab_w2;     /* ... the slab kernel's 128-channel form: -1 policy (two waves per SIMD), 0 one wave per SIMD */
     int f16_pw_patch;    /* 64 / 32-channel bottleneck pair: -1 policy (si_hip_conv2d_pw_slab_f16_supported may say 2), 0 never 2 */
+    int split3_bm;       /* si_hip_conv2d_split3_f32 family over >= 128 output channels: 0 policy (launch size), 32 / 64 / 128 rows per workgroup tile */
 } SiConvPlan;
-#define SI_CONV_PLAN_DEFAULT { -1, 0, 0, -1, -1, -1, -1, -1, -1 }
+#define SI_CONV_PLAN_DEFAULT { -1, 0, 0, -1, -1, -1, -1, -1, -1, 0 }
 
 /* Weight layout expected by the kernels: [oc][kh][kw][icg_pad] ("OHWI",
  * K = kh*kw*icg_pad contiguous per output channel), icg_pad = ic/groups
@@ -207,6 +208,10 @@ size_t si_hip_conv2d_split3_weight_elems(const SiConv2dDesc* d);
 int si_hip_conv2d_split3_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
 int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const float* residual, float* out,
                              si_stream_t stream);
+/* ... with a split destination, as si_hip_conv2d_split_f32 (two sibling 1x1 convs as ONE over the concatenated filters: YOLOv5 C3's cv1 | cv2):
+ * output channels [0, split_oc) to `out` (stride d->out_ld), [split_oc, d->oc) to `out2` (stride out2_ld); split_oc a multiple of 32 (round 6) */
+int si_hip_conv2d_split3_split_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, float* out, int split_oc,
+                                   float* out2, int out2_ld, si_stream_t stream);
 
 /* ---- fused Winograd F(2x2,3x3) with its plane GEMMs on the fp16 matrix cores by operand splitting (round 5, late; csrc/hip/conv_wino23_split.hip;
  * OPT-IN: engine option f32_split).  si_hip_conv2d_wino23_f32's kernel around another channel loop: the transformed input V and the

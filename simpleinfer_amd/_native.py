@@ -34,9 +34,9 @@ def _load(path):
 class SiConvPlan(C.Structure):
     """include/si_hip.h SiConvPlan: kernel-form choices of one call (every form of a family produces the same bits)"""
     _fields_ = [(k, C.c_int) for k in ("f32_tile", "wino23_form", "wino23_ocg", "f16_tile", "f16_detect_tile", "f16_s2c32", "f16_slab",
-                                       "f16_slab_w2", "f16_pw_patch")]
+                                       "f16_slab_w2", "f16_pw_patch", "split3_bm")]
     DEFAULTS = dict(f32_tile=-1, wino23_form=0, wino23_ocg=0, f16_tile=-1, f16_detect_tile=-1, f16_s2c32=-1, f16_slab=-1, f16_slab_w2=-1,
-                    f16_pw_patch=-1)
+                    f16_pw_patch=-1, split3_bm=0)
 
     def __init__(self, **kw):
         super().__init__()
@@ -124,6 +124,7 @@ def hip():
         "si_hip_conv2d_split3_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_split3_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_split3_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
+        "si_hip_conv2d_split3_split_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_wino23_split_supported": (i, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino23_split_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino23_split_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),

@@ -71,6 +71,8 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "f16_slab") { opt_plan_.f16_slab = value; opt_plan_set_ = true; }
     else if (key == "f16_slab_w2") { opt_plan_.f16_slab_w2 = value; opt_plan_set_ = true; }
     else if (key == "f16_pw_patch") { opt_plan_.f16_pw_patch = value; opt_plan_set_ = true; }
+    else if (key == "split3_bm") { opt_plan_.split3_bm = value; opt_plan_set_ = true; }
+    else if (key == "f32_split_policy") opt_f32_split_policy_ = value;   // which layers f32_split takes: 1 round 5's, 2 (default) + sibling-fused / wide 1x1 from K = 256
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else if (key == "streams") opt_streams_ = value;  // 2: two half-batch lanes on two streams, 1 (default): one stream
     else if (key == "_fail_slicer") debug_fail_slicer_ = value != 0;  // tests: the sliced pipeline's setup fails half way
@@ -311,6 +313,7 @@ Status EngineImpl::CreateLayers() {
         // kernels can write; 1024 words: more convs than that simply run unguarded-by-flag on the fp32 kernels)
         auto arm_split = [&](Conv2d& cv, bool on) {
             cv.f32_split_ = on;
+            cv.f32_split_level_ = opt_f32_split_policy_;
             if (opt_plan_set_) cv.SetPlan(opt_plan_);
             if (!on) return;
             if (!split_flags_) {
@@ -1166,6 +1169,7 @@ Status EngineImpl::LoadLanes(int lanes) {
         lane->opt_arena_ = opt_arena_;
         lane->opt_winograd_ = opt_winograd_;
         lane->opt_f32_split_ = opt_f32_split_;
+        lane->opt_f32_split_policy_ = opt_f32_split_policy_;
         lane->opt_plan_ = opt_plan_;
         lane->opt_plan_set_ = opt_plan_set_;
         lane->opt_detect_stream_ = opt_detect_stream_;
@@ -1305,6 +1309,7 @@ Status EngineImpl::SetupSlicer(int slices) {
     slicer_->opt_arena_ = opt_arena_;
     slicer_->opt_winograd_ = opt_winograd_;
     slicer_->opt_f32_split_ = opt_f32_split_;
+    slicer_->opt_f32_split_policy_ = opt_f32_split_policy_;
     slicer_->opt_plan_ = opt_plan_;
     slicer_->opt_plan_set_ = opt_plan_set_;
     slicer_->opt_detect_stream_ = opt_detect_stream_;

@@ -136,6 +136,7 @@ private:
     int opt_fuse_stem_ = 2;
     bool opt_fuse_pw_ = true;
     bool opt_f32_split_ = false;
+    int opt_f32_split_policy_ = 2;
     SiConvPlan opt_plan_ = SI_CONV_PLAN_DEFAULT;   // kernel-form choices handed to every conv launch (options f32_tile, f16_slab, ...; all default: the policy)
     bool opt_plan_set_ = false;
     bool opt_arena_ = true;      // intermediate operands share one HBM arena by lifetime (0: one allocation per operand, as the reference)

@@ -353,6 +353,27 @@ def conv2d_split(x, w_a, b_a, w_b, b_b, act1="none", out2_ld=None, out2_c_off=0)
     return dya.to_numpy((n, ih, iw, oa)), yb[..., out2_c_off:out2_c_off + ob].copy()
 
 
+def conv2d_split3_split(x, w_a, b_a, w_b, b_b, act1="none", out2_ld=None, out2_c_off=0):
+    """si_hip_conv2d_split3_split_f32: two sibling 1x1 convs as one launch on the f32_split arithmetic; returns (y_a, y_b)"""
+    H = _native.hip()
+    x, w_a, w_b = _f32(x), _f32(w_a), _f32(w_b)
+    n, ih, iw, ic = x.shape
+    oa, ob = w_a.shape[0], w_b.shape[0]
+    out2_ld = out2_ld or ob
+    wcat = _f32(np.concatenate([w_a, w_b], 0))
+    bcat = np.concatenate([_f32(b_a), _f32(b_b)])
+    d = SiConv2dDesc(n, ih, iw, ic, ic, ih, iw, oa + ob, oa, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, ACT[act1], 0, 0, 0, 0.0)
+    packed = np.zeros(H.si_hip_conv2d_split3_weight_elems(C.byref(d)), np.float16)
+    _chk(H.si_hip_conv2d_split3_pack_weight_host(C.byref(d), wcat.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack split3")
+    dx, dw, db = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(packed), DeviceBuffer.from_numpy(bcat)
+    dya, dyb = DeviceBuffer(n * ih * iw * oa * 4), DeviceBuffer(n * ih * iw * out2_ld * 4)
+    dyb.fill(0)
+    _chk(H.si_hip_conv2d_split3_split_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr, dya.ptr, oa, dyb.ptr + 4 * out2_c_off, out2_ld, None),
+         "si_hip_conv2d_split3_split_f32")
+    yb = dyb.to_numpy((n, ih, iw, out2_ld))
+    return dya.to_numpy((n, ih, iw, oa)), yb[..., out2_c_off:out2_c_off + ob].copy()
+
+
 def linear(x, w, b=None):
     H = _native.hip()
     x, w = _f32(x), _f32(w)
