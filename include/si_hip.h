@@ -475,6 +475,16 @@ int si_hip_conv2d_yolo_f16(const SiConv2dDesc* d, const void* in, const void* w_
 int si_hip_conv2d_pw_slab_f16_supported(const SiConv2dDesc* pw, const SiConv2dDesc* conv);
 int si_hip_conv2d_pw_slab_f16(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const void* in, const void* pw_w_packed, const float* pw_bias,
                               const void* w_packed, const float* bias, const void* residual, void* out, si_stream_t stream);
+/* Round 6: ... and the C3's CLOSING conv behind its last bottleneck pair in the same launch (the 64-channel pair form, conv_pw_patch_f16.hip).
+ * `cv3`: 1x1, stride 1, 128 -> 128, SiLU over torch.cat([y, z], channels) with y the pair's output and `z` ([n][h][w][z_ld] halves, 64 channels,
+ * z_ld a multiple of 8) the C3's other branch.  The pair's output tile goes to LDS beside z's pixels and is multiplied there: neither y nor the
+ * concat buffer is written -- one launch and two tensor round trips less per C3.  Weights: the three convs' si_hip_conv2d_f16_pack_weight_host
+ * images.  Same bits as si_hip_conv2d_pw_slab_f16 into a concat slice followed by si_hip_conv2d_f16 (replaces three Conv2d::Forward calls, an
+ * add and a cat of the reference: src/layer/conv_2d.cpp:108-118, binary_op.cpp:52-94, cat.cpp:59-108). */
+int si_hip_conv2d_pw_cv3_f16_supported(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const SiConv2dDesc* cv3);
+int si_hip_conv2d_pw_cv3_f16(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const SiConv2dDesc* cv3, const void* in, const void* pw_w_packed,
+                             const float* pw_bias, const void* w_packed, const float* bias, const void* residual, const void* z, int z_ld,
+                             const void* cv3_w_packed, const float* cv3_bias, void* out, si_stream_t stream);
 /* Round 4: YOLOv5's first two convs in one persistent kernel (conv_stem_s2c32_f16.hip): `stem` = 6x6 s2 p2, 3 -> 32, SiLU on the
  * dense fp32 image (src/layer/conv_2d.cpp:207-283), `conv` = 3x3 s2 p1, 32 -> 32 / 64, SiLU; the 32-channel intermediate is computed
  * tile by tile into LDS and never written.  Weights: si_hip_conv2d_stem_f16_pack_weight_host(stem) and

@@ -177,6 +177,9 @@ def hip():
         "si_hip_conv2d_yolo_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),
         "si_hip_conv2d_pw_slab_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_pw_slab_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp, vp, vp]),
+        "si_hip_conv2d_pw_cv3_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_pw_cv3_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp, vp, i, vp, vp,
+                                         vp, vp]),
         "si_hip_conv2d_stem_s2c32_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_stem_s2c32_f16": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_stem_s2c32_pw_f16_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dDesc), i]),

@@ -43,15 +43,31 @@ struct PwPatchArgs {
     int ih, iw, x_ld, out_ld, res_ld;
     unsigned x_bytes;
     int tiles_x, tiles_y, items;
+    // CV3 form (round 6): the C3's closing 1x1 conv over cat(y, z) -- y this pair's output, z the C3's other branch -- computed from the tile
+    const half_t* z;            // [n][ih][iw][z_ld], 64 channels
+    int z_ld;
+    unsigned z_bytes;
+    const half_t* w3;           // lane-order weights of the 128 -> 128 conv: 4 column blocks x 8 k-steps x 1 KB
+    const float* bias3;
+    half_t* out3;
+    int out3_ld;
 };
 
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // CB = 64: the geometry of conv_c32_patch_f16_kernel<1, 2, .., 64> -- 4 x 16-pixel tiles, waves 2 (row pairs) x 2 (column blocks), 144-byte
 // pixels, 2816-byte patch rows; CB = 32: of <1, 1, .., 32> -- 8 x 16-pixel tiles, four row-pair waves, 80-byte pixels, 1536-byte rows.
-template <bool HAS_RES, int CB>
+// CV3 (CB = 64 only; round 6): the pair is the LAST bottleneck of a YOLOv5 C3 and the C3's closing 1x1 conv (cv3: 128 -> 128 over cat(y, z), SiLU)
+// follows in the same launch.  The pair's output tile y (4 x 16 pixels x 64 channels, rounded to fp16 exactly as it would have been stored) goes
+// to LDS as [pixel][channel 0..63] beside z's 64 channels of the same pixels (fetched under the 3x3's MFMAs) -- the image lies over the dead x
+// buffer --; after a barrier every wave multiplies its 32 pixels by 64 of cv3's 128 output columns (its weights: 32 KB of LDS, lane order; eight
+// 16-deep steps over y's block then z's: the generic tiles' k order on the concat buffer, hence their bits), bias + SiLU, and the C3's OUTPUT
+// leaves.  Neither y nor the concat buffer is written; one launch and two tensor round trips less per C3.
+template <bool HAS_RES, int CB, bool CV3 = false>
 __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_pw_patch_f16_kernel(const PwPatchArgs a) {
     static_assert(CB == 64 || CB == 32, "instantiated forms");
+    static_assert(!CV3 || CB == 64, "the cv3 form exists for the 64-channel pair");
+    constexpr int TP3 = 272;   // CV3: bytes per pixel of the [64 pixels][128 channels + 8] image (conflict-free ds_read_b128)
     constexpr int PITCH = CB * 2 + 16, ROWP = CB == 64 ? 2816 : 1536, NBW = CB / 32, TR = 2 * (4 / NBW), PR = TR + 2, PC = 18, QS = CB / 16, KS = 9 * QS;
     constexpr int CH8 = CB / 8, NPIX = PR * PC, NCH = NPIX * CH8, N_IT = (NCH + 255) / 256, MT0 = (NPIX + 31) / 32;
     __shared__ __attribute__((aligned(16))) unsigned char patch[PR * ROWP];
@@ -59,6 +75,8 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_pw_patch_f16_kerne
     // the 1x1's weights (lane order: column blocks x k-steps x 64 lanes x 16 B) and bias: registers are what this kernel is short of
     __shared__ __attribute__((aligned(16))) unsigned char wa_s[NBW * QS * 1024];
     __shared__ __attribute__((aligned(16))) float bias_a[CB];
+    __shared__ __attribute__((aligned(16))) unsigned char w3_s[CV3 ? 4 * 8 * 1024 : 16];
+    static_assert(!CV3 || MT0 * 32 * PITCH >= 64 * TP3, "the cv3 tile image fits the x buffer it overlays");
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / NBW, wn = wave - wm * NBW;
@@ -109,6 +127,13 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_pw_patch_f16_kerne
             if (tid + 256 * i < NBW * QS * 64)
                 *reinterpret_cast<u32x4*>(wa_s + (tid + 256 * i) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_wa, (unsigned)(tid + 256 * i) * 16u, 0, 0);
     }
+    if (CV3) {
+        const __amdgpu_buffer_rsrc_t rs_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.w3), 0, 4u * 8u * 1024u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<u32x4*>(w3_s + (tid + 256 * i) * 16) = __builtin_amdgcn_raw_buffer_load_b128(rs_w3, (unsigned)(tid + 256 * i) * 16u, 0, 0);
+    }
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(CV3 ? a.z : a.x), 0, CV3 ? a.z_bytes : 0u, 0x00020000);
     const unsigned char* const WA = wa_s + wn * QS * 1024 + lane * 16;
     const int o = wn * 32 + l31;
     const float bv = a.bias ? a.bias[o] : 0.0f;
@@ -201,9 +226,19 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_pw_patch_f16_kerne
             }
         }
         __syncthreads();   // the patch is complete (and x of this item is dead)
+        // CV3: z's 64 channels of the tile's 64 pixels, requested here, written beside y behind the 3x3's MFMAs (512 16-byte chunks: two per thread)
+        u32x4 zr[CV3 ? 2 : 1];
+        if (CV3) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + 256 * i, px = c >> 3, oy = ty * TR + (px >> 4), ox = tx * 16 + (px & 15);
+                const unsigned off = (unsigned)((img * a.ih + oy) * a.iw + ox) * (unsigned)(a.z_ld * 2) + (unsigned)((c & 7) * 16);
+                zr[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, (oy < a.ih && ox < a.iw) ? off : OOB, 0, 0);
+            }
+        }
         // ---- the 3x3 conv from the patch: conv_c32_patch_f16_kernel's loop and epilogue
         half_t rv[HAS_RES ? 16 : 1];
-        if (HAS_RES) {
+        auto load_res = [&]() {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
@@ -211,7 +246,9 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_pw_patch_f16_kerne
                 const bool in = oy < a.ih && ox < a.iw;
                 rv[e] = a.res[in ? (size_t)((img * a.ih + oy) * a.iw + ox) * a.res_ld + o : (size_t)0];
             }
-        }
+        };
+        // (CV3: the kernel has no registers left for sixteen values held across the matrix loop -- the shortcut is fetched behind it)
+        if (HAS_RES && !CV3) load_res();
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
@@ -233,7 +270,57 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_pw_patch_f16_kerne
 #pragma unroll
             for (int i = 0; i < 3; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fg[g & 1][i], wf[3 * g + i], acc, 0, 0, 0);
         }
-        {
+        if constexpr (CV3) {
+            // y into the tile image [pixel 32 wm + r][channel o] (over the dead x buffer), z beside it; one barrier; cv3
+            if (HAS_RES) load_res();
+            unsigned char* const T = xbuf;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                float v = silu(acc[e] + bv);
+                if (HAS_RES) v += (float)rv[e];
+                *reinterpret_cast<half_t*>(T + (32 * wm + r) * TP3 + o * 2) = si_store_cast<half_t>(v);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + 256 * i;
+                *reinterpret_cast<u32x4*>(T + (c >> 3) * TP3 + 128 + (c & 7) * 16) = zr[i];
+            }
+            __syncthreads();
+            const unsigned char* const TA = T + (32 * wm + l31) * TP3 + lh * 16;
+#pragma unroll
+            for (int cbk = 0; cbk < 2; ++cbk) {
+                const int nb3 = 2 * wn + cbk;   // this wave's column blocks of cv3: 2 wn, 2 wn + 1
+                const unsigned char* const W3 = w3_s + nb3 * 8 * 1024 + lane * 16;
+                f32x16 acc3;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc3[e] = 0.0f;
+                // (fragments in two groups of four k-steps: y's block, then z's -- the kernel has no registers to spare)
+#pragma unroll
+                for (int g3 = 0; g3 < 2; ++g3) {
+                    f16x8 ta[4], tb[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        ta[i] = *reinterpret_cast<const f16x8*>(TA + (4 * g3 + i) * 32);
+                        tb[i] = *reinterpret_cast<const f16x8*>(W3 + (4 * g3 + i) * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ta[i], tb[i], acc3, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int o3 = nb3 * 32 + l31;
+                const float b3 = a.bias3 ? a.bias3[o3] : 0.0f;
+                half_t* const ob = a.out3 + o3;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+                    if (oy < a.ih && ox < a.iw) ob[(size_t)((img * a.ih + oy) * a.iw + ox) * a.out3_ld] = si_store_cast<half_t>(silu(acc3[e] + b3));
+                }
+            }
+            if (next < a.items) __syncthreads();   // every wave is done with the tile image: the next item's x goes over it
+        } else {
             half_t* const ob = a.out + o;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -286,8 +373,43 @@ bool si_conv_pw_patch_f16_ok(const SiConv2dDesc* pw, const SiConv2dDesc* d) {
     return xb < 0xFFFFFF00ull && items <= 0x7fffffffLL;
 }
 
+// the C3's closing 1x1 conv of the CV3 form: 128 -> 128 over cat(y, z) with y the 64-channel pair's output, SiLU, no shortcut
+static bool cv3_ok(const SiConv2dDesc* pw, const SiConv2dDesc* d, const SiConv2dDesc* c3) {
+    return c3 && si_conv_pw_patch_f16_ok(pw, d) && d->ic == 64 && c3->groups == 1 && c3->ic == 128 && c3->oc == 128 && c3->kh == 1 && c3->kw == 1 &&
+           c3->sh == 1 && c3->sw == 1 && c3->dh == 1 && c3->dw == 1 && c3->pt == 0 && c3->pl == 0 && !c3->has_residual && c3->act1 == SI_ACT_SILU &&
+           c3->act2 == SI_ACT_NONE && c3->n == d->n && c3->ih == d->oh && c3->iw == d->ow && c3->oh == d->oh && c3->ow == d->ow;
+}
+
+static int pw_patch_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, const void* in, const void* wlA, const float* biasA, const void* wl,
+                           const float* bias, const void* residual, void* out, hipStream_t s, const SiConv2dDesc* c3, const void* z, int z_ld,
+                           const void* w3, const float* bias3);
+
 int si_conv_pw_patch_f16_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, const void* in, const void* wlA, const float* biasA, const void* wl,
                                 const float* bias, const void* residual, void* out, hipStream_t s) {
+    return pw_patch_launch(pw, d, in, wlA, biasA, wl, bias, residual, out, s, nullptr, nullptr, 0, nullptr, nullptr);
+}
+
+extern "C" int si_hip_conv2d_pw_cv3_f16_supported(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const SiConv2dDesc* cv3) {
+    return (pw && conv && cv3_ok(pw, conv, cv3)) ? 1 : 0;
+}
+
+extern "C" int si_hip_conv2d_pw_cv3_f16(const SiConv2dDesc* pw, const SiConv2dDesc* conv, const SiConv2dDesc* cv3, const void* in, const void* pw_w_packed,
+                                        const float* pw_bias, const void* w_packed, const float* bias, const void* residual, const void* z, int z_ld,
+                                        const void* cv3_w_packed, const float* cv3_bias, void* out, si_stream_t stream) {
+    if (!pw || !conv || !cv3 || !in || !pw_w_packed || !w_packed || !z || !cv3_w_packed || !out) return SI_E_BADARG;
+    if ((pw->has_bias && !pw_bias) || (conv->has_bias && !bias) || (cv3->has_bias && !cv3_bias) || (conv->has_residual && !residual)) return SI_E_BADARG;
+    if (!cv3_ok(pw, conv, cv3) || z_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(z) & 15) != 0 || (reinterpret_cast<uintptr_t>(cv3_w_packed) & 15) != 0) return SI_E_UNSUPPORTED;
+    // (si_hip_conv2d_f16_pack_weight_host: the row-major image, then the lane-order one)
+    const size_t cc = (size_t)conv->ic * conv->ic;
+    const half_t* const wA = static_cast<const half_t*>(pw_w_packed) + cc;
+    const half_t* const wB = static_cast<const half_t*>(w_packed) + 9 * cc;
+    const half_t* const w3 = static_cast<const half_t*>(cv3_w_packed) + (size_t)128 * 128;
+    return pw_patch_launch(pw, conv, in, wA, pw_bias, wB, bias, residual, out, static_cast<hipStream_t>(stream), cv3, z, z_ld, w3, cv3_bias);
+}
+
+static int pw_patch_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, const void* in, const void* wlA, const float* biasA, const void* wl,
+                           const float* bias, const void* residual, void* out, hipStream_t s, const SiConv2dDesc* c3, const void* z, int z_ld,
+                           const void* w3, const float* bias3) {
     if (!si_conv_pw_patch_f16_ok(pw, d)) return SI_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(in) & 15) != 0 || (d->has_residual && (reinterpret_cast<uintptr_t>(residual) & 1) != 0)) return SI_E_UNSUPPORTED;
     PwPatchArgs a;
@@ -302,6 +424,15 @@ int si_conv_pw_patch_f16_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, c
     a.x_bytes = (unsigned)((unsigned long long)pw->n * pw->ih * pw->iw * pw->in_ld * 2ull);
     a.tiles_x = d->ow / 16; a.tiles_y = d->oh / (d->ic == 64 ? 4 : 8);
     a.items = d->n * a.tiles_x * a.tiles_y;
+    a.z = nullptr; a.z_ld = 0; a.z_bytes = 0; a.w3 = nullptr; a.bias3 = nullptr; a.out3 = nullptr; a.out3_ld = 0;
+    if (c3) {
+        const unsigned long long zb = (unsigned long long)d->n * d->oh * d->ow * z_ld * 2ull;
+        if (zb >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+        a.z = static_cast<const half_t*>(z); a.z_ld = z_ld; a.z_bytes = (unsigned)zb;
+        a.w3 = static_cast<const half_t*>(w3); a.bias3 = c3->has_bias ? bias3 : nullptr;
+        a.out3 = static_cast<half_t*>(out); a.out3_ld = c3->out_ld;
+        a.out = nullptr;
+    }
     auto go = [&](auto kern) {
         const int per_cu = si_resident_blocks(kern, 256, 0);
         long long grid = (long long)cu_count() * per_cu;
@@ -309,6 +440,7 @@ int si_conv_pw_patch_f16_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, c
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, s, a);
         return (int)hipGetLastError();
     };
+    if (c3) return d->has_residual ? go(conv_pw_patch_f16_kernel<true, 64, true>) : go(conv_pw_patch_f16_kernel<false, 64, true>);
     if (d->ic == 32) return d->has_residual ? go(conv_pw_patch_f16_kernel<true, 32>) : go(conv_pw_patch_f16_kernel<false, 32>);
     return d->has_residual ? go(conv_pw_patch_f16_kernel<true, 64>) : go(conv_pw_patch_f16_kernel<false, 64>);
 }

@@ -54,7 +54,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "fp16") opt_fp16_ = value != 0;
     else if (key == "batch") opt_batch_ = value;  // > 0: re-batch the graph at load (the file bakes its batch into every shape)
     else if (key == "arena") opt_arena_ = value != 0;  // 1 (default): intermediates share one arena by lifetime; 0: one hipMalloc each
-    else if (key == "fuse_pw") opt_fuse_pw_ = value != 0;      // fp16: a C3 bottleneck's 1x1 conv computed inside the slab kernel of its 3x3 conv (default 1)
+    else if (key == "fuse_pw") opt_fuse_pw_ = value;           // fp16: 1 a C3 bottleneck's 1x1 conv computed inside the kernel of its 3x3 conv; 2 (default) ... and the C3's closing conv behind its last pair; 0 off
     else if (key == "fuse_stem") opt_fuse_stem_ = value;       // fp16: 1 RGB stem conv + the 3x3 s2 conv behind it in one launch; 2 (default) ... and the 1x1 conv(s) reading that; 0 off
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "detect_priority") opt_detect_priority_ = value < 0 ? -1 : (value > 0 ? 1 : 0);   // priority of Detect's side stream: -1 low, 0 default, +1 high
@@ -427,6 +427,7 @@ Status EngineImpl::CreatePipeline() {
         if (opt_fp16_ && opt_fuse_stem_) CHECK_STATUS(FuseStemPairs(order));
         if (opt_fp16_ && opt_fuse_stem_ > 1) CHECK_STATUS(FuseStemTriples(order));
         if (opt_fp16_ && opt_fuse_pw_) CHECK_STATUS(FuseBottleneckPairs(order));
+        if (opt_fp16_ && opt_fuse_pw_ > 1 && opt_alias_cat_) CHECK_STATUS(FuseCv3IntoPairs(order));
     }
     if (opt_fp16_) {
         CHECK_STATUS(InsertOutputCasts(order));
@@ -809,6 +810,44 @@ Status EngineImpl::FuseBottleneckPairs(std::vector<Step>& order) {
         conv->SetPointwiseProducer(pw);
         dead_operands_.insert(mid->name);
         removed[i] = true;
+        fused_ops_.insert(order[i].op->name);
+    }
+    std::vector<Step> out;
+    for (size_t i = 0; i < order.size(); ++i)
+        if (!removed[i]) out.push_back(order[i]);
+    order.swap(out);
+    return Status::kSuccess;
+}
+
+// fp16 storage (round 6): torch.cat([y, z], channels) -> 1x1 conv (a YOLOv5 C3's closing cv3) where y is the output of a fused bottleneck pair
+// (FuseBottleneckPairs) that only the concat reads: the pair, the concat and the conv become ONE launch at the conv's slot
+// (si_hip_conv2d_pw_cv3_f16); y and the concat operand are never allocated, z keeps a buffer of its own (nothing aliases into a concat
+// that no longer exists).
+Status EngineImpl::FuseCv3IntoPairs(std::vector<Step>& order) {
+    std::map<const pnnx::Operator*, size_t> index;
+    for (size_t i = 0; i < order.size(); ++i) index[order[i].op] = i;
+    std::vector<bool> removed(order.size(), false);
+    for (size_t i = 0; i < order.size(); ++i) {
+        Cat* cat = dynamic_cast<Cat*>(order[i].layer);
+        if (!cat || order[i].op->type != "torch.cat" || cat->NhwcAxis() != 3 || order[i].op->inputs.size() != 2 || order[i].op->outputs.size() != 1) continue;
+        const pnnx::Operand* y = order[i].op->inputs[0];
+        const pnnx::Operand* z = order[i].op->inputs[1];
+        const pnnx::Operand* cc = order[i].op->outputs[0];
+        if (!y || !z || !cc || y == z || output_tensor_nodes_.count(y->name) || output_tensor_nodes_.count(cc->name)) continue;
+        if (y->consumers.size() != 1 || cc->consumers.size() != 1 || !y->producer || !index.count(y->producer) || removed[index[y->producer]]) continue;
+        const pnnx::Operator* c3 = cc->consumers[0];
+        if (!c3 || c3->type != "nn.Conv2d" || !index.count(c3) || sibling_ops_.count(c3->name)) continue;
+        Conv2d* pair = dynamic_cast<Conv2d*>(order[index[y->producer]].layer);
+        Conv2d* conv = dynamic_cast<Conv2d*>(order[index[c3]].layer);
+        if (!pair || !conv || !pair->PointwiseProducer() || pair->OutputNodes().size() != 1 || pair->OutputNodes()[0]->operand != y) continue;
+        TensorNode* zn = tensor_nodes_[z->name];
+        if (!conv->CanFuseCv3Pair(*pair, zn)) continue;
+        conv->SetCv3Pair(pair, zn);
+        dead_operands_.insert(y->name);
+        dead_operands_.insert(cc->name);
+        removed[index[y->producer]] = true;
+        removed[i] = true;
+        fused_ops_.insert(y->producer->name);
         fused_ops_.insert(order[i].op->name);
     }
     std::vector<Step> out;

@@ -102,6 +102,7 @@ private:
     Status FuseUpsampleIntoConvs(std::vector<Step>& order);
     Status FuseStemPairs(std::vector<Step>& order);
     Status FuseStemTriples(std::vector<Step>& order);
+    Status FuseCv3IntoPairs(std::vector<Step>& order);
     Status FuseBottleneckPairs(std::vector<Step>& order);
     Status InsertOutputCasts(std::vector<Step>& order);
     Status InsertFp32Fallbacks(std::vector<Step>& order);
@@ -134,7 +135,7 @@ private:
     bool opt_alias_cat_ = true;
     bool opt_fuse_upsample_ = true;
     int opt_fuse_stem_ = 2;
-    bool opt_fuse_pw_ = true;
+    int opt_fuse_pw_ = 2;
     bool opt_f32_split_ = false;
     int opt_f32_split_policy_ = 2;
     SiConvPlan opt_plan_ = SI_CONV_PLAN_DEFAULT;   // kernel-form choices handed to every conv launch (options f32_tile, f16_slab, ...; all default: the policy)

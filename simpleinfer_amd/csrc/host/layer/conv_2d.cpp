@@ -187,6 +187,58 @@ Status Conv2d::LaunchStemTriple(const Tensor& image, Tensor& out0, Tensor* out1)
                     "conv2d stem + 3x3 s2 + 1x1 (fp16, one launch)");
 }
 
+bool Conv2d::CanFuseCv3Pair(const Conv2d& pair, const TensorNode* z) const {
+    if (!pair.pw_producer_ || !pair.pw_mid_ || pair.sibling_ || pair.up_node_ || pair.stem_producer_ || pair.stem_pair_ || pair.cv3_pair_) return false;
+    if (residual_node_ || sibling_ || up_node_ || stem_producer_ || stem_pair_ || pw_producer_ || cv3_pair_ || act2_ != SI_ACT_NONE) return false;
+    if (!z || input_tensor_nodes_.size() != 1 || output_tensor_nodes_.size() != 1 || pair.output_tensor_nodes_.size() != 1 || pair.input_tensor_nodes_.size() != 1) return false;
+    const Tensor& x = pair.input_tensor_nodes_[0]->tensor;     // (the pair reads its 1x1 conv's input)
+    const Tensor& y = pair.output_tensor_nodes_[0]->tensor;
+    const Tensor& cat = input_tensor_nodes_[0]->tensor;
+    const Tensor& out = output_tensor_nodes_[0]->tensor;
+    if (!IsHalf(x) || !IsHalf(y) || !IsHalf(z->tensor) || !IsHalf(cat) || !IsHalf(out)) return false;
+    if (pair.residual_node_ && !IsHalf(pair.residual_node_->tensor)) return false;
+    Dims4 dy, dz, dc;
+    if (!GetDims4(y, dy) || !GetDims4(z->tensor, dz) || !GetDims4(cat, dc)) return false;
+    if (dy.c != 64 || dz.c != 64 || dc.c != 128 || dy.pixels() != dz.pixels() || dy.pixels() != dc.pixels() || dy.n != dz.n) return false;
+    SiConv2dDesc d0 = pair.pw_producer_->MakeDesc(x, pair.pw_mid_->tensor), d1 = pair.MakeDesc(pair.pw_mid_->tensor, y), d2 = MakeDesc(cat, out);
+    d0.in_ld = d0.ic; d0.out_ld = d0.oc; d1.in_ld = d1.ic; d1.out_ld = d1.oc; d2.in_ld = d2.ic; d2.out_ld = d2.oc;
+    d1.has_residual = pair.residual_node_ ? 1 : 0;
+    d1.res_ld = d1.oc;
+    return si_hip_conv2d_pw_cv3_f16_supported(&d0, &d1, &d2) == 1;
+}
+
+void Conv2d::SetCv3Pair(Conv2d* pair, TensorNode* z) {
+    cv3_pair_ = pair;
+    cv3_z_ = z;
+    cv3_cat_ = input_tensor_nodes_.empty() ? nullptr : input_tensor_nodes_[0];
+    if (pair) SetInputNodes(pair->InputNodes());
+    device_ready_ = false;
+}
+
+// the C3's last bottleneck pair and this closing 1x1 conv in one launch: `x` is the pair's input
+Status Conv2d::LaunchCv3(const Tensor& x, Tensor& output) {
+    Conv2d* const pair = cv3_pair_;
+    Conv2d* const pw = pair ? pair->pw_producer_ : nullptr;
+    if (!pw || !pair->pw_mid_ || !cv3_z_ || !cv3_cat_ || pair->output_tensor_nodes_.empty() || !IsHalf(x) || !IsHalf(output)) return Status::kUnsupport;
+    CHECK_STATUS(PrepareDevice(1));
+    CHECK_STATUS(pair->PrepareDevice(1));
+    CHECK_STATUS(pw->PrepareDevice(1));
+    const Tensor& y = pair->output_tensor_nodes_[0]->tensor;   // (shape only: never allocated)
+    SiConv2dDesc d0 = pw->MakeDesc(x, pair->pw_mid_->tensor), d1 = pair->MakeDesc(pair->pw_mid_->tensor, y), d2 = MakeDesc(cv3_cat_->tensor, output);
+    d0.out_ld = d0.oc; d1.in_ld = d1.ic; d1.out_ld = d1.oc; d2.in_ld = d2.ic;
+    const Tensor* res = pair->residual_node_ ? &pair->residual_node_->tensor : nullptr;
+    if (res) {
+        d1.has_residual = 1;
+        d1.res_ld = res->PixelStride();
+    }
+    const Tensor& z = cv3_z_->tensor;
+    return CheckHip(si_hip_conv2d_pw_cv3_f16(&d0, &d1, &d2, x.RawData(), pw->weight_dev_.As<void>(), pw->use_bias_ ? pw->bias_dev_.As<float>() : nullptr,
+                                             pair->weight_dev_.As<void>(), pair->use_bias_ ? pair->bias_dev_.As<float>() : nullptr,
+                                             res ? res->RawData() : nullptr, z.RawData(), z.PixelStride(), weight_dev_.As<void>(),
+                                             use_bias_ ? bias_dev_.As<float>() : nullptr, output.RawData(), Stream()),
+                    "conv2d 1x1 + 3x3 + cat + 1x1 (fp16, one launch)");
+}
+
 bool Conv2d::CanFusePointwiseProducer(const Conv2d& pw) const {
     if (sibling_ || up_node_ || stem_producer_ || pw_producer_ || pw.residual_node_ || pw.sibling_ || pw.up_node_ || pw.stem_producer_ || pw.pw_producer_) return false;
     if (input_tensor_nodes_.size() != 1 || output_tensor_nodes_.size() != 1 || pw.input_tensor_nodes_.size() != 1 ||
@@ -525,6 +577,7 @@ Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
 
 Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& output) {
     if (stem_pair_) return residual ? Status::kUnsupport : LaunchStemTriple(input, output, nullptr);
+    if (cv3_pair_) return residual ? Status::kUnsupport : LaunchCv3(input, output);
     if (stem_producer_) {
         // the stem conv and this one in one launch: `input` is the fp32 image
         if (residual || !stem_mid_ || IsHalf(input) || !IsHalf(output)) return Status::kUnsupport;
@@ -760,6 +813,7 @@ const char* Conv2d::KernelName() const {
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (in.Shape().size() != 4 || out.Shape().size() != 4) return "conv_igemm_f32";
     if (stem_pair_) return "conv_stem_s2c32_f16_kernel<true>";
+    if (cv3_pair_) return "conv_pw_patch_f16_kernel<pw + 3x3 + cv3>";
     if (stem_producer_) return "conv_stem_s2c32_f16_kernel<false>";
     if (pw_producer_) return in_channels_ <= 64 ? "conv_pw_patch_f16_kernel<pw + 3x3>" : "conv3x3s1_slab_f16_kernel<pw + 3x3>";
     SiConv2dDesc d = MakeDesc(in, out);
@@ -800,6 +854,7 @@ double Conv2d::Flops() const {
     if (pw_producer_ && pw_mid_) f += 2.0 * (double)pw_mid_->tensor.NumElements() * pw_producer_->in_channels_;   // the fused-away 1x1 conv's multiplies
     if (stem_producer_ && stem_mid_)   // the fused-away stem's own multiplies (its recomputed seam not counted)
         f += 2.0 * (double)stem_mid_->tensor.NumElements() * stem_producer_->kernel_h_ * stem_producer_->kernel_w_ * stem_producer_->in_channels_;
+    if (cv3_pair_) f += cv3_pair_->Flops();   // the fused-away bottleneck pair (its own 1x1 included)
     if (stem_pair_ && stem_pair_mid_) {   // the fused-away 3x3 stride-2 conv and the stem inside it
         f += 2.0 * (double)stem_pair_mid_->tensor.NumElements() * 9.0 * stem_pair_->in_channels_;
         if (stem_pair_->stem_producer_ && stem_pair_->stem_mid_)
@@ -814,6 +869,12 @@ double Conv2d::Bytes() const {
     if (sibling_) b += (double)sibling_->weight_.size() * sizeof(float);
     if (residual_node_) b += (double)residual_node_->tensor.ByteSize();
     if (stem_producer_) b += (double)stem_producer_->weight_.size() * sizeof(float);
+    if (cv3_pair_) {
+        b += (double)cv3_pair_->weight_.size() * sizeof(float);
+        if (cv3_pair_->pw_producer_) b += (double)cv3_pair_->pw_producer_->weight_.size() * sizeof(float);
+        if (cv3_pair_->residual_node_) b += (double)cv3_pair_->residual_node_->tensor.ByteSize();
+        if (cv3_z_) b += (double)cv3_z_->tensor.ByteSize();
+    }
     if (stem_pair_) {
         b += (double)stem_pair_->weight_.size() * sizeof(float);
         if (stem_pair_->stem_producer_) b += (double)stem_pair_->stem_producer_->weight_.size() * sizeof(float);
@@ -827,7 +888,7 @@ bool Conv2d::HalfStorageOk(std::string& why) const {
     const Tensor& in = input_tensor_nodes_[0]->tensor;
     const Tensor& out = output_tensor_nodes_[0]->tensor;
     if (!IsHalf(in) && !IsHalf(out)) return true;
-    if (stem_producer_ || pw_producer_ || stem_pair_) return true;   // (asked of the kernel when the pair was fused: CanFuseStemProducer / CanFusePointwiseProducer)
+    if (stem_producer_ || pw_producer_ || stem_pair_ || cv3_pair_) return true;   // (asked of the kernel when the pair was fused: CanFuseStemProducer / CanFusePointwiseProducer)
     SiConv2dDesc d;
     memset(&d, 0, sizeof(d));
     d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;

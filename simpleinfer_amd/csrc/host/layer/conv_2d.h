@@ -36,6 +36,8 @@ public:
     virtual void ExtraReads(std::vector<TensorNode*>& nodes) const override {
         if (residual_node_) nodes.push_back(residual_node_);
         if (up_node_) nodes.push_back(up_node_);
+        if (cv3_pair_ && cv3_pair_->residual_node_) nodes.push_back(cv3_pair_->residual_node_);
+        if (cv3_z_) nodes.push_back(cv3_z_);
     }
     virtual bool ReplaceExtraRead(TensorNode* from, TensorNode* to) override {
         if (from && from == residual_node_) { residual_node_ = to; return true; }
@@ -87,6 +89,14 @@ public:
     bool CanFuseStemPairProducer(const Conv2d& conv) const;
     void SetStemPairProducer(Conv2d* conv);
     Conv2d* StemPairProducer() const { return stem_pair_; }
+
+    // engine fusion hook (fp16 storage, round 6): this 1x1 conv is a YOLOv5 C3's closing conv over cat(y, z); `pair` is the C3's LAST bottleneck
+    // (a 3x3 conv that carries its 1x1 producer: SetPointwiseProducer) whose output y only the concat reads, `z` the C3's other branch.  This
+    // layer then reads the pair's INPUT (and shortcut) and z and computes all three convs in one launch (si_hip_conv2d_pw_cv3_f16); neither y
+    // nor the concat buffer exists.  Same bits as the launches it replaces.
+    bool CanFuseCv3Pair(const Conv2d& pair, const TensorNode* z) const;
+    void SetCv3Pair(Conv2d* pair, TensorNode* z);
+    Conv2d* Cv3Pair() const { return cv3_pair_; }
 
     Status PrepareDevice(int mode = 0);
     Status PrepareDeviceHalf(const SiConv2dDesc& d);
@@ -149,6 +159,9 @@ public:
     TensorNode* stem_mid_ = nullptr;  // the fused-away intermediate (shape only: it is never allocated)
     Conv2d* stem_pair_ = nullptr;     // see SetStemPairProducer
     TensorNode* stem_pair_mid_ = nullptr;
+    Conv2d* cv3_pair_ = nullptr;      // see SetCv3Pair
+    TensorNode* cv3_z_ = nullptr;
+    TensorNode* cv3_cat_ = nullptr;   // the concat operand this conv used to read (shape only)
     Conv2d* pw_producer_ = nullptr;   // see SetPointwiseProducer
     TensorNode* pw_mid_ = nullptr;    // its fused-away output (shape only)
     int up_c0_ = 0;
@@ -157,6 +170,7 @@ public:
 private:
     Status Launch(const Tensor& input, const Tensor* residual, Tensor& output);
     Status LaunchStemTriple(const Tensor& image, Tensor& out0, Tensor* out1);
+    Status LaunchCv3(const Tensor& x, Tensor& output);
     SiConv2dDesc MakeDesc(const Tensor& input, const Tensor& output) const;
     Status MakeUpsampledSource(SiConv2dUpsampledSource& up) const;
 

@@ -944,6 +944,44 @@ def conv_pw_slab_f16(x, w0, b0, w1, b1, residual=None, out_ld=None, out_c_off=0,
     return y[..., out_c_off:out_c_off + oc].copy() if out_ld != oc else y
 
 
+def conv_pw_cv3_f16(x, w0, b0, w1, b1, z, w3, b3, residual=None, z_ld=None, z_c_off=0, out_ld=None, out_c_off=0):
+    """si_hip_conv2d_pw_cv3_f16: a C3's last bottleneck pair (1x1 c -> c SiLU, 3x3 c -> c SiLU, optional shortcut) AND the C3's closing 1x1
+    conv over cat([pair output, z]) in one launch (c = 64, z 64 channels, w3 [128][128][1][1]).  x, z, residual NHWC fp16; returns NHWC fp16
+    [n][h][w][128].  z_ld / z_c_off: z read as a channel slice of a wider buffer."""
+    H = _native.hip()
+    x, z, w0, w1, w3 = _f16(x), _f16(z), _f32(w0), _f32(w1), _f32(w3)
+    n, ih, iw, c = x.shape
+    oc3 = w3.shape[0]
+    z_ld = z_ld or z.shape[-1]
+    out_ld = out_ld or oc3
+    d0 = SiConv2dDesc(n, ih, iw, c, c, ih, iw, c, c, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1 if b0 is not None else 0, ACT["silu"], 0, c, 0, 0.0)
+    d1 = SiConv2dDesc(n, ih, iw, c, c, ih, iw, c, c, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1 if b1 is not None else 0, ACT["silu"],
+                      1 if residual is not None else 0, c, 0, 0.0)
+    d2 = SiConv2dDesc(n, ih, iw, 2 * c, 2 * c, ih, iw, oc3, out_ld, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1 if b3 is not None else 0, ACT["silu"], 0, oc3, 0, 0.0)
+    if not H.si_hip_conv2d_pw_cv3_f16_supported(C.byref(d0), C.byref(d1), C.byref(d2)):
+        raise HipError("si_hip_conv2d_pw_cv3_f16: unsupported shape")
+    packs = []
+    for d, w in ((d0, w0), (d1, w1), (d2, w3)):
+        p = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d)), np.float16)
+        _chk(H.si_hip_conv2d_f16_pack_weight_host(C.byref(d), w.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p)), "pack f16")
+        packs.append(DeviceBuffer.from_numpy(p))
+    zs = z
+    if z_ld != z.shape[-1] or z_c_off:
+        zs = np.zeros((n, ih, iw, z_ld), np.float16)
+        zs[..., z_c_off:z_c_off + z.shape[-1]] = z
+    dx, dz = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(zs)
+    db = [DeviceBuffer.from_numpy(_f32(b)) if b is not None else None for b in (b0, b1, b3)]
+    dr = DeviceBuffer.from_numpy(_f16(residual)) if residual is not None else None
+    dy = DeviceBuffer(n * ih * iw * out_ld * 2)
+    dy.fill(0)
+    _chk(H.si_hip_conv2d_pw_cv3_f16(C.byref(d0), C.byref(d1), C.byref(d2), dx.ptr, packs[0].ptr, db[0].ptr if db[0] else None, packs[1].ptr,
+                                    db[1].ptr if db[1] else None, dr.ptr if dr else None, dz.ptr + 2 * z_c_off, z_ld, packs[2].ptr,
+                                    db[2].ptr if db[2] else None, dy.ptr + 2 * out_c_off, None), "si_hip_conv2d_pw_cv3_f16")
+    sync()
+    y = dy.to_numpy((n, ih, iw, out_ld), np.float16)
+    return y[..., out_c_off:out_c_off + oc3].copy() if out_ld != oc3 else y
+
+
 def yolo_detect_f16(feats, weights, biases, grids, anchor_grids, strides, na=3):
     """si_hip_conv2d_yolo_f16 per level: fp16 features, fp32 [n][rows_total][ne] detections."""
     H = _native.hip()

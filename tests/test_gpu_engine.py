@@ -301,7 +301,7 @@ def test_bottleneck_pairs_in_one_launch_with_fp16_storage(si, tmp_path):
     hipGraph replay and repeated forwards agree; the fp32 schedule is untouched."""
     pp, bp = _save(tmp_path, si.modelgen.build_yolov5s(32, 640), "bp32")
     x = si.modelgen.synth_input((32, 640, 640, 3))
-    e1, oname, fused = _run(si, pp, bp, x, fp16=1)
+    e1, oname, fused = _run(si, pp, bp, x, fp16=1, fuse_pw=1)
     e0, _, plain = _run(si, pp, bp, x, fp16=1, fuse_pw=0)
     assert_exact(fused, plain, "fp16: bottleneck pairs in one launch vs two")
     s1, s0 = e1.schedule(), e0.schedule()
@@ -312,16 +312,27 @@ def test_bottleneck_pairs_in_one_launch_with_fp16_storage(si, tmp_path):
     for _ in range(2):
         e1.forward()
         assert_exact(e1.extract(oname), plain, "repeated forwards")
-    eg, _, replay = _run(si, pp, bp, x, fp16=1, graph=1)
-    eg.forward()
-    assert_exact(eg.extract(oname), plain, "hipGraph replay")
+    # round 6 (FuseCv3IntoPairs, si_hip_conv2d_pw_cv3_f16; fuse_pw = 2, the default): the two 80x80 C3s' closing convs behind their last
+    # bottleneck pair in the same launch -- per C3 the pair's step and the concat's disappear, neither the pair's output nor the concat buffer
+    # is allocated (the arena shrinks), and not a bit changes; eager, replayed as a hipGraph, forward after forward
+    for opts in ({}, {"graph": 1}):
+        e3, _, tail = _run(si, pp, bp, x, fp16=1, **opts)
+        assert_exact(tail, plain, "fp16: C3 tails (pair + concat + cv3) in one launch")
+        s3 = e3.schedule()
+        assert len(s1["run"]) == len(s3["run"]) + 4, (len(s1["run"]), len(s3["run"]))
+        assert sum(n.startswith("cat_") for n in s3["fused"]) == 2 and s3["arena_bytes"] < s1["arena_bytes"], (s3["fused"], s3["arena_bytes"], s1["arena_bytes"])
+        k3 = [L["kernel"] for L in e3.profile()]
+        assert k3.count("conv_pw_patch_f16_kernel<pw + 3x3 + cv3>") == 2 and k3.count("conv_pw_patch_f16_kernel<pw + 3x3>") == 2, k3
+        for _ in range(2):
+            e3.forward()
+            assert_exact(e3.extract(oname), plain, "repeated forwards")
     # the same file served at batch 2: the slab grids do not cover the chip, only the 64-channel pairs are fused, and an image's bits are the same
     e2 = si.Engine(fp16=1, batch=2)
     e2.load_model(pp, bp)
     e2.input("0", x[:2])
     e2.forward()
     k2 = [L["kernel"] for L in e2.profile()]
-    assert not any("slab_f16_kernel<pw + 3x3>" in k for k in k2) and k2.count("conv_pw_patch_f16_kernel<pw + 3x3>") == 4, k2
+    assert not any("slab_f16_kernel<pw + 3x3>" in k for k in k2) and sum(k.startswith("conv_pw_patch_f16_kernel<pw + 3x3") for k in k2) == 4, k2
     assert_exact(e2.extract(oname), plain[:2], "batch 2 (two launches per pair) vs batch 32 (one)")
     e32 = si.Engine()
     e32.load_model(pp, bp)

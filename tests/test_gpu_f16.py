@@ -463,6 +463,37 @@ def test_bottleneck_pair_in_one_launch_same_bits(hops, orc, gpu, n, hh, ww, c, r
     assert_parity(got.astype(np.float32), ref, F16_TOL, what="fused pair (3x3 stage vs oracle on the rounded intermediate)")
 
 
+@pytest.mark.parametrize("n,hh,ww,res", [
+    (2, 16, 32, True),        # more items than workgroups may get, the shortcut
+    (1, 80, 80, True),        # YOLOv5s' 80x80 C3 (backbone: with the shortcut)
+    (2, 80, 80, False),       # ... the head's C3 (no shortcut)
+    (3, 8, 16, False),        # two tiles per image, every patch touches three image borders
+])
+def test_c3_tail_pair_concat_cv3_in_one_launch_same_bits(hops, orc, gpu, n, hh, ww, res):
+    """Round 6: a C3's last bottleneck pair AND its closing 1x1 conv over cat([pair output, z]) in one launch (si_hip_conv2d_pw_cv3_f16; the
+    64-channel pair form): the pair's output tile is multiplied from LDS beside z's pixels, neither it nor the concat buffer is written.  The
+    same MFMA steps in the same k order (y's 64-channel block, then z's), the same epilogue expressions, y rounded to fp16 exactly as the
+    separate launch stores it: bit-identical to pair launch -> concat -> conv launch, with z read as a channel slice of a wider buffer and
+    the output written into one, at any batch position; and the fp16 bar against the oracle holds (src/layer/conv_2d.cpp:207-283)."""
+    c = 64
+    x = h(rng_uniform(930, (n, hh, ww, c), -1, 1))
+    z = h(rng_uniform(931, (n, hh, ww, c), -1, 1))
+    w0, b0 = h(rng_uniform(932, (c, c, 1, 1), -0.15, 0.15)), rng_uniform(933, (c,), -0.5, 0.5)
+    w1, b1 = h(rng_uniform(934, (c, c, 3, 3), -0.1, 0.1)), rng_uniform(935, (c,), -0.5, 0.5)
+    w3, b3 = h(rng_uniform(936, (2 * c, 2 * c, 1, 1), -0.15, 0.15)), rng_uniform(937, (2 * c,), -0.5, 0.5)
+    r = x if res else None
+    y = hops.conv_pw_slab_f16(x, w0, b0, w1, b1, residual=r)
+    want = hops.conv2d_f16(np.concatenate([y, z], -1), w3, b3, (1, 1), (0, 0), act1="silu")
+    got = hops.conv_pw_cv3_f16(x, w0, b0, w1, b1, z, w3, b3, residual=r)
+    assert_exact(got, want, "pair + concat + cv3 in one launch vs the launches it replaces")
+    wide = hops.conv_pw_cv3_f16(x, w0, b0, w1, b1, z, w3, b3, residual=r, z_ld=160, z_c_off=64, out_ld=192, out_c_off=32)
+    assert_exact(wide, want, "... z and the output as channel slices of wider buffers")
+    last = hops.conv_pw_cv3_f16(x[n - 1:], w0, b0, w1, b1, z[n - 1:], w3, b3, residual=None if r is None else r[n - 1:])
+    assert_exact(last, got[n - 1:], "... batch position")
+    ref = orc.activation("silu", orc.conv2d(np.concatenate([y, z], -1).astype(np.float32), w3, b3, (1, 1), (0, 0), path="naive"))
+    assert_parity(got.astype(np.float32), ref, F16_TOL, what="pair + concat + cv3 (cv3 stage vs the oracle on the rounded intermediate)")
+
+
 @pytest.mark.parametrize("n,ih,iw,oc", [
     (2, 128, 128, 64),     # whole tiles (32 x 32 outputs)
     (3, 76, 100, 64),      # ragged tiles both ways (19 x 25 outputs)
