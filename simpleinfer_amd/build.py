@@ -114,9 +114,37 @@ def build_host(force=False):
     return LIB_HOST
 
 
+def pybind_target():
+    import sysconfig
+    return os.path.join(ROOT, "python", "simpleinfer_pybind" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_pybind(force=False):
+    """python/simpleinfer_pybind*.so: the reference's pybind11 module (python/pybind11_main.cpp:13-68) compiled over this repo's C++ Engine /
+    Tensor.  Needs the pybind11 headers (the wheel) and Python.h; returns None -- the ctypes mirror python/simpleinfer.py serves the same
+    surface -- when either is missing."""
+    try:
+        import pybind11
+        import sysconfig
+    except ImportError:
+        return None
+    inc_py = sysconfig.get_paths().get("include") or ""
+    if not os.path.exists(os.path.join(inc_py, "Python.h")):
+        return None
+    src = os.path.join(ROOT, "python", "pybind11_main.cpp")
+    out = pybind_target()
+    if not force and not _stale(out, [src, LIB_HOST] + glob.glob(os.path.join(INC, "*.h"))):
+        return out
+    cxx = os.environ.get("CXX", "g++")
+    _run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + INC, "-I" + pybind11.get_include(), "-I" + inc_py, src, "-o", out,
+          "-L" + PKG, "-lsimpleinfer_amd", "-Wl,-rpath,$ORIGIN/../simpleinfer_amd"])
+    return out
+
+
 def build_all(force=False):
     build_hip(force)
     build_host(force)
+    build_pybind(force)
     return LIB_HIP, LIB_HOST
 
 

@@ -834,20 +834,28 @@ Status EngineImpl::FuseCv3IntoPairs(std::vector<Step>& order) {
         const pnnx::Operand* z = order[i].op->inputs[1];
         const pnnx::Operand* cc = order[i].op->outputs[0];
         if (!y || !z || !cc || y == z || output_tensor_nodes_.count(y->name) || output_tensor_nodes_.count(cc->name)) continue;
-        if (y->consumers.size() != 1 || cc->consumers.size() != 1 || !y->producer || !index.count(y->producer) || removed[index[y->producer]]) continue;
+        if (y->consumers.size() != 1 || cc->consumers.size() != 1) continue;
+        // the scheduled step that WRITES y: after the epilogue fusion that is the conv whose output node y's is (y's pnnx producer is then the
+        // folded SiLU / add operator, which no longer has a step)
+        size_t pi = order.size();
+        for (size_t j = 0; j < i && pi == order.size(); ++j)
+            if (!removed[j])
+                for (TensorNode* n : order[j].layer->OutputNodes())
+                    if (n && n->operand == y) pi = j;
+        if (pi == order.size()) continue;
         const pnnx::Operator* c3 = cc->consumers[0];
         if (!c3 || c3->type != "nn.Conv2d" || !index.count(c3) || sibling_ops_.count(c3->name)) continue;
-        Conv2d* pair = dynamic_cast<Conv2d*>(order[index[y->producer]].layer);
+        Conv2d* pair = dynamic_cast<Conv2d*>(order[pi].layer);
         Conv2d* conv = dynamic_cast<Conv2d*>(order[index[c3]].layer);
-        if (!pair || !conv || !pair->PointwiseProducer() || pair->OutputNodes().size() != 1 || pair->OutputNodes()[0]->operand != y) continue;
+        if (!pair || !conv || !pair->PointwiseProducer() || pair->OutputNodes().size() != 1) continue;
         TensorNode* zn = tensor_nodes_[z->name];
         if (!conv->CanFuseCv3Pair(*pair, zn)) continue;
         conv->SetCv3Pair(pair, zn);
         dead_operands_.insert(y->name);
         dead_operands_.insert(cc->name);
-        removed[index[y->producer]] = true;
+        removed[pi] = true;
         removed[i] = true;
-        fused_ops_.insert(y->producer->name);
+        fused_ops_.insert(order[pi].op->name);
         fused_ops_.insert(order[i].op->name);
     }
     std::vector<Step> out;

@@ -973,15 +973,19 @@ def test_full_size_properties_resnet18_224_batch64(si, orc, tmp_path):
     assert_parity(e16.extract(oname), full, F16_GRAPH_TOL, what="fp16 storage vs fp32 at full size")
 
 
-def test_reference_python_module_call_sequence(si, orc, tmp_path):
-    """the reference's Python surface (python/pybind11_main.cpp:13-68), name for name, in `python/simpleinfer.py`.
+@pytest.mark.parametrize("module", ["simpleinfer", "simpleinfer_pybind"])
+def test_reference_python_module_call_sequence(si, orc, tmp_path, module):
+    """the reference's Python surface (python/pybind11_main.cpp:13-68), name for name, in `python/simpleinfer.py` (ctypes over
+    the C-ABI) and -- round 6 -- as a COMPILED pybind11 module over the C++ Engine / Tensor (`python/pybind11_main.cpp` ->
+    simpleinfer_pybind, zero-copy SetTensorDim4 / GetTensorDim4).
     The call sequence of the reference's binding smoke test (InitializeContext, Engine, LoadModel, InputNames / OutputNames,
     Tensor(DataType.Float32, shape), SetTensorDim4(constant 42.0 image), Input, Forward, Extract into an empty Tensor,
     GetTensorDim4) on a synthesized narrow YOLOv5 -- checked against the oracle, which the reference's own test never does."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "python"))
-    import simpleinfer as infer
+    import importlib
+    infer = importlib.import_module(module)
     pp, bp = _save(tmp_path, si.modelgen.build_toy_yolo(4, 96), "py")
     infer.InitializeContext()
     engine = infer.Engine()
@@ -998,7 +1002,7 @@ def test_reference_python_module_call_sequence(si, orc, tmp_path):
     assert engine.Input("nope", input_tensor) == infer.Status.Fail
     assert engine.Forward() == infer.Status.Success
     output_tensor = infer.Tensor()
-    assert output_tensor.GetDataType() == infer.DataType["None"]
+    assert output_tensor.GetDataType() == getattr(infer.DataType, "None")
     assert engine.Extract(output_names[0], output_tensor) == infer.Status.Success
     output_np = output_tensor.GetTensorDim4()
     rows = 3 * (12 * 12 + 6 * 6 + 3 * 3)
