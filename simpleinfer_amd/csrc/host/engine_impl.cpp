@@ -54,7 +54,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "fp16") opt_fp16_ = value != 0;
     else if (key == "batch") opt_batch_ = value;  // > 0: re-batch the graph at load (the file bakes its batch into every shape)
     else if (key == "arena") opt_arena_ = value != 0;  // 1 (default): intermediates share one arena by lifetime; 0: one hipMalloc each
-    else if (key == "fuse_pw") opt_fuse_pw_ = value;           // fp16: 1 a C3 bottleneck's 1x1 conv computed inside the kernel of its 3x3 conv; 2 (default) ... and the C3's closing conv behind its last pair; 0 off
+    else if (key == "fuse_pw") opt_fuse_pw_ = value;           // fp16: 1 (default) a C3 bottleneck's 1x1 conv computed inside the kernel of its 3x3 conv; 2 ... and the C3's closing conv behind its last 64-channel pair (measured slower: opt-in); 0 off
     else if (key == "fuse_stem") opt_fuse_stem_ = value;       // fp16: 1 RGB stem conv + the 3x3 s2 conv behind it in one launch; 2 (default) ... and the 1x1 conv(s) reading that; 0 off
     else if (key == "fuse_upsample") opt_fuse_upsample_ = value != 0;  // upsample -> cat -> 1x1 conv read at the source (default 1)
     else if (key == "detect_priority") opt_detect_priority_ = value < 0 ? -1 : (value > 0 ? 1 : 0);   // priority of Detect's side stream: -1 low, 0 default, +1 high

@@ -312,11 +312,11 @@ def test_bottleneck_pairs_in_one_launch_with_fp16_storage(si, tmp_path):
     for _ in range(2):
         e1.forward()
         assert_exact(e1.extract(oname), plain, "repeated forwards")
-    # round 6 (FuseCv3IntoPairs, si_hip_conv2d_pw_cv3_f16; fuse_pw = 2, the default): the two 80x80 C3s' closing convs behind their last
-    # bottleneck pair in the same launch -- per C3 the pair's step and the concat's disappear, neither the pair's output nor the concat buffer
-    # is allocated (the arena shrinks), and not a bit changes; eager, replayed as a hipGraph, forward after forward
+    # round 6 (FuseCv3IntoPairs, si_hip_conv2d_pw_cv3_f16; fuse_pw = 2, OPT-IN: measured 0.74-0.84x of the launches it replaces): the two 80x80
+    # C3s' closing convs behind their last bottleneck pair in the same launch -- per C3 the pair's step and the concat's disappear, neither the
+    # pair's output nor the concat buffer is allocated (the arena shrinks), and not a bit changes; eager, replayed as a hipGraph, repeatedly
     for opts in ({}, {"graph": 1}):
-        e3, _, tail = _run(si, pp, bp, x, fp16=1, **opts)
+        e3, _, tail = _run(si, pp, bp, x, fp16=1, fuse_pw=2, **opts)
         assert_exact(tail, plain, "fp16: C3 tails (pair + concat + cv3) in one launch")
         s3 = e3.schedule()
         assert len(s1["run"]) == len(s3["run"]) + 4, (len(s1["run"]), len(s3["run"]))
@@ -336,7 +336,7 @@ def test_bottleneck_pairs_in_one_launch_with_fp16_storage(si, tmp_path):
     assert_exact(e2.extract(oname), plain[:2], "batch 2 (two launches per pair) vs batch 32 (one)")
     e32 = si.Engine()
     e32.load_model(pp, bp)
-    assert len(e32.schedule()["run"]) == len(s0["run"]) + 1      # (fp32: no stem pair, no bottleneck pairs)
+    assert len(e32.schedule()["run"]) == len(s0["run"]) + 2      # (fp32: no stem triple, no bottleneck pairs)
 
 
 @pytest.mark.parametrize("graph", [0, 1])
