@@ -148,6 +148,17 @@ def build_all(force=False):
     return LIB_HIP, LIB_HOST
 
 
+def build_experiment():
+    """build_variants/libsi_hip_exp.so: the kernel library compiled with -DSI_EXPERIMENT -- the ONLY build in which the SI_CONV_* / SI_WINO_* /
+    SI_DETECT_* / SI_SPLIT3_* environment switches of the sweep / ablation scripts under tools/ exist (the product library reads no environment
+    variable and has no process-global setter: kernel-form choices travel in SiConv2dDesc::plan).  Select it with SI_HIP_LIB=<path>."""
+    vdir = os.path.join(ROOT, "build_variants")
+    return build_hip(defines=("SI_EXPERIMENT",), out=os.path.join(vdir, "libsi_hip_exp.so"), objdir=os.path.join(vdir, "obj_exp"))
+
+
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
-    print("built:", LIB_HIP, LIB_HOST)
+    if "--experiment" in sys.argv:
+        print("built:", build_experiment())
+    else:
+        build_all(force="--force" in sys.argv)
+        print("built:", LIB_HIP, LIB_HOST)

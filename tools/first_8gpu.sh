@@ -23,6 +23,15 @@ O=${1:-gpurun_out/first8}
 mkdir -p "$O"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 B="--steps 20 --warmup 3 --min-time 4 --no-cpu-baseline --no-aux --no-secondary"
+# Preflight (round 6): what the batch-256 configuration allocates PER RANK -- [B/G, 25200, 85] fp32 = 274.2 MB per slab, a gathered buffer of
+# G = 8 slabs, 4 slots of those, all IPC-exported: 8 x 4 x 274.2 MB = 8.8 GB of shared buffers per rank beside the engine's ~3 GB arena.  Allocated
+# and run once on ONE device shared by eight ranks in round 6 (profiles/r06_bench_y256_shared_device.json: handle exchange, 21 peer copies per
+# rank, checksums of every slab on every rank -- 70 GB of the 288); on eight devices each holds one eighth of that.
+python3 - <<'PY' | tee -a "$O/log.txt"
+slab = 32 * 25200 * 85 * 4
+print("preflight: slab %.1f MB, gathered buffer %.2f GB, 4 slots %.2f GB per rank" % (slab / 1e6, 8 * slab / 1e9, 4 * 8 * slab / 1e9))
+PY
+rocm-smi --showmeminfo vram 2>/dev/null | grep -E "Total Memory|Used" | tee -a "$O/log.txt"
 run() { name=$1; shift; echo "== $name: $*" | tee -a "$O/log.txt"; timeout 600 "$@" > "$O/$name.json" 2>> "$O/log.txt"; echo "rc=$?" >> "$O/log.txt"; }
 
 # A: strong scaling, batch 32 total
