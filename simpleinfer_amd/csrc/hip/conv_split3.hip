@@ -423,22 +423,24 @@ static int split3_launch(const SiConv2dDesc* d, const float* in, const void* w_p
         hipLaunchKernelGGL(kern, dim3(chunks * 8 * a.n_tiles), dim3(256), lds, static_cast<hipStream_t>(stream), a);
         return (int)hipGetLastError();
     };
-    // tiles: <= 64 output channels -> 128 x 64 as 2 x 2 waves (the 1 x 4 form would leave two waves without columns); 64 x 128 as 1 x 4
-    // waves otherwise, 128 x 128 for >= 512 output channels on a grid that still covers the chip twice (a weight fragment then feeds four
-    // pixel blocks: half the L2 -> L1 weight traffic per FLOP; measured 117 vs 125 us on 40x40x256 -> 512, 139 vs 118 on 80x80x128 -> 256)
+    // Tiles.  <= 64 output channels: 2 x 2 waves over 64 columns (the 1 x 4 form would leave two waves without columns), 64 rows (128 on request);
+    // otherwise 1 x 4 waves over 128 columns and -- round 6 -- THIRTY-TWO rows: measured on YOLOv5s under the option, same box, interleaved
+    // (profiles/r06_f32_split.txt), 32-row tiles everywhere beat round 5's 64 / 128-row choice at every batch (batch 32 +1.7 %, 16 +2.8 %, 8 +6 %,
+    // 4 +14 %): twice the workgroups, half the LDS each (18 KB: more of them per CU), and the K loop of a 32-row tile is the same three MFMAs per
+    // fragment pair.  An output element is the same two accumulator chains over the same k order whatever the tile -- the same bits
+    // (tests/test_gpu_ops.py) -- so an image's result does not depend on its batch.  SiConvPlan::split3_bm forces 32 / 64 / 128 for a call.
     const int forced_bm = (d->plan && d->plan->split3_bm > 0) ? d->plan->split3_bm : SI_ENV_INT("SI_SPLIT3_BM", 0);
-    if (yolo) return go(conv_split3_f32_kernel<64, 1, 4, 64, true>, 64, 128, 64);
-    if (split3_blk(d) == 32) return d->oc <= 64 ? go(conv_split3_f32_kernel<128, 2, 2, 32>, 128, 64, 32) : go(conv_split3_f32_kernel<64, 1, 4, 32>, 64, 128, 32);
-    if (d->oc <= 64) return go(conv_split3_f32_kernel<128, 2, 2, 64>, 128, 64, 64);
-    const long long tiles128 = (((long long)a.M + 127) / 128) * ((d->oc + 127) / 128);
-    const bool big = forced_bm ? forced_bm == 128 : (d->oc >= 512 && tiles128 >= 2LL * cus);
-    if (big) return go(conv_split3_f32_kernel<128, 1, 4, 64>, 128, 128, 64);
-    // launch-size tiles (round 6, VERDICT r05 item 2c: the option LOST 7 % at batch 4 on 64-row tiles alone): a launch whose 64 x 128 tiles would
-    // leave the chip part empty takes 32-row tiles -- twice the workgroups, half the LDS each.  An output element is the same two accumulator
-    // chains over the same k order whatever the tile: the same bits (tests/test_gpu_ops.py), so an image's result still does not depend on its batch.
-    const long long tiles64 = (((long long)a.M + 63) / 64) * ((d->oc + 127) / 128);
-    const bool small = forced_bm ? forced_bm == 32 : tiles64 < 2LL * cus;
-    return small ? go(conv_split3_f32_kernel<32, 1, 4, 64>, 32, 128, 64) : go(conv_split3_f32_kernel<64, 1, 4, 64>, 64, 128, 64);
+    (void)cus;
+    // (the Detect form: 201 vs 206 us on 32-row tiles; <= 64 columns: the 2 x 2-wave form on 64 rows -- YOLOv5s conv_1 252 vs 266 us on 128)
+    if (yolo) return forced_bm == 64 ? go(conv_split3_f32_kernel<64, 1, 4, 64, true>, 64, 128, 64) : go(conv_split3_f32_kernel<32, 1, 4, 64, true>, 32, 128, 64);
+    if (d->oc <= 64) {
+        if (split3_blk(d) == 32) return forced_bm == 128 ? go(conv_split3_f32_kernel<128, 2, 2, 32>, 128, 64, 32) : go(conv_split3_f32_kernel<64, 2, 2, 32>, 64, 64, 32);
+        return forced_bm == 128 ? go(conv_split3_f32_kernel<128, 2, 2, 64>, 128, 64, 64) : go(conv_split3_f32_kernel<64, 2, 2, 64>, 64, 64, 64);
+    }
+    if (split3_blk(d) == 32) return forced_bm == 32 ? go(conv_split3_f32_kernel<32, 1, 4, 32>, 32, 128, 32) : go(conv_split3_f32_kernel<64, 1, 4, 32>, 64, 128, 32);
+    if (forced_bm == 128) return go(conv_split3_f32_kernel<128, 1, 4, 64>, 128, 128, 64);
+    if (forced_bm == 64) return go(conv_split3_f32_kernel<64, 1, 4, 64>, 64, 128, 64);
+    return go(conv_split3_f32_kernel<32, 1, 4, 64>, 32, 128, 64);
 }
 
 int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const float* residual, float* out,
