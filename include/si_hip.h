@@ -212,6 +212,12 @@ int si_hip_conv2d_split3_f32(const SiConv2dDesc* d, const float* in, const void*
  * output channels [0, split_oc) to `out` (stride d->out_ld), [split_oc, d->oc) to `out2` (stride out2_ld); split_oc a multiple of 32 (round 6) */
 int si_hip_conv2d_split3_split_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, float* out, int split_oc,
                                    float* out2, int out2_ld, si_stream_t stream);
+/* ... and with dual-source rows, as si_hip_conv2d_upcat_f32 (a 1x1 conv over torch.cat(..., nn.Upsample(x, nearest), ...) reads the upsampled
+ * channels from the low-resolution tensor at the reference's source pixel, src/layer/upsample.cpp:85-92): up->c0 and up->c multiples of 64 (the
+ * kernel's K-tile), ic % 64 == 0, more than 64 output columns; split_oc > 0: the sibling-fused form.  _supported: shapes only (round 6) */
+int si_hip_conv2d_split3_upcat_supported(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up);
+int si_hip_conv2d_split3_upcat_f32(const SiConv2dDesc* d, const float* in, const SiConv2dUpsampledSource* up, const void* w_packed, const float* bias,
+                                   float* out, int split_oc, float* out2, int out2_ld, si_stream_t stream);
 
 /* ---- fused Winograd F(2x2,3x3) with its plane GEMMs on the fp16 matrix cores by operand splitting (round 5, late; csrc/hip/conv_wino23_split.hip;
  * OPT-IN: engine option f32_split).  si_hip_conv2d_wino23_f32's kernel around another channel loop: the transformed input V and the

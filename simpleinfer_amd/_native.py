@@ -125,6 +125,8 @@ def hip():
         "si_hip_conv2d_split3_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_split3_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_split3_split_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, i, vp, i, vp]),
+        "si_hip_conv2d_split3_upcat_supported": (i, [C.POINTER(SiConv2dDesc), C.POINTER(SiConv2dUpsampledSource)]),
+        "si_hip_conv2d_split3_upcat_f32": (i, [C.POINTER(SiConv2dDesc), vp, C.POINTER(SiConv2dUpsampledSource), vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_wino23_split_supported": (i, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino23_split_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
         "si_hip_conv2d_wino23_split_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),

@@ -60,6 +60,12 @@ struct Split3Args {
     // split destination (si_hip_conv2d_split3_split_f32: two sibling convs as one): output channels [split, oc) go to out2 (stride out2_ld)
     float* out2;
     int out2_ld, split;
+    // dual-source rows (si_hip_conv2d_split3_upcat_f32, round 6): K-tiles [up_cb0, up_cb1) of this 1x1 conv's input are nn.Upsample(nearest) of
+    // `up` -- read at the row's source pixel of the LOW-RESOLUTION tensor (conv_igemm.hip's UPS form: reference src/layer/upsample.cpp:85-92)
+    const float* up;
+    int up_ih, up_iw, up_ld, up_cb0, up_cb1;
+    float up_inv_h, up_inv_w;
+    unsigned up_bytes;
 };
 
 // An operand that rounds to fp16 infinity makes its hi half Inf and its lo half Inf / NaN, so every accumulator it feeds is Inf or NaN (the fp16
@@ -95,7 +101,9 @@ constexpr float kLoScale = 2048.0f;   // 2^11
 // weight fragment fetched once per workgroup; 2 x 2 for 64), BKH-channel K-tiles (64; 32 for 32-channel layers)
 // YOLO: a Detect level (1x1 conv to na * ne columns) with the decode of src/layer/yolo_detect.cpp:223-266 in the epilogue, written into the
 // [n][rows_total][ne] detections -- the fp32 kernels' epilogue (si_yolo_tile_one_image) on the combined accumulators
-template <int BM, int WM, int WN, int BKH, bool YOLO = false>
+// UPS: a pointwise conv some of whose K-tiles come from a low-resolution tensor at the row's nearest-neighbour source pixel (the upsample + concat
+// in front of YOLOv5's PAN convs, read at the source)
+template <int BM, int WM, int WN, int BKH, bool YOLO = false, bool UPS = false>
 __global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Args a) {
     static_assert(WM * WN == 4 && (BKH == 64 || BKH == 32), "4 waves; 64- or 32-channel K-tiles");
     constexpr int BN = 32 * WN, LDH = BKH + 8, QS = BKH / 16;
@@ -124,18 +132,28 @@ __global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Arg
     const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wl_hi), 0, wl_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wl_lo), 0, wl_bytes, 0x00020000);
 
+    const __amdgpu_buffer_rsrc_t rs_up = UPS ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.up), 0, a.up_bytes, 0x00020000) : rs_in;
     unsigned a_off[A_IT];
+    unsigned u_off[UPS ? A_IT : 1];   // UPS: byte offset of the row's source pixel in the low-resolution tensor
     unsigned a_mask[A_IT];   // tap validity bits (at most 32 taps)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + r0 + RPP * i;
         a_off[i] = 0;
         a_mask[i] = 0u;
+        if (UPS) u_off[i] = OOB_A;
         if (m < a.M) {
             const int img = fdiv(m, a.ohow, a.mg_ohow);
             const int rem = m - img * a.ohow;
             const int oy = fdiv(rem, a.ow, a.mg_ow);
             const int ox = rem - oy * a.ow;
+            if (UPS) {
+                // upsample.cpp:85-92: src = clamp(int(float(dst) * (1 / scale)), 0, in - 1)
+                int sy = (int)((float)oy * a.up_inv_h), sx = (int)((float)ox * a.up_inv_w);
+                sy = max(0, min(a.up_ih - 1, sy));
+                sx = max(0, min(a.up_iw - 1, sx));
+                u_off[i] = (unsigned)((img * a.up_ih + sy) * a.up_iw + sx) * (unsigned)(a.up_ld * 4) + (unsigned)(kv * 16);
+            }
             const int y0 = oy * a.sh - a.pt, x0 = ox * a.sw - a.pl;
             a_off[i] = (unsigned)((img * a.ih + y0) * a.iw + x0) * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16);
             unsigned mk = 0u;
@@ -170,10 +188,18 @@ __global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Arg
         const unsigned delta = (unsigned)((ky * a.iw + kx) * a.in_ld + cb * BKH) * 4u;
         const int tapbit = ky * a.kw + kx;
         const bool live = kt < nk;
+        const bool from_up = UPS && cb >= a.up_cb0 && cb < a.up_cb1;   // wave-uniform: this K-tile's channels are upsampled ones
+        if (from_up) {
+            const unsigned du = (unsigned)(cb - a.up_cb0) * (unsigned)(BKH * 4);
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const bool ok = ((a_mask[i] >> tapbit) & 1u) && live;
-            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
+            for (int i = 0; i < A_IT; ++i)
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_up, (live && u_off[i] != OOB_A) ? u_off[i] + du : OOB_A, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const bool ok = ((a_mask[i] >> tapbit) & 1u) && live;
+                ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? a_off[i] + delta : OOB_A, 0, 0);
+            }
         }
         ++kx;
         const int wx = kx == a.kw ? 1 : 0;
@@ -368,9 +394,17 @@ int si_hip_conv2d_split3_pack_weight_host(const SiConv2dDesc* d, const float* w_
     return 0;
 }
 
+static bool split3_upcat_shape_ok(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up) {
+    if (!d || !up || !split3_ok(d) || d->ic % 64 != 0 || d->oc <= 64) return false;
+    const bool pointwise = d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow;
+    if (!pointwise || d->has_residual) return false;
+    if (up->c <= 0 || up->c % 64 != 0 || up->c0 % 64 != 0 || up->c0 + up->c > d->ic || up->ld % 4 != 0 || up->ih <= 0 || up->iw <= 0) return false;
+    return (unsigned long long)d->n * up->ih * up->iw * up->ld * 4ull < 0xFFFFFF00ull;
+}
+
 static int split3_launch(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const float* residual, float* out,
                          si_stream_t stream, const SiYoloLevel* yolo, const float* ygrid, const float* yanchor, int split_oc = 0, float* out2 = nullptr,
-                         int out2_ld = 0) {
+                         int out2_ld = 0, const SiConv2dUpsampledSource* up = nullptr) {
     if (!d || !in || !w_packed || !out) return SI_E_BADARG;
     if (!split3_ok(d) || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return SI_E_UNSUPPORTED;
     if ((d->has_bias && !bias) || (d->has_residual && !residual)) return SI_E_BADARG;
@@ -398,6 +432,13 @@ static int split3_launch(const SiConv2dDesc* d, const float* in, const void* w_p
     a.yna = a.yne = a.yrows_total = a.yrow_off = 0; a.ystride = 0.0f; a.ygrid = a.yanchor = nullptr;
     a.range_flag = d->range_flag;
     a.out2 = nullptr; a.out2_ld = 0; a.split = 0;
+    a.up = nullptr; a.up_ih = a.up_iw = a.up_ld = a.up_cb0 = a.up_cb1 = 0; a.up_inv_h = a.up_inv_w = 0.0f; a.up_bytes = 0;
+    if (up) {
+        if (yolo || !up->src || !split3_upcat_shape_ok(d, up) || (reinterpret_cast<uintptr_t>(up->src) & 15) != 0) return SI_E_UNSUPPORTED;
+        a.up = up->src; a.up_ih = up->ih; a.up_iw = up->iw; a.up_ld = up->ld; a.up_cb0 = up->c0 / 64; a.up_cb1 = (up->c0 + up->c) / 64;
+        a.up_inv_h = up->inv_scale_h; a.up_inv_w = up->inv_scale_w;
+        a.up_bytes = (unsigned)((unsigned long long)d->n * up->ih * up->iw * up->ld * 4ull);
+    }
     if (split_oc > 0) {
         if (yolo || d->has_residual || split_oc >= d->oc || split_oc % 32 != 0 || !out2) return SI_E_BADARG;
         a.out2 = out2; a.out2_ld = out2_ld; a.split = split_oc;
@@ -431,6 +472,7 @@ static int split3_launch(const SiConv2dDesc* d, const float* in, const void* w_p
     // (tests/test_gpu_ops.py) -- so an image's result does not depend on its batch.  SiConvPlan::split3_bm forces 32 / 64 / 128 for a call.
     const int forced_bm = (d->plan && d->plan->split3_bm > 0) ? d->plan->split3_bm : SI_ENV_INT("SI_SPLIT3_BM", 0);
     (void)cus;
+    if (up) return forced_bm == 64 ? go(conv_split3_f32_kernel<64, 1, 4, 64, false, true>, 64, 128, 64) : go(conv_split3_f32_kernel<32, 1, 4, 64, false, true>, 32, 128, 64);
     // (the Detect form: 201 vs 206 us on 32-row tiles; <= 64 columns: the 2 x 2-wave form on 64 rows -- YOLOv5s conv_1 252 vs 266 us on 128)
     if (yolo) return forced_bm == 64 ? go(conv_split3_f32_kernel<64, 1, 4, 64, true>, 64, 128, 64) : go(conv_split3_f32_kernel<32, 1, 4, 64, true>, 32, 128, 64);
     if (d->oc <= 64) {
@@ -452,6 +494,14 @@ int si_hip_conv2d_split3_split_f32(const SiConv2dDesc* d, const float* in, const
                                    float* out2, int out2_ld, si_stream_t stream) {
     if (!d || d->has_residual || split_oc <= 0) return SI_E_BADARG;
     return split3_launch(d, in, w_packed, bias, nullptr, out, stream, nullptr, nullptr, nullptr, split_oc, out2, out2_ld);
+}
+
+int si_hip_conv2d_split3_upcat_supported(const SiConv2dDesc* d, const SiConv2dUpsampledSource* up) { return split3_upcat_shape_ok(d, up) ? 1 : 0; }
+
+int si_hip_conv2d_split3_upcat_f32(const SiConv2dDesc* d, const float* in, const SiConv2dUpsampledSource* up, const void* w_packed, const float* bias,
+                                   float* out, int split_oc, float* out2, int out2_ld, si_stream_t stream) {
+    if (!d || !up || d->has_residual) return SI_E_BADARG;
+    return split3_launch(d, in, w_packed, bias, nullptr, out, stream, nullptr, nullptr, nullptr, split_oc, out2, out2_ld, up);
 }
 
 int si_hip_conv2d_split3_yolo_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, const SiYoloLevel* level,

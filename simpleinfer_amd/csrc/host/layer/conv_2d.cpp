@@ -449,7 +449,13 @@ Status Conv2d::PrepareDeviceHalf(const SiConv2dDesc& d) {
 static const int kSplit3DetectMinChannels = 128;
 
 bool Conv2d::UseSplit3() const {
-    if (!f32_split_ || up_node_ || stem_producer_ || groups_ != 1 || dilation_h_ != 1 || dilation_w_ != 1) return false;
+    if (!f32_split_ || stem_producer_ || groups_ != 1 || dilation_h_ != 1 || dilation_w_ != 1) return false;
+    // (round 6: the dual-source form -- upsample + concat read at the source -- exists on the split kernel too, for 64-channel granularity)
+    if (up_node_ && (f32_split_level_ < 3 || residual_node_ || up_c0_ % 64 != 0 || in_channels_ % 64 != 0)) return false;
+    if (up_node_) {
+        Dims4 lo;
+        if (!GetDims4(up_node_->tensor, lo) || lo.c % 64 != 0) return false;
+    }
     // (round 6: a sibling-fused conv -- C3's cv1 | cv2 -- is ONE conv over the concatenated filters here too: si_hip_conv2d_split3_split_f32)
     if (sibling_ && (f32_split_level_ < 2 || residual_node_ || out_channels_ % 32 != 0)) return false;
     const int oc_all = out_channels_ + (sibling_ ? sibling_->out_channels_ : 0);
@@ -469,7 +475,8 @@ bool Conv2d::UseSplit3() const {
     const bool strided_spatial = kernel_h_ * kernel_w_ > 1 && (stride_h_ > 1 || stride_w_ > 1);
     // round 6: ... and the wide 1x1 layers from K = 256 with >= 256 output columns (C3's cv1 | cv2 and cv3 over 256
     // channels at 40x40: 1.29x standalone in round 5, left on the fp32 template then because the policy asked for K >= 512)
-    const bool wide_pw = f32_split_level_ >= 2 && kernel_h_ * kernel_w_ == 1 && K >= 256 && oc_all >= 256;
+    // (thin 1x1 layers, K = 128 over 128 columns, measured flat at batch 32 and -3 % at batch 4 on the split kernel: profiles/r06_f32_split.txt)
+    const bool wide_pw = f32_split_level_ >= 2 && kernel_h_ * kernel_w_ == 1 && K >= 256 && (oc_all >= 256 || (up_node_ && oc_all >= 128));
     if (strided_spatial ? (K < 288 || oc_all < 64) : ((K < 512 || oc_all < 128) && !wide_pw)) return false;
     const bool wino_shape = kernel_h_ == 3 && kernel_w_ == 3 && stride_h_ == 1 && stride_w_ == 1;
     return !(wino_shape && in_channels_ < 256 && algo_ != Algo::kImplicitGemm);
@@ -535,7 +542,14 @@ Status Conv2d::Forward(const Tensor& input, std::vector<Tensor>& outputs) {
         d.oc = out_channels_ + sibling_->out_channels_;
         if (mode == 4) {
             d.range_flag = range_flag_;
-            const int rc = si_hip_conv2d_split3_split_f32(&d, in[0].Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+            int rc;
+            if (up_node_) {
+                SiConv2dUpsampledSource up;
+                CHECK_STATUS(MakeUpsampledSource(up));
+                rc = si_hip_conv2d_split3_upcat_f32(&d, in[0].Data<float>(), &up, weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                    out[0].Data<float>(), out_channels_, out[1].Data<float>(), out[1].PixelStride(), Stream());
+            } else
+            rc = si_hip_conv2d_split3_split_f32(&d, in[0].Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
                                                           out[0].Data<float>(), out_channels_, out[1].Data<float>(), out[1].PixelStride(), Stream());
             if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (fused siblings, fp32 by three fp16 products)");
             DemoteSplit();   // an unaligned / oversized view: the true-fp32 kernels from here on
@@ -641,7 +655,15 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
     }
     if (mode == 4) {
         d.range_flag = range_flag_;
-        const int rc = si_hip_conv2d_split3_f32(&d, input.Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+        int rc;
+        if (up_node_) {
+            if (residual) return Status::kUnsupport;
+            SiConv2dUpsampledSource up;
+            CHECK_STATUS(MakeUpsampledSource(up));
+            rc = si_hip_conv2d_split3_upcat_f32(&d, input.Data<float>(), &up, weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                output.Data<float>(), 0, nullptr, 0, Stream());
+        } else
+        rc = si_hip_conv2d_split3_f32(&d, input.Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
                                                 residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream());
         if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (fp32 by three fp16 products)");
         // an unaligned / oversized view: the true-fp32 kernels from here on.  (The re-pack uploads weights: inside a hipGraph capture that

@@ -135,8 +135,8 @@ public:
     bool f32_split_ = false;
     // ... its range guard (round 6): the word the split kernels set to 1 when an operand left fp16's range (engine-owned pinned host memory;
     // nullptr: unguarded), and what the engine does when it finds it set -- back to the true-fp32 kernels for this layer, for good
-    int f32_split_level_ = 2;   // engine option f32_split = 1: round 5's layer policy; 2 (what `1` means since round 6 unless asked otherwise): + sibling-fused
-                                // and wide 1x1 layers from K = 256 (A/B: option f32_split_policy)
+    int f32_split_level_ = 3;   // which layers the option takes (A/B: engine option f32_split_policy): 1 round 5's; 2 + sibling-fused and wide 1x1 layers
+                                // from K = 256; 3 (default) + the dual-source layers (upsample + concat read at the source)
     unsigned* range_flag_ = nullptr;
     bool split_demoted_ = false;
     void DemoteSplit() { f32_split_ = false; split_demoted_ = true; device_ready_ = false; }

@@ -220,9 +220,9 @@ def conv2d_wino23_split(x, w_oihw, bias=None, padding=(1, 1), act1="none", resid
     return (y, int(flag.to_numpy((1,), np.uint32)[0])) if return_flag else y
 
 
-def conv2d_upcat(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1="none", split_oc=0):
+def conv2d_upcat(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1="none", split_oc=0, split3=False):
     """si_hip_conv2d_upcat_f32: a 1x1 conv over cat([upsample(low), skip]) (or [skip, upsample(low)]) that reads `low` at the
-    source pixel.  Returns y, or (y, y2) for the sibling-split form."""
+    source pixel.  Returns y, or (y, y2) for the sibling-split form.  split3: the same on the f32_split arithmetic (si_hip_conv2d_split3_upcat_f32)."""
     H = _native.hip()
     low, skip, w_oihw = _f32(low), _f32(skip), _f32(w_oihw)
     n, oh, ow, cs = skip.shape
@@ -230,9 +230,14 @@ def conv2d_upcat(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1=
     ic, oc = cl + cs, w_oihw.shape[0]
     assert w_oihw.shape[1] == ic and w_oihw.shape[2:] == (1, 1)
     d = SiConv2dDesc(n, oh, ow, ic, ic, oh, ow, oc, oc, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1 if bias is not None else 0, ACT[act1], 0, oc, 0, 0.0)
-    wn = H.si_hip_conv2d_weight_elems(C.byref(d))
-    wp = np.empty(wn, np.float32)
-    _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p)), "pack")
+    if split3:
+        wp = np.zeros(H.si_hip_conv2d_split3_weight_elems(C.byref(d)), np.float16)
+        _chk(H.si_hip_conv2d_split3_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p)), "pack split3")
+    else:
+        wn = H.si_hip_conv2d_weight_elems(C.byref(d))
+        wp = np.empty(wn, np.float32)
+        _chk(H.si_hip_conv2d_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), wp.ctypes.data_as(C.c_void_p)), "pack")
+    fn, fname = (H.si_hip_conv2d_split3_upcat_f32, "si_hip_conv2d_split3_upcat_f32") if split3 else (H.si_hip_conv2d_upcat_f32, "si_hip_conv2d_upcat_f32")
     # the concat buffer: only the skip channels are ever written; the upsampled range is poisoned to prove nobody reads it
     cat = np.full((n, oh, ow, ic), np.nan, np.float32)
     c0 = 0 if up_first else cs
@@ -243,12 +248,10 @@ def conv2d_upcat(low, skip, w_oihw, bias, scale=(2.0, 2.0), up_first=True, act1=
     if split_oc:
         d.out_ld = split_oc
         dy, dy2 = DeviceBuffer(n * oh * ow * split_oc * 4), DeviceBuffer(n * oh * ow * (oc - split_oc) * 4)
-        _chk(H.si_hip_conv2d_upcat_f32(C.byref(d), dcat.ptr, C.byref(up), dw.ptr, db.ptr if db else None, dy.ptr, split_oc, dy2.ptr,
-                                       oc - split_oc, None), "si_hip_conv2d_upcat_f32")
+        _chk(fn(C.byref(d), dcat.ptr, C.byref(up), dw.ptr, db.ptr if db else None, dy.ptr, split_oc, dy2.ptr, oc - split_oc, None), fname)
         return dy.to_numpy((n, oh, ow, split_oc)), dy2.to_numpy((n, oh, ow, oc - split_oc))
     dy = DeviceBuffer(n * oh * ow * oc * 4)
-    _chk(H.si_hip_conv2d_upcat_f32(C.byref(d), dcat.ptr, C.byref(up), dw.ptr, db.ptr if db else None, dy.ptr, 0, None, 0, None),
-         "si_hip_conv2d_upcat_f32")
+    _chk(fn(C.byref(d), dcat.ptr, C.byref(up), dw.ptr, db.ptr if db else None, dy.ptr, 0, None, 0, None), fname)
     return dy.to_numpy((n, oh, ow, oc))
 
 
