@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--algo", default="direct", choices=["direct", "wino", "wino43"], help="wino: si_hip_conv2d_wino23_f32 on eligible shapes only")
     ap.add_argument("--shape", action="append", default=[], help="n,h,w,ci,co,k,s,p[,groups] (repeatable): custom shapes instead of a model")
     ap.add_argument("--graph", type=int, default=0, help="(--f16) time a replayed hipGraph of this many launches instead of host-issued launches")
+    ap.add_argument("--f16-tile", type=int, default=-1, help="(--f16) SiConvPlan::f16_tile for every launch (-1: the policy; a forced tile also bypasses the slab / patch kernels)")
     ap.add_argument("--f16", action="store_true", help="the fp16 storage path (si_hip_conv2d_f16; SI_CONV_F16_VARIANT picks the tile); stems are skipped")
     args = ap.parse_args()
     H = _native.hip()
@@ -78,6 +79,9 @@ def main():
         if args.f16:
             if H.si_hip_conv2d_f16_supported(C.byref(d)) != 1:
                 continue
+            if args.f16_tile >= 0:
+                _plan = _native.SiConvPlan(f16_tile=args.f16_tile)
+                d.plan = C.pointer(_plan)
             wn = H.si_hip_conv2d_f16_weight_elems(C.byref(d))
             rng = np.random.default_rng(0)
             w32 = ((rng.random((co, ci // g, k[0], k[1]), dtype=np.float32) - 0.5) * 0.1)
@@ -132,7 +136,7 @@ def main():
                 ms = ms.value / reps
             flops = 2.0 * n * oh * ow * co * k[0] * k[1] * (ci // g)
             byts = 2.0 * (n * ih * iw * ci + n * oh * ow * co + co * (ci // g) * k[0] * k[1])   # (wn counts both packed weight images)
-            rows.append((key, count, "f16 v%s" % os.environ.get("SI_CONV_F16_VARIANT", "policy"), ms, flops / ms / 1e9, byts / ms / 1e6, flops))
+            rows.append((key, count, "f16 v%s" % (args.f16_tile if args.f16_tile >= 0 else "policy"), ms, flops / ms / 1e9, byts / ms / 1e6, flops))
             for buf in (dx, dw, db, dy):
                 buf.free()
             continue
