@@ -446,6 +446,13 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
                                                     "executed_f16_mfma_tflops": round(3.0 * wfl / 2.25 / (wms * 1e-3) / 1e12, 1), "bound": "vector issue (transform + split), not a pipe",
                                                     "peak": PEAK_F16_MFMA_TFLOPS, "frac": round(3.0 * wfl / 2.25 / (wms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                                                     "frac_is": "3 x (direct-conv FLOPs / 2.25) of the Winograd layers / their event-timed durations / 2500 TF/s"}
+                st = [L for L in convs if L["kernel"].startswith("conv_stem_split")]
+                if st and st[0]["ms"] > 0:
+                    # the RGB stem on the split form of the fp16 stem kernel: 108-deep contraction, 420 MB of fp32 activations out -- HBM-bound
+                    gbs = st[0]["bytes"] / (st[0]["ms"] * 1e-3) / 1e9
+                    rec["split_stem_kernel"] = {"kernel": "conv_stem_split_f32_kernel", "ms_per_step": round(st[0]["ms"], 3), "bound": "hbm",
+                                                "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                                                "frac_is": "(image + activations + weights, once each) / event-timed duration / 8 TB/s"}
                 bt, bsrc = _busy_table(rec["workload"] + " f32_split=1")
                 rec["guard"] = {"split_reruns": e.schedule().get("split_reruns"), "split_demoted": e.schedule().get("split_demoted"),
                                 "note": "range guard (include/si_hip.h): a layer whose operands leave fp16's range goes back to the true-fp32 kernels and "

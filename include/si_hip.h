@@ -447,6 +447,14 @@ size_t si_hip_conv2d_stem_f16_weight_elems(const SiConv2dDesc* d);
 int si_hip_conv2d_stem_f16_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
 int si_hip_conv2d_stem_f16(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, void* out,
                            si_stream_t stream);
+/* ... the same stem under f32_split (round 6; shapes: si_hip_conv2d_f16_supported == 2, a dense image -- in_ld == ic): fp32 image in, FP32
+ * activations out, every product from three fp16 MFMA products on operands split hi + 2^-11 lo (the scheme and the RANGE contract of
+ * si_hip_conv2d_split3_f32: d->range_flag is set when an accumulator left the matrix cores non-finite; the pack function returns
+ * SI_E_UNSUPPORTED for a weight fp16 cannot hold).  Weights: the B fragments above twice, hi image then lo image. */
+size_t si_hip_conv2d_stem_split3_weight_elems(const SiConv2dDesc* d);
+int si_hip_conv2d_stem_split3_pack_weight_host(const SiConv2dDesc* d, const float* w_oihw, void* w_packed);
+int si_hip_conv2d_stem_split3_f32(const SiConv2dDesc* d, const float* in, const void* w_packed, const float* bias, float* out,
+                                  si_stream_t stream);
 /* si_hip_conv2d_upcat_f32 with fp16 storage (round 4): `up->src` points at HALF data (cast to the struct's pointer type), up->ld /
  * up->c / up->c0 in elements; c0 and c multiples of the K block (64 when ic % 64 == 0, else 32), up->ld and in_ld multiples of 8.
  * Same index rule, same bits as running si_hip_upsample_nearest on the half tensor, the concat copy and si_hip_conv2d_f16. */

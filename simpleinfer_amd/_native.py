@@ -174,6 +174,9 @@ def hip():
         "si_hip_conv2d_depthwise_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp, vp]),
         "si_hip_conv2d_stem_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp]),
         "si_hip_conv2d_stem_f16_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_stem_split3_f32": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, vp]),
+        "si_hip_conv2d_stem_split3_weight_elems": (sz, [C.POINTER(SiConv2dDesc)]),
+        "si_hip_conv2d_stem_split3_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_stem_f16_pack_weight_host": (i, [C.POINTER(SiConv2dDesc), vp, vp]),
         "si_hip_conv2d_split_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, vp, i, vp, i, vp]),
         "si_hip_conv2d_yolo_f16": (i, [C.POINTER(SiConv2dDesc), vp, vp, vp, C.POINTER(SiYoloLevel), vp, vp, vp, vp]),

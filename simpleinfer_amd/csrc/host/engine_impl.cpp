@@ -72,7 +72,7 @@ Status EngineImpl::SetOption(const std::string& key, int value) {
     else if (key == "f16_slab_w2") { opt_plan_.f16_slab_w2 = value; opt_plan_set_ = true; }
     else if (key == "f16_pw_patch") { opt_plan_.f16_pw_patch = value; opt_plan_set_ = true; }
     else if (key == "split3_bm") { opt_plan_.split3_bm = value; opt_plan_set_ = true; }
-    else if (key == "f32_split_policy") opt_f32_split_policy_ = value;   // which layers f32_split takes: 1 round 5's, 2 + sibling-fused / wide 1x1 from K = 256, 3 (default) + dual-source (upsampled) layers
+    else if (key == "f32_split_policy") opt_f32_split_policy_ = value;   // which layers f32_split takes: 1 round 5's, 2 + sibling-fused / wide 1x1 from K = 256, 3 + dual-source (upsampled) layers, 4 (default) + the RGB stem
     else if (key == "winograd") opt_winograd_ = value;  // 0 off, 1 F(2,3) where faster (default), 2 F(4,3) on those layers
     else if (key == "streams") opt_streams_ = value;  // 2: two half-batch lanes on two streams, 1 (default): one stream
     else if (key == "_fail_slicer") debug_fail_slicer_ = value != 0;  // tests: the sliced pipeline's setup fails half way

@@ -138,7 +138,7 @@ private:
     int opt_fuse_pw_ = 1;   // (2: ... and the C3's closing conv behind its last 64-channel pair -- built in round 6, bit-identical, 0.74-0.84x of the launches
                             // it replaces: the fused workgroup is bound by its three SiLU epilogues on two waves per SIMD; opt-in, LAB_NOTEBOOK R6.4)
     bool opt_f32_split_ = false;
-    int opt_f32_split_policy_ = 3;
+    int opt_f32_split_policy_ = 4;
     SiConvPlan opt_plan_ = SI_CONV_PLAN_DEFAULT;   // kernel-form choices handed to every conv launch (options f32_tile, f16_slab, ...; all default: the policy)
     bool opt_plan_set_ = false;
     bool opt_arena_ = true;      // intermediate operands share one HBM arena by lifetime (0: one allocation per operand, as the reference)

@@ -370,6 +370,22 @@ Status Conv2d::PrepareDevice(int mode) {
         device_ready_ = true;
         return Status::kSuccess;
     }
+    if (mode == 6) {
+        wino_tile_ = 0;
+        use_winograd_ = false;
+        std::vector<uint16_t> packed(si_hip_conv2d_stem_split3_weight_elems(&d));
+        CHECK_BOOL(!packed.empty());
+        if (si_hip_conv2d_stem_split3_pack_weight_host(&d, weight_.data(), packed.data()) == SI_E_UNSUPPORTED) {
+            LOG(WARNING) << "f32_split: stem conv " << in_channels_ << " -> " << out_channels_ << " has a weight outside fp16's range; the layer stays on the fp32 kernels";
+            DemoteSplit();
+            return Status::kUnsupport;
+        }
+        CHECK_STATUS(CheckHip(si_hip_conv2d_stem_split3_pack_weight_host(&d, weight_.data(), packed.data()), "split stem weights (hi / lo halves)"));
+        CHECK_STATUS(CheckHip(weight_dev_.Upload(packed.data(), packed.size() * sizeof(uint16_t)), "upload weight"));
+        if (use_bias_) CHECK_STATUS(CheckHip(bias_dev_.Upload(bias_.data(), bias_.size() * sizeof(float)), "upload bias"));
+        device_ready_ = true;
+        return Status::kSuccess;
+    }
     if (mode == 2) {
         wino_tile_ = 0;
         use_winograd_ = false;
@@ -493,8 +509,18 @@ bool Conv2d::UseWinoSplit() const {
     return WinogradTile(d) == 2 && si_hip_conv2d_wino23_split_supported(&d) != 0;
 }
 
+// (6: f32_split on the RGB stem -- the fp16 stem kernel's staging and MFMA loop on operands split hi + 2^-11 lo, fp32 out: conv_stem_f16.hip)
+bool Conv2d::UseStemSplit() const {
+    if (!f32_split_ || f32_split_level_ < 4 || sibling_ || up_node_ || stem_producer_ || residual_node_) return false;
+    SiConv2dDesc d;
+    memset(&d, 0, sizeof(d));
+    d.ic = in_channels_; d.oc = out_channels_; d.kh = kernel_h_; d.kw = kernel_w_; d.groups = groups_;
+    d.sh = stride_h_; d.sw = stride_w_; d.dh = dilation_h_; d.dw = dilation_w_; d.pt = padding_t_; d.pl = padding_l_;
+    return si_hip_conv2d_f16_supported(&d) == 2;
+}
+
 int Conv2d::PrecisionMode(const Tensor& input, const Tensor& output) const {
-    if (!IsHalf(input) && !IsHalf(output)) return UseSplit3() ? 4 : (UseWinoSplit() ? 5 : 0);
+    if (!IsHalf(input) && !IsHalf(output)) return UseSplit3() ? 4 : (UseWinoSplit() ? 5 : (UseStemSplit() ? 6 : 0));
     if (groups_ > 1 && groups_ == in_channels_ && in_channels_ == out_channels_ && IsHalf(input) && IsHalf(output)) return 3;   // depthwise, fp16 storage
     if (!IsHalf(input)) {
         SiConv2dDesc d;
@@ -636,7 +662,7 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
     int mode = PrecisionMode(input, output);
     {
         Status st = PrepareDevice(mode);
-        if (Status::kUnsupport == st && (mode == 4 || mode == 5) && !f32_split_) {   // (a weight out of fp16's range: see PrepareDevice)
+        if (Status::kUnsupport == st && (mode == 4 || mode == 5 || mode == 6) && !f32_split_) {   // (a weight out of fp16's range: see PrepareDevice)
             mode = PrecisionMode(input, output);
             st = PrepareDevice(mode);
         }
@@ -678,6 +704,14 @@ Status Conv2d::Launch(const Tensor& input, const Tensor* residual, Tensor& outpu
                                                       residual ? residual->Data<float>() : nullptr, output.Data<float>(), Stream());
         if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d (winograd, fp32 by three fp16 products)");
         DemoteSplit();   // an unaligned / oversized view: the true-fp32 kernels from here on
+        return Launch(input, residual, output);
+    }
+    if (mode == 6) {
+        d.range_flag = range_flag_;
+        const int rc = si_hip_conv2d_stem_split3_f32(&d, input.Data<float>(), weight_dev_.As<void>(), use_bias_ ? bias_dev_.As<float>() : nullptr,
+                                                     output.Data<float>(), Stream());
+        if (rc != SI_E_UNSUPPORTED) return CheckHip(rc, "conv2d stem (fp32 by three fp16 products)");
+        DemoteSplit();   // a strided / unaligned image view: the true-fp32 stem kernel from here on
         return Launch(input, residual, output);
     }
     if (mode == 2)
@@ -849,6 +883,7 @@ const char* Conv2d::KernelName() const {
     if (mode == 3) return "conv_depthwise_f16_kernel<2>";
     if (mode == 4) return "conv_split3_f32_kernel";
     if (mode == 5) return "conv_wino23s_kernel";
+    if (mode == 6) return "conv_stem_split_f32_kernel";
     const int tile = WinogradTile(d);
     if (tile) return tile == 4 ? "conv_wino43_kernel" : "conv_wino23_kernel";
     return si_hip_conv2d_kernel_name_form(&d, in.Data<float>(), up_node_ ? 1 : 0);

@@ -135,14 +135,15 @@ public:
     bool f32_split_ = false;
     // ... its range guard (round 6): the word the split kernels set to 1 when an operand left fp16's range (engine-owned pinned host memory;
     // nullptr: unguarded), and what the engine does when it finds it set -- back to the true-fp32 kernels for this layer, for good
-    int f32_split_level_ = 3;   // which layers the option takes (A/B: engine option f32_split_policy): 1 round 5's; 2 + sibling-fused and wide 1x1 layers
-                                // from K = 256; 3 (default) + the dual-source layers (upsample + concat read at the source)
+    int f32_split_level_ = 4;   // which layers the option takes (A/B: engine option f32_split_policy): 1 round 5's; 2 + sibling-fused and wide 1x1 layers
+                                // from K = 256; 3 + the dual-source layers (upsample + concat read at the source); 4 (default) + the RGB stem
     unsigned* range_flag_ = nullptr;
     bool split_demoted_ = false;
     void DemoteSplit() { f32_split_ = false; split_demoted_ = true; device_ready_ = false; }
     // kernel-form choices handed to every launch of this layer (engine options f32_tile, f16_slab, ...; SiConvPlan in include/si_hip.h)
     void SetPlan(const SiConvPlan& plan) { plan_ = plan; has_plan_ = true; }
     bool UseSplit3() const;
+    bool UseStemSplit() const;   // ... the RGB stem on the split form of the fp16 stem kernel (si_hip_conv2d_stem_split3_f32; level 4)
     bool UseWinoSplit() const;   // ... and the Winograd layers on the split form of the fused Winograd kernel (si_hip_conv2d_wino23_split_f32)
     bool prefer_wino43_ = false;  // kAuto: take F(4,3) instead of F(2,3) wherever F(2,3) would have been chosen
     bool use_winograd_ = false;  // resolved at PrepareDevice (same name as the reference's flag, conv_2d.h:60)

@@ -196,6 +196,28 @@ def conv2d_split3(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), act1="non
     return (y, int(flag.to_numpy((1,), np.uint32)[0])) if return_flag else y
 
 
+def conv2d_stem_split3(x, w_oihw, bias=None, stride=(2, 2), padding=(2, 2), act1="none", return_flag=False):
+    """si_hip_conv2d_stem_split3_f32: the RGB stem conv on the f32_split arithmetic (fp32 image in, fp32 activations out)"""
+    H = _native.hip()
+    x, w_oihw = _f32(x), _f32(w_oihw)
+    n, ih, iw, ic = x.shape
+    oc, _, kh, kw = w_oihw.shape
+    oh, ow = conv_out_hw(ih, iw, (kh, kw), stride, padding, (1, 1))
+    d = SiConv2dDesc(n, ih, iw, ic, ic, oh, ow, oc, oc, kh, kw, stride[0], stride[1], 1, 1, padding[0], padding[1], 1,
+                     1 if bias is not None else 0, ACT[act1], 0, oc, ACT["none"], 0.0)
+    if H.si_hip_conv2d_f16_supported(C.byref(d)) != 2:
+        raise HipError("si_hip_conv2d_stem_split3_f32: not a stem shape")
+    packed = np.zeros(H.si_hip_conv2d_stem_split3_weight_elems(C.byref(d)), np.float16)
+    _chk(H.si_hip_conv2d_stem_split3_pack_weight_host(C.byref(d), w_oihw.ctypes.data_as(C.c_void_p), packed.ctypes.data_as(C.c_void_p)), "pack stem split3")
+    dx, dw = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(packed)
+    db = DeviceBuffer.from_numpy(_f32(bias)) if bias is not None else None
+    dy = DeviceBuffer(n * oh * ow * oc * 4)
+    flag = _range_flag(d, return_flag)
+    _chk(H.si_hip_conv2d_stem_split3_f32(C.byref(d), dx.ptr, dw.ptr, db.ptr if db else None, dy.ptr, None), "si_hip_conv2d_stem_split3_f32")
+    y = dy.to_numpy((n, oh, ow, oc))
+    return (y, int(flag.to_numpy((1,), np.uint32)[0])) if return_flag else y
+
+
 def conv2d_wino23_split(x, w_oihw, bias=None, padding=(1, 1), act1="none", residual=None, act2="none", return_flag=False):
     """si_hip_conv2d_wino23_split_f32: fused Winograd F(2,3) with the plane GEMMs on the fp16 matrix cores by operand splitting"""
     H = _native.hip()

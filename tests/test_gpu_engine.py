@@ -145,6 +145,42 @@ def test_f32_split_range_guard_reruns_the_step_in_true_fp32(si, tmp_path, c, cou
     assert e.schedule()["split_reruns"] == 1
 
 
+def test_f32_split_stem_on_the_split_kernel(si, orc, tmp_path):
+    """f32_split_policy = 4: the RGB stem (YOLOv5's 6x6 s2, ResNet18's 7x7 s2) on the split form of the fp16 stem kernel -- parity at the fp32 bars
+    against the oracle, the kernel really runs, and an image holding a value fp16 cannot hold sends the stem back to the fp32 stem kernel with
+    the default engine's bits."""
+    mg = si.modelgen
+    for name, mk, shape in (("ys", lambda: mg.build_yolov5s(2, 160), (2, 160, 160, 3)), ("rs", lambda: mg.build_resnet18(2, 64), (2, 64, 64, 3))):
+        pp, bp = _save(tmp_path, mk(), "stem" + name)
+        x = mg.synth_input(shape)
+        ref = orc.run_graph(pp, bp, {"0": x})
+        e, oname, got = _run(si, pp, bp, x, f32_split=1, f32_split_policy=4)
+        (assert_detect_parity if name == "ys" else assert_parity)(got, ref[oname], what="f32_split stem " + name)
+        convs = [L for L in e.profile() if L["type"] == "nn.Conv2d"]
+        assert convs[0]["kernel"] == "conv_stem_split_f32_kernel", convs[0]
+        e3, _, _ = _run(si, pp, bp, x, f32_split=1, f32_split_policy=3)
+        assert "split" not in [L for L in e3.profile() if L["type"] == "nn.Conv2d"][0]["kernel"]
+    b = _one_conv(mg, 2, 3, 64, 32, 6, 2)
+    pp, bp = _save(tmp_path, b, "stemguard")
+    x = mg.synth_input((2, 64, 64, 3))
+    hot = x.copy()
+    hot[1, 30, 31, 2] = 1.0e5
+    e0, oname, _ = _run(si, pp, bp, hot)
+    want = e0.extract(oname).copy()
+    e, _, got = _run(si, pp, bp, hot, f32_split=1, f32_split_policy=4)
+    assert_exact(got, want, "a pixel at 1e5: the stem re-ran on the true-fp32 kernel")
+    sch = e.schedule()
+    assert sch["split_reruns"] == 1 and sch["split_demoted"] == ["conv_0"], sch
+    # an image whose rows do not start on 16-byte boundaries (33 x 3 floats): the split stem refuses it, the layer runs on the fp32 stem kernel
+    pp, bp = _save(tmp_path, _one_conv(mg, 2, 3, 33, 32, 6, 2), "stemodd")
+    x = mg.synth_input((2, 33, 33, 3))
+    _, oname, want = _run(si, pp, bp, x)
+    e, _, got = _run(si, pp, bp, x, f32_split=1, f32_split_policy=4)
+    assert_exact(got, want, "odd image width: the fp32 stem kernel")
+    sch = e.schedule()
+    assert sch["split_reruns"] == 0 and sch["split_demoted"] == ["conv_0"], sch
+
+
 def test_f32_split_weights_out_of_range_keep_the_layer_in_fp32(si, tmp_path):
     """weights are checked where they are split, at load: a layer with a weight fp16 cannot hold never runs on the split kernels"""
     mg = si.modelgen

@@ -867,6 +867,75 @@ def test_f32_split_range_guard_flags_an_overflow_and_nothing_else(hops, orc, ker
         conv(x, wbig, b)
 
 
+@pytest.mark.parametrize("k,s,p,oc,n,ih,iw,act", [
+    (6, 2, 2, 32, 2, 64, 64, "silu"),       # YOLOv5's stem form (even fragments)
+    (6, 2, 2, 32, 3, 40, 328, "silu"),      # two 160-pixel column tiles + a ragged one, odd row-block count
+    (6, 2, 2, 64, 2, 32, 48, "relu"),       # 64 channels: two channel waves per workgroup
+    (6, 2, 1, 32, 2, 30, 36, "none"),       # pad 1: fragments start on odd half indices (funnel-shift path)
+    (7, 2, 3, 64, 2, 56, 56, "relu"),       # ResNet18's stem
+    (7, 2, 3, 32, 1, 32, 44, "silu"),
+    (6, 2, 2, 32, 2, 36, 100, "silu"),      # a last column tile of 18 pixels; 50 output rows: segments of uneven length
+    (3, 2, 1, 16, 2, 48, 48, "hardswish"),  # MobileNetV2's stem
+    (3, 2, 1, 96, 1, 24, 40, "silu"),       # > 64 channels: channel tiles as items
+])
+def test_stem_split3_vs_oracle_and_fp64(hops, orc, k, s, p, oc, n, ih, iw, act):
+    """The RGB stem on the f32_split arithmetic (si_hip_conv2d_stem_split3_f32: the fp16 stem kernel's staging and MFMA loop on hi / lo halves,
+    fp32 out) against the reference's convolution (src/layer/conv_2d.cpp:207-283) at the FP32 bars -- 1e-4 vs the oracle, 2e-5 vs float64 --
+    element-wise too, no further from float64 than twice the true-fp32 stem kernel, and an image's bits do not depend on the batch."""
+    from util import mixed_err
+    x = rng_uniform(4500 + k, (n, ih, iw, 3), 0, 1)
+    w = rng_uniform(4501 + k, (oc, 3, k, k), -0.3, 0.3)
+    b = rng_uniform(4502 + k, (oc,), -0.5, 0.5)
+    fact = (lambda t: t) if act == "none" else (lambda t: orc.activation(act, t))
+    got, flag = hops.conv2d_stem_split3(x, w, b, (s, s), (p, p), act1=act, return_flag=True)
+    assert flag == 0 and got.dtype == np.float32
+    assert_parity(got, fact(orc.conv2d(x, w, b, (s, s), (p, p), path="auto")), what="split stem %dx%d" % (k, k))
+    plain = hops.conv2d_stem_split3(x, w, b, (s, s), (p, p))
+    naive = orc.conv2d(x, w, b, (s, s), (p, p), path="naive")
+    e3 = np.abs(plain - naive).max() / np.abs(naive).max()
+    f32 = hops.conv2d(x, w, b, (s, s), (p, p))
+    e32 = np.abs(f32 - naive).max() / np.abs(naive).max()
+    assert e3 <= 2e-5 and e3 <= 2.0 * e32 + 1e-7, (e3, e32)
+    m, m32 = mixed_err(plain, naive), mixed_err(f32, naive)
+    assert m <= 1e-4 and m <= 2.0 * m32 + 1e-7, (m, m32)
+    if n > 1:
+        one = hops.conv2d_stem_split3(x[n - 1:], w, b, (s, s), (p, p), act1=act)
+        assert_exact(one, got[n - 1:], "split stem: batch position")
+
+
+def test_stem_split3_range_guard_and_dynamic_range(hops, orc):
+    """The split stem's range contract: a pixel value fp16 cannot hold sets the guard word (relu in front of the store would have hidden the NaN),
+    values at fp16's edge and tiny images do not; images on 0..255 (un-normalised) hold the element-wise bar; weights out of range are refused
+    at the pack."""
+    from util import mixed_err
+    x = rng_uniform(4600, (2, 48, 64, 3), 0, 1)
+    w = rng_uniform(4601, (32, 3, 6, 6), -0.3, 0.3)
+    b = rng_uniform(4602, (32,), -0.5, 0.5)
+    y, flag = hops.conv2d_stem_split3(x, w, b, act1="relu", return_flag=True)
+    assert flag == 0 and np.isfinite(y).all()
+    hot = x.copy()
+    hot[1, 17, 33, 2] = 1.0e5
+    _, flag = hops.conv2d_stem_split3(hot, w, b, act1="relu", return_flag=True)
+    assert flag == 1
+    edge = x.copy()
+    edge[0, 5, 5, 1] = 65519.0
+    y, flag = hops.conv2d_stem_split3(edge, w, b, return_flag=True)
+    assert flag == 0
+    assert_parity(y, orc.conv2d(edge, w, b, (2, 2), (2, 2), path="naive"), what="split stem at fp16's edge")
+    for scale in (1e-6, 1e-3, 255.0, 1e4):
+        xs, bs = x * np.float32(scale), b * np.float32(scale)
+        ref = orc.conv2d(xs, w, bs, (2, 2), (2, 2), path="naive")
+        y, flag = hops.conv2d_stem_split3(xs, w, bs, return_flag=True)
+        assert flag == 0 and mixed_err(y, ref) <= 1e-4, (scale, flag, mixed_err(y, ref))
+    wbig = w.copy()
+    wbig[5, 1, 2, 3] = 2.0e5
+    with pytest.raises(hops.HipError):
+        hops.conv2d_stem_split3(x, wbig, b)
+    # image rows that do not start on 16-byte boundaries (width * channels not a multiple of 4): refused -- the engine keeps such a stem in fp32
+    with pytest.raises(hops.HipError):
+        hops.conv2d_stem_split3(rng_uniform(4603, (1, 33, 47, 3), 0, 1), w, b)
+
+
 @pytest.mark.parametrize("kernel", ["split3", "wino_split"])
 def test_f32_split_dynamic_range_sweep_elementwise(hops, orc, kernel):
     """The opt-in arithmetic across the dynamic range (round 5 tested x in U[-2, 2] only): tensor scales 1e-6 ... 1e4, under
