@@ -75,6 +75,9 @@ public:
     //                          product, fp32 accumulation (Ootomo & Yokota 2022; conv_split3.hip).  Measured closer to the float64
     //                          convolution than the fp32 MFMA chain and 1.8-2.1x faster on the K-heavy layers; another arithmetic
     //                          than the reference's fp32.  Default 0 -- the headline path is true fp32; ignored with "fp16".
+    //                          Which layers: "f32_split_policy" 1..4 (4, the default: the K-heavy dense convs, sibling-fused and wide 1x1
+    //                          layers, the layers that read upsample + concat at the source, the Winograd layers, the Detect levels and
+    //                          the RGB stem; lower levels are the earlier rounds' sets, kept for A/B runs).
     //                          RANGE GUARD (round 6): the reference convolves any finite fp32; a value that rounds to fp16 infinity
     //                          (|x| >= 65520; in the Winograd layers a transformed value, i.e. a sum of four inputs) cannot be split.
     //                          Weights are checked at load (such a layer never leaves the fp32 kernels); activations by the split
