@@ -50,6 +50,7 @@ struct FusedArgs {
     const float* bp;      // its bias (64) or null
     half_t* out_b;        // destination of output channels [32, 64) (`out` takes [0, 32)); strides in elements
     int out_b_ld;
+    unsigned out_bytes, out_b_bytes;   // extents of the two destinations (buffer stores: an out-of-range pixel is an out-of-range OFFSET)
 };
 
 // SI_FUSED_ABL (diagnostic builds only, tools/stem_fused_ablate.sh): bit 0 no SiLU (bias add only), 1 no stem MFMAs, 2 no phase B,
@@ -87,7 +88,11 @@ constexpr int TP = 72;   // PW form: halves per pixel of the tile image [64 pixe
 // to LDS as [pixel][channel]; after one barrier every wave multiplies ITS 32 pixels by ITS 32 output columns of the 1x1 conv (four 16-deep MFMA
 // steps over the 64 channels, ascending: the generic fp16 tiles' k order, so the bits are si_hip_conv2d_split_f16's), bias + SiLU, and writes
 // output channels [0, 32) to `out`, [32, 64) to `out_b` (the C3's cv1 result and cv2's slice of the concat buffer).
-template <bool PW>
+// BST (round 6, the form the product launches): the output stores are raw buffer stores whose out-of-range case is an out-of-range offset -- no
+// branch around a store, so the compiler can COUNT the stores between the next window's loads and commit(): the wait there is vmcnt(<stores> + n)
+// instead of vmcnt(n), which drained the item's own stores before the next window could be staged (conv_stem_f16.hip's split form, LAB_NOTEBOOK
+// R6.10).  Same values to the same addresses.  BST = false (the pointer stores under `if`) exists in experiment builds only, for the A/B.
+template <bool PW, bool BST = true>
 __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel(const FusedArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char patch[PATCH_BYTES];
     __shared__ __attribute__((aligned(16))) half_t stage[IR * RL];
@@ -167,6 +172,8 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
 #pragma unroll
         for (int s = 0; s < 9; ++s) wsf[s] = *reinterpret_cast<const f16x8*>(wfrag + s * (2 * 32 * 8));
     }
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out_b = __builtin_amdgcn_make_buffer_rsrc(PW ? a.out_b : a.out, 0, PW ? a.out_b_bytes : a.out_bytes, 0x00020000);
     const uint32_t* const stage_w = reinterpret_cast<const uint32_t*>(stage);
     const int a_base = (2 * (2 * wm + (l31 >> 4))) * ROWP + (l31 & 15) * PITCH + lh * 16;
     // conv_1's weights and the biases have LANDED before the loop: otherwise every MFMA of phase B carries a vmcnt(N) wait for "its"
@@ -295,14 +302,34 @@ __global__ __launch_bounds__(256, SI_FUSED_MINW) void conv_stem_s2c32_f16_kernel
                     const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
                     unsigned h0, h1;
                     silu2_bits(acc2[e], acc2[e + 1], bpv, h0, h1);
+                    if constexpr (BST) {
+                        const int ow_live = oy < a.oh ? a.ow : 0;   // (uniform: r >> 4 is a compile-time 0 / 1)
+                        const unsigned off = ((unsigned)((img * a.oh + oy) * a.ow + ox) * (unsigned)old + (unsigned)l31) * 2u;
+                        const __amdgpu_buffer_rsrc_t rs = wn == 0 ? rs_out : rs_out_b;
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)h0, rs, ox < ow_live ? off : OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)h1, rs, ox + 1 < ow_live ? off : OOB, old * 2, 0);
+                    } else {
                     unsigned short* const op = reinterpret_cast<unsigned short*>(ob + (size_t)((img * a.oh + oy) * a.ow + ox) * old);
                     if (oy < a.oh && ox < a.ow) op[0] = (unsigned short)h0;
                     if (oy < a.oh && ox + 1 < a.ow) op[old] = (unsigned short)h1;
+                    }
                 }
                 continue;   // (the next item's commit() writes `stage`, its barrier orders this item's tile reads before the next tile writes)
             }
             half_t* const ob = a.out + o;
-            if (o < a.oc) {
+            if constexpr (BST) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;   // rows r, r + 1: the same output row (r & 15 is even)
+                    const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+                    unsigned h0, h1;
+                    silu2_bits(acc[e], acc[e + 1], bcv, h0, h1);
+                    const int ow_live = (oy < a.oh && o < a.oc && !(SI_FUSED_ABL & 8)) ? a.ow : 0;
+                    const unsigned off = ((unsigned)((img * a.oh + oy) * a.ow + ox) * (unsigned)a.out_ld + (unsigned)o) * 2u;
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)h0, rs_out, ox < ow_live ? off : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)h1, rs_out, ox + 1 < ow_live ? off : OOB, a.out_ld * 2, 0);
+                }
+            } else if (o < a.oc) {
 #pragma unroll
                 for (int e = 0; e < 16; e += 2) {
                     const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;   // rows r, r + 1: the same output row (r & 15 is even)
@@ -357,6 +384,14 @@ int fused_launch(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const SiCon
     a.items = (int)items;
     a.in_bytes = (unsigned)in_bytes;
     a.wp = nullptr; a.bp = nullptr; a.out_b = nullptr; a.out_b_ld = 0;
+    const unsigned long long px = (unsigned long long)conv->n * conv->oh * conv->ow;
+    unsigned long long ob0 = ((px - 1) * (unsigned long long)conv->out_ld + conv->oc) * 2ull, ob1 = 0;
+    if (pw) {
+        ob0 = ((px - 1) * (unsigned long long)pw->out_ld + 32) * 2ull;
+        ob1 = ((px - 1) * (unsigned long long)(split_oc ? out2_ld : pw->out_ld) + 32) * 2ull;
+    }
+    if (ob0 >= 0xFFFFFF00ull || ob1 >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;   // (a destination past 4 GB: 1300 images of 640 x 640)
+    a.out_bytes = (unsigned)ob0; a.out_b_bytes = (unsigned)ob1;
     if (pw) {
         a.wp = static_cast<const half_t*>(pw_w_packed) + (size_t)64 * 64;   // (row-major image first, as above)
         a.bp = pw->has_bias ? pw_bias : nullptr;
@@ -376,7 +411,10 @@ int fused_launch(const SiConv2dDesc* stem, const SiConv2dDesc* conv, const SiCon
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
         return (int)hipGetLastError();
     };
-    return pw ? go(conv_stem_s2c32_f16_kernel<true>) : go(conv_stem_s2c32_f16_kernel<false>);
+#ifdef SI_EXPERIMENT
+    if (SI_ENV_INT("SI_FUSED_BST", 1) == 0) return pw ? go(conv_stem_s2c32_f16_kernel<true, false>) : go(conv_stem_s2c32_f16_kernel<false, false>);
+#endif
+    return pw ? go(conv_stem_s2c32_f16_kernel<true, true>) : go(conv_stem_s2c32_f16_kernel<false, true>);
 }
 
 }  // namespace

@@ -38,6 +38,19 @@ conv = lambda: H.si_hip_conv2d_f16(C.byref(d1), dm.ptr, dp1.ptr, db1.ptr, None, 
 def both(): stem(); conv()
 fused = lambda: H.si_hip_conv2d_stem_s2c32_f16(C.byref(d0), C.byref(d1), dx.ptr, dp0.ptr, db0.ptr, dp1.ptr, db1.ptr, dz.ptr, None)
 assert fused() == 0
+# the triple: + the first C3's cv1 | cv2 (64 -> 32 + 32) inside the launch (si_hip_conv2d_stem_s2c32_pw_f16)
+d2 = SiConv2dDesc(n, s2, s2, 64, 64, s2, s2, 64, 64, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1, A["silu"], 0, 64, 0, 0.0)
+w2 = (rng.random((64, 64, 1, 1), dtype=np.float32) - 0.5) * 0.2
+p2 = np.zeros(H.si_hip_conv2d_f16_weight_elems(C.byref(d2)), np.float16)
+H.si_hip_conv2d_f16_pack_weight_host(C.byref(d2), w2.ctypes.data_as(C.c_void_p), p2.ctypes.data_as(C.c_void_p))
+dp2, db2 = hipops.DeviceBuffer.from_numpy(p2), hipops.DeviceBuffer.from_numpy(rng.random(64, dtype=np.float32))
+dt = hipops.DeviceBuffer(n * s2 * s2 * 64 * 2)
+triple = lambda: H.si_hip_conv2d_stem_s2c32_pw_f16(C.byref(d0), C.byref(d1), C.byref(d2), dx.ptr, dp0.ptr, db0.ptr, dp1.ptr, db1.ptr, dp2.ptr, db2.ptr, dt.ptr, 0, None, 0, None)
+assert triple() == 0
+for r in range(2):
+    print("SI_FUSED_BST=%s: pair %.4f ms   triple %.4f ms   (400 launches each)" % (os.environ.get("SI_FUSED_BST", "1"), t(fused, 400), t(triple, 400)))
+if os.environ.get("SI_FUSED_ONLY"):
+    sys.exit(0)
 for r in range(2):
     a, b, c, f = t(stem), t(conv), t(both), t(fused)
     print("stem %.4f ms  conv_1 %.4f ms  both %.4f ms   fused %.4f ms (%.0f GB/s over %d MB in + %d MB out)" % (
