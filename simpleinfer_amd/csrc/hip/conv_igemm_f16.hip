@@ -65,6 +65,7 @@ struct ConvArgsH {
     int act1, act2;
     float act_param;
     unsigned in_bytes;
+    unsigned out_bytes;         // extent of `out` when it fits a buffer resource (the patch kernels' countable stores), else 0
     int pointwise;              // 1x1 stride 1 pad 0: the A matrix is the input tensor itself
     int out_f32;                // plain epilogue writing fp32 (graph outputs)
     half_t* out2;               // split output (sibling convs): channels >= split go to out2
@@ -1068,19 +1069,23 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_c32_patch_f16_kern
         }
         // epilogue (epilogue_lean_h's expressions): C/D map col = lane & 31 (channel), row = (e & 3) + 8 (e >> 2) + 4 lh (tile pixel)
         {
-            half_t* const ob = static_cast<half_t*>(a.out) + o;
-            if (o < a.ocg) {
+            // buffer stores, everything that keeps a value from being written (its pixel outside the tensor, its channel past the last one) as an
+            // out-of-range OFFSET: no branch around a store, so the wait in front of the next patch's commit() counts the stores instead of
+            // draining them (conv_stem_s2c32_f16.hip BST; LAB_NOTEBOOK R6.10)
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
+            const int ow_live = o < a.ocg ? a.ow : 0;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
-                    const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
-                    // ACT1 == SiLU: SiLU then nothing (the YOLOv5 forms); otherwise whatever act1 / act2 the layer carries (ResNet's
-                    // ReLU before or behind the shortcut), as epilogue_plain evaluates them
-                    float v = ACT1 == SI_ACT_SILU ? act_c<SI_ACT_SILU>(acc[e] + bv, a.act_param) : act_h(a.act1, acc[e] + bv, a.act_param);
-                    if (HAS_RES) v += (float)rv[e];
-                    if (ACT1 != SI_ACT_SILU) v = act_h(a.act2, v, a.act_param);
-                    if (oy < a.oh && ox < a.ow) ob[(size_t)((img * a.oh + oy) * a.ow + ox) * a.out_ld] = si_store_cast<half_t>(v);
-                }
+            for (int e = 0; e < 16; ++e) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+                // ACT1 == SiLU: SiLU then nothing (the YOLOv5 forms); otherwise whatever act1 / act2 the layer carries (ResNet's
+                // ReLU before or behind the shortcut), as epilogue_plain evaluates them
+                float v = ACT1 == SI_ACT_SILU ? act_c<SI_ACT_SILU>(acc[e] + bv, a.act_param) : act_h(a.act1, acc[e] + bv, a.act_param);
+                if (HAS_RES) v += (float)rv[e];
+                if (ACT1 != SI_ACT_SILU) v = act_h(a.act2, v, a.act_param);
+                const unsigned off = ((unsigned)((img * a.oh + oy) * a.ow + ox) * (unsigned)a.out_ld + (unsigned)o) * 2u;
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, si_store_cast<half_t>(v)), rs_out,
+                                                      (oy < a.oh && ox < ow_live) ? off : OOB_A, 0, 0);
             }
         }
         if (next < items) {
@@ -1114,7 +1119,7 @@ int launch_c32_patch(const ConvArgsH& a, const SiConv2dDesc* d, hipStream_t s) {
     constexpr int TR = 2 * (4 / NBW);
     const int tiles_x = (d->ow + 15) / 16, tiles_y = (d->oh + TR - 1) / TR;
     const long long items = (long long)d->n * tiles_x * tiles_y;
-    if (items > 0x7fffffffLL) return SI_E_UNSUPPORTED;
+    if (items > 0x7fffffffLL || a.out_bytes == 0) return SI_E_UNSUPPORTED;
     auto go = [&](auto kern) {
         const int per_cu = si_resident_blocks(kern, 256, 0);
         long long grid = (long long)f16_cu_count() * per_cu;
@@ -1265,6 +1270,10 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
     a.m_tiles = a.n_tiles = 0;
     a.act1 = d->act1; a.act2 = d->act2; a.act_param = d->act_param;
     a.in_bytes = (unsigned)in_bytes;
+    {
+        const unsigned long long ob = (((unsigned long long)d->n * d->oh * d->ow - 1) * d->out_ld + d->oc) * (out_f32 ? 4ull : 2ull);
+        a.out_bytes = ob < 0xFFFFFF00ull ? (unsigned)ob : 0u;
+    }
     a.pointwise = (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 && d->ih == d->oh && d->iw == d->ow) ? 1 : 0;
     a.out_f32 = out_f32;
     a.out2 = nullptr; a.out2_ld = 0; a.split = 0;
@@ -1297,7 +1306,7 @@ int dispatch_h(const SiConv2dDesc* d, const void* in, const void* w_packed, cons
             default: return launch_detect_tile<4>(a, d->n, s);
         }
     }
-    if (!up && !yolo && !split && !out_f32 && s2c32_on(d) && f16_forced_variant(d) < 0 && s2c32_shape_ok(d) &&
+    if (!up && !yolo && !split && !out_f32 && s2c32_on(d) && f16_forced_variant(d) < 0 && s2c32_shape_ok(d) && a.out_bytes != 0 &&
         (!d->has_residual || (reinterpret_cast<uintptr_t>(residual) & 1) == 0))
         return launch_s2c32(a, d, s);
     if (!up && !yolo && !split && !out_f32 && f16_forced_variant(d) < 0 && si_conv_slab_f16_ok(d) && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&

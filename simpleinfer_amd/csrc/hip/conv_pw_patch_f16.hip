@@ -42,6 +42,7 @@ struct PwPatchArgs {
     half_t* out;
     int ih, iw, x_ld, out_ld, res_ld;
     unsigned x_bytes;
+    unsigned out_bytes;         // extent of `out`: the output stores are buffer stores (countable: see conv_stem_s2c32_f16.hip BST); 0 = pointer stores
     int tiles_x, tiles_y, items;
     // CV3 form (round 6): the C3's closing 1x1 conv over cat(y, z) -- y this pair's output, z the C3's other branch -- computed from the tile
     const half_t* z;            // [n][ih][iw][z_ld], 64 channels
@@ -321,14 +322,18 @@ __global__ __launch_bounds__(256, CB == 64 ? 2 : 3) void conv_pw_patch_f16_kerne
             }
             if (next < a.items) __syncthreads();   // every wave is done with the tile image: the next item's x goes over it
         } else {
-            half_t* const ob = a.out + o;
+            // buffer stores, the out-of-range pixel as an out-of-range offset: no branch around a store, so the wait in front of the next item's
+            // commit() counts them instead of draining them (conv_stem_s2c32_f16.hip BST; LAB_NOTEBOOK R6.10)
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.out_bytes, 0x00020000);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r = (e & 3) + 8 * (e >> 2) + 4 * lh;
                 const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
                 float v = silu(acc[e] + bv);
                 if (HAS_RES) v += (float)rv[e];
-                if (oy < a.ih && ox < a.iw) ob[(size_t)((img * a.ih + oy) * a.iw + ox) * a.out_ld] = si_store_cast<half_t>(v);
+                const unsigned off = ((unsigned)((img * a.ih + oy) * a.iw + ox) * (unsigned)a.out_ld + (unsigned)o) * 2u;
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, si_store_cast<half_t>(v)), rs_out,
+                                                      (oy < a.ih && ox < a.iw) ? off : OOB, 0, 0);
             }
         }
         if (next < a.items) {
@@ -422,6 +427,9 @@ static int pw_patch_launch(const SiConv2dDesc* pw, const SiConv2dDesc* d, const 
     a.out = static_cast<half_t*>(out);
     a.ih = d->ih; a.iw = d->iw; a.x_ld = pw->in_ld; a.out_ld = d->out_ld; a.res_ld = d->res_ld;
     a.x_bytes = (unsigned)((unsigned long long)pw->n * pw->ih * pw->iw * pw->in_ld * 2ull);
+    const unsigned long long ob = (((unsigned long long)d->n * d->oh * d->ow - 1) * d->out_ld + d->oc) * 2ull;
+    if (ob >= 0xFFFFFF00ull) return SI_E_UNSUPPORTED;
+    a.out_bytes = (unsigned)ob;
     a.tiles_x = d->ow / 16; a.tiles_y = d->oh / (d->ic == 64 ? 4 : 8);
     a.items = d->n * a.tiles_x * a.tiles_y;
     a.z = nullptr; a.z_ld = 0; a.z_bytes = 0; a.w3 = nullptr; a.bias3 = nullptr; a.out3 = nullptr; a.out3_ld = 0;
