@@ -172,15 +172,20 @@ def _range_flag(d, want):
     return f
 
 
-def conv2d_split3(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), act1="none", residual=None, act2="none", return_flag=False):
+def conv2d_split3(x, w_oihw, bias=None, stride=(1, 1), padding=(0, 0), act1="none", residual=None, act2="none", return_flag=False, in_ld=None):
     """si_hip_conv2d_split3_f32: fp32 conv on the fp16 matrix cores by operand splitting (three fp16 MFMAs per product, fp32 accumulate).
-    return_flag: also return the range-guard word (1: an operand overflowed fp16 on its way through the split)"""
+    return_flag: also return the range-guard word (1: an operand overflowed fp16 on its way through the split).  in_ld: the input as a channel
+    slice of a wider tensor (pixel stride in_ld > ic; what lies between is NaN)"""
     H = _native.hip()
     x, w_oihw = _f32(x), _f32(w_oihw)
     n, ih, iw, ic = x.shape
     oc, _, kh, kw = w_oihw.shape
     oh, ow = conv_out_hw(ih, iw, (kh, kw), stride, padding, (1, 1))
-    d = SiConv2dDesc(n, ih, iw, ic, ic, oh, ow, oc, oc, kh, kw, stride[0], stride[1], 1, 1, padding[0], padding[1], 1,
+    if in_ld and in_ld != ic:
+        xw = np.full((n, ih, iw, in_ld), np.nan, np.float32)
+        xw[..., :ic] = x
+        x = xw
+    d = SiConv2dDesc(n, ih, iw, ic, in_ld or ic, oh, ow, oc, oc, kh, kw, stride[0], stride[1], 1, 1, padding[0], padding[1], 1,
                      1 if bias is not None else 0, ACT[act1], 1 if residual is not None else 0, oc, ACT[act2], 0.0)
     if not H.si_hip_conv2d_split3_supported(C.byref(d)):
         raise HipError("si_hip_conv2d_split3_f32: unsupported shape")
