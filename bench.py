@@ -458,8 +458,9 @@ def secondary_measurements(args, si, hipops, H, mg, td, dev):
                                 "note": "range guard (include/si_hip.h): a layer whose operands leave fp16's range goes back to the true-fp32 kernels and "
                                         "the step is re-run; synthetic U[0,1) images never trip it"}
                 if sp and sms > 0:
-                    rec["split_kernel_mfma_busy"] = {"conv_split3_f32_kernel": _busy_of(bt, "conv_split3_f32_kernel<64, 1, 4, 64, false>"),
-                                                     "conv_wino23s_kernel": _busy_of(bt, "conv_wino23s_kernel<"), "source": bsrc}
+                    rec["split_kernel_mfma_busy"] = {"conv_split3_f32_kernel": _busy_of(bt, "conv_split3_f32_kernel<"),   # (launch-weighted over its instantiations)
+                                                     "conv_wino23s_kernel": _busy_of(bt, "conv_wino23s_kernel<"),
+                                                     "conv_stem_split_f32_kernel": _busy_of(bt, "conv_stem_split_f32_kernel<"), "source": bsrc}
                     rec["split_kernel"] = {"kernel": "conv_split3_f32_kernel", "launches_per_step": len(sp), "ms_per_step": round(sms, 3),
                                            "share_of_conv_time": round(sms / sum(L["ms"] for L in convs), 3),
                                            "tflops_direct_equivalent": round(sfl / (sms * 1e-3) / 1e12, 1),
