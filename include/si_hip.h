@@ -119,7 +119,7 @@ typedef struct SiConv2dDesc {
     float act_param;    /* leaky-relu slope */
     /* -- trailing fields; all-zero (memset / fewer initialisers) = the defaults ------------------------------------------------------ */
     const struct SiConvPlan* plan; /* kernel-form choices for THIS call (tests, sweeps, an engine's plan); NULL: the shape / launch-size policy */
-    unsigned int* range_flag;      /* f32_split entry points (si_hip_conv2d_split3_* / _wino23_split_f32) only: NULL, or a word the device can
+    unsigned int* range_flag;      /* f32_split entry points (si_hip_conv2d_split3_* / _wino23_split_f32 / _stem_split3_f32) only: NULL, or a word the device can
                                     * write (device memory or pinned host memory) that the kernel sets to 1 when an operand left fp16's range
                                     * on its way through the split -- see the f32_split section below.  Never written otherwise. */
 } SiConv2dDesc;
