@@ -548,6 +548,27 @@ def test_stem_pair_plus_pointwise_fused_same_bits(hops, orc, gpu, n, ih, iw, spl
     assert_parity(got.astype(np.float32), ref, 2 * F16_TOL, what="fused stem + conv + 1x1")
 
 
+def test_fused_stem_kernels_full_size_same_bits(hops, gpu):
+    """BASELINE's size (YOLOv5s 640 x 640, batch 32: 12 800 items, every workgroup walks ~25 of them): the stem pair and the stem triple against the
+    launches they replace, bit for bit, over the WHOLE tensors -- the persistent kernels' buffer stores (out-of-range cases as offsets, the pixel's
+    distance in the scalar offset) write the same values to the same addresses as the pointer stores of the generic tiles on every image, not only
+    on the small cases above.  GPU against GPU: no oracle at this size."""
+    n, sz = 32, 640
+    x = rng_uniform(830, (n, sz, sz, 3), 0, 1)
+    w0, b0 = rng_uniform(831, (32, 3, 6, 6), -0.3, 0.3), rng_uniform(832, (32,), -0.5, 0.5)
+    w1, b1 = h(rng_uniform(833, (64, 32, 3, 3), -0.3, 0.3)), rng_uniform(834, (64,), -0.5, 0.5)
+    w2, b2 = h(rng_uniform(835, (64, 64, 1, 1), -0.3, 0.3)), rng_uniform(836, (64,), -0.5, 0.5)
+    stem = hops.conv2d_f16(x, w0, b0, (2, 2), (2, 2), act1="silu")
+    with hops.plan(f16_s2c32=0):
+        want1 = hops.conv2d_f16(stem, w1, b1, (2, 2), (1, 1), act1="silu")       # generic tiles: pointer stores
+    pair = hops.conv_stem_s2c32_f16(x, w0, b0, w1, b1)
+    assert_exact(pair, want1, "stem pair, 32 x 640 x 640")
+    assert_exact(hops.conv2d_f16(stem, w1, b1, (2, 2), (1, 1), act1="silu"), want1, "3x3 s2 patch kernel, 32 x 320 x 320 x 32")
+    want2 = hops.conv2d_f16(want1, w2, b2, act1="silu")
+    ya, yb = hops.conv_stem_s2c32_pw_f16(x, w0, b0, w1, b1, w2, b2, split_oc=32, out2_ld=64, out2_c_off=32)
+    assert_exact(np.concatenate([ya, yb], -1), want2, "stem triple, 32 x 640 x 640")
+
+
 @pytest.mark.parametrize("op", list(range(18)))
 def test_unary_ops_with_fp16_storage(hops, orc, op):
     """si_hip_unary_f16 (round 5; UnaryOp of expand_expression.cpp:123-165 on fp16 tensors): the fp32 function of si_hip_unary_f32 on the

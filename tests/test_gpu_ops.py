@@ -953,6 +953,23 @@ def test_stem_split3_random_shapes(hops, orc):
     assert cases == 18
 
 
+def test_stem_split3_full_size_against_the_fp32_stem(hops):
+    """BASELINE's size (32 x 640 x 640 x 3 -> 320 x 320 x 32): 3840 wave segments of 13-14 row blocks, every store a buffer store with the pixel's
+    distance in the scalar offset.  The whole output against the true-fp32 stem kernel under the element-wise bar (two arithmetics of fp32 class:
+    |d| <= 1e-4 (|ref| + rms)), every image; the guard word stays 0; and the last image alone gives the bits it has in the batch."""
+    from util import mixed_err
+    n, sz = 32, 640
+    x = rng_uniform(4900, (n, sz, sz, 3), 0, 1)
+    w = rng_uniform(4901, (32, 3, 6, 6), -0.3, 0.3)
+    b = rng_uniform(4902, (32,), -0.5, 0.5)
+    got, flag = hops.conv2d_stem_split3(x, w, b, (2, 2), (2, 2), act1="silu", return_flag=True)
+    ref = hops.conv2d(x, w, b, (2, 2), (2, 2), act1="silu")
+    assert flag == 0 and got.shape == ref.shape == (n, 320, 320, 32)
+    worst = max(mixed_err(got[i], ref[i]) for i in range(n))
+    assert worst <= 1e-4, worst
+    assert_exact(hops.conv2d_stem_split3(x[n - 1:], w, b, (2, 2), (2, 2), act1="silu"), got[n - 1:], "split stem: image 31 alone")
+
+
 def test_stem_split3_range_guard_and_dynamic_range(hops, orc):
     """The split stem's range contract: a pixel value fp16 cannot hold sets the guard word (relu in front of the store would have hidden the NaN),
     values at fp16's edge and tiny images do not; images on 0..255 (un-normalised) hold the element-wise bar; weights out of range are refused
