@@ -629,6 +629,8 @@ def test_detect_tile_kernel_same_bits_as_generic_tiles(hops, orc, gpu, n, levels
     (2, 10, 10, 128, 128, 128, (2.0, 2.0), True),    # the YOLOv5 PAN form, 64-wide K blocks
     (3, 5, 7, 64, 192, 96, (2.0, 2.0), False),       # upsampled tensor second, ragged column block
     (1, 4, 6, 32, 64, 64, (3.0, 2.0), True),         # 96 channels: 32-wide K blocks; non-square scale
+    (2, 10, 10, 256, 256, 256, (2.0, 2.0), True),    # YOLOv5s conv_34's form (K = 512, 256 columns)
+    (1, 7, 9, 128, 384, 160, (2.0, 2.0), False),     # ... upsampled tensor second, 160 columns, ragged M
 ])
 def test_conv_f16_reads_upsampled_source(hops, orc, n, lh, lw, cl, cs, oc, scale, up_first):
     """si_hip_conv2d_upcat_f16 (round 4): the 1x1 conv behind cat(upsample(x), skip) reads x at the source pixel with the reference's
@@ -646,3 +648,5 @@ def test_conv_f16_reads_upsampled_source(hops, orc, n, lh, lw, cl, cs, oc, scale
     if oc >= 64:
         ya, yb = hops.conv2d_upcat_f16(low, skip, w, b, scale, up_first, act1="silu", split_oc=32)
         assert_exact(np.concatenate([ya, yb], -1), got, "sibling-split form")
+    with hops.plan(f16_tile=0):   # (a forced tile and the policy agree: the dual-source form lives in the one-stage 64 x 64 kernel)
+        assert_exact(hops.conv2d_upcat_f16(low, skip, w, b, scale, up_first, act1="silu"), got, "dual-source form: forced tile vs the policy's")
