@@ -139,7 +139,9 @@ typedef struct SiConvPlan {
     int f16_slab;        /* 3x3 s1 over 128 / 256 channels: -1 policy (row slabs), 0 the generic tiles */
     int f16_slab_w2;     /* ... the slab kernel's 128-channel form: -1 policy (two waves per SIMD), 0 one wave per SIMD */
     int f16_pw_patch;    /* 64 / 32-channel bottleneck pair: -1 policy (si_hip_conv2d_pw_slab_f16_supported may say 2), 0 never 2 */
-    int split3_bm;       /* si_hip_conv2d_split3_f32 family: 0 policy (32-row tiles; 64 for <= 64 output columns), 32 / 64 / 128 rows per workgroup tile */
+    int split3_bm;       /* si_hip_conv2d_split3_f32 family: 0 policy (32-row tiles; 64 for <= 64 output columns; a Detect level over 128 / 256 channels as
+                          * 64-pixel runs of the output from four such tiles per CU on), 32 / 64 / 128 rows per workgroup tile (a Detect level then takes
+                          * the generic kernel's decode epilogue), -1 the 64-pixel Detect tile whatever the launch size (other convs: the policy) */
 } SiConvPlan;
 #define SI_CONV_PLAN_DEFAULT { -1, 0, 0, -1, -1, -1, -1, -1, -1, 0 }
 

@@ -349,6 +349,228 @@ __global__ __launch_bounds__(256, 2) void conv_split3_f32_kernel(const Split3Arg
     }
 }
 
+
+// ---- a Detect level as ONE tile shape of its own, on the split arithmetic (round 6, late) ----------------------------------------------------
+// detect_f16_tile_kernel's structure (conv_igemm_f16.hip): a Detect level is a 1x1 conv to na * ne = 255 columns whose decoded fp32 result is
+// 8.5 x (K = 128: 2 x) its fp32 input -- a WRITE stream.  Through the YOLO form of the kernel above level 0 (80x80x128 at batch 32: 105 MB in, 209 MB out)
+// ran as 12 800 workgroups of two K-tiles, every one a load -> split -> LDS -> barrier -> MFMA -> decode chain ending in 4-byte stores 1020 bytes
+// apart: 280 us beside the neck's launches against a 63 us stream.  Here a workgroup owns 64 CONSECUTIVE PIXELS of one image and ALL columns (one
+// contiguous run of 64 * 255 floats of the output: src/layer/yolo_detect.cpp:223-266 writes the same bytes); the whole A tile is split once into two
+// LDS images, the weights come from the lane-order images (L2 -> registers, four waves x 64 columns), and the decoded values are staged through LDS
+// in two 32-pixel halves and leave as 16-byte-per-lane stores down the run.  The two halves are multiplied one after the other (two accumulator
+// sets per 32 x 32 block: both halves at once would be 128 registers of accumulators).  Same k-steps in the same order on the same two chains and
+// the same decode expressions as the YOLO form above: the same bits (tests/test_gpu_ops.py).  NCH = K / 128 (1, 2: the K = 512 level is 400 pixels
+// per image and stays on the YOLO form -- its A images alone would be 133 KB of LDS).
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void detect_split_tile_kernel(const Split3Args a) {
+    constexpr int K = NCH * 128;
+    constexpr int LDH = K + 8;            // halves per LDS row: (2K + 16) mod 128 = 16, the conflict-free pitch
+    constexpr int VPR = K / 4;            // 16-byte fp32 vectors per row
+    constexpr int A_IT = 64 * VPR / 256;  // vectors per thread
+    constexpr int KS = K / 16;            // MFMA k-steps
+    constexpr int RING = 4;               // weight fragment pairs in flight, in k-steps
+    extern __shared__ __attribute__((aligned(16))) unsigned char det_smem[];
+    half_t* const Ah = reinterpret_cast<half_t*>(det_smem);
+    half_t* const Al = Ah + 64 * LDH;
+    float* const stage = reinterpret_cast<float*>(det_smem);   // 32 pixels x 255 floats, over the A images once the MFMAs are done
+
+    const int tiles_per_img = (a.ohow + 63) >> 6;
+    const int img = blockIdx.x / tiles_per_img;
+    const int pix0 = (blockIdx.x - img * tiles_per_img) * 64;
+    const int valid = min(64, a.ohow - pix0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, a.in_bytes, 0x00020000);
+    const unsigned wl_bytes = (unsigned)a.wl_nb * (unsigned)a.wl_ks * 1024u;
+    const __amdgpu_buffer_rsrc_t rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wl_hi), 0, wl_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.wl_lo), 0, wl_bytes, 0x00020000);
+
+    // the A tile: fp32 -> (hi, lo) on the way into LDS, eight vectors per thread at a time
+    static_assert(A_IT % 8 == 0, "A tile in batches of eight vectors per thread");
+#pragma unroll
+    for (int c = 0; c < A_IT; c += 8) {
+        u32x4 ra[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * (c + i);
+            const int row = idx / VPR, kv = idx - row * VPR;
+            const unsigned off = (unsigned)(img * a.ohow + pix0 + row) * (unsigned)(a.in_ld * 4) + (unsigned)(kv * 16);
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, row < valid ? off : OOB_A, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * (c + i);
+            const int row = idx / VPR, kv = idx - row * VPR;
+            const f32x4 x = __builtin_bit_cast(f32x4, ra[i]);
+            f16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = (half_t)x[j];
+                lo[j] = (half_t)((x[j] - (float)hi[j]) * kLoScale);
+            }
+            *reinterpret_cast<f16x4*>(Ah + row * LDH + kv * 4) = hi;
+            *reinterpret_cast<f16x4*>(Al + row * LDH + kv * 4) = lo;
+        }
+    }
+    unsigned b_off[2];
+    float bv[2];
+    int col[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int nb = wave * 2 + u;
+        b_off[u] = nb < a.wl_nb ? (unsigned)nb * (unsigned)a.wl_ks * 1024u + (unsigned)lane * 16u : OOB_B;
+        col[u] = wave * 64 + u * 32 + l31;
+        bv[u] = (a.bias && col[u] < a.ocg) ? a.bias[col[u]] : 0.0f;
+    }
+    __syncthreads();
+
+    f32x16 accc[2][2];   // the combined accumulators of the two 32-pixel halves
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x16 acc_h[2], acc_x[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_h[u][e] = acc_x[u][e] = 0.0f;
+        f16x8 rbh[RING][2], rbl[RING][2];
+#pragma unroll
+        for (int s = 0; s < RING; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                rbh[s][u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, b_off[u], (unsigned)(s * 1024), 0));
+                rbl[s][u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_lo, b_off[u], (unsigned)(s * 1024), 0));
+            }
+        const half_t* const Arh = Ah + (32 * t + l31) * LDH + lh * 8;
+        const half_t* const Arl = Al + (32 * t + l31) * LDH + lh * 8;
+        f16x8 fh[2], fl[2];
+        fh[0] = *reinterpret_cast<const f16x8*>(Arh);
+        fl[0] = *reinterpret_cast<const f16x8*>(Arl);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
+                fh[(s + 1) & 1] = *reinterpret_cast<const f16x8*>(Arh + (s + 1) * 16);
+                fl[(s + 1) & 1] = *reinterpret_cast<const f16x8*>(Arl + (s + 1) * 16);
+            }
+            const f16x8 bh[2] = {rbh[s % RING][0], rbh[s % RING][1]}, bl[2] = {rbl[s % RING][0], rbl[s % RING][1]};
+            if (s + RING < KS) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    rbh[s % RING][u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_hi, b_off[u], (unsigned)((s + RING) * 1024), 0));
+                    rbl[s % RING][u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_lo, b_off[u], (unsigned)((s + RING) * 1024), 0));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                acc_h[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s & 1], bh[u], acc_h[u], 0, 0, 0);
+                acc_x[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[s & 1], bl[u], acc_x[u], 0, 0, 0);
+                acc_x[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl[s & 1], bh[u], acc_x[u], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                accc[t][u][e] = acc_h[u][e] + acc_x[u][e] * (1.0f / kLoScale);
+                bad |= !__builtin_isfinite(accc[t][u][e]);
+            }
+    }
+    split_range_report(bad, a.range_flag);
+
+    // decode (si_yolo_tile_one_image's expressions) -> LDS -> the contiguous run, 32 pixels at a time (detect_f16_tile_kernel's epilogue)
+    const int per_pix = a.yna * a.yne;
+    const bool coco = a.yna == 3 && a.yne == 85 && valid == 64;   // workgroup-uniform
+    float* const orun = a.out + ((size_t)img * a.yrows_total + a.yrow_off) * a.yne + (size_t)pix0 * per_pix;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        __syncthreads();   // t = 0: every wave is done reading A; t = 1: the first half has left the stage
+        const int rows = min(32, valid - 32 * t);
+        if (coco) {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int blk = wave * 2 + u;   // wave-uniform
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = __builtin_amdgcn_rcpf(1.0f + __expf(-(accc[t][u][e] + bv[u])));
+                if (blk == 0 || blk == 2 || blk == 5) {   // (the 32-column blocks that hold x, y, w, h of an anchor: columns 0-3, 85-88, 170-173)
+                    const int oo = col[u] < 255 ? col[u] : 0;
+                    const int anc = oo / 85;
+                    const int e_ = oo - anc * 85;
+                    const bool is_xy = e_ < 2, is_box = e_ < 4;
+                    const float* const ap = (is_xy ? a.ygrid + e_ : a.yanchor + (is_box ? e_ - 2 : 0)) + anc * 2 + (size_t)(pix0 + 32 * t + 4 * lh) * 6;
+                    float auxv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) auxv[e] = 0.0f;
+                    if (is_box) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) auxv[e] = ap[((e & 3) + 8 * (e >> 2)) * 6];
+                    }
+                    const unsigned mxy = is_xy ? ~0u : 0u, mwh = (is_box && !is_xy) ? ~0u : 0u, msg = is_box ? 0u : ~0u;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float t2 = v[e] * 2.0f;
+                        const float xy = (t2 + auxv[e]) * a.ystride;
+                        const float wh = t2 * t2 * auxv[e];
+                        v[e] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, xy) & mxy) | (__builtin_bit_cast(unsigned, wh) & mwh) |
+                                                             (__builtin_bit_cast(unsigned, v[e]) & msg));
+                    }
+                }
+                if (col[u] < 255) {
+                    float* const sp = stage + 4 * lh * 255 + col[u];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sp[((e & 3) + 8 * (e >> 2)) * 255] = v[e];
+                }
+            }
+        } else if (rows > 0) {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool live = col[u] < a.ocg;
+                const int oo = live ? col[u] : 0;
+                const int anc = oo / a.yne;
+                const int e_ = oo - anc * a.yne;
+                const bool is_xy = e_ < 2, is_box = e_ < 4;
+                const float* const ap = (is_xy ? a.ygrid + e_ : a.yanchor + (is_box ? e_ - 2 : 0)) + anc * 2 + (size_t)(pix0 + 32 * t) * a.yna * 2;
+                float auxv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) auxv[e] = 0.0f;
+                if (is_box) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int dm = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                        auxv[e] = ap[(dm < rows ? dm : 0) * a.yna * 2];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dm = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-(accc[t][u][e] + bv[u])));
+                    const float aux = auxv[e];
+                    const float t2 = sg * 2.0f;
+                    const float xy = (t2 + aux) * a.ystride;
+                    const float wh = t2 * t2 * aux;
+                    const float v = is_xy ? xy : (is_box ? wh : sg);
+                    if (live && dm < rows) stage[dm * per_pix + oo] = v;
+                }
+            }
+        }
+        __syncthreads();
+        if (rows > 0) {
+            float* const dst = orun + (size_t)(32 * t) * per_pix;
+            const int nfl = rows * per_pix;
+            if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                const int n4 = nfl >> 2;
+                for (int i = tid; i < n4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(stage)[i];
+                const int done = n4 << 2;
+                if (tid < nfl - done) dst[done + tid] = stage[done + tid];
+            } else {
+                for (int i = tid; i < nfl; i += 256) dst[i] = stage[i];
+            }
+        }
+    }
+}
+
 bool split3_ok(const SiConv2dDesc* d) {
     return d && d->groups == 1 && d->ic > 0 && d->ic % 32 == 0 && d->oc > 0 && d->kh * d->kw <= 32 && d->dh == 1 && d->dw == 1 && d->in_ld % 4 == 0;
 }
@@ -471,9 +693,27 @@ static int split3_launch(const SiConv2dDesc* d, const float* in, const void* w_p
     // fragment pair.  An output element is the same two accumulator chains over the same k order whatever the tile -- the same bits
     // (tests/test_gpu_ops.py) -- so an image's result does not depend on its batch.  SiConvPlan::split3_bm forces 32 / 64 / 128 for a call.
     const int forced_bm = (d->plan && d->plan->split3_bm > 0) ? d->plan->split3_bm : SI_ENV_INT("SI_SPLIT3_BM", 0);
-    (void)cus;
     if (up) return forced_bm == 64 ? go(conv_split3_f32_kernel<64, 1, 4, 64, false, true>, 64, 128, 64) : go(conv_split3_f32_kernel<32, 1, 4, 64, false, true>, 32, 128, 64);
     // (the Detect form: 201 vs 206 us on 32-row tiles; <= 64 columns: the 2 x 2-wave form on 64 rows -- YOLOv5s conv_1 252 vs 266 us on 128)
+    // (launch-size policy -- the two forms give the same bits: FOUR 64-pixel tiles per CU or more; below that the generic kernel's 32-row tiles fill
+    // the chip as well or better: unconditionally the tile kernel measured -0.5 % at batch 4 and at batch 8 (two per CU), +1.0 % at batch 32;
+    // with this threshold batch 32 keeps +0.9 % (level 0 alone), batch 16 / 8 / 4 are flat: profiles/r06_f32_split.txt)
+    const bool force_detect_tile = d->plan && d->plan->split3_bm == -1;   // (tests: the tile kernel on launches the policy would not give it)
+    if (yolo && forced_bm == 0 && (d->ic == 128 || d->ic == 256) && d->oc <= 256 &&
+        (force_detect_tile || ((long long)((a.ohow + 63) >> 6) * d->n >= 4LL * cus && SI_ENV_INT("SI_SPLIT3_DETECT_TILE", 1)))) {
+        // (the level as 64-pixel runs of the output: detect_split_tile_kernel; a forced tile height takes the YOLO form of the generic kernel)
+        auto tile = [&](auto kern, int K) {
+            const size_t a_bytes = (size_t)2 * 64 * (K + 8) * 2, st_bytes = (size_t)32 * d->oc * 4;
+            const size_t lds = a_bytes > st_bytes ? a_bytes : st_bytes;
+            const hipError_t e = si_allow_dynamic_lds(kern, lds);
+            if (e != hipSuccess) return (int)e;
+            const long long tiles = (long long)((a.ohow + 63) >> 6) * d->n;
+            if (tiles > 0x7fffffffLL) return (int)SI_E_UNSUPPORTED;
+            hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+            return (int)hipGetLastError();
+        };
+        return d->ic == 128 ? tile(detect_split_tile_kernel<1>, 128) : tile(detect_split_tile_kernel<2>, 256);
+    }
     if (yolo) return forced_bm == 64 ? go(conv_split3_f32_kernel<64, 1, 4, 64, true>, 64, 128, 64) : go(conv_split3_f32_kernel<32, 1, 4, 64, true>, 32, 128, 64);
     if (d->oc <= 64) {
         if (split3_blk(d) == 32) return forced_bm == 128 ? go(conv_split3_f32_kernel<128, 2, 2, 32>, 128, 64, 32) : go(conv_split3_f32_kernel<64, 2, 2, 32>, 64, 64, 32);

@@ -492,7 +492,38 @@ def test_yolo_detect_head_f32_split(hops, orc, n, levels):
         anchors.append(np.broadcast_to(rng_uniform(280 + i, (1, na, 1, 1, 2), 5, 300), (1, na, h, h, 2)).copy())
     strides = [8.0, 16.0, 32.0]
     ref = orc.yolo_detect(feats, ws, bs, grids, anchors, strides, na)
-    assert_detect_parity(hops.yolo_detect_split3(feats, ws, bs, grids, anchors, strides, na), ref, what="Detect on the f32_split arithmetic")
+    got = hops.yolo_detect_split3(feats, ws, bs, grids, anchors, strides, na)
+    assert_detect_parity(got, ref, what="Detect on the f32_split arithmetic")
+    # round 6: from four 64-pixel tiles per CU on, the 128- and 256-channel levels run as 64-pixel runs of the output (detect_split_tile_kernel;
+    # SiConvPlan::split3_bm = -1 takes it at any size); a forced tile height takes the YOLO form of the generic split kernel -- the same k-steps on
+    # the same two chains, the same decode expressions: the same bits
+    with hops.plan(split3_bm=-1):
+        assert_exact(hops.yolo_detect_split3(feats, ws, bs, grids, anchors, strides, na), got, "Detect tile kernel vs the generic kernel's YOLO form")
+
+
+@pytest.mark.parametrize("n,h,c,na,ne", [(2, 24, 128, 3, 85), (3, 12, 256, 3, 85), (2, 10, 128, 3, 30), (1, 9, 256, 2, 40)])
+def test_detect_split_tile_kernel_shapes(hops, orc, n, h, c, na, ne):
+    """detect_split_tile_kernel alone: nine whole 64-pixel tiles per image; tiles across the 32-pixel halves' ends (144, 100, 81 pixels per image: a
+    last tile of 16 / 36 / 17 pixels); heads that are not 3 x 85 (the general decode path: 90 and 80 columns) -- against the oracle
+    (src/layer/yolo_detect.cpp:223-266) at the fp32 bars and bit for bit against the generic kernel's YOLO form; the guard word stays 0, and one
+    feature value at 1e5 sets it."""
+    feats = [rng_uniform(5000, (n, h, h, c), -1, 1)]
+    ws = [rng_uniform(5001, (na * ne, c, 1, 1), -0.3, 0.3)]
+    bs = [rng_uniform(5002, (na * ne,), -0.5, 0.5)]
+    gy, gx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(h, dtype=np.float32), indexing="ij")
+    grids = [np.broadcast_to(np.stack([gx - 0.5, gy - 0.5], -1)[None, None], (1, na, h, h, 2)).copy()]
+    anchors = [np.broadcast_to(rng_uniform(5003, (1, na, 1, 1, 2), 5, 300), (1, na, h, h, 2)).copy()]
+    ref = orc.yolo_detect(feats, ws, bs, grids, anchors, [8.0], na)
+    hot = [feats[0].copy()]
+    hot[0][n - 1, h // 2, h // 3, 5] = 1.0e5
+    with hops.plan(split3_bm=-1):   # (these launches are far below four tiles per CU: the policy alone would give them the generic kernel)
+        got, flags = hops.yolo_detect_split3(feats, ws, bs, grids, anchors, [8.0], na, return_flags=True)
+        assert list(hops.yolo_detect_split3(hot, ws, bs, grids, anchors, [8.0], na, return_flags=True)[1]) == [1]
+    assert list(flags) == [0]
+    assert_detect_parity(got, ref, what="Detect tile kernel, %d x %d x %d, %d x %d columns" % (h, h, c, na, ne))
+    assert_exact(hops.yolo_detect_split3(feats, ws, bs, grids, anchors, [8.0], na), got, "tile kernel vs the YOLO form of the generic kernel (the policy's choice here)")
+    with hops.plan(split3_bm=32):
+        assert_exact(hops.yolo_detect_split3(feats, ws, bs, grids, anchors, [8.0], na), got, "tile kernel vs the YOLO form, 32-row tiles forced")
 
 
 # ---- letterbox + detection post-processing (test/test_yolo/test_yolo.cpp:194-259, 337-428) ----
