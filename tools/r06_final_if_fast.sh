@@ -7,7 +7,7 @@ P=$(python3 bench.py --no-cpu-baseline --no-aux --no-secondary --min-time 2 2>/d
 Q=$(python3 bench.py --no-cpu-baseline --no-aux --no-secondary --min-time 2 --fp16 1 2>/dev/null | python3 -c "import json,sys; print(json.loads([l for l in sys.stdin if l.startswith('{')][-1])['value'])")
 echo "probe: fp32 $P img/s, fp16 $Q img/s"
 mkdir -p gpurun_out; echo "probe: fp32 $P fp16 $Q" >> gpurun_out/r06_probe.txt
-if python3 -c "import sys; sys.exit(0 if float('$Q') >= 25700 else 1)"; then
+if python3 -c "import sys; sys.exit(0 if float('$Q') >= 25850 else 1)"; then
   bash tools/r06_profile_all.sh
 else
   echo "slow-class box: evidence run skipped"
